@@ -1,0 +1,349 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz from the *reference itself* (build container only).
+
+Runs ONLY where /root/reference exists.  It imports the reference's hot-path modules
+unmodified (model/implicit.py, model/renderer.py, model/loss.py, utils/camera.py,
+utils/util.py with termcolor/vigra stubbed), feeds them seeded inputs, checks the
+oracle restatement (oracle/reference_ops.py) against them, and freezes inputs +
+reference outputs as small fp32 fixtures.  Fixtures are data only -- no reference source.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+for name in ("termcolor", "vigra", "mcubes", "trimesh", "chamfer_3D"):
+    if name not in sys.modules:
+        sys.modules[name] = types.ModuleType(name)
+sys.modules["termcolor"].colored = lambda s, **k: s
+sys.path.insert(0, REF)
+
+import utils.camera as ref_camera            # noqa: E402  (reference)
+import utils.util as ref_util                # noqa: E402
+import model.implicit as ref_implicit        # noqa: E402
+import model.renderer as ref_renderer        # noqa: E402
+import model.loss as ref_loss                # noqa: E402
+import utils.eval_3D as ref_eval3d           # noqa: E402
+
+from oracle import reference_ops as R        # noqa: E402
+from oracle import chamfer_ref               # noqa: E402
+
+torch.set_num_threads(4)
+
+
+def ref_opt(H=224, W=224):
+    with open(os.path.join(REF, "options/pix3d/config.yaml")) as f:
+        opt = ref_util.EasyDict(yaml.safe_load(f))
+    opt.H, opt.W = H, W
+    opt.device = "cpu"
+    return opt
+
+
+def sd_np(module, prefix=""):
+    return {prefix + k: v.detach().numpy().copy() for k, v in module.state_dict().items()}
+
+
+def perturb_(module, scale, gen):
+    """Make every weight non-zero ('trained-like') so column-order bugs cannot hide behind the
+    zeros of the geometric init."""
+    with torch.no_grad():
+        for p in module.parameters():
+            p.add_(scale * torch.randn(p.shape, generator=gen))
+
+
+def close(a, b, tol=1e-6, what=""):
+    a, b = torch.as_tensor(a), torch.as_tensor(b)
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    assert err <= tol * max(1.0, b.abs().max().item() if b.numel() else 1.0), (what, err)
+    return err
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().numpy()
+        out[k] = v
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, sum(np.asarray(v).nbytes for v in out.values()) // 1024, "KiB")
+
+
+def weights_from(module):
+    return {k: v.detach().clone() for k, v in module.state_dict().items()}
+
+
+def main():
+    opt = ref_opt()
+    cfg = R.Cfg()
+    gen = torch.Generator().manual_seed(1234)
+
+    # ---------------- G1: positional encoding -----------------------------------------
+    embed, out_dim = ref_implicit.get_embedder(6)
+    x = torch.randn(16, 3, generator=gen)
+    pe = embed(x)
+    assert out_dim == 39
+    close(R.posenc(x, 6), pe, 0, "posenc")
+    save("g1_posenc", x=x, pe=pe)
+
+    # ---------------- G2: SDF / RGB networks ------------------------------------------
+    torch.manual_seed(0)
+    sdf_net = ref_implicit.SDFNetwork(opt)
+    rgb_net = ref_implicit.RGBNetwork(opt)
+    # oracle init reproduces the reference's RNG stream
+    W0 = R.init_sdf_weights(cfg, 0)
+    for k, v in sdf_net.state_dict().items():
+        close(W0[k], v, 0, "sdf init " + k)
+    init_sdf = sd_np(sdf_net, "sdf.")
+    init_rgb = sd_np(rgb_net, "rgb.")
+    perturb_(sdf_net, 0.05, gen)
+    perturb_(rgb_net, 0.05, gen)
+    Wsdf, Wrgb = weights_from(sdf_net), weights_from(rgb_net)
+    B, N = 2, 128
+    pts = (torch.rand(B * N, 3, generator=gen) * 2 - 1) * 0.8
+    pts[0] = torch.tensor([0.0, 0.3, -0.2])          # x0 == 0: sign(0) = 0 gradient path
+    z_sdf = torch.randn(B, 64, generator=gen)
+    z_rgb = torch.randn(B, 64, generator=gen)
+    p1 = pts.clone()
+    sdf, feat, grad = sdf_net.get_conditional_output(opt, B, p1, z_sdf, compute_grad=True)
+    p2 = pts.clone()
+    o_sdf, o_feat, o_grad = R.sdf_conditional(cfg, Wsdf, B, p2, z_sdf, compute_grad=True)
+    close(o_sdf, sdf, 0, "sdf"); close(o_feat, feat, 0, "feat"); close(o_grad, grad, 0, "grad")
+    lat_rgb = z_rgb.unsqueeze(1).repeat(1, N, 1).view(B * N, -1)
+    rgb = rgb_net(pts, lat_rgb, feat.detach())
+    close(R.rgb_mlp(cfg, Wrgb, pts, lat_rgb, feat.detach()), rgb, 0, "rgb")
+    # geometric-init known answers
+    z0 = torch.zeros(1, 64)
+    torch.manual_seed(0)
+    net0 = ref_implicit.SDFNetwork(opt)
+    s0 = net0.get_conditional_output(opt, 1, torch.tensor([[0.0, 0, 0], [0.5, 0, 0], [-0.5, 0, 0]]),
+                                     z0.repeat(1, 1), compute_grad=False)[0]
+    save("g2_networks", pts=pts, z_sdf=z_sdf, z_rgb=z_rgb, sdf=sdf, feat=feat, grad=grad, rgb=rgb,
+         init_probe_sdf=s0, **init_sdf, **init_rgb,
+         **{"pert." + k: v for k, v in sd_np(sdf_net, "sdf.").items()},
+         **{"pert." + k: v for k, v in sd_np(rgb_net, "rgb.").items()})
+
+    # ---------------- G3: Laplace density ---------------------------------------------
+    dens = ref_implicit.LaplaceDensity(params_init={"beta": 0.1})
+    s = torch.tensor([[-0.2], [0.0], [0.2], [1e-3], [-3.0], [3.0]])
+    d = dens(s)
+    close(R.laplace_density(s, torch.tensor(0.1)), d, 0, "laplace")
+    save("g3_laplace", sdf=s, beta=np.float32(0.1), density=d)
+
+    # ---------------- renderer set-up (shared by G4-G6) -------------------------------
+    renderer = ref_renderer.Renderer(opt, sdf_net, rgb_net)
+    with torch.no_grad():
+        renderer.density.beta.fill_(0.07)
+    beta = renderer.density.beta.detach().clone()
+
+    # ---------------- G4: volume rendering --------------------------------------------
+    zv = torch.sort(torch.rand(32, 64, generator=gen) * 1.4 + 4.3, dim=1)[0]
+    sv = torch.randn(32 * 64, 1, generator=gen) * 0.2
+    w, a = renderer.volume_rendering(zv, sv)
+    ow, oa = R.volume_rendering(zv, sv, beta)
+    close(ow, w, 0, "weights"); close(oa, a, 0, "alpha")
+    save("g4_volume_rendering", z_vals=zv, sdf=sv, beta=beta, weights=w, alpha=a)
+
+    # ---------------- G8: camera -------------------------------------------------------
+    def random_cameras(B):
+        azim = (torch.rand(B, generator=gen) * 2 - 1) * np.pi
+        elev = (torch.rand(B, generator=gen) * 2 - 1) * np.pi / 6
+        roll = (torch.rand(B, generator=gen) * 2 - 1) * 0.1
+        trig = lambda t: torch.stack([torch.cos(t), torch.sin(t)], dim=1)
+        scale_dist = 0.8 + 0.4 * torch.rand(B, generator=gen)
+        scale_focal = torch.ones(B)
+        return trig(azim), trig(elev), trig(roll), scale_focal, scale_dist
+
+    def ref_pose(ta, te, tt, scale_dist):
+        Ry = ref_camera.azim_to_rotation_matrix(ta, representation="trig")
+        Rx = ref_camera.elev_to_rotation_matrix(te, representation="trig")
+        Rz = ref_camera.roll_to_rotation_matrix(tt, representation="trig")
+        P = torch.tensor([[-1, 0, 0], [0, 0, -1], [0, -1, 0]]).float().unsqueeze(0).expand_as(Ry)
+        pose_R = ref_camera.pose(R=Rz @ Rx @ Ry @ P)
+        tz = scale_dist * opt.camera.dist
+        pose_T = ref_camera.pose(t=torch.stack([torch.zeros_like(tz), torch.zeros_like(tz), tz], dim=-1))
+        return ref_camera.pose.compose([pose_R, pose_T])
+
+    opt8 = ref_opt(8, 8)
+    cfg8 = R.Cfg(H=8, W=8)
+    ta, te, tt, sf, sdist = random_cameras(2)
+    pose = ref_pose(ta, te, tt, sdist)
+    close(R.pose_from_trig(cfg8, ta, te, tt, sdist), pose, 0, "pose")
+    intr = ref_camera.get_intr(opt8, sf)
+    close(R.get_intr(cfg8, sf), intr, 0, "intr")
+    c, r = ref_camera.get_center_and_ray(opt8, pose, intr=intr, device="cpu")
+    oc, orr = R.get_center_and_ray(cfg8, pose, intr)
+    close(oc, c, 0, "center"); close(orr, r, 0, "ray")
+    # identity-R known answer at 224x224
+    pose_id = ref_camera.pose(t=torch.tensor([[0.0, 0.0, 5.0]]))
+    intr224 = ref_camera.get_intr(opt, torch.ones(1))
+    c224, r224 = ref_camera.get_center_and_ray(opt, pose_id, intr=intr224, device="cpu")
+    nrm = torch.randn(2, 5, 3, generator=gen)
+    tn = ref_camera.transform_normal(nrm, pose)
+    close(R.transform_normal(nrm, pose), tn, 0, "transform_normal")
+    save("g8_camera", trig_azim=ta, trig_elev=te, trig_theta=tt, scale_focal=sf, scale_dist=sdist,
+         pose=pose, intr=intr, center=c, ray=r, center224=c224, ray224_first=r224[0, :4],
+         normals=nrm, normals_transformed=tn)
+
+    # ---------------- G5: eval render, B=2, 8x8 ---------------------------------------
+    torch.manual_seed(77)
+    state = torch.get_rng_state()
+    with torch.no_grad():
+        out = renderer(opt8, pose, intr, sdist, z_sdf, z_rgb, ray_idx=None, training=False)
+    torch.set_rng_state(state)
+    t_rand, eik_idx, eik_pts = R.draw_render_randoms(2 * 64, 64, False)
+    o = R.render(cfg8, Wsdf, Wrgb, beta, pose, intr, sdist, z_sdf, z_rgb, None, False, t_rand, eik_idx, eik_pts)
+    for k, v in zip(("rgb", "mask", "mask_hard", "depth", "normal"), out[:5]):
+        close(o[k], v, 0, "render eval " + k)
+    save("g5_render_eval", pose=pose, intr=intr, scale_dist=sdist, z_sdf=z_sdf, z_rgb=z_rgb, beta=beta,
+         rgb=out[0], mask=out[1], mask_hard=out[2], depth=out[3], normal=out[4],
+         sdf=o["sdf"].detach(), weights=o["weights"].detach(), normal_flat=o["normal_flat"].detach(),
+         rgb_flat=o["rgb_flat"].detach(), points=o["points"].detach())
+
+    # ---------------- G6: training render + all gradients -----------------------------
+    Rr = 32
+    ray_idx = torch.stack([torch.randperm(64, generator=gen)[:Rr] for _ in range(2)], 0)
+    leaves = dict(pose=pose.clone().requires_grad_(True), intr=intr.clone().requires_grad_(True),
+                  scale_dist=sdist.clone().requires_grad_(True),
+                  z_sdf=z_sdf.clone().requires_grad_(True), z_rgb=z_rgb.clone().requires_grad_(True))
+    cot = dict(rgb=torch.randn(2, Rr, 3, generator=gen), mask=torch.randn(2, Rr, 1, generator=gen),
+               depth=torch.randn(2, Rr, 1, generator=gen), normal=torch.randn(2, Rr, 3, generator=gen),
+               eik=torch.randn(2 * 2 * Rr, generator=gen))
+
+    def functional(outs):
+        rgb, mask, _, depth, normal, eik = outs[:6]
+        return ((rgb * cot["rgb"]).sum() + (mask * cot["mask"]).sum() + (depth * cot["depth"]).sum()
+                + (normal * cot["normal"]).sum() + (eik * cot["eik"]).sum())
+
+    torch.manual_seed(78)
+    state = torch.get_rng_state()
+    outs = renderer(opt8, leaves["pose"], leaves["intr"], leaves["scale_dist"], leaves["z_sdf"], leaves["z_rgb"],
+                    ray_idx=ray_idx, training=True)
+    params = dict(renderer.named_parameters())      # sdf_network.*, rgb_network.*, density.beta
+    names = list(params.keys()) + list(leaves.keys())
+    tens = list(params.values()) + list(leaves.values())
+    grads = torch.autograd.grad(functional(outs), tens, allow_unused=True)
+    ref_grads = {n: (g if g is not None else torch.zeros_like(t)) for n, g, t in zip(names, grads, tens)}
+
+    torch.set_rng_state(state)
+    t_rand, eik_idx, eik_pts = R.draw_render_randoms(2 * Rr, 64, True)
+    oW_sdf = {k: v.clone().requires_grad_(True) for k, v in Wsdf.items()}
+    oW_rgb = {k: v.clone().requires_grad_(True) for k, v in Wrgb.items()}
+    obeta = beta.clone().requires_grad_(True)
+    ol = {k: v.detach().clone().requires_grad_(True) for k, v in leaves.items()}
+    o = R.render(cfg8, oW_sdf, oW_rgb, obeta, ol["pose"], ol["intr"], ol["scale_dist"], ol["z_sdf"], ol["z_rgb"],
+                 ray_idx, True, t_rand, eik_idx, eik_pts)
+    ofun = functional((o["rgb"], o["mask"], None, o["depth"], o["normal"], o["grad_eikonal"]))
+    for k, v in zip(("rgb", "mask", "mask_hard", "depth", "normal", "grad_eikonal"), outs[:6]):
+        close(o[k], v, 0, "render train " + k)
+    otens = ([oW_sdf[k[len("sdf_network."):]] for k in params if k.startswith("sdf_network.")]
+             + [oW_rgb[k[len("rgb_network."):]] for k in params if k.startswith("rgb_network.")]
+             + [obeta] + list(ol.values()))
+    onames = ([k for k in params if k.startswith("sdf_network.")] + [k for k in params if k.startswith("rgb_network.")]
+              + ["density.beta"] + list(ol.keys()))
+    ograds = torch.autograd.grad(ofun, otens, allow_unused=True)
+    for n, g in zip(onames, ograds):
+        g = g if g is not None else torch.zeros_like(ref_grads[n])
+        close(g, ref_grads[n], 1e-5, "grad " + n)
+    save("g6_render_train", ray_idx=ray_idx, t_rand=t_rand, eik_idx=eik_idx, eik_pts=eik_pts,
+         pose=pose, intr=intr, scale_dist=sdist, z_sdf=z_sdf, z_rgb=z_rgb, beta=beta,
+         rgb=outs[0], mask=outs[1], mask_hard=outs[2], depth=outs[3], normal=outs[4], grad_eikonal=outs[5],
+         **{"cot." + k: v for k, v in cot.items()}, **{"grad." + k: v for k, v in ref_grads.items()})
+
+    # ---------------- G7: losses -------------------------------------------------------
+    loss = ref_loss.Loss(opt)
+    torch.manual_seed(0)
+    Bq, Rq = 4, 512
+    pred3 = torch.rand(Bq, Rq, 3); tgt3 = torch.rand(Bq, Rq, 3)
+    pm = torch.rand(Bq, Rq, 1); tm = (torch.rand(Bq, Rq, 1) > 0.5).float()
+    npred = torch.nn.functional.normalize(torch.randn(Bq, Rq, 3), dim=-1)
+    ngt = torch.nn.functional.normalize(torch.randn(Bq, Rq, 3), dim=-1)
+    nmask = (pm > 0.5) & (tm > 0.5)
+    eik = torch.rand(Bq, 2 * Rq) + 0.5
+    trig_t = torch.randn(Bq, 2)
+    trig = torch.nn.functional.normalize(trig_t, dim=1)
+    trig_e = torch.nn.functional.normalize(torch.tensor([[1.0, 0.1], [0.2, 1.0], [1.0, -0.05], [-0.3, 1.0]]), dim=1)
+    vals = dict(
+        mse=loss.MSE_loss(pred3, tgt3), mse_tol=loss.MSE_loss(pred3, tgt3, tolerance=0.2),
+        mse_eik=loss.MSE_loss(eik, 1), l1=loss.L1_loss(pred3, tgt3),
+        iou=loss.iou_loss(pm, tm), iou_tol=loss.iou_loss(pm.clone(), tm, tolerance=0.1),
+        mask=loss.mask_loss(pm, tm),
+        normal=loss.normal_loss(npred, ngt, nmask, tolerance=0.2),
+        normal_notol=loss.normal_loss(npred, ngt, nmask),
+        cam_uniform=loss.cam_uniform_loss(opt, trig),
+        cam_margin=loss.cam_margin(opt, trig_e, [-90 + 1e-3, 90 - 1e-3]),
+    )
+    cfgl = R.Cfg()
+    ov = dict(
+        mse=R.mse_loss(pred3, tgt3), mse_tol=R.mse_loss(pred3, tgt3, tolerance=0.2), mse_eik=R.mse_loss(eik, 1),
+        l1=R.l1_loss(pred3, tgt3), iou=R.iou_loss(pm, tm), iou_tol=R.iou_loss(pm.clone(), tm, tolerance=0.1),
+        mask=R.mask_loss(cfgl, pm, tm), normal=R.normal_loss(cfgl, npred, ngt, nmask, tolerance=0.2),
+        normal_notol=R.normal_loss(cfgl, npred, ngt, nmask), cam_uniform=R.cam_uniform_loss(cfgl, trig),
+        cam_margin=R.cam_margin(trig_e, [-90 + 1e-3, 90 - 1e-3]),
+    )
+    for k in vals:
+        close(ov[k], vals[k], 0, "loss " + k)
+    # gradients of the three hot reductions (for the fused loss backward)
+    pm_g = pm.clone().requires_grad_(True); pr_g = pred3.clone().requires_grad_(True)
+    np_g = npred.clone().requires_grad_(True); ek_g = eik.clone().requires_grad_(True)
+    tot = (loss.MSE_loss(pr_g, tgt3) + 0.5 * loss.mask_loss(pm_g, tm)
+           + 0.01 * loss.normal_loss(np_g, ngt, nmask, tolerance=0.2) + 0.03 * loss.MSE_loss(ek_g, 1))
+    g_pr, g_pm, g_np, g_ek = torch.autograd.grad(tot, [pr_g, pm_g, np_g, ek_g])
+    # NN-view scores (graph.py:119-134)
+    mNN = (torch.rand(Bq, Rq, 1, 5) > 0.5).float()
+    probs = R.nn_view_scores(tm, mNN, 4)
+    save("g7_losses", pred3=pred3, tgt3=tgt3, pm=pm, tm=tm, npred=npred, ngt=ngt, nmask=nmask, eik=eik,
+         trig=trig, trig_e=trig_e, mask_NN=mNN, nn_probs=probs,
+         g_pred3=g_pr, g_pm=g_pm, g_npred=g_np, g_eik=g_ek,
+         **{"val." + k: v.detach() for k, v in vals.items()})
+
+    # ---------------- G9: chamfer ------------------------------------------------------
+    rng = np.random.RandomState(5)
+    a = rng.uniform(-0.5, 0.5, (2, 700, 3)).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, (2, 1300, 3)).astype(np.float32)
+    b[0, 100] = b[0, 7]; b[0, 900] = b[0, 7]        # exact duplicates -> tie rule (lowest index)
+    a[1, 50] = b[1, 1100]; b[1, 20] = b[1, 1100]    # zero distance, duplicate target
+    d1, d2, i1, i2 = chamfer_ref.chamfer_forward(a, b)
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    D = ((a64[:, :, None] - b64[:, None]) ** 2).sum(-1)
+    assert np.abs(D.min(2) - d1).max() < 1e-6 and np.abs(D.min(1) - d2).max() < 1e-6
+    # index must be a true minimiser up to fp32 rounding, and the lowest index among exact ties
+    assert np.all(np.take_along_axis(D, i1[..., None].astype(np.int64), 2)[..., 0] - D.min(2) < 1e-6)
+    dup = np.where((b[0] == b[0, 7]).all(-1))[0]
+    hit = np.where(np.isin(i1[0], dup))[0]
+    assert np.all(i1[0][hit] == 7), "tie rule"
+    gd1 = rng.randn(2, 700).astype(np.float32); gd2 = rng.randn(2, 1300).astype(np.float32)
+    g1, g2 = chamfer_ref.chamfer_backward(a, b, gd1, gd2, i1, i2)
+    g1d, g2d = R.chamfer_backward_ref(a, b, gd1, gd2, i1, i2)
+    assert np.abs(g1 - g1d).max() < 1e-4 and np.abs(g2 - g2d).max() < 1e-4
+    save("g9_chamfer", xyz1=a, xyz2=b, dist1=d1, dist2=d2, idx1=i1, idx2=i2, gd1=gd1, gd2=gd2, g1=g1, g2=g2)
+
+    # ---------------- G10: eval_3D helpers --------------------------------------------
+    dA = torch.rand(2, 500) * 0.3; dB = torch.rand(2, 400) * 0.3
+    fs = ref_eval3d.compute_fscore(dA, dB, opt.eval.f_thresholds)
+    close(R.compute_fscore(dA, dB, opt.eval.f_thresholds), fs, 0, "fscore")
+    pc = torch.randn(2, 300, 3) * torch.tensor([1.0, 2.0, 5.0]) + 3
+    pcn = ref_eval3d.normalize_pc(pc)
+    close(R.normalize_pc(pc), pcn, 0, "normalize_pc")
+    optg = ref_opt(); optg.eval.vox_res = 6
+    var = ref_util.EasyDict(idx=torch.arange(2))
+    grid = ref_eval3d.get_dense_3D_grid(optg, var)
+    close(R.dense_grid(-0.6, 0.6, 6, 2), grid, 0, "grid")
+    lvl = ref_eval3d.compute_level_grid(optg, sdf_net, z_sdf, grid)
+    close(R.level_grid(cfg, Wsdf, z_sdf, grid), lvl, 0, "level grid")
+    save("g10_eval3d", dist1=dA, dist2=dB, fscore=fs, pc=pc, pc_normalized=pcn, grid=grid, level=lvl, z_sdf=z_sdf)
+
+    print("all oracle-vs-reference checks passed; fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
