@@ -1,0 +1,43 @@
+"""chamfer_3D -- drop-in for the reference's pybind extension of the same name.
+
+Same two entry points and argument meaning as external/chamfer3D/chamfer_cuda.cpp:17-33:
+
+    forward(xyz1, xyz2, dist1, dist2, idx1, idx2) -> int
+    backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2) -> int
+
+The caller allocates every output (zero-filled; the backward *accumulates* into the gradients),
+tensors are fp32 / int32, contiguous, on one ROCm device.  Returns 1 on success like the
+reference (chamfer3D.cu:151,193); unlike the reference a failed launch raises instead of
+printf-and-return-0, and kernels go to torch's current stream rather than the legacy default one.
+The work is done by the hand-written gfx950 kernels in shapeclipper_amd/csrc/chamfer.hip through the
+C ABI (include/shapeclipper_hip.h); there is no CPU fallback.
+"""
+import ctypes
+
+from shapeclipper_amd import _lib
+
+
+def _dims(xyz1, xyz2):
+    assert xyz1.dim() == 3 and xyz2.dim() == 3 and xyz1.shape[2] == 3 and xyz2.shape[2] == 3
+    assert xyz1.shape[0] == xyz2.shape[0]
+    return xyz1.shape[0], xyz1.shape[1], xyz2.shape[1]
+
+
+def forward(xyz1, xyz2, dist1, dist2, idx1, idx2):
+    lib = _lib.load()
+    b, n, m = _dims(xyz1, xyz2)
+    code = lib.sc_chamfer3d_forward(_lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(dist1), _lib.ptr(dist2),
+                                    _lib.ptr(idx1), _lib.ptr(idx2), ctypes.c_int(b), ctypes.c_int(n),
+                                    ctypes.c_int(m), _lib.stream())
+    _lib.check(code, "sc_chamfer3d_forward")
+    return 1
+
+
+def backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2):
+    lib = _lib.load()
+    b, n, m = _dims(xyz1, xyz2)
+    code = lib.sc_chamfer3d_backward(_lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(gradxyz1), _lib.ptr(gradxyz2),
+                                     _lib.ptr(graddist1), _lib.ptr(graddist2), _lib.ptr(idx1), _lib.ptr(idx2),
+                                     ctypes.c_int(b), ctypes.c_int(n), ctypes.c_int(m), _lib.stream())
+    _lib.check(code, "sc_chamfer3d_backward")
+    return 1

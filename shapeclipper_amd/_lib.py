@@ -1,0 +1,61 @@
+"""ctypes binding of libshapeclipper_hip.so (the C ABI declared in include/shapeclipper_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a tensor is not on a
+ROCm device, calls raise.  Tensors are passed as raw device pointers (``tensor.data_ptr()``) plus
+explicit sizes; kernels are enqueued on torch's *current* stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libshapeclipper_hip.so")
+
+SYMBOLS = (
+    "sc_chamfer3d_forward", "sc_chamfer3d_backward", "sc_sdf_forward",
+)
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load the library once.  Raises HipLibraryMissing (never falls back)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C shapeclipper_amd/csrc`; there is no CPU fallback for the HIP hot path")
+        _lib = ctypes.CDLL(LIB_PATH)
+        for name in SYMBOLS:
+            getattr(_lib, name).restype = ctypes.c_int
+    return _lib
+
+
+def ptr(t: Optional[torch.Tensor]):
+    """Device pointer of a contiguous CUDA/ROCm tensor (NULL for None)."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    if not t.is_cuda:
+        raise RuntimeError("shapeclipper_amd: HIP kernels need device tensors (got a CPU tensor); "
+                           "the product path has no CPU fallback")
+    if not t.is_contiguous():
+        raise RuntimeError("shapeclipper_amd: tensor must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(code: int, what: str):
+    if code != 0:
+        raise RuntimeError(f"shapeclipper_amd: {what} failed with hipError_t {code}")

@@ -1,0 +1,245 @@
+// mlp_tile.hpp -- per-wavefront MLP tile primitives for gfx950 (CDNA4), fp32 MFMA.
+//
+// One wave64 owns a tile of 16 sample points and walks the whole MLP chain in registers with
+// v_mfma_f32_16x16x4_f32 (exact fp32 fma chain; runs on the matrix pipe at the fp32 peak rate, so
+// the VALU stays free for softplus / sin / cos / exp).  Convention ("transposed GEMM"):
+//        Y^T[ch, pt] = W[ch, k] * X^T[k, pt]
+//   A operand  = weights    : lane l holds W[i = l&15][k = l>>4]         (one float per lane)
+//   B operand  = activations: lane l holds X[k = l>>4][pt = l&15]
+//   C/D        = 16 ch x 16 pt: lane l, reg r holds ch = 4*(l>>4) + r, pt = l&15
+//
+// The point of this orientation: C/D register r of lane group g=(l>>4) in channel tile T is
+// channel 16T+4g+r of point l&15 -- exactly a legal B operand for K-step 4T+r of the next layer
+// when the weight columns are visited in that (permuted) order.  Layer outputs feed the next layer
+// with NO cross-lane movement, no LDS round trip, no transposes; only the weight reads (LDS,
+// plain row-major, odd row stride) know about the permutation.  Transposed products (W^T q, for
+// d(sdf)/dx and all backward passes) read the same LDS image column-wise.
+// (A 32x32x2 variant of the same idea needs 2x the registers per lane: the d(sdf)/dx sweep keeps
+// sp'(a_l) of five layers live, 160 VGPRs at 32 points vs 80 at 16 -- it spilled; this one fits.)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TP = 16;         // points per wave tile
+constexpr int HID = 64;        // hidden width (arch.impl_sdf.n_channels / impl_rgb.n_channels)
+constexpr int NT = 4;          // 16-channel tiles per 64-channel activation
+constexpr int ACT_STEPS = 16;  // K-steps for a 64-channel activation (4 channels per step)
+constexpr int PE_STEPS = 12;   // K-steps for the positional encoding: 3 coords x 4 steps
+constexpr int PE_COLS = 48;    // 39 real PE columns + 9 zero pads, in "slot order" (see pe_slot_col)
+
+// channel visited by lane group 0 at K-step s of a 64-channel activation (group g visits kp(s)+4g)
+__host__ __device__ constexpr int kp(int s) { return 16 * (s >> 2) + (s & 3); }
+
+// Slot order of the positional encoding.  Packed column = 4*(4*c + j) + g  (c coord, j step in 0..3,
+// g lane group):
+//   g = 0..2 : frequency index m = 2*g + (j>>1), sin if (j&1)==0 else cos
+//              -> reference column 3 + 6*m + 3*(j&1) + c           (model/implicit.py:12-34 order)
+//   g = 3    : j==0 -> raw coordinate, reference column c;  j>0 -> zero pad (column -1)
+// Lane group g of a point therefore evaluates frequencies {2^(2g), 2^(2g+1)} of all three
+// coordinates, sin/cos of one argument live in the same lane, and the 13 slots that depend on
+// coordinate c are exactly K-steps 4c..4c+3 (the forward-mode PE Jacobian uses that).
+__host__ __device__ constexpr int pe_slot_col(int col) {
+    const int g = col & 3, cj = col >> 2, c = cj >> 2, j = cj & 3;
+    return g < 3 ? 3 + 6 * (2 * g + (j >> 1)) + 3 * (j & 1) + c : (j == 0 ? c : -1);
+}
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ---- products ------------------------------------------------------------------------------------
+// acc[mt] += W[row0 + 16*mt + i][col0 + kp(s) + 4*g] * in[s]       wl = W + (row0+i)*LD + col0 + 4*g
+template <int LD, int MT>
+__device__ __forceinline__ void mm_act(const float* wl, const float (&in)[ACT_STEPS], f32x4 (&acc)[MT]) {
+#pragma unroll
+    for (int s = 0; s < ACT_STEPS; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(wl[mt * 16 * LD + kp(s)], in[s], acc[mt]);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// acc[mt] += W[row0 + kp(s) + 4*g][col0 + 16*mt + i] * in[s]       wl = W + (row0+4*g)*LD + col0 + i
+template <int LD, int MT>
+__device__ __forceinline__ void mm_act_t(const float* wl, const float (&in)[ACT_STEPS], f32x4 (&acc)[MT]) {
+#pragma unroll
+    for (int s = 0; s < ACT_STEPS; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(wl[kp(s) * LD + 16 * mt], in[s], acc[mt]);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// acc[mt] += W[row0 + 16*mt + i][col0 + 4*(S0+s) + g] * in[s]      wl = W + (row0+i)*LD + col0 + g
+template <int LD, int MT, int S0, int NS>
+__device__ __forceinline__ void mm_pe(const float* wl, const float* in, f32x4 (&acc)[MT]) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(wl[mt * 16 * LD + 4 * (S0 + s)], in[s], acc[mt]);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// acc[t][r] = b[kp(4t+r)]   (b already offset by 4*g) -- the bias seeds the accumulator
+template <int MT>
+__device__ __forceinline__ void acc_init(f32x4 (&acc)[MT], const float* b) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = b[kp(4 * t + r)];
+}
+template <int MT>
+__device__ __forceinline__ void acc_zero(f32x4 (&acc)[MT]) {
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = 0.f;
+}
+
+// ---- activations -----------------------------------------------------------------------------------
+// softplus(beta=100) and derivatives (model/implicit.py:136; torch threshold=20 is reproduced to
+// well below fp32 resolution: beyond it log1p(t) < 2.1e-9*0.01).  t = exp(-|100a|), r = 1/(1+t):
+//   sp = max(a,0) + log(1+t)/100,  sp' = (a>=0 ? 1 : t) * r,  sp'' = 100 * t * r^2
+__device__ __forceinline__ void softplus_parts(float a, float& t, float& r) {
+    t = __expf(-fabsf(100.f * a));
+    r = __builtin_amdgcn_rcpf(1.f + t);
+}
+__device__ __forceinline__ float softplus_val(float a, float t) { return fmaxf(a, 0.f) + 0.01f * __logf(1.f + t); }
+__device__ __forceinline__ float softplus_d1(float a, float t, float r) { return (a >= 0.f ? 1.f : t) * r; }
+__device__ __forceinline__ float softplus_d2(float t, float r) { return 100.f * t * r * r; }
+
+// ---- positional encoding in slot order ---------------------------------------------------------------
+// e[4c+j]: value, d1[4c+j]: d/dx_c, d2[4c+j]: d2/dx_c^2 of the slot this lane (group g) owns.
+// Symmetry (implicit.py:139-145): coordinate 0 enters as |x0|; chain-rule factor sign(x0) with
+// sign(0)=0 exactly as torch.abs' backward; the second derivative carries sign^2.
+template <bool D1, bool D2>
+__device__ __forceinline__ void pe_slots(float x0, float x1, float x2, int g, bool symmetric,
+                                         float (&e)[PE_STEPS], float (&d1)[PE_STEPS], float (&d2)[PE_STEPS]) {
+    const float fbase = g == 0 ? 1.f : (g == 1 ? 4.f : 16.f);
+    const float xs[3] = {symmetric ? fabsf(x0) : x0, x1, x2};
+    const float sg0 = symmetric ? (x0 > 0.f ? 1.f : (x0 < 0.f ? -1.f : 0.f)) : 1.f;
+    const bool raw = g == 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float sg = c == 0 ? sg0 : 1.f;
+        const float sg2 = sg * sg;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const float f = fbase * (float)(1 << m);
+            float sn, cs;
+            sincosf(xs[c] * f, &sn, &cs);
+            e[4 * c + 2 * m] = raw ? (m == 0 ? xs[c] : 0.f) : sn;
+            e[4 * c + 2 * m + 1] = raw ? 0.f : cs;
+            if (D1) {
+                d1[4 * c + 2 * m] = raw ? (m == 0 ? sg : 0.f) : f * cs * sg;
+                d1[4 * c + 2 * m + 1] = raw ? 0.f : -f * sn * sg;
+            }
+            if (D2) {
+                d2[4 * c + 2 * m] = raw ? 0.f : -f * f * sn * sg2;
+                d2[4 * c + 2 * m + 1] = raw ? 0.f : -f * f * cs * sg2;
+            }
+        }
+    }
+}
+
+// ---- tile-blocked activation layout (TBL64) ----------------------------------------------------------
+// A 64-channel per-point tensor is stored as float4 blocks  [tile][ch/4 = 16][pt = 16][4]
+// (1024 floats per 16-point tile).  In C/D layout a lane holds 4 consecutive channels per
+// accumulator, so a tile is written/read with 4 fully coalesced dwordx4 accesses per lane, and the
+// weight-gradient kernel restages the same image through LDS.  v[4T+r] <-> channel 16T + 4g + r.
+__device__ __forceinline__ void tbl_store(float* base, int tile, int p, int g, const float (&v)[ACT_STEPS]) {
+    float4* dst = reinterpret_cast<float4*>(base) + (size_t)tile * 256;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        dst[(4 * t + g) * 16 + p] = make_float4(v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]);
+}
+__device__ __forceinline__ void tbl_load(const float* base, int tile, int p, int g, float (&v)[ACT_STEPS]) {
+    const float4* src = reinterpret_cast<const float4*>(base) + (size_t)tile * 256;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float4 q = src[(4 * t + g) * 16 + p];
+        v[4 * t] = q.x; v[4 * t + 1] = q.y; v[4 * t + 2] = q.z; v[4 * t + 3] = q.w;
+    }
+}
+__device__ __forceinline__ void acc_to_regs(const f32x4 (&acc)[NT], float (&v)[ACT_STEPS]) {
+#pragma unroll
+    for (int s = 0; s < ACT_STEPS; ++s) v[s] = acc[s >> 2][s & 3];
+}
+
+// sum over the four lane groups (the groups of a point hold disjoint channel sets)
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16);
+    return v + __shfl_xor(v, 32);
+}
+
+// ---- packed weight images ------------------------------------------------------------------------------
+// Global (unpadded, row-major) layout handed over by the host, see include/shapeclipper_hip.h.
+struct SdfPack {
+    static constexpr int W0 = 0;                      // [64][48]   PE slots
+    static constexpr int W1 = W0 + 64 * 48;           // [64][112]  cols 0..63 hidden, 64..111 PE slots (pre-scaled 1/sqrt2)
+    static constexpr int W2 = W1 + 64 * 112;          // [64][112]
+    static constexpr int W3 = W2 + 64 * 112;          // [64][64]
+    static constexpr int W4 = W3 + 64 * 64;           // [64][64]
+    static constexpr int W5 = W4 + 64 * 64;           // [65][64]   row 0 = sdf, rows 1..64 = feature
+    static constexpr int B5 = W5 + 65 * 64;           // [65]
+    static constexpr int TOTAL = B5 + 65;             // floats
+};
+// LDS image: same matrices with odd row strides (bank-conflict-free row- and column-wise reads).
+struct SdfLds {
+    static constexpr int LD0 = 49, LD1 = 113, LD3 = 65;
+    static constexpr int W0 = 0;
+    static constexpr int W1 = W0 + 64 * LD0;
+    static constexpr int W2 = W1 + 64 * LD1;
+    static constexpr int W3 = W2 + 64 * LD1;
+    static constexpr int W4 = W3 + 64 * LD3;
+    static constexpr int W5 = W4 + 64 * LD3;
+    static constexpr int B5 = W5 + 65 * LD3;
+    static constexpr int TOTAL = B5 + 68;             // floats
+};
+
+struct RgbPack {
+    static constexpr int V0 = 0;                      // [64][112]  cols 0..47 PE slots, 48..111 sdf feature
+    static constexpr int V1 = V0 + 64 * 112;          // [64][64]
+    static constexpr int V2 = V1 + 64 * 64;           // [64][64]
+    static constexpr int V3 = V2 + 64 * 64;           // [3][64]
+    static constexpr int B3 = V3 + 3 * 64;            // [3] (+1 pad)
+    static constexpr int TOTAL = B3 + 4;
+};
+struct RgbLds {
+    static constexpr int LD0 = 113, LD1 = 65;
+    static constexpr int V0 = 0;
+    static constexpr int V1 = V0 + 64 * LD0;
+    static constexpr int V2 = V1 + 64 * LD1;
+    static constexpr int V3 = V2 + 64 * LD1;          // [3][64] stride 64 (broadcast reads only)
+    static constexpr int B3 = V3 + 3 * 64;
+    static constexpr int TOTAL = B3 + 4;
+};
+
+// copy a [rows][cols] matrix from global (row stride cols) into LDS (row stride ld)
+__device__ __forceinline__ void stage_matrix(float* lds, const float* g, int rows, int cols, int ld, int tid, int nthreads) {
+    for (int idx = tid; idx < rows * cols; idx += nthreads) {
+        const int r = idx / cols, c = idx - r * cols;
+        lds[r * ld + c] = g[idx];
+    }
+}
+
+__device__ __forceinline__ void stage_sdf_weights(float* lds, const float* w, int tid, int nthreads) {
+    stage_matrix(lds + SdfLds::W0, w + SdfPack::W0, 64, 48, SdfLds::LD0, tid, nthreads);
+    stage_matrix(lds + SdfLds::W1, w + SdfPack::W1, 64, 112, SdfLds::LD1, tid, nthreads);
+    stage_matrix(lds + SdfLds::W2, w + SdfPack::W2, 64, 112, SdfLds::LD1, tid, nthreads);
+    stage_matrix(lds + SdfLds::W3, w + SdfPack::W3, 64, 64, SdfLds::LD3, tid, nthreads);
+    stage_matrix(lds + SdfLds::W4, w + SdfPack::W4, 64, 64, SdfLds::LD3, tid, nthreads);
+    stage_matrix(lds + SdfLds::W5, w + SdfPack::W5, 65, 64, SdfLds::LD3, tid, nthreads);
+    stage_matrix(lds + SdfLds::B5, w + SdfPack::B5, 1, 65, 68, tid, nthreads);
+}
+
+__device__ __forceinline__ void stage_rgb_weights(float* lds, const float* w, int tid, int nthreads) {
+    stage_matrix(lds + RgbLds::V0, w + RgbPack::V0, 64, 112, RgbLds::LD0, tid, nthreads);
+    stage_matrix(lds + RgbLds::V1, w + RgbPack::V1, 64, 64, RgbLds::LD1, tid, nthreads);
+    stage_matrix(lds + RgbLds::V2, w + RgbPack::V2, 64, 64, RgbLds::LD1, tid, nthreads);
+    stage_matrix(lds + RgbLds::V3, w + RgbPack::V3, 1, 3 * 64 + 4, 3 * 64 + 4, tid, nthreads);
+}
+
+}  // namespace sc
