@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libshapeclipper_hip.so")
 
 SYMBOLS = (
-    "sc_chamfer3d_forward", "sc_chamfer3d_backward", "sc_sdf_forward",
+    "sc_chamfer3d_forward", "sc_chamfer3d_backward", "sc_sdf_forward", "sc_rgb_composite_forward",
 )
 
 _lib: Optional[ctypes.CDLL] = None

@@ -1,0 +1,130 @@
+// rgb_fwd.hip -- RGB MLP + Laplace density + VolSDF alpha compositing, one wavefront per ray.
+//
+// Replaces, for one render call: RGBNetwork.forward (model/implicit.py:220-239),
+// LaplaceDensity.density_func (:65-83), Renderer.volume_rendering (model/renderer.py:187-209) and the
+// per-ray reductions of Renderer.forward (:117-152).  Consumes what sdf_fwd.hip left in HBM
+// (sdf, d sdf/dx, 64-channel feature in TBL64 layout).
+//
+// A wave owns one ray = 64 samples = four 16-point MFMA tiles.  After the RGB chain of tile k the
+// per-point results (density, colour, unit normal) are kept by lane group g==k, so that at the end
+// lane i holds sample i of the ray and the compositing is a 64-lane scan + eight wave reductions.
+#include "rgb_common.hpp"
+
+namespace sc {
+
+struct RgbFwdArgs {
+    const float* points;     // [n_rays*64][3]
+    const float* z_vals;     // [n_rays][64]
+    const float* depth_fac;  // [n_rays]
+    const float* sdf;        // [n_rays*64]
+    const float* grad;       // [n_rays*64][3]   d sdf / d point
+    const float* feat;       // TBL64
+    const float* v;          // RgbPack image
+    const float* dbias;      // [n_images][3][64]
+    const float* beta_param; // scalar parameter (renderer.density.beta), device memory
+    int n_rays, rays_per_image, n_images, symmetric;
+    float beta_min, bgcolor, normal_pow;
+    float* rgb;        // [n_rays][3]
+    float* mask;       // [n_rays]
+    float* mask_hard;  // [n_rays]   {0,1}
+    float* depth;      // [n_rays]
+    float* normal;     // [n_rays][3]
+    float* weights;    // [n_rays][64] or null (kept for tests / visualisation: alpha in `alpha`)
+    float* alpha;      // [n_rays][64] or null
+    float* rgb_flat;   // [n_rays*64][3] or null (visualisation path, renderer.py:176)
+};
+
+__global__ __launch_bounds__(256) void rgb_composite_fwd_kernel(RgbFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    stage_rgb_weights(lds, a.v, threadIdx.x, 256);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = lane & 15, g = lane >> 4;
+    RgbLanePtrs L(lds, p, g);
+    const float beta = fabsf(a.beta_param[0]) + a.beta_min;
+
+    for (int ray = blockIdx.x * 4 + wave; ray < a.n_rays; ray += gridDim.x * 4) {
+        const int img = min(ray / a.rays_per_image, a.n_images - 1);
+        const float* db = a.dbias + (size_t)img * 192 + 4 * g;
+        float sigma = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f;
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) {
+            const int tile = ray * 4 + k;
+            const size_t pt = (size_t)tile * TP + p;
+            const float x0 = a.points[pt * 3 + 0], x1 = a.points[pt * 3 + 1], x2 = a.points[pt * 3 + 2];
+            float e[PE_STEPS], d1[PE_STEPS], d2[PE_STEPS];
+            pe_slots<false, false>(x0, x1, x2, g, a.symmetric != 0, e, d1, d2);
+            float f[ACT_STEPS];
+            tbl_load(a.feat, tile, p, g, f);
+            float y[3][ACT_STEPS];
+            float col[3];
+            rgb_chain(L, db, e, f, y, col);
+            const float s = a.sdf[pt];
+            const float gx = a.grad[pt * 3 + 0], gy = a.grad[pt * 3 + 1], gz = a.grad[pt * 3 + 2];
+            const float ex = expf(-fabsf(s) / beta);
+            const float sg = (1.f / beta) * (s >= 0.f ? 0.5f * ex : 1.f - 0.5f * ex);
+            // normal_flat = -d(density)/dx = (0.5/beta^2) exp(-|s|/beta) * g; then F.normalize (eps 1e-12)
+            const float kk = (0.5f / (beta * beta)) * ex;
+            const float vx = kk * gx, vy = kk * gy, vz = kk * gz;
+            const float inv = 1.f / fmaxf(sqrtf(vx * vx + vy * vy + vz * vz), 1e-12f);
+            if (g == k) {
+                sigma = sg; c0 = col[0]; c1 = col[1]; c2 = col[2];
+                n0 = vx * inv; n1 = vy * inv; n2 = vz * inv;
+            }
+        }
+        // ---- compositing over the 64 samples of the ray (lane == sample index) ----
+        const float z = a.z_vals[(size_t)ray * 64 + lane];
+        const float znext = __shfl_down(z, 1);
+        const float delta = lane == 63 ? 0.f : znext - z;
+        const float E = delta * sigma;
+        const float alpha = 1.f - expf(-E);
+        const float T = expf(-(wave_inclusive_scan(E) - E));
+        const float w = alpha * T;
+        const float wn = a.normal_pow == 1.f ? w : powf(w, a.normal_pow);
+        const float dfac = a.depth_fac[ray];
+        const float acc = wave_sum(w);
+        const float dep = wave_sum(w * (z * dfac));
+        const float r0 = wave_sum(w * c0), r1 = wave_sum(w * c1), r2 = wave_sum(w * c2);
+        const float m0 = wave_sum(wn * n0), m1 = wave_sum(wn * n1), m2 = wave_sum(wn * n2);
+        if (a.weights) a.weights[(size_t)ray * 64 + lane] = w;
+        if (a.alpha) a.alpha[(size_t)ray * 64 + lane] = alpha;
+        if (a.rgb_flat) {
+            a.rgb_flat[((size_t)ray * 64 + lane) * 3 + 0] = c0;
+            a.rgb_flat[((size_t)ray * 64 + lane) * 3 + 1] = c1;
+            a.rgb_flat[((size_t)ray * 64 + lane) * 3 + 2] = c2;
+        }
+        if (lane == 0) {
+            const float bg = (1.f - acc) * a.bgcolor;
+            a.rgb[(size_t)ray * 3 + 0] = r0 + bg;
+            a.rgb[(size_t)ray * 3 + 1] = r1 + bg;
+            a.rgb[(size_t)ray * 3 + 2] = r2 + bg;
+            a.mask[ray] = acc;
+            a.mask_hard[ray] = acc > 0.5f ? 1.f : 0.f;
+            a.depth[ray] = dep;
+            const float inv = 1.f / fmaxf(sqrtf(m0 * m0 + m1 * m1 + m2 * m2), 1e-12f);
+            a.normal[(size_t)ray * 3 + 0] = m0 * inv;
+            a.normal[(size_t)ray * 3 + 1] = m1 * inv;
+            a.normal[(size_t)ray * 3 + 2] = m2 * inv;
+        }
+    }
+}
+
+}  // namespace sc
+
+extern "C" int sc_rgb_composite_forward(const float* points, const float* z_vals, const float* depth_fac,
+                                        const float* sdf, const float* grad, const float* feat,
+                                        const float* v_pack, const float* dbias, const float* beta_param,
+                                        int n_rays, int rays_per_image, int n_images, int symmetric,
+                                        float beta_min, float bgcolor, float normal_pow,
+                                        float* rgb, float* mask, float* mask_hard, float* depth, float* normal,
+                                        float* weights, float* alpha, float* rgb_flat, void* stream_) {
+    if (n_rays <= 0) return 0;
+    sc::RgbFwdArgs a{points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta_param, n_rays, rays_per_image,
+                     n_images, symmetric, beta_min, bgcolor, normal_pow, rgb, mask, mask_hard, depth, normal,
+                     weights, alpha, rgb_flat};
+    int blocks = (n_rays + 3) / 4;
+    if (blocks > 512) blocks = 512;   // two 4-wave workgroups per CU (63 KiB LDS each)
+    const size_t lds_bytes = sc::RgbLds::TOTAL * sizeof(float);
+    hipLaunchKernelGGL(sc::rgb_composite_fwd_kernel, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream_, a);
+    return (int)hipGetLastError();
+}
