@@ -1,0 +1,223 @@
+// sdf_bwd.hip -- reverse pass of sdf_fwd.hip, including the second-order terms.
+//
+// Replaces what autograd does for SDFNetwork.get_conditional_output (model/implicit.py:163-189) when the
+// outputs (sdf, feature, d sdf/dx) are all differentiated: the reference reaches this through
+// loss.backward() over a graph built with create_graph=True (model/renderer.py:101-107,
+// implicit.py:180-186) -- a double backward through five softplus layers.  Here it is one
+// hand-derived reverse sweep over the value chain *and* the adjoint chain of sdf_fwd.hip:
+//
+//   upstream:  Gs = dL/dsdf, Gg = dL/d(dsdf/dx) (3), Gf = dL/dfeat (64)
+//   R pass (reverse of the adjoint chain, only when Gg is given), eps_j = Gg_c(j) * dE_j/dx:
+//     Gq0 = W0e eps;                    Gp0 = Gq0*sp'(a0);  pend0 = Gq0*p0*sp''(a0)
+//     Gq1 = W1h Gp0 + W1e eps;          Gp1 = ...           pend1 = Gq1*p1*sp''(a1)   (same for 2)
+//     Gq3 = W3 Gp2; Gq4 = W4 Gp3;       pend4 = Gq4*w5*sp''(a4);  u4 = Gq4*sp'(a4)
+//     Gx_c += Gg_c * sum_l q_l . (W_le d2E/dx_c^2)                  (l = 0,1,2; q_l = p_l*sp'(a_l))
+//   V pass (reverse of the value chain):
+//     Gh4 = W5f^T Gf + w5*Gs;  Ga4 = Gh4*sp'(a4) + pend4;  Gh3 = W4^T Ga4; ... ; Ga0
+//     Gx_c += sum_l Ga_l . (W_le dE/dx_c)
+//   written for the weight-gradient GEMMs (wgrad.hip): Ga_0..4, Gp_0..3, r0 = Gs*h4 + u4.
+// a_l and p_l come from the forward stash (TBL64).  1008 v_mfma_f32_16x16x4 per 16 points.
+#include "mlp_tile.hpp"
+
+namespace sc {
+
+struct SdfBwdArgs {
+    const float* points;   // [n_points][3]
+    const float* w;        // SdfPack image
+    int n_points, symmetric;
+    const float* stash_a;  // 5 x TBL64
+    const float* stash_p;  // 4 x TBL64 (required when g_grad)
+    const float* g_sdf;    // [n_points] or null
+    const float* g_grad;   // [n_points][3] or null
+    const float* g_feat;   // TBL64 or null
+    float* g_points;       // [n_points][3] or null
+    float* ga;             // 5 x TBL64 out
+    float* gp;             // 4 x TBL64 out (written only when g_grad)
+    float* r0;             // TBL64 out
+};
+
+template <bool HAS_GG>
+__global__ __launch_bounds__(256) void sdf_bwd_kernel(SdfBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    stage_sdf_weights(lds, a.w, threadIdx.x, 256);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = lane & 15, g = lane >> 4;
+    const int ntiles = (a.n_points + TP - 1) / TP;
+    const size_t tbl = (size_t)ntiles * 1024;
+
+    const float* w0 = lds + SdfLds::W0 + p * SdfLds::LD0 + g;
+    const float* w1h = lds + SdfLds::W1 + p * SdfLds::LD1 + 4 * g;
+    const float* w1e = lds + SdfLds::W1 + p * SdfLds::LD1 + 64 + g;
+    const float* w2h = lds + SdfLds::W2 + p * SdfLds::LD1 + 4 * g;
+    const float* w2e = lds + SdfLds::W2 + p * SdfLds::LD1 + 64 + g;
+    const float* w3 = lds + SdfLds::W3 + p * SdfLds::LD3 + 4 * g;
+    const float* w4 = lds + SdfLds::W4 + p * SdfLds::LD3 + 4 * g;
+    const float* w5s = lds + SdfLds::W5 + 4 * g;
+    const float* w5ft = lds + SdfLds::W5 + (1 + 4 * g) * SdfLds::LD3 + p;
+    const float* w4t = lds + SdfLds::W4 + 4 * g * SdfLds::LD3 + p;
+    const float* w3t = lds + SdfLds::W3 + 4 * g * SdfLds::LD3 + p;
+    const float* w2t = lds + SdfLds::W2 + 4 * g * SdfLds::LD1 + p;
+    const float* w1t = lds + SdfLds::W1 + 4 * g * SdfLds::LD1 + p;
+
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+        const int pt = tile * TP + p;
+        const bool valid = pt < a.n_points;
+        const int ptc = valid ? pt : a.n_points - 1;
+        const float x0 = a.points[(size_t)ptc * 3 + 0], x1 = a.points[(size_t)ptc * 3 + 1], x2 = a.points[(size_t)ptc * 3 + 2];
+        float e[PE_STEPS], d1[PE_STEPS], d2[PE_STEPS];
+        pe_slots<true, HAS_GG>(x0, x1, x2, g, a.symmetric != 0, e, d1, d2);
+        const float Gs = (valid && a.g_sdf) ? a.g_sdf[pt] : 0.f;
+        float gam[3] = {0.f, 0.f, 0.f};
+        if (HAS_GG && valid) { gam[0] = a.g_grad[(size_t)pt * 3]; gam[1] = a.g_grad[(size_t)pt * 3 + 1]; gam[2] = a.g_grad[(size_t)pt * 3 + 2]; }
+        float gx[3] = {0.f, 0.f, 0.f};
+        float pend4[ACT_STEPS];   // pend_0..3 are parked in the Ga output buffers (L2-hot) to save 64 VGPRs
+        float u4[ACT_STEPS];
+        f32x4 acc[NT];
+        float av[ACT_STEPS], pv[ACT_STEPS], gq[ACT_STEPS], gpv[ACT_STEPS];
+
+// d(gx_c)/.. helper: gx_c += scale_c * sum_s V[s] * (W_le * DV[4c..4c+3])[s]
+#define SC_PE_DOT(WE, LD, V, DV, SCALE)                                                     \
+        _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                      \
+            f32x4 tacc[NT];                                                                  \
+            acc_zero(tacc);                                                                  \
+            if (c == 0) mm_pe<LD, NT, 0, 4>(WE, DV + 0, tacc);                               \
+            if (c == 1) mm_pe<LD, NT, 4, 4>(WE, DV + 4, tacc);                               \
+            if (c == 2) mm_pe<LD, NT, 8, 4>(WE, DV + 8, tacc);                               \
+            float dsum = 0.f;                                                                \
+            _Pragma("unroll") for (int s = 0; s < ACT_STEPS; ++s)                             \
+                dsum = __builtin_fmaf(V[s], tacc[s >> 2][s & 3], dsum);                      \
+            gx[c] = __builtin_fmaf(SCALE, dsum, gx[c]);                                      \
+        }
+
+        if (HAS_GG) {
+            float eps[PE_STEPS];
+#pragma unroll
+            for (int j = 0; j < PE_STEPS; ++j) eps[j] = gam[j >> 2] * d1[j];
+// one reverse-adjoint step for a layer with a PE skip input (l = 0,1,2)
+#define SC_R_STEP(L, WE, LD)                                                                \
+            acc_to_regs(acc, gq);                                                            \
+            tbl_load(a.stash_a + (size_t)(L) * tbl, tile, p, g, av);                         \
+            tbl_load(a.stash_p + (size_t)(L) * tbl, tile, p, g, pv);                         \
+            {                                                                                \
+                float ql[ACT_STEPS], pn[ACT_STEPS];                                          \
+                _Pragma("unroll") for (int s = 0; s < ACT_STEPS; ++s) {                       \
+                    float t, r;                                                              \
+                    softplus_parts(av[s], t, r);                                             \
+                    const float ds = softplus_d1(av[s], t, r);                               \
+                    gpv[s] = gq[s] * ds;                                                     \
+                    pn[s] = gq[s] * pv[s] * softplus_d2(t, r);                               \
+                    ql[s] = pv[s] * ds;                                                      \
+                }                                                                            \
+                tbl_store(a.gp + (size_t)(L) * tbl, tile, p, g, gpv);                        \
+                tbl_store(a.ga + (size_t)(L) * tbl, tile, p, g, pn);                         \
+                if ((L) < 3) { SC_PE_DOT(WE, LD, ql, d2, gam[c]) }                           \
+            }
+            acc_zero(acc);
+            mm_pe<SdfLds::LD0, NT, 0, PE_STEPS>(w0, eps, acc);                 // Gq0
+            SC_R_STEP(0, w0, SdfLds::LD0)
+            acc_zero(acc);
+            mm_act<SdfLds::LD1, NT>(w1h, gpv, acc);
+            mm_pe<SdfLds::LD1, NT, 0, PE_STEPS>(w1e, eps, acc);                // Gq1
+            SC_R_STEP(1, w1e, SdfLds::LD1)
+            acc_zero(acc);
+            mm_act<SdfLds::LD1, NT>(w2h, gpv, acc);
+            mm_pe<SdfLds::LD1, NT, 0, PE_STEPS>(w2e, eps, acc);                // Gq2
+            SC_R_STEP(2, w2e, SdfLds::LD1)
+            acc_zero(acc);
+            mm_act<SdfLds::LD3, NT>(w3, gpv, acc);                             // Gq3
+            SC_R_STEP(3, w3, SdfLds::LD3)
+#undef SC_R_STEP
+            acc_zero(acc);
+            mm_act<SdfLds::LD3, NT>(w4, gpv, acc);                             // Gq4
+            acc_to_regs(acc, gq);
+            tbl_load(a.stash_a + 4 * tbl, tile, p, g, av);
+#pragma unroll
+            for (int s = 0; s < ACT_STEPS; ++s) {
+                float t, r;
+                softplus_parts(av[s], t, r);
+                pend4[s] = gq[s] * w5s[kp(s)] * softplus_d2(t, r);
+                u4[s] = gq[s] * softplus_d1(av[s], t, r);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < ACT_STEPS; ++s) { u4[s] = 0.f; pend4[s] = 0.f; }
+        }
+
+        // ---- V pass ----
+        float gav[ACT_STEPS];
+        acc_zero(acc);
+        if (a.g_feat) {
+            float gf[ACT_STEPS];
+            tbl_load(a.g_feat, tile, p, g, gf);
+            mm_act_t<SdfLds::LD3, NT>(w5ft, gf, acc);
+        }
+        tbl_load(a.stash_a + 4 * tbl, tile, p, g, av);
+        {
+            float r0v[ACT_STEPS];
+#pragma unroll
+            for (int s = 0; s < ACT_STEPS; ++s) {
+                float t, r;
+                softplus_parts(av[s], t, r);
+                const float gh = acc[s >> 2][s & 3] + w5s[kp(s)] * Gs;
+                r0v[s] = Gs * softplus_val(av[s], t) + u4[s];
+                gav[s] = gh * softplus_d1(av[s], t, r) + pend4[s];
+            }
+            tbl_store(a.r0, tile, p, g, r0v);
+            tbl_store(a.ga + 4 * tbl, tile, p, g, gav);
+        }
+#define SC_V_STEP(L, WT, LD)                                                                \
+        acc_zero(acc);                                                                       \
+        mm_act_t<LD, NT>(WT, gav, acc);                                                      \
+        tbl_load(a.stash_a + (size_t)(L) * tbl, tile, p, g, av);                             \
+        if (HAS_GG) tbl_load(a.ga + (size_t)(L) * tbl, tile, p, g, pv);                      \
+        _Pragma("unroll") for (int s = 0; s < ACT_STEPS; ++s) {                               \
+            float t, r;                                                                      \
+            softplus_parts(av[s], t, r);                                                     \
+            gav[s] = acc[s >> 2][s & 3] * softplus_d1(av[s], t, r) + (HAS_GG ? pv[s] : 0.f); \
+        }                                                                                    \
+        tbl_store(a.ga + (size_t)(L) * tbl, tile, p, g, gav);
+        SC_V_STEP(3, w4t, SdfLds::LD3)
+        SC_V_STEP(2, w3t, SdfLds::LD3)
+        SC_PE_DOT(w2e, SdfLds::LD1, gav, d1, 1.f)
+        SC_V_STEP(1, w2t, SdfLds::LD1)
+        SC_PE_DOT(w1e, SdfLds::LD1, gav, d1, 1.f)
+        SC_V_STEP(0, w1t, SdfLds::LD1)
+        SC_PE_DOT(w0, SdfLds::LD0, gav, d1, 1.f)
+#undef SC_V_STEP
+#undef SC_PE_DOT
+        if (a.g_points) {
+            const float o0 = group_sum(gx[0]), o1 = group_sum(gx[1]), o2 = group_sum(gx[2]);
+            if (valid && g == 0) {
+                a.g_points[(size_t)pt * 3 + 0] = o0;
+                a.g_points[(size_t)pt * 3 + 1] = o1;
+                a.g_points[(size_t)pt * 3 + 2] = o2;
+            }
+        }
+    }
+}
+
+}  // namespace sc
+
+extern "C" int sc_sdf_backward(const float* points, const float* w_pack, int n_points, int symmetric,
+                               const float* stash_a, const float* stash_p, const float* g_sdf,
+                               const float* g_grad, const float* g_feat, float* g_points, float* ga,
+                               float* gp, float* r0, void* stream_) {
+    if (n_points <= 0) return 0;
+    sc::SdfBwdArgs a{points, w_pack, n_points, symmetric, stash_a, stash_p, g_sdf, g_grad, g_feat, g_points, ga, gp, r0};
+    const int ntiles = (n_points + sc::TP - 1) / sc::TP;
+    int blocks = (ntiles + 3) / 4;
+    if (blocks > 256) blocks = 256;
+    const size_t lds_bytes = sc::SdfLds::TOTAL * sizeof(float);
+    hipStream_t stream = (hipStream_t)stream_;
+    if (g_grad) {
+        static bool attr_g = false;
+        if (!attr_g) { (void)hipFuncSetAttribute((const void*)sc::sdf_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_g = true; }
+        hipLaunchKernelGGL(sc::sdf_bwd_kernel<true>, dim3(blocks), dim3(256), lds_bytes, stream, a);
+    } else {
+        static bool attr_v = false;
+        if (!attr_v) { (void)hipFuncSetAttribute((const void*)sc::sdf_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_v = true; }
+        hipLaunchKernelGGL(sc::sdf_bwd_kernel<false>, dim3(blocks), dim3(256), lds_bytes, stream, a);
+    }
+    return (int)hipGetLastError();
+}

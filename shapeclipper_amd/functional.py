@@ -1,0 +1,42 @@
+"""torch.autograd.Function wrappers around the HIP kernels (forward AND hand-written backward)."""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class SdfFunction(torch.autograd.Function):
+    """points [N,3], w_pack, cbias [B,5,64] -> sdf [N], grad [N,3] (d sdf/d point), feat (TBL64).
+
+    Mirrors SDFNetwork.get_conditional_output (reference model/implicit.py:163-189): `grad` is the
+    create_graph=True gradient, and it is itself differentiable here (double backward is the
+    hand-written sdf_bwd.hip / wgrad.hip path)."""
+
+    @staticmethod
+    def forward(ctx, points, w_pack, cbias, n_per_image, symmetric, want_grad, want_feat):
+        points = points.contiguous()
+        need = any(ctx.needs_input_grad[:3])
+        res = ops.sdf_forward(points, w_pack, cbias, n_per_image, symmetric=symmetric, want_grad=want_grad,
+                              want_feat=want_feat, stash=need)
+        sdf, grad, feat = res[0], res[1], res[2]
+        ctx.meta = (n_per_image, cbias.shape[0], symmetric, want_grad, want_feat)
+        if need:
+            ctx.save_for_backward(points, w_pack, res[3], res[4] if want_grad else None)
+        empty = points.new_empty(0)
+        outs = (sdf, grad if want_grad else empty, feat if want_feat else empty)
+        nd = [o for o, w in zip(outs[1:], (want_grad, want_feat)) if not w]
+        if nd:
+            ctx.mark_non_differentiable(*nd)
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_sdf, g_grad, g_feat):
+        n_per_image, n_images, symmetric, want_grad, want_feat = ctx.meta
+        points, w_pack, stash_a, stash_p = ctx.saved_tensors
+        g_sdf = g_sdf.contiguous() if g_sdf is not None else None
+        g_grad = g_grad.contiguous() if (want_grad and g_grad is not None) else None
+        g_feat = g_feat.contiguous() if (want_feat and g_feat is not None) else None
+        gp, gw, gc = ops.sdf_backward(points, w_pack, n_per_image, n_images, symmetric, stash_a, stash_p,
+                                      g_sdf, g_grad, g_feat, want_points_grad=ctx.needs_input_grad[0])
+        return gp, gw, gc, None, None, None, None

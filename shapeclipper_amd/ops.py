@@ -62,3 +62,97 @@ def rgb_composite_forward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, db
         _lib.ptr(out.get("rgb_flat")), _lib.stream())
     _lib.check(code, "sc_rgb_composite_forward")
     return out
+
+
+# operand transform codes of sc_wgrad (csrc/wgrad.hip)
+OP_NONE, OP_PLAIN, OP_SP, OP_Q, OP_Q4, OP_PE, OP_EPS = range(7)
+WGRAD_PARTS = 256
+
+
+def _wgrad(lib, terms, points, g_grad, w5row, n_points, symmetric, nb0, nb1, partial, stride, out_offset, out_ld):
+    """terms: list of 1 or 2 tuples (a0, a1, aop, b0, bop0, b1, bop1)."""
+    t = list(terms) + [(None, None, OP_NONE, None, OP_NONE, None, OP_NONE)] * (2 - len(terms))
+    args = []
+    for (a0, a1, aop, b0, bop0, b1, bop1) in t:
+        args += [_lib.ptr(a0), _lib.ptr(a1), c_int(aop), _lib.ptr(b0), c_int(bop0), _lib.ptr(b1), c_int(bop1)]
+    code = lib.sc_wgrad(c_int(len(terms)), *args, _lib.ptr(points), _lib.ptr(g_grad), _lib.ptr(w5row),
+                        c_int(n_points), c_int(1 if symmetric else 0), c_int(nb0), c_int(nb1), _lib.ptr(partial),
+                        c_int(WGRAD_PARTS), c_int(stride), c_int(out_offset), c_int(out_ld), _lib.stream())
+    _lib.check(code, "sc_wgrad")
+
+
+def tbl_sum(x, n_points, n_per_image, n_images, coef=None):
+    """sum over the points of each image of a TBL64 tensor -> [n_images, K, 64] (K = 3 with coef [N,3])."""
+    lib = _lib.load()
+    K = 3 if coef is not None else 1
+    out = torch.zeros(n_images, K, 64, device=x.device, dtype=torch.float32)
+    code = lib.sc_tbl_sum(_lib.ptr(x), _lib.ptr(coef), c_int(n_points), c_int(n_per_image), c_int(n_images),
+                          _lib.ptr(out), _lib.stream())
+    _lib.check(code, "sc_tbl_sum")
+    return out
+
+
+def sdf_backward(points, w_pack, n_per_image, n_images, symmetric, stash_a, stash_p, g_sdf, g_grad, g_feat,
+                 want_points_grad=True):
+    """Reverse pass of sdf_forward (incl. second-order terms) -> (g_points | None, g_w_pack, g_cbias)."""
+    from .packing import SDF_OFF, SDF_PACK_FLOATS
+    lib = _lib.load()
+    n = points.shape[0]
+    dev = points.device
+    nt = n_tiles(n)
+    T = nt * 1024
+    f32 = dict(device=dev, dtype=torch.float32)
+    ga = torch.empty(5 * T, **f32)
+    gp = torch.empty(4 * T, **f32) if g_grad is not None else None
+    r0 = torch.empty(T, **f32)
+    g_points = torch.empty(n, 3, **f32) if want_points_grad else None
+    code = lib.sc_sdf_backward(_lib.ptr(points), _lib.ptr(w_pack), c_int(n), c_int(1 if symmetric else 0),
+                               _lib.ptr(stash_a), _lib.ptr(stash_p), _lib.ptr(g_sdf), _lib.ptr(g_grad),
+                               _lib.ptr(g_feat), _lib.ptr(g_points), _lib.ptr(ga), _lib.ptr(gp), _lib.ptr(r0),
+                               _lib.stream())
+    _lib.check(code, "sc_sdf_backward")
+
+    A = lambda l: stash_a[l * T:(l + 1) * T]
+    P = lambda l: stash_p[l * T:(l + 1) * T]
+    GA = lambda l: ga[l * T:(l + 1) * T]
+    GP = lambda l: gp[l * T:(l + 1) * T]
+    gg = g_grad is not None
+    stride = SDF_PACK_FLOATS
+    partial = torch.zeros(WGRAD_PARTS * stride, **f32)
+    w5row = w_pack[SDF_OFF["W5"]:SDF_OFF["W5"] + 64]
+    common = (points, g_grad, w5row, n, symmetric)
+
+    def launch(terms, nb0, nb1, off, ld):
+        _wgrad(lib, terms, *common, nb0, nb1, partial, stride, off, ld)
+
+    t = [(GA(0), None, OP_PLAIN, None, OP_PE, None, OP_NONE)]
+    if gg:
+        t.append((P(0), A(0), OP_Q, None, OP_EPS, None, OP_NONE))
+    launch(t, 48, 0, SDF_OFF["W0"], 48)
+    for l, key in ((1, "W1"), (2, "W2")):
+        t = [(GA(l), None, OP_PLAIN, A(l - 1), OP_SP, None, OP_PE)]
+        if gg:
+            t.append((P(l), A(l), OP_Q, GP(l - 1), OP_PLAIN, None, OP_EPS))
+        launch(t, 64, 48, SDF_OFF[key], 112)
+    t = [(GA(3), None, OP_PLAIN, A(2), OP_SP, None, OP_NONE)]
+    if gg:
+        t.append((P(3), A(3), OP_Q, GP(2), OP_PLAIN, None, OP_NONE))
+    launch(t, 64, 0, SDF_OFF["W3"], 64)
+    t = [(GA(4), None, OP_PLAIN, A(3), OP_SP, None, OP_NONE)]
+    if gg:
+        t.append((None, A(4), OP_Q4, GP(3), OP_PLAIN, None, OP_NONE))
+    launch(t, 64, 0, SDF_OFF["W4"], 64)
+    if g_feat is not None:
+        launch([(g_feat, None, OP_PLAIN, A(4), OP_SP, None, OP_NONE)], 64, 0, SDF_OFF["W5"] + 64, 64)
+
+    g_w = torch.empty(stride, **f32)
+    code = lib.sc_partial_reduce(_lib.ptr(partial), c_int(WGRAD_PARTS), c_int(stride), c_int(stride), _lib.ptr(g_w),
+                                 _lib.stream())
+    _lib.check(code, "sc_partial_reduce")
+    # W5 row 0 (sdf row):  sum_p (Gs * h4 + Gq4 * sp'(a4))   and the output bias
+    g_w[SDF_OFF["W5"]:SDF_OFF["W5"] + 64] = tbl_sum(r0, n, n, 1).view(64)
+    g_w[SDF_OFF["B5"]] = g_sdf.sum() if g_sdf is not None else 0.0
+    if g_feat is not None:
+        g_w[SDF_OFF["B5"] + 1:SDF_OFF["B5"] + 65] = tbl_sum(g_feat, n, n, 1).view(64)
+    g_c = torch.stack([tbl_sum(GA(l), n, n_per_image, n_images).view(n_images, 64) for l in range(5)], dim=1)
+    return g_points, g_w, g_c

@@ -19,6 +19,12 @@ PE_COLS = 48
 SDF_PACK_FLOATS = 64 * 48 + 2 * 64 * 112 + 2 * 64 * 64 + 65 * 64 + 65
 RGB_PACK_FLOATS = 64 * 112 + 2 * 64 * 64 + 3 * 64 + 4
 TILE = 16
+# float offsets inside the packed images (must match SdfPack / RgbPack in csrc/mlp_tile.hpp)
+SDF_OFF = dict(W0=0, W1=64 * 48, W2=64 * 48 + 64 * 112, W3=64 * 48 + 2 * 64 * 112,
+               W4=64 * 48 + 2 * 64 * 112 + 64 * 64, W5=64 * 48 + 2 * 64 * 112 + 2 * 64 * 64,
+               B5=64 * 48 + 2 * 64 * 112 + 2 * 64 * 64 + 65 * 64)
+RGB_OFF = dict(V0=0, V1=64 * 112, V2=64 * 112 + 64 * 64, V3=64 * 112 + 2 * 64 * 64,
+               B3=64 * 112 + 2 * 64 * 64 + 3 * 64)
 
 
 def pe_slot_col(col: int) -> int:
