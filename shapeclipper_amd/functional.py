@@ -40,3 +40,41 @@ class SdfFunction(torch.autograd.Function):
         gp, gw, gc = ops.sdf_backward(points, w_pack, n_per_image, n_images, symmetric, stash_a, stash_p,
                                       g_sdf, g_grad, g_feat, want_points_grad=ctx.needs_input_grad[0])
         return gp, gw, gc, None, None, None, None
+
+
+class RgbCompositeFunction(torch.autograd.Function):
+    """Per-point SDF results -> per-ray render outputs (reference model/renderer.py:110-152,187-209).
+
+    inputs : points [P,3], z_vals [n_rays,64], depth_fac [n_rays], sdf [P], grad [P,3], feat TBL64,
+             v_pack, dbias [B,3,64], beta (raw parameter, shape [1] or [])
+    outputs: rgb [n_rays,3], mask [n_rays], mask_hard [n_rays], depth [n_rays], normal [n_rays,3]
+             (+ weights, alpha [n_rays,64], rgb_flat [P,3] when keep_samples; non-differentiable)"""
+
+    @staticmethod
+    def forward(ctx, points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta, rays_per_image, symmetric,
+                beta_min, bgcolor, normal_pow, keep_samples):
+        need = any(ctx.needs_input_grad[:9])
+        beta1 = beta.reshape(1).contiguous()
+        out = ops.rgb_composite_forward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta1,
+                                        rays_per_image, symmetric, beta_min, bgcolor, normal_pow,
+                                        keep_samples=keep_samples, keep_rgb_flat=need)
+        ctx.meta = (rays_per_image, symmetric, beta_min, bgcolor, normal_pow, beta.shape)
+        if need:
+            ctx.save_for_backward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta1, out["rgb_flat"])
+        ctx.mark_non_differentiable(out["mask_hard"])
+        extra = ()
+        if keep_samples:
+            extra = (out["weights"], out["alpha"], out["rgb_flat"])
+            ctx.mark_non_differentiable(*extra)
+        return (out["rgb"], out["mask"], out["mask_hard"], out["depth"], out["normal"]) + extra
+
+    @staticmethod
+    def backward(ctx, G_rgb, G_mask, G_mask_hard, G_depth, G_normal, *unused):
+        rays_per_image, symmetric, beta_min, bgcolor, normal_pow, beta_shape = ctx.meta
+        points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta1, rgb_flat = ctx.saved_tensors
+        c = lambda t: t.contiguous() if t is not None else None
+        g = ops.rgb_composite_backward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta1, rgb_flat,
+                                       rays_per_image, symmetric, beta_min, bgcolor, normal_pow,
+                                       c(G_rgb), c(G_mask), c(G_depth), c(G_normal))
+        return (g["points"], g["z_vals"], g["depth_fac"], g["sdf"], g["grad"], g["feat"], g["v_pack"], g["dbias"],
+                g["beta"].reshape(beta_shape), None, None, None, None, None, None)

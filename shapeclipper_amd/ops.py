@@ -36,7 +36,7 @@ def sdf_forward(points: torch.Tensor, w_pack: torch.Tensor, cbias: torch.Tensor,
 
 def rgb_composite_forward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta_param,
                           rays_per_image: int, symmetric: bool, beta_min: float, bgcolor: float,
-                          normal_pow: float, keep_samples: bool = False):
+                          normal_pow: float, keep_samples: bool = False, keep_rgb_flat: bool = False):
     """Per-ray outputs of the renderer from the per-point SDF results.
 
     points [n_rays*64,3], z_vals [n_rays,64], depth_fac [n_rays], sdf [P], grad [P,3], feat TBL64.
@@ -51,8 +51,9 @@ def rgb_composite_forward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, db
                mask_hard=torch.empty(n_rays, **f32), depth=torch.empty(n_rays, **f32),
                normal=torch.empty(n_rays, 3, **f32))
     if keep_samples:
-        out.update(weights=torch.empty(n_rays, 64, **f32), alpha=torch.empty(n_rays, 64, **f32),
-                   rgb_flat=torch.empty(n_rays * 64, 3, **f32))
+        out.update(weights=torch.empty(n_rays, 64, **f32), alpha=torch.empty(n_rays, 64, **f32))
+    if keep_samples or keep_rgb_flat:
+        out.update(rgb_flat=torch.empty(n_rays * 64, 3, **f32))
     code = lib.sc_rgb_composite_forward(
         _lib.ptr(points), _lib.ptr(z_vals), _lib.ptr(depth_fac), _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(feat),
         _lib.ptr(v_pack), _lib.ptr(dbias), _lib.ptr(beta_param), c_int(n_rays), c_int(rays_per_image),
@@ -156,3 +157,52 @@ def sdf_backward(points, w_pack, n_per_image, n_images, symmetric, stash_a, stas
         g_w[SDF_OFF["B5"] + 1:SDF_OFF["B5"] + 65] = tbl_sum(g_feat, n, n, 1).view(64)
     g_c = torch.stack([tbl_sum(GA(l), n, n_per_image, n_images).view(n_images, 64) for l in range(5)], dim=1)
     return g_points, g_w, g_c
+
+
+def rgb_composite_backward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta_param, rgb_flat,
+                           rays_per_image, symmetric, beta_min, bgcolor, normal_pow,
+                           G_rgb, G_mask, G_depth, G_normal):
+    """Reverse pass of rgb_composite_forward.
+    -> dict(points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta) gradients."""
+    from .packing import RGB_OFF, RGB_PACK_FLOATS
+    lib = _lib.load()
+    n_rays = z_vals.shape[0]
+    n_images = dbias.shape[0]
+    P = n_rays * 64
+    T = n_rays * 4 * 1024
+    dev = points.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    g = dict(sdf=torch.empty(P, **f32), grad=torch.empty(P, 3, **f32), feat=torch.empty(T, **f32),
+             points=torch.empty(P, 3, **f32), z_vals=torch.empty(n_rays, 64, **f32),
+             depth_fac=torch.empty(n_rays, **f32), beta=torch.zeros(1, **f32))
+    gy = torch.empty(3 * T, **f32)
+    rr = torch.empty(3 * T, **f32)
+    gy3 = torch.empty(P, 3, **f32)
+    code = lib.sc_rgb_composite_backward(
+        _lib.ptr(points), _lib.ptr(z_vals), _lib.ptr(depth_fac), _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(feat),
+        _lib.ptr(v_pack), _lib.ptr(dbias), _lib.ptr(beta_param), _lib.ptr(rgb_flat), c_int(n_rays),
+        c_int(rays_per_image), c_int(n_images), c_int(1 if symmetric else 0), ctypes.c_float(beta_min),
+        ctypes.c_float(bgcolor), ctypes.c_float(normal_pow), _lib.ptr(G_rgb), _lib.ptr(G_mask), _lib.ptr(G_depth),
+        _lib.ptr(G_normal), _lib.ptr(g["sdf"]), _lib.ptr(g["grad"]), _lib.ptr(g["feat"]), _lib.ptr(g["points"]),
+        _lib.ptr(g["z_vals"]), _lib.ptr(g["depth_fac"]), _lib.ptr(g["beta"]), _lib.ptr(gy), _lib.ptr(rr),
+        _lib.ptr(gy3), _lib.stream())
+    _lib.check(code, "sc_rgb_composite_backward")
+
+    GY = lambda l: gy[l * T:(l + 1) * T]
+    RR = lambda l: rr[l * T:(l + 1) * T]
+    stride = RGB_PACK_FLOATS
+    partial = torch.zeros(WGRAD_PARTS * stride, **f32)
+    common = (points, None, None, P, symmetric)
+    _wgrad(lib, [(GY(0), None, OP_PLAIN, None, OP_PE, feat, OP_PLAIN)], *common, 48, 64, partial, stride, RGB_OFF["V0"], 112)
+    _wgrad(lib, [(GY(1), None, OP_PLAIN, RR(0), OP_PLAIN, None, OP_NONE)], *common, 64, 0, partial, stride, RGB_OFF["V1"], 64)
+    _wgrad(lib, [(GY(2), None, OP_PLAIN, RR(1), OP_PLAIN, None, OP_NONE)], *common, 64, 0, partial, stride, RGB_OFF["V2"], 64)
+    g_v = torch.empty(stride, **f32)
+    code = lib.sc_partial_reduce(_lib.ptr(partial), c_int(WGRAD_PARTS), c_int(stride), c_int(stride), _lib.ptr(g_v),
+                                 _lib.stream())
+    _lib.check(code, "sc_partial_reduce")
+    g_v[RGB_OFF["V3"]:RGB_OFF["V3"] + 192] = tbl_sum(RR(2), P, P, 1, coef=gy3).view(192)
+    g_v[RGB_OFF["B3"]:RGB_OFF["B3"] + 3] = gy3.sum(dim=0)
+    g_v[RGB_OFF["B3"] + 3] = 0.0
+    g["v_pack"] = g_v
+    g["dbias"] = torch.stack([tbl_sum(GY(l), P, rays_per_image * 64, n_images).view(n_images, 64) for l in range(3)], dim=1)
+    return g
