@@ -1,0 +1,179 @@
+#!/usr/bin/env python
+"""bench.py -- train-step images/sec of the ShapeClipper hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one full training iteration on a synthetic Pix3D-shaped batch that is already resident in
+HBM: Graph.forward(training=True) (ResNet-34 encoder, ResNet-18 estimator on stock PyTorch-ROCm; TWO
+HIP training renders of 512 rays x 64 samples per image incl. the eikonal branch) -> losses ->
+backward (hand-written HIP backward kernels) -> one flat RCCL all-reduce of all gradients (N > 1) ->
+Adam.  Batch = 32 images per GPU (BASELINE.json configs[1]/[2]/[3]; weak scaling).
+
+One JSON line on rank 0; see the repository prompt for the contract.  Extras:
+  roofline      dominant hand-written kernel: achieved = algorithmic FLOPs / mean
+                launch duration measured with events on the launch stream inside the timed region
+  cpu_baseline  the CPU oracle (pure PyTorch restatement of the reference, oracle/reference_ops.py) timed
+                on this box's host cores on a bounded sample (hot path only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic (un-padded, reference-dense) FLOPs per sample point of each entry point -- DESIGN.md "kernels"
+SDF_VALUE = 2 * 40320          # SDFNetwork.forward incl. latent columns (80,640 FLOP/pt)
+SDF_GRAD = 2 * 40320           # d(sdf)/dx reverse sweep through the same layers
+RGB_VALUE = 2 * 19072
+FLOPS_PER_POINT = {
+    "sc_sdf_forward": SDF_VALUE + SDF_GRAD,
+    "sc_sdf_backward": 2 * (SDF_VALUE + SDF_GRAD) // 2,     # input-gradient half of the double backward
+    "sc_rgb_composite_forward": RGB_VALUE,
+    "sc_rgb_composite_backward": RGB_VALUE + RGB_VALUE,     # recompute + input-gradient sweep
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    return ap.parse_args()
+
+
+def cpu_baseline(batch, rays=512):
+    """Oracle hot path on the host cores: two training renders (fwd + bwd incl. eikonal) per step."""
+    from oracle import reference_ops as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = R.Cfg()
+    torch.manual_seed(0)
+    Ws = {k: v.requires_grad_(True) for k, v in R.init_sdf_weights(cfg).items()}
+    Wr = {k: v.requires_grad_(True) for k, v in R.init_rgb_weights(cfg).items()}
+    beta = torch.tensor(0.1, requires_grad=True)
+    B = batch
+    az = (torch.rand(B) * 2 - 1) * 3.14159
+    trig = lambda t: torch.stack([torch.cos(t), torch.sin(t)], 1)
+    sd = (0.8 + 0.4 * torch.rand(B)).requires_grad_(True)
+    pose = R.pose_from_trig(cfg, trig(az), trig(torch.zeros(B)), trig(torch.zeros(B)), sd)
+    intr = R.get_intr(cfg, torch.ones(B))
+    zs, zr = torch.randn(B, 64, requires_grad=True), torch.randn(B, 64, requires_grad=True)
+    ray_idx = torch.stack([torch.randperm(cfg.H * cfg.W)[:rays] for _ in range(B)])
+
+    def step():
+        total = 0
+        for _ in range(2):
+            t_rand, eik_idx, eik_pts = R.draw_render_randoms(B * rays, 64, True)
+            o = R.render(cfg, Ws, Wr, beta, pose, intr, sd, zs, zr, ray_idx, True, t_rand, eik_idx, eik_pts)
+            total = total + o["rgb"].sum() + o["mask"].sum() + o["normal"].sum() + ((o["grad_eikonal"] - 1) ** 2).mean()
+        total.backward()
+    step()
+    t0, n = time.time(), 0
+    while n < 2 or (time.time() - t0 < 10 and n < 10):
+        step(); n += 1
+    dt = (time.time() - t0) / n
+    return dict(value=round(B / dt, 3), unit="images/s", cores=cores, kind="port",
+                sample="oracle hot path only: 2 training renders fwd+bwd (512 rays x 64 samples, eikonal incl.), "
+                       "B=%d, %d timed steps, no encoders/optimizer" % (B, n))
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl")
+
+    from shapeclipper_amd import _lib, synthetic
+    from shapeclipper_amd.model.runner import Runner
+    from shapeclipper_amd.utils import options, util
+    from shapeclipper_amd.utils.util import EasyDict as edict
+
+    opt = options.set(options.parse_arguments([
+        "--yaml=%s/options/pix3d/config.yaml" % ROOT, "--name=bench", "--output_root=/tmp/sc_bench_%d" % rank,
+        "--batch_size=%d" % (a.batch * world), "--tb!", "--arch.enc_pretrained!"]), verbose=False)
+    opt.device, opt.world_size, opt.port = local, world, 0
+    opt.freq.scalar, opt.freq.ckpt_latest = 0, 10 ** 9
+    torch.manual_seed(rank)
+    runner = Runner(opt)                       # divides batch_size by world_size
+    runner.build_networks(opt)
+    runner.setup_optimizer(opt)
+    runner.graph.train()
+    runner.it, runner.ep, runner.best_val = 1, 0, 0.0
+    runner.timer = edict(start=time.time(), it_mean=None)
+    batch = util.move_to_device(synthetic.make_batch(opt, a.batch, seed=rank, training=True), "cuda:%d" % local)
+
+    def step():
+        opt.H, opt.W = opt.image_size
+        return runner.train_iteration(opt, edict(batch), None)
+
+    for _ in range(a.warmup):
+        step()
+    _lib.TIMING = {}
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(a.steps):
+        loss = step()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    timing, _lib.TIMING = _lib.TIMING, None
+    if world > 1:
+        t = torch.tensor([dt], device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    assert torch.isfinite(loss.all.detach()).item(), "non-finite loss in the timed region"
+
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        # per-entry-point GPU time inside the timed region
+        per = {}
+        for name, evs in timing.items():
+            durs = [s.elapsed_time(e) for s, e, _ in evs]
+            per[name] = dict(calls=len(durs), total_ms=sum(durs), mean_ms=sum(durs) / len(durs), max_ms=max(durs))
+        n_pts_main = a.batch * opt.render.rand_sample * 64
+        dom = max((n for n in per if n in FLOPS_PER_POINT), key=lambda n: per[n]["total_ms"])
+        # the big launches are the two main renders of a step (eikonal launches are 32x smaller): use them
+        big = sorted([s.elapsed_time(e) for s, e, _ in timing[dom]], reverse=True)[:2 * a.steps]
+        mean_big = sum(big) / len(big)
+        achieved = FLOPS_PER_POINT[dom] * n_pts_main / (mean_big * 1e-3) / 1e12
+        roofline = dict(kernel=dom, bound="mfma", achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS,
+                        unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                        launch_ms=round(mean_big, 4), points_per_launch=n_pts_main,
+                        flops_per_point=FLOPS_PER_POINT[dom])
+        out = dict(metric="train-step images/sec (Pix3D cfg, bs32/GPU)", value=round(a.batch * world / (dt / a.steps), 2),
+                   unit="images/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3),
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload="Pix3D train step: bs32/GPU, 224x224 inputs, 512 rays x 64 samples, 2 renders "
+                                        "(input + CLIP-NN view) + eikonal, ResNet-34 encoder + ResNet-18 estimator, Adam",
+                               global_batch=a.batch * world, rays_per_image=opt.render.rand_sample, samples_per_ray=64,
+                               parallelism="dp%d" % world),
+                   roofline=roofline,
+                   hip_ms_per_step={k: round(v["total_ms"] / a.steps, 3) for k, v in sorted(per.items())})
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_batch)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

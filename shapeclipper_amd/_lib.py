@@ -22,12 +22,42 @@ SYMBOLS = (
 
 _lib: Optional[ctypes.CDLL] = None
 
+# Optional per-entry-point GPU timing (bench.py): when TIMING is a dict every C-ABI call is bracketed by
+# two events on torch's current stream (the stream the kernels are enqueued on).
+TIMING = None
+
+
+class _Timed:
+    """Wraps a ctypes function: records (start, end) events around the call when TIMING is enabled."""
+
+    def __init__(self, name, fn):
+        self.name, self.fn = name, fn
+
+    def __call__(self, *args):
+        if TIMING is None:
+            return self.fn(*args)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        code = self.fn(*args)
+        e.record()
+        TIMING.setdefault(self.name, []).append((s, e, args))
+        return code
+
+
+class _LibProxy:
+    def __init__(self, cdll):
+        self._cdll = cdll
+        for name in SYMBOLS:
+            fn = getattr(cdll, name)
+            fn.restype = ctypes.c_int
+            setattr(self, name, _Timed(name, fn))
+
 
 class HipLibraryMissing(RuntimeError):
     pass
 
 
-def load() -> ctypes.CDLL:
+def load():
     """Load the library once.  Raises HipLibraryMissing (never falls back)."""
     global _lib
     if _lib is None:
@@ -35,9 +65,7 @@ def load() -> ctypes.CDLL:
             raise HipLibraryMissing(
                 f"{LIB_PATH} not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C shapeclipper_amd/csrc`; there is no CPU fallback for the HIP hot path")
-        _lib = ctypes.CDLL(LIB_PATH)
-        for name in SYMBOLS:
-            getattr(_lib, name).restype = ctypes.c_int
+        _lib = _LibProxy(ctypes.CDLL(LIB_PATH))
     return _lib
 
 

@@ -1,0 +1,222 @@
+"""Computation graph of one ShapeClipper step -- call surface of the reference's model/graph.py.
+
+`Graph(opt)` is an nn.Module whose direct children are named exactly as in the reference
+(estimator, sdf_network, rgb_network, renderer, encoder, latent_proj_shape, latent_proj_rgb,
+loss_fns): those names are the checkpoint ABI (utils/util.py restore iterates named_children).
+`forward(opt, var, training, get_loss, visualize)` fills the same `var` keys and returns the same
+loss dictionary keys as reference graph.py:68-112,220-265.  The two render calls per training step
+(input view, graph.py:92-93; CLIP-nearest-neighbour view, :207-209) run on the HIP renderer.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as torch_F
+
+from ..utils import camera
+from ..utils.util import EasyDict as edict
+from . import loss, resnet
+from .implicit import RGBNetwork, SDFNetwork
+from .renderer import Renderer
+from .view_estimator import Bottleneck_Linear as _EstimatorBottleneck
+from .view_estimator import Estimator
+
+
+class Bottleneck_Linear(_EstimatorBottleneck):
+    """Latent projector block; unlike the estimator's heads bn2 is NOT zero-initialised (graph.py:16-40)."""
+
+    def __init__(self, n_channels):
+        super().__init__(n_channels, zero_init=False)
+
+
+# world axes -> camera axes permutation applied before the Euler rotations (graph.py:278-283)
+_AXIS_PERMUTE = [[-1.0, 0.0, 0.0], [0.0, 0.0, -1.0], [0.0, -1.0, 0.0]]
+
+
+def rotation_from_trig(trig_azim, trig_elev, trig_theta):
+    Ry = camera.azim_to_rotation_matrix(trig_azim, representation="trig")
+    Rx = camera.elev_to_rotation_matrix(trig_elev, representation="trig")
+    Rz = camera.roll_to_rotation_matrix(trig_theta, representation="trig")
+    perm = torch.tensor(_AXIS_PERMUTE, device=Ry.device).unsqueeze(0).expand_as(Ry)
+    return Rz @ Rx @ Ry @ perm
+
+
+def _latent_projector(dim_in, dim_out):
+    return nn.Sequential(Bottleneck_Linear(dim_in), Bottleneck_Linear(dim_in), nn.Linear(dim_in, dim_out))
+
+
+class Graph(nn.Module):
+
+    def __init__(self, opt):
+        super().__init__()
+        self.estimator = Estimator(opt)
+        self.sdf_network = SDFNetwork(opt)
+        self.rgb_network = RGBNetwork(opt)
+        self.renderer = Renderer(opt, self.sdf_network, self.rgb_network)
+        self.encoder = resnet.build(opt.arch.enc_network, pretrained=opt.arch.enc_pretrained)
+        self.encoder.fc = nn.Linear(self.encoder.fc.in_features, opt.arch.latent_dim_shape + opt.arch.latent_dim_rgb)
+        self.latent_proj_shape = _latent_projector(opt.arch.latent_dim_shape, opt.arch.impl_sdf.proj_latent_dim)
+        self.latent_proj_rgb = _latent_projector(opt.arch.latent_dim_rgb, opt.arch.impl_rgb.proj_latent_dim)
+        self.loss_fns = loss.Loss(opt)
+
+    # ------------------------------------------------------------------------------------------------
+    def forward(self, opt, var, training=False, get_loss=True, visualize=False):
+        B = len(var.idx)
+        sampled = bool(opt.render.rand_sample and training)
+        ray_idx = var.ray_idx if sampled else None
+
+        var.latent_raw = var.latent if "latent" in var else self.encoder(var.rgb_input_map)
+        var.latent_shape = var.latent_raw[:, :opt.arch.latent_dim_shape]
+        var.latent_rgb = var.latent_raw[:, opt.arch.latent_dim_shape:]
+        var.proj_latent_sdf = self.latent_proj_shape(var.latent_shape)
+        var.proj_latent_rgb = self.latent_proj_rgb(var.latent_rgb)
+
+        var.pose, var.intr, var.scale_dist = self.pred_pose(opt, var)
+        var.normal_transformed = camera.transform_normal(var.normal_gt if "normal_gt" in var else var.normal_input, var.pose)
+
+        out = self.renderer(opt, var.pose, var.intr, var.scale_dist, var.proj_latent_sdf, var.proj_latent_rgb,
+                            ray_idx=ray_idx, training=training, visualize=visualize)
+        var.rgb_recon, var.mask_recon, var.mask_hard, var.depth_recon, var.normal_recon, var.grad_eikonal = out[:6]
+        if visualize:
+            var.rendering_points, var.rendering_transparency, var.rendering_rgb = out[6:9]
+
+        if not sampled:
+            as_map = lambda x, c, h, w: x.view(B, h, w, c).permute(0, 3, 1, 2).contiguous()
+            var.rgb_recon_map = as_map(var.rgb_recon, 3, opt.H, opt.W)
+            var.mask_recon_map = as_map(var.mask_recon, 1, opt.H, opt.W)
+            var.mask_hard_map = as_map(var.mask_hard, 1, opt.H, opt.W)
+            var.normal_recon_map = as_map(var.normal_recon, 3, opt.H, opt.W)
+            var.normal_transformed_map = as_map(var.normal_transformed, 3, opt.image_size[0], opt.image_size[1])
+
+        if (opt.loss_weight.nearest_img is not None or opt.loss_weight.nearest_mask is not None) and training:
+            self.forward_NN(opt, var)
+
+        if get_loss:
+            return var, self.compute_loss(opt, var, training)
+        return var
+
+    # ------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def select_neighbours(self, opt, var):
+        """IoU-weighted choice of n_views of the K CLIP neighbours per image (graph.py:119-142).
+        One device->host copy of the [B,K] probabilities (the reference syncs once per image)."""
+        B, K = len(var.idx), opt.data.k_nearest
+        inp = var.mask_input.view(B, -1, 1)
+        nn_masks = var.mask_input_NN.reshape(B, -1, K)
+        inter = (nn_masks * inp).sum(dim=1)
+        union = (nn_masks + inp - nn_masks * inp + 1.e-8).sum(dim=1)
+        probs = torch_F.normalize((1 - inter / union) ** opt.reg.sample_temp, dim=-1, p=1).cpu().numpy()
+        picks = []
+        for i in range(B):
+            p = probs[i] / np.sum(probs[i])
+            picks.append(np.random.choice(K, size=(opt.reg.n_views,), replace=False, p=p))
+        return torch.tensor(np.stack(picks, axis=0)).long().to(var.rgb_input_map.device)
+
+    def forward_NN(self, opt, var, training=True):
+        B = len(var.idx)
+        assert opt.reg.n_views <= opt.data.k_nearest
+        sampled = bool(opt.render.rand_sample and training)
+        idx_NN = self.select_neighbours(opt, var)                       # [B, V]
+        if sampled:
+            assert len(var.ray_idx.shape) == 2
+        rows = torch.arange(B, device=idx_NN.device)
+        for v in range(opt.reg.n_views):
+            pick = lambda stack: stack[rows, ..., idx_NN[:, v]]          # [B, ..., K] -> [B, ...]
+            nn_in = edict()
+            nn_in.rgb_input_map = pick(var.rgb_input_map_NN)
+            nn_in.mask_input_map = pick(var.mask_input_map_NN)
+            nn_in.normal_input_map = pick(var.normal_input_map_NN)
+            nn_in.rgb_input = pick(var.rgb_input_NN)
+            nn_in.mask_input = pick(var.mask_input_NN)
+            nn_in.normal_input = pick(var.normal_input_NN)
+            if sampled:
+                nn_in.ray_idx = pick(var.ray_idx_NN)
+            nn_in.pose_gt = pick(var.pose_gt_NN)
+            var["input_NN_{}".format(v)] = nn_in
+            ray_idx = nn_in.ray_idx if sampled else None
+
+            latent_NN = self.encoder(nn_in.rgb_input_map)
+            proj_latent_rgb_NN = self.latent_proj_rgb(latent_NN[:, opt.arch.latent_dim_shape:])
+            var.proj_latent_rgb_NN = proj_latent_rgb_NN
+            pose_NN, intr_NN, scale_NN = self.pred_pose(opt, var, pred_NN=True, given_input=nn_in.rgb_input_map)
+            var["pose_NN_{}".format(v)], var["intr_NN_{}".format(v)], var["scale_dist_NN_{}".format(v)] = pose_NN, intr_NN, scale_NN
+
+            # the neighbour is rendered with the INPUT image's shape code and its own colour code
+            rgb, mask, _, depth, normal, _ = self.renderer(opt, pose_NN, intr_NN, scale_NN, var.proj_latent_sdf,
+                                                           proj_latent_rgb_NN, ray_idx=ray_idx, training=training)
+            var["rgb_recon_NN_{}".format(v)], var["mask_recon_NN_{}".format(v)] = rgb, mask
+            var["depth_recon_NN_{}".format(v)], var["normal_recon_NN_{}".format(v)] = depth, normal
+            if not sampled:
+                as_map = lambda x, c: x.view(B, opt.H, opt.W, c).permute(0, 3, 1, 2).contiguous()
+                var["rgb_recon_map_NN_{}".format(v)] = as_map(rgb, 3)
+                var["mask_recon_map_NN_{}".format(v)] = as_map(mask, 1)
+                var["normal_recon_map_NN_{}".format(v)] = as_map(normal, 3)
+
+    # ------------------------------------------------------------------------------------------------
+    def compute_loss(self, opt, var, training=False):
+        out = edict()
+        B = len(var.idx)
+        w3 = var.category_weight.view(B, 1, 1) if "category_weight" in var else None
+        w2 = var.category_weight.view(B, 1) if "category_weight" in var else None
+        lw, fns = opt.loss_weight, self.loss_fns
+        mask_gt = var.mask_gt if "mask_gt" in var else var.mask_input
+        if lw.render is not None:
+            out.render = fns.MSE_loss(var.rgb_recon, var.rgb_gt if "rgb_gt" in var else var.rgb_input, weight=w3)
+        if lw.mask is not None:
+            out.mask = fns.mask_loss(var.mask_recon, mask_gt, weight=w3)
+        if lw.normal is not None:
+            valid = (mask_gt > 0.5) & (var.mask_recon > 0.5)
+            out.normal = fns.normal_loss(var.normal_recon, var.normal_transformed, valid, weight=w3, tolerance=opt.reg.normal_tol)
+        if training:
+            if lw.eikonal is not None:
+                out.eikonal = fns.MSE_loss(var.grad_eikonal.view(B, -1), 1, weight=w2)
+            if lw.cam_margin is not None:
+                out.cam_margin = fns.cam_margin_loss(opt, var)
+            if lw.cam_uniform is not None:
+                out.cam_uniform = fns.cam_uniform_loss(opt, var.trig_azim)
+            if lw.cam_sym is not None:
+                out.cam_sym = fns.cam_sym_loss(opt, var, self.estimator)
+            views = [(var["input_NN_{}".format(v)], v) for v in range(opt.reg.n_views)] if \
+                (lw.nearest_img is not None or lw.nearest_mask is not None or lw.nearest_normal is not None) else []
+            if lw.nearest_img is not None:
+                out.nearest_img = sum(fns.MSE_loss(var["rgb_recon_NN_{}".format(v)], nn_in.rgb_input, weight=w3) for nn_in, v in views)
+            if lw.nearest_mask is not None:
+                out.nearest_mask = sum(fns.mask_loss(var["mask_recon_NN_{}".format(v)], nn_in.mask_input, weight=w3) for nn_in, v in views)
+            if lw.nearest_normal is not None:
+                total = 0
+                for nn_in, v in views:
+                    valid = (nn_in.mask_input > 0.5) & (var["mask_recon_NN_{}".format(v)] > 0.5)
+                    target = camera.transform_normal(nn_in.normal_input, var["pose_NN_{}".format(v)])
+                    total = total + fns.normal_loss(var["normal_recon_NN_{}".format(v)], target, valid, weight=w3,
+                                                    tolerance=opt.reg.normal_tol)
+                out.nearest_normal = total
+        return out
+
+    # ------------------------------------------------------------------------------------------------
+    def pred_pose(self, opt, var, pred_NN=False, given_input=None):
+        image = given_input if given_input is not None else var.rgb_input_map
+        trig_azim, trig_elev, trig_theta, scale_focal, scale_dist = self.estimator(image)
+        pose_R = camera.pose(R=rotation_from_trig(trig_azim, trig_elev, trig_theta))
+        tz = scale_dist * opt.camera.dist
+        pose_T = camera.pose(t=torch.stack([torch.zeros_like(tz), torch.zeros_like(tz), tz], dim=-1))
+        pose = camera.pose.compose([pose_R, pose_T]).to(image.device)
+        intr = camera.get_intr(opt, scale_focal)
+        if not pred_NN:
+            var.trig_azim, var.trig_elev, var.trig_theta = trig_azim, trig_elev, trig_theta
+            var.scale_focal, var.scale_dist = scale_focal, scale_dist
+        return pose, intr, scale_dist
+
+    @torch.no_grad()
+    def get_rotate_pose(self, opt, var, n_views=50):
+        """[n_views,3,4] turn-table poses for visualisation (graph.py:295-322)."""
+        dev = var.rgb_input_map.device
+        r = opt.data[opt.data.dataset]
+        azim = torch.linspace(0, 2, n_views).to(dev).view(n_views, 1) * np.pi
+        elev = torch.zeros(n_views, 1).to(dev) + ((r.elev_range[1] + r.elev_range[0]) / 2 + 15) * np.pi / 180
+        theta = torch.zeros(n_views, 1).to(dev) + ((r.theta_range[1] + r.theta_range[0]) / 2) * np.pi / 180
+        trig = lambda a: torch.cat([torch.cos(a), torch.sin(a)], dim=1)
+        pose_R = camera.pose(R=rotation_from_trig(trig(azim), trig(elev), trig(theta))).to(dev)
+        pose_cam = camera.pose(t=[0, 0, opt.camera.dist]).to(dev)
+        var.vis_pose = camera.pose.compose([pose_R, pose_cam]).to(dev)
+        return var

@@ -1,0 +1,303 @@
+"""Training / evaluation engine -- call surface of the reference's model/runner.py
+(Runner: load_dataset, build_networks, setup_optimizer, restore_checkpoint, setup_visualizer,
+train, evaluate, ...).  Differences that matter on MI355X:
+
+  * data parallelism is one process per GPU with ONE flat RCCL all-reduce of all gradients per step
+    (shapeclipper_amd/parallel.py) instead of DistributedDataParallel's bucketed reducer;
+  * the per-loss `.mean()` + isnan/isinf asserts (two host syncs per loss key, runner.py:294-305) are
+    folded into a single device-side check that is read once per step;
+  * TensorBoard / image dumps are optional (used when importable), never required by the step.
+"""
+from __future__ import annotations
+
+import importlib
+import os
+import shutil
+import time
+from copy import deepcopy
+
+import numpy as np
+import torch
+import tqdm
+
+from ..parallel import FlatGradAllReduce, ModuleHolder
+from ..utils import eval_3D, util
+from ..utils.util import EasyDict as edict
+from ..utils.util import cleanup, log, setup
+
+try:
+    from ..utils import util_vis
+except Exception:  # pragma: no cover
+    util_vis = None
+
+
+def _rank0(opt):
+    return opt.device == 0 or opt.device in ("cuda:0", "cpu")
+
+
+class Runner:
+
+    def __init__(self, opt):
+        if os.path.isdir(opt.output_path) and opt.resume is False and _rank0(opt):
+            for fn in os.listdir(opt.output_path):
+                if "tfevents" in fn:
+                    os.remove(os.path.join(opt.output_path, fn))
+                if "vis" in fn:
+                    shutil.rmtree(os.path.join(opt.output_path, fn), ignore_errors=True)
+        if _rank0(opt):
+            os.makedirs(opt.output_path, exist_ok=True)
+        if "world_size" not in opt:
+            opt.world_size = 1
+        if opt.world_size > 1 and not torch.distributed.is_initialized():
+            setup(opt.device, opt.world_size, opt.port)
+        opt.batch_size = opt.batch_size // opt.world_size
+        self.optimizer = getattr(torch.optim, opt.optim.algo)
+        self.tb = None
+        self.reducer = None
+
+    # ---- data -----------------------------------------------------------------------------------------
+    def load_dataset(self, opt, eval_split="val"):
+        data = importlib.import_module("data.{}".format(opt.data.dataset))
+        if _rank0(opt): log.info("loading training data...")
+        self.train_data = data.Dataset(opt, split="train")
+        self.train_loader = self.train_data.setup_loader(opt, shuffle=True)
+        self.num_batches = len(self.train_loader)
+        if _rank0(opt): log.info("loading test data...")
+        self.test_data = data.Dataset(opt, split=eval_split)
+        self.test_loader = self.test_data.setup_loader(opt, shuffle=False, drop_last=False, batch_size=opt.eval.batch_size)
+        self.viz_data = []
+
+    # ---- networks / optimisers ------------------------------------------------------------------------
+    def build_networks(self, opt):
+        if _rank0(opt): log.info("building networks...")
+        name = "pretrainer" if opt.pretrain else "graph"
+        module = importlib.import_module("shapeclipper_amd.model.{}".format(name))
+        dev = torch.device("cuda", opt.device) if isinstance(opt.device, int) else torch.device(opt.device)
+        self.graph = ModuleHolder(module.Graph(opt).to(dev))
+        if opt.world_size > 1:
+            self.reducer = FlatGradAllReduce(self.graph.module, opt.world_size)
+
+    def setup_optimizer(self, opt):
+        if _rank0(opt): log.info("setting up optimizers...")
+        kwargs = {k: (tuple(v) if k == "betas" else v) for k, v in opt.optim.params.items()}
+        full, view = [], []
+        for k, v in self.graph.named_parameters():
+            full.append(v)
+            if "estimator" in k:
+                view.append(v)
+        self.optim_full = self.optimizer([dict(params=full, lr=opt.optim.lr)], **kwargs)
+        self.optim_V = self.optimizer([dict(params=view, lr=opt.optim.lr)], **kwargs)
+
+    def restore_checkpoint(self, opt, best=False, evaluate=False):
+        epoch_start, iter_start = None, None
+        if opt.resume:
+            if _rank0(opt): log.info("resuming from previous checkpoint...")
+            epoch_start, iter_start, self.best_val = util.restore_checkpoint(
+                opt, self, resume=opt.resume, best=best if opt.data.dataset != "openimage" else False, evaluate=evaluate)
+        elif opt.load is not None:
+            if _rank0(opt): log.info("loading weights from checkpoint {}...".format(opt.load))
+            epoch_start, iter_start, _ = util.restore_checkpoint(opt, self, load_name=opt.load)
+        elif _rank0(opt):
+            log.info("initializing weights from scratch...")
+        self.epoch_start = epoch_start or 0
+        self.iter_start = iter_start or 0
+
+    def setup_visualizer(self, opt):
+        if _rank0(opt) and opt.tb:
+            try:
+                from torch.utils.tensorboard import SummaryWriter
+                self.tb = SummaryWriter(log_dir=opt.output_path, flush_secs=10)
+            except Exception:
+                log.info("tensorboard not available; scalar logging goes to stdout only")
+
+    # ---- training -------------------------------------------------------------------------------------
+    def train(self, opt):
+        if _rank0(opt): log.title("TRAINING START")
+        self.graph.module.estimator.reset_scales()
+        self.timer = edict(start=time.time(), it_mean=None)
+        self.iter_skip = self.iter_start % len(self.train_loader)
+        self.it = self.iter_start
+        if not opt.resume:
+            self.best_val, self.best_ep = np.inf, 1
+        if self.iter_start == 0 and _rank0(opt) and opt.freq.eval:
+            self.evaluate(opt, ep=0, training=True)
+        for self.ep in range(self.epoch_start, opt.max_epoch):
+            self.train_epoch(opt)
+        if _rank0(opt):
+            self.save_checkpoint(opt, ep=self.ep + 1, it=self.it, best_val=self.best_val)
+            if self.tb is not None:
+                self.tb.flush(); self.tb.close()
+            log.title("TRAINING DONE")
+            log.info("Best CD: %.4f @ epoch %d" % (self.best_val, self.best_ep))
+        if opt.world_size > 1:
+            cleanup()
+
+    def train_epoch(self, opt):
+        if opt.world_size > 1:
+            torch.distributed.barrier()
+            if hasattr(self.train_loader, "sampler") and hasattr(self.train_loader.sampler, "set_epoch"):
+                self.train_loader.sampler.set_epoch(self.ep)
+        progress = tqdm.tqdm(range(self.num_batches), desc="training epoch {}".format(self.ep + 1), leave=False) \
+            if _rank0(opt) else range(self.num_batches)
+        self.graph.train()
+        loader = iter(self.train_loader)
+        loss = None
+        for _ in progress:
+            if self.iter_skip > 0:          # fast-forward after --resume
+                self.iter_skip -= 1
+                continue
+            var = edict(next(loader))
+            opt.H, opt.W = opt.image_size
+            var = util.move_to_device(var, opt.device)
+            loss = self.train_iteration(opt, var, progress)
+        if _rank0(opt) and loss is not None:
+            log.loss_train(opt, self.ep + 1, opt.optim.lr, loss, self.timer)
+        if (self.ep + 1) % opt.freq.eval == 0 and _rank0(opt):
+            val = self.evaluate(opt, ep=self.ep + 1, training=True)
+            if val < self.best_val:
+                self.best_val, self.best_ep = val, self.ep + 1
+                self.save_checkpoint(opt, ep=self.ep + 1, it=self.it, best_val=self.best_val, best=True, latest=True)
+
+    def train_iteration(self, opt, var, loader=None):
+        self.timer.it_start = time.time()
+        frozen_keys = []
+        if self.it > opt.optim.iter_camera:
+            optim = self.optim_full
+        else:                                  # camera warm-up: only the estimator learns
+            for m in self.graph.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.eval()
+            optim = self.optim_V
+            frozen_keys = ["nearest_img", "nearest_mask", "nearest_normal", "eikonal"]
+        if self.reducer is not None:
+            self.reducer.zero_grad()
+            self.reducer.broadcast_buffers()
+        else:
+            optim.zero_grad()
+        var, loss = self.graph.forward(opt, var, training=True, get_loss=True)
+        loss = self.summarize_loss(opt, var, loss, non_act_loss_key=frozen_keys)
+        loss.all.backward()
+        if self.reducer is not None:
+            self.reducer.all_reduce()
+        optim.step()
+
+        if _rank0(opt):
+            if (self.it + 1) % opt.freq.ckpt_latest == 0:
+                self.save_checkpoint(opt, ep=self.ep, it=self.it + 1, best_val=self.best_val, latest=True)
+            if opt.freq.scalar and self.it % opt.freq.scalar == 0 and self.tb is not None:
+                self.log_scalars(opt, var, loss, step=self.it, split="train")
+                self.tb.add_scalar("train/beta", self.graph.module.renderer.density.beta, global_step=self.it)
+        self.it += 1
+        if loader is not None and hasattr(loader, "set_postfix") and self.it % 10 == 0:
+            loader.set_postfix(it=self.it, loss="{:.3f}".format(float(loss.all)))
+        self.timer.it_end = time.time()
+        util.update_timer(opt, self.timer, self.ep if hasattr(self, "ep") else 0, len(loader) if loader is not None else 1)
+        return loss
+
+    def summarize_loss(self, opt, var, loss, non_act_loss_key=[]):
+        """all = sum_k float(w_k) * loss_k (keys in non_act_loss_key weigh 0).  NaN/Inf are checked with ONE
+        host read of a device flag instead of two syncs per key (reference runner.py:296-302)."""
+        assert "all" not in loss
+        total, bad = 0., None
+        for key in loss:
+            assert key in opt.loss_weight
+            if opt.loss_weight[key] is None:
+                continue
+            value = loss[key].mean()
+            flag = ~torch.isfinite(value)
+            bad = flag if bad is None else (bad | flag)
+            total = total + (0.0 if key in non_act_loss_key else float(opt.loss_weight[key])) * value
+        if bad is not None and opt.get("check_finite", True) and bool(bad):
+            for key in loss:
+                v = loss[key].mean()
+                assert not torch.isinf(v), "loss {} is Inf".format(key)
+                assert not torch.isnan(v), "loss {} is NaN".format(key)
+        loss.update(all=total)
+        return loss
+
+    # ---- evaluation -----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def evaluate(self, opt, ep, training=False):
+        self.graph.eval()
+        opt.H, opt.W = opt.eval.image_size
+        f_scores = []
+        metric = dict(dist_acc=0., dist_cov=0.)
+        C = opt.data.num_classes
+        acc_cat, comp_cat, counts = [0.] * C, [0.] * C, [0.001] * C
+        loader = tqdm.tqdm(self.test_loader, desc="evaluating", leave=False)
+        for it, batch in enumerate(loader):
+            var = self.evaluate_batch(opt, edict(batch), ep, it, single_gpu=True)
+            dist_acc, dist_cov = eval_3D.eval_metrics(opt, var, self.graph.module.sdf_network)
+            f_scores.append(var.f_score)
+            for i in range(len(var.idx)):
+                c = var.category_label[i].item()
+                counts[c] += 1; acc_cat[c] += var.cd_acc[i].item(); comp_cat[c] += var.cd_comp[i].item()
+            metric["dist_acc"] += dist_acc * len(var.idx)
+            metric["dist_cov"] += dist_cov * len(var.idx)
+            loader.set_postfix(CD="{:.3f}".format(float((dist_acc + dist_cov) / 2)))
+            if not training:
+                self.dump_results(opt, var, ep, write_new=(it == 0))
+        if not training:
+            with open(os.path.join(opt.output_path, "cd_cat.txt"), "w") as f:
+                f.write("CD     Acc    Comp   Count Cat\n")
+                names = getattr(self.test_data, "label2cat", {i: str(i) for i in range(C)})
+                for i in range(C):
+                    a, c = acc_cat[i] / counts[i], comp_cat[i] / counts[i]
+                    f.write("%.4f %.4f %.4f %5d %s\n" % ((a + c) / 2, a, c, counts[i], names[i]))
+            fs = torch.cat(f_scores, dim=0).mean(dim=0)
+            with open(os.path.join(opt.output_path, "f_score.txt"), "w") as f:
+                for i, th in enumerate(opt.eval.f_thresholds):
+                    line = "F-score @ %.2f: %.4f" % (th * 100, fs[i].item())
+                    print(line); f.write(line + "\n")
+        n = max(len(self.test_data), 1)
+        for k in metric:
+            metric[k] /= n
+        log.loss_eval(opt, loss=None, chamfer=(metric["dist_acc"], metric["dist_cov"]))
+        opt.H, opt.W = opt.image_size
+        return float((metric["dist_acc"] + metric["dist_cov"]) / 2)
+
+    def evaluate_batch(self, opt, var, ep=None, it=None, single_gpu=False, visualize=False):
+        var = util.move_to_device(var, opt.device)
+        return self.graph.module(opt, var, training=False, visualize=visualize, get_loss=False)
+
+    def vis_rotate(self, opt, var, n_views=50, vis_NN=False):
+        B = len(var.idx)
+        imgs, masks, normals = [], [], []
+        as_map = lambda x, c: x.view(B, opt.H, opt.W, c).permute(0, 3, 1, 2).contiguous()
+        for i in range(n_views):
+            pose_i = var.vis_pose[i].unsqueeze(0).expand(B, -1, -1)
+            rgb, mask, _, _, normal, _ = self.graph.module.renderer(
+                opt, pose_i, var.intr, torch.ones_like(var.scale_dist), var.proj_latent_sdf,
+                var.proj_latent_rgb_NN if vis_NN else var.proj_latent_rgb, training=False)
+            imgs.append(as_map(rgb, 3)); masks.append(as_map(mask, 1)); normals.append(as_map(normal, 3) / 2 + 0.5)
+        var.rotating_imgs, var.rotating_masks, var.rotating_normals = imgs, masks, normals
+
+    @torch.no_grad()
+    def log_scalars(self, opt, var, loss, metric=None, step=0, split="train"):
+        if self.tb is None:
+            return
+        for key, value in loss.items():
+            if key != "all":
+                self.tb.add_scalar("{0}/loss_{1}".format(split, key), value.mean(), step)
+        for key, value in (metric or {}).items():
+            self.tb.add_scalar("{0}/{1}".format(split, key), value, step)
+
+    @torch.no_grad()
+    def dump_results(self, opt, var, ep, write_new=False, train=False):
+        folder = "dump" if not train else "vis_{}".format(ep)
+        os.makedirs("{}/{}/".format(opt.output_path, folder), exist_ok=True)
+        if util_vis is not None:
+            util_vis.dump_images(opt, var.idx, "image_recon", var.rgb_recon_map, masks=var.mask_hard_map, folder=folder)
+            util_vis.dump_images(opt, var.idx, "mask_recon", var.mask_recon_map, folder=folder)
+        if not train:
+            with open("{}/chamfer.txt".format(opt.output_path), "w" if write_new else "a") as f:
+                for i, acc, comp in zip(var.idx, var.cd_acc, var.cd_comp):
+                    f.write("{} {:.8f} {:.8f}\n".format(i, acc, comp))
+
+    def save_checkpoint(self, opt, ep=0, it=0, best_val=np.inf, latest=False, best=False):
+        assert _rank0(opt)
+        util.save_checkpoint(opt, self, ep=ep, it=it, best_val=best_val, latest=latest, best=best)
+        if not latest:
+            log.info("checkpoint saved: ({0}) {1}, epoch {2} (iteration {3})".format(opt.group, opt.name, ep, it))
+        if best:
+            log.info("Saving the current model as the best...")

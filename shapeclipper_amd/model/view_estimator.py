@@ -1,0 +1,67 @@
+"""Viewpoint / scale estimator -- same module tree and state-dict keys as the reference's
+model/view_estimator.py (ResNet-18 trunk `feature_extractor`, three bottleneck heads, extr_fc /
+size_fc / perspect_fc).  Stock PyTorch-ROCm ops (out of the hand-written hot path)."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as torch_F
+
+from . import resnet
+
+
+class Bottleneck_Linear(nn.Module):
+    """1x1-conv residual bottleneck on a feature vector (reference view_estimator.py:6-33)."""
+
+    def __init__(self, n_channels, zero_init=True):
+        super().__init__()
+        self.linear1 = nn.Conv2d(n_channels, n_channels, kernel_size=1, padding=0, bias=False)
+        self.bn1 = nn.BatchNorm2d(n_channels)
+        self.linear2 = nn.Conv2d(n_channels, n_channels, kernel_size=1, padding=0, bias=False)
+        self.bn2 = nn.BatchNorm2d(n_channels)
+        self.relu = nn.ReLU(inplace=True)
+        if zero_init:
+            nn.init.constant_(self.bn2.weight, 0)
+
+    def forward(self, x):
+        v = x[..., None, None]
+        out = self.relu(self.bn1(self.linear1(v)))
+        out = self.bn2(self.linear2(out))
+        return self.relu(out + v)[..., 0, 0]
+
+
+class Estimator(nn.Module):
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.dataset = opt.data.dataset
+        self.feature_extractor = resnet.build("resnet18", pretrained=True)
+        n_features = self.feature_extractor.fc.in_features
+        self.feature_extractor.fc = nn.Identity()
+        self.extr_head = nn.Sequential(Bottleneck_Linear(n_features))
+        self.size_head = nn.Sequential(Bottleneck_Linear(n_features))
+        self.perspect_head = nn.Sequential(Bottleneck_Linear(n_features))
+        self.extr_fc = nn.Linear(n_features, 6)
+        self.size_fc = nn.Linear(n_features, 1)
+        self.perspect_fc = nn.Linear(n_features, 1)
+        # elevation / roll start at zero: (cos, sin) = (1, 0) after normalisation
+        with torch.no_grad():
+            self.extr_fc.weight[2:, :].zero_()
+            self.extr_fc.bias[2:] = torch.tensor([1.0, 0.0, 1.0, 0.0])
+        self.reset_scales()
+
+    def reset_scales(self):
+        for fc in (self.size_fc, self.perspect_fc):
+            nn.init.constant_(fc.weight, 0.0)
+            nn.init.constant_(fc.bias, 0.0)
+
+    def forward(self, inputs):
+        feat = self.feature_extractor(inputs)
+        trig = self.extr_fc(self.extr_head(feat))
+        azim, elev, theta = (torch_F.normalize(trig[:, 2 * k:2 * k + 2], dim=1, p=2) for k in range(3))
+        size_raw = torch.tanh(self.size_fc(self.size_head(feat))).squeeze(-1)
+        persp_raw = torch.tanh(self.perspect_fc(self.perspect_head(feat))).squeeze(-1)
+        scale_size = 1 + size_raw * self.opt.camera.size_range
+        scale_perspect = 1 + persp_raw * self.opt.camera.perspect_range
+        return azim, elev, theta, scale_perspect, scale_size * scale_perspect

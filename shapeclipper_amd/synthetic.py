@@ -1,0 +1,61 @@
+"""Synthetic Pix3D-shaped batches: the dataset, its CLIP-NN CSV and the pretrained
+encoders are not available offline, so benchmarks / smoke tests / multi-process tests use random
+images with disc masks in exactly the batch-dict schema of the reference's data/pix3d.py:110-228."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .utils.util import EasyDict as edict
+
+
+def _disc_masks(n, H, W, gen):
+    yy, xx = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
+    rad = 40 + 50 * torch.rand(n, generator=gen)
+    rad = rad * (H / 224.0)
+    d2 = (yy - H / 2) ** 2 + (xx - W / 2) ** 2
+    return (d2[None] <= (rad ** 2)[:, None, None]).float().unsqueeze(1)        # [n,1,H,W]
+
+
+def _views(n, H, W, R, gen):
+    rgb = torch.rand(n, 3, H, W, generator=gen)
+    mask = _disc_masks(n, H, W, gen)
+    normal = torch.nn.functional.normalize(torch.randn(n, 3, H, W, generator=gen), dim=1) * mask
+    out = dict(rgb_input_map=rgb, mask_input_map=mask, normal_input_map=normal)
+    if R:
+        ray_idx = torch.stack([torch.randperm(H * W, generator=gen)[:R] for _ in range(n)], 0)
+        take = lambda m: m.flatten(2).permute(0, 2, 1).gather(1, ray_idx[..., None].expand(-1, -1, m.shape[1]))
+        out.update(ray_idx=ray_idx, rgb_input=take(rgb), mask_input=take(mask), normal_input=take(normal))
+    else:
+        flat = lambda m: m.flatten(2).permute(0, 2, 1).contiguous()
+        out.update(rgb_input=flat(rgb), mask_input=flat(mask), normal_input=flat(normal))
+    return out
+
+
+def make_batch(opt, batch_size, seed=0, training=True, n_gt_points=2048):
+    """One batch with the reference's keys; neighbour stacks carry a trailing K dimension."""
+    gen = torch.Generator().manual_seed(seed)
+    H, W = opt.image_size
+    R = opt.render.rand_sample if training else 0
+    K = opt.data.k_nearest
+    v = _views(batch_size, H, W, R, gen)
+    batch = edict(idx=torch.arange(batch_size), category_label=torch.zeros(batch_size, dtype=torch.long), **v)
+    azim = (torch.rand(batch_size, generator=gen) * 2 - 1) * np.pi
+    elev = (torch.rand(batch_size, generator=gen) * 2 - 1) * np.pi / 6
+    ca, sa, ce, se = torch.cos(azim), torch.sin(azim), torch.cos(elev), torch.sin(elev)
+    Rm = torch.zeros(batch_size, 3, 3)
+    Rm[:, 0, 0], Rm[:, 0, 2], Rm[:, 1, 1], Rm[:, 2, 0], Rm[:, 2, 2] = ca, sa, 1.0, -sa, ca
+    Rx = torch.zeros(batch_size, 3, 3)
+    Rx[:, 0, 0], Rx[:, 1, 1], Rx[:, 1, 2], Rx[:, 2, 1], Rx[:, 2, 2] = 1.0, ce, -se, se, ce
+    pose = torch.cat([Rx @ Rm, torch.tensor([0.0, 0.0, 5.0]).expand(batch_size, 3)[..., None]], dim=-1)
+    f = 4.0
+    intr = torch.tensor([[f * W, 0, W / 2], [0, f * H, H / 2], [0, 0, 1]]).expand(batch_size, 3, 3).contiguous()
+    batch.pose_gt, batch.intr = pose, intr
+    pts = torch.rand(batch_size, n_gt_points, 3, generator=gen) - 0.5
+    batch.dpc = edict(points=pts, normals=torch.nn.functional.normalize(torch.randn(batch_size, n_gt_points, 3, generator=gen), dim=-1))
+    if training:
+        stacks = [_views(batch_size, H, W, R, gen) for _ in range(K)]
+        for key in ("rgb_input", "mask_input", "normal_input", "rgb_input_map", "mask_input_map", "normal_input_map", "ray_idx"):
+            batch[key + "_NN"] = torch.stack([s[key] for s in stacks], dim=-1)
+        batch.pose_gt_NN = pose[..., None].expand(-1, -1, -1, K).contiguous()
+    return batch

@@ -1,0 +1,51 @@
+"""Quick hot-path timing: one training render (fwd + bwd) at B images x 512 rays x 64 samples."""
+import argparse
+import sys, os, time
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+import torch
+from shapeclipper_amd.utils import options
+from shapeclipper_amd.model.implicit import SDFNetwork, RGBNetwork
+from shapeclipper_amd.model.renderer import Renderer
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--B", type=int, default=32)
+ap.add_argument("--R", type=int, default=512)
+ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--eval", action="store_true")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+opt = options.set(options.parse_arguments(["--yaml=options/pix3d/config.yaml", "--name=perf", "--output_root=/tmp/sc_perf"]), verbose=False)
+torch.manual_seed(0)
+sdf, rgb = SDFNetwork(opt), RGBNetwork(opt)
+r = Renderer(opt, sdf, rgb).to(dev)
+B, R = a.B, a.R
+az = (torch.rand(B) * 2 - 1) * 3.14159
+trig = lambda t: torch.stack([torch.cos(t), torch.sin(t)], 1)
+from shapeclipper_amd.utils import camera
+Ry = camera.azim_to_rotation_matrix(trig(az), "trig"); Rx = camera.elev_to_rotation_matrix(trig(torch.zeros(B)), "trig")
+P = torch.tensor([[-1., 0, 0], [0, 0, -1], [0, -1, 0]])[None].expand(B, 3, 3)
+pose = camera.pose.compose([camera.pose(R=Rx @ Ry @ P), camera.pose(t=torch.tensor([[0., 0, 5.]]).expand(B, 3))]).to(dev).requires_grad_(True)
+intr = camera.get_intr(opt, torch.ones(B)).to(dev)
+sd = torch.ones(B, device=dev, requires_grad=True)
+zs = torch.randn(B, 64, device=dev, requires_grad=True); zr = torch.randn(B, 64, device=dev, requires_grad=True)
+ray_idx = torch.stack([torch.randperm(224 * 224)[:R] for _ in range(B)]).to(dev)
+
+
+def step():
+    if a.eval:
+        with torch.no_grad():
+            return r(opt, pose, intr, sd, zs, zr, ray_idx=ray_idx, training=False)
+    out = r(opt, pose, intr, sd, zs, zr, ray_idx=ray_idx, training=True)
+    L = out[0].sum() + out[1].sum() + out[4].sum() + ((out[5] - 1) ** 2).mean()
+    L.backward()
+    return out
+
+for _ in range(2):
+    step()
+torch.cuda.synchronize()
+t0 = time.time()
+for _ in range(a.iters):
+    step()
+torch.cuda.synchronize()
+dt = (time.time() - t0) / a.iters
+print("B=%d R=%d  %s: %.2f ms per render call  -> %.1f img/s  (%.2f Mrays/s)" % (B, R, "eval fwd" if a.eval else "train fwd+bwd", dt * 1e3, B / dt, B * R / dt / 1e6))
