@@ -22,6 +22,7 @@ import os
 import sys
 import time
 
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")   # immediate-mode conv selection: no exhaustive MIOpen search on a fresh box
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -66,13 +67,13 @@ def cpu_baseline(batch, rays=512):
     az = (torch.rand(B) * 2 - 1) * 3.14159
     trig = lambda t: torch.stack([torch.cos(t), torch.sin(t)], 1)
     sd = (0.8 + 0.4 * torch.rand(B)).requires_grad_(True)
-    pose = R.pose_from_trig(cfg, trig(az), trig(torch.zeros(B)), trig(torch.zeros(B)), sd)
     intr = R.get_intr(cfg, torch.ones(B))
     zs, zr = torch.randn(B, 64, requires_grad=True), torch.randn(B, 64, requires_grad=True)
     ray_idx = torch.stack([torch.randperm(cfg.H * cfg.W)[:rays] for _ in range(B)])
 
     def step():
         total = 0
+        pose = R.pose_from_trig(cfg, trig(az), trig(torch.zeros(B)), trig(torch.zeros(B)), sd)
         for _ in range(2):
             t_rand, eik_idx, eik_pts = R.draw_render_randoms(B * rays, 64, True)
             o = R.render(cfg, Ws, Wr, beta, pose, intr, sd, zs, zr, ray_idx, True, t_rand, eik_idx, eik_pts)

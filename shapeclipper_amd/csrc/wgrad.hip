@@ -6,13 +6,13 @@
 // twice for the SDF net because d(sdf)/dx is itself differentiated (renderer.py:101-107).
 //
 // Operands live in HBM in the tile-blocked layout the chain kernels write (TBL64, lane<->point).
-// MFMA needs K<->point across lanes, i.e. a transpose: each workgroup restages 32 points per round
-// through LDS as [channel][point] (row stride 34 => conflict-free fragment reads), applying cheap
-// element-wise operand transforms on the way (softplus(a), p*softplus'(a), positional encoding
-// from the raw point, ...) so that those tensors never have to be materialised in HBM.
-// Wave w of a workgroup owns output rows 16w..16w+15 and all N tiles; accumulators stay in
-// registers over the whole grid-stride loop; every workgroup writes one partial image, a second
-// tiny kernel sums the partials in a fixed order (deterministic, no atomics).
+// MFMA needs K<->point across lanes, i.e. a transpose; it is done in registers (4x4 quad transposes
+// on coalesced float4 loads, see quad_transpose) -- no LDS staging, no barriers, every wave streams
+// its own 16-point tiles independently.  Cheap element-wise operand transforms are applied on the
+// way (softplus(a), p*softplus'(a), positional encoding from the raw point, ...) so those tensors are
+// never materialised in HBM.  A wave keeps the whole [64 x N] accumulator in registers over its
+// grid-stride loop; the four waves of a workgroup are combined in LDS and every workgroup writes one
+// partial image; a second tiny kernel sums the partials in a fixed order.
 // Bound: HBM (every operand byte is read once per GEMM it takes part in).
 #include "mlp_tile.hpp"
 
@@ -42,139 +42,163 @@ struct WgradArgs {
     int partial_stride, out_offset, out_ld;
 };
 
-constexpr int WG_PT = 32;      // points per round
-constexpr int WG_LDP = 34;     // LDS row stride (floats): (2*i + g) mod 32 distinct for i<16, g<2
 constexpr int WG_MAXNB = 112;
 
 __device__ __forceinline__ float4 wg_load4(const float* base, int tile, int grp, int pt) {
     return reinterpret_cast<const float4*>(base)[((size_t)tile * 16 + grp) * 16 + pt];
 }
-
-__device__ __forceinline__ void wg_store_col(float* dst, int ch, int col, float4 v) {
-    dst[(ch + 0) * WG_LDP + col] = v.x;
-    dst[(ch + 1) * WG_LDP + col] = v.y;
-    dst[(ch + 2) * WG_LDP + col] = v.z;
-    dst[(ch + 3) * WG_LDP + col] = v.w;
-}
-
 __device__ __forceinline__ float sp_d1(float a) { float t, r; softplus_parts(a, t, r); return softplus_d1(a, t, r); }
 __device__ __forceinline__ float sp_val(float a) { float t, r; softplus_parts(a, t, r); return softplus_val(a, t); }
 
-// stage one 64-channel TBL operand (two 16-point tiles) into dst[64][WG_LDP]
-__device__ __forceinline__ void wg_stage_tbl(float* dst, int op, const float* x0, const float* x1, const float* w5row,
-                                             int tile0, int ntiles, int n_points, int tid) {
-    for (int e = tid; e < 512; e += 256) {
-        const int k = e >> 8, grp = (e >> 4) & 15, pt = e & 15;
-        const int tile = tile0 + k;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tile < ntiles && tile * TP + pt < n_points) {
-            if (op == OP_PLAIN) {
-                v = wg_load4(x0, tile, grp, pt);
-            } else if (op == OP_SP) {
-                const float4 a = wg_load4(x0, tile, grp, pt);
-                v = make_float4(sp_val(a.x), sp_val(a.y), sp_val(a.z), sp_val(a.w));
-            } else if (op == OP_Q) {
-                const float4 pz = wg_load4(x0, tile, grp, pt);
-                const float4 a = wg_load4(x1, tile, grp, pt);
-                v = make_float4(pz.x * sp_d1(a.x), pz.y * sp_d1(a.y), pz.z * sp_d1(a.z), pz.w * sp_d1(a.w));
-            } else if (op == OP_Q4) {
-                const float4 a = wg_load4(x1, tile, grp, pt);
-                const float4 w = reinterpret_cast<const float4*>(w5row)[grp];
-                v = make_float4(w.x * sp_d1(a.x), w.y * sp_d1(a.y), w.z * sp_d1(a.z), w.w * sp_d1(a.w));
-            }
-        }
-        wg_store_col(dst, 4 * grp, 16 * k + pt, v);
-    }
+// ---- fragment loads straight from the TBL64 image --------------------------------------------------
+// MFMA 16x16x4 wants  A[i = channel][k = point]: lane (i = l&15, g = l>>4) supplies channel i of point
+// "slot g" at each of the 4 K-steps of a 16-point tile.  K order is free, so slot g / step s := point
+// 4g + s.  A lane therefore needs ONE channel for FOUR consecutive points, while TBL64 stores FOUR
+// consecutive channels of ONE point per float4.  Let lane (i,g) load the float4 of channel group
+// (i>>2) at point 4g + (i&3): the four lanes of a quad now hold a 4x4 (channel x point) block, and a
+// 4x4 transpose inside the quad (two DPP-able xor-shuffle stages) leaves every lane with its channel
+// at points 4g..4g+3.  The wave's 64 loads are one fully coalesced 1 KiB request; no LDS, no barrier.
+__device__ __forceinline__ void quad_transpose(float4& v, int j) {
+    const bool odd = j & 1;
+    float s0 = odd ? v.x : v.y, s1 = odd ? v.z : v.w;
+    float t0 = __shfl_xor(s0, 1), t1 = __shfl_xor(s1, 1);
+    if (odd) { v.x = t0; v.z = t1; } else { v.y = t0; v.w = t1; }
+    const bool hi = j & 2;
+    s0 = hi ? v.x : v.z; s1 = hi ? v.y : v.w;
+    t0 = __shfl_xor(s0, 2); t1 = __shfl_xor(s1, 2);
+    if (hi) { v.x = t0; v.y = t1; } else { v.z = t0; v.w = t1; }
 }
 
-// stage the 48-column positional-encoding operand (OP_PE: E, OP_EPS: g_grad[c] * dE/dx) for 32 points
-__device__ __forceinline__ void wg_stage_pe(float* dst, int op, const float* points, const float* g_grad,
-                                            int pt0, int n_points, bool symmetric, int tid) {
-    const int pt = tid & 31, role = tid >> 5;   // role 0..5: frequency 2^role; role 6: raw + pads; role 7 idle
-    if (role > 6) return;
-    const int gp = pt0 + pt;
-    const bool valid = gp < n_points;
-    float x[3] = {0.f, 0.f, 0.f}, gm[3] = {0.f, 0.f, 0.f};
+// channel tile T (16 channels) of a TBL operand for this lane: x..w = K-steps 0..3
+__device__ __forceinline__ float4 wg_frag(int op, const float* x0, const float* x1, const float* w5row,
+                                          int tile, int T, int i, int g, bool valid) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int grp = 4 * T + (i >> 2), pt = 4 * g + (i & 3);
     if (valid) {
-        x[0] = points[(size_t)gp * 3]; x[1] = points[(size_t)gp * 3 + 1]; x[2] = points[(size_t)gp * 3 + 2];
-        if (op == OP_EPS) { gm[0] = g_grad[(size_t)gp * 3]; gm[1] = g_grad[(size_t)gp * 3 + 1]; gm[2] = g_grad[(size_t)gp * 3 + 2]; }
+        if (op == OP_PLAIN) {
+            v = wg_load4(x0, tile, grp, pt);
+        } else if (op == OP_SP) {
+            const float4 a = wg_load4(x0, tile, grp, pt);
+            v = make_float4(sp_val(a.x), sp_val(a.y), sp_val(a.z), sp_val(a.w));
+        } else if (op == OP_Q) {
+            const float4 pz = wg_load4(x0, tile, grp, pt);
+            const float4 a = wg_load4(x1, tile, grp, pt);
+            v = make_float4(pz.x * sp_d1(a.x), pz.y * sp_d1(a.y), pz.z * sp_d1(a.z), pz.w * sp_d1(a.w));
+        } else if (op == OP_Q4) {
+            const float4 a = wg_load4(x1, tile, grp, pt);
+            const float4 w = reinterpret_cast<const float4*>(w5row)[grp];
+            v = make_float4(w.x * sp_d1(a.x), w.y * sp_d1(a.y), w.z * sp_d1(a.z), w.w * sp_d1(a.w));
+        }
     }
-    const float sg0 = symmetric ? (x[0] > 0.f ? 1.f : (x[0] < 0.f ? -1.f : 0.f)) : 1.f;
-    if (symmetric) x[0] = fabsf(x[0]);
+    quad_transpose(v, i & 3);
+    return v;
+}
+
+// sin/cos of this lane's PE column for the 4 points of its slot and the 3 coordinates (shared by the
+// OP_PE and OP_EPS operands of one tile).  Column j of coordinate tile c: step = j>>2, owner gq = j&3.
+struct PeLane {
+    float pe[3][4];   // E column value at the 4 points of this lane's slot, per coordinate tile
+    float ep[3][4];   // g_grad[c] * dE/dx_c   (OP_EPS)
+};
+
+__device__ __forceinline__ void pe_lane_setup(PeLane& P, const float* points, const float* g_grad, bool want_eps,
+                                              int tile, int j, int g, int n_points, bool symmetric) {
+    const int step = j >> 2, gq = j & 3;
+    const bool raw = gq == 3, first = step == 0, iscos = step & 1;
+    const float f = raw ? 0.f : (float)(1 << (2 * gq + (step >> 1)));
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float sg = c == 0 ? sg0 : 1.f;
-        if (role < 6) {
-            const int gq = role >> 1, j0 = 2 * (role & 1);          // packed col = 4*(4c+j) + gq
-            const float f = (float)(1 << role);
+    for (int s = 0; s < 4; ++s) {
+        const int gp = tile * TP + 4 * g + s;
+        const bool valid = gp < n_points;
+        float x[3] = {0.f, 0.f, 0.f}, gm[3] = {0.f, 0.f, 0.f};
+        if (valid) {
+            x[0] = points[(size_t)gp * 3]; x[1] = points[(size_t)gp * 3 + 1]; x[2] = points[(size_t)gp * 3 + 2];
+            if (want_eps) { gm[0] = g_grad[(size_t)gp * 3]; gm[1] = g_grad[(size_t)gp * 3 + 1]; gm[2] = g_grad[(size_t)gp * 3 + 2]; }
+        }
+        const float sg0 = symmetric ? (x[0] > 0.f ? 1.f : (x[0] < 0.f ? -1.f : 0.f)) : 1.f;
+        if (symmetric) x[0] = fabsf(x[0]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
             float sn, cs;
             sincosf(x[c] * f, &sn, &cs);
-            float v0, v1;
-            if (op == OP_PE) { v0 = sn; v1 = cs; } else { v0 = gm[c] * f * cs * sg; v1 = -gm[c] * f * sn * sg; }
-            if (!valid) { v0 = 0.f; v1 = 0.f; }
-            dst[(4 * (4 * c + j0) + gq) * WG_LDP + pt] = v0;
-            dst[(4 * (4 * c + j0 + 1) + gq) * WG_LDP + pt] = v1;
-        } else {
-            float v0 = op == OP_PE ? x[c] : gm[c] * sg;
-            if (!valid) v0 = 0.f;
-            dst[(4 * (4 * c + 0) + 3) * WG_LDP + pt] = v0;
-            dst[(4 * (4 * c + 1) + 3) * WG_LDP + pt] = 0.f;
-            dst[(4 * (4 * c + 2) + 3) * WG_LDP + pt] = 0.f;
-            dst[(4 * (4 * c + 3) + 3) * WG_LDP + pt] = 0.f;
+            const float val = raw ? (first ? x[c] : 0.f) : (iscos ? cs : sn);
+            const float der = raw ? (first ? 1.f : 0.f) : (iscos ? -f * sn : f * cs);
+            P.pe[c][s] = valid ? val : 0.f;
+            P.ep[c][s] = gm[c] * der * (c == 0 ? sg0 : 1.f);   // gm == 0 for out-of-range points
         }
     }
 }
 
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
-    __shared__ float Al[2][64 * WG_LDP];
-    __shared__ float Bl[2][WG_MAXNB * WG_LDP];
+// B fragment of PE coordinate tile c (x..w = K-steps = points 4g..4g+3)
+__device__ __forceinline__ float4 pe_frag(const PeLane& P, int op, int c) {
+    return op == OP_PE ? make_float4(P.pe[c][0], P.pe[c][1], P.pe[c][2], P.pe[c][3])
+                       : make_float4(P.ep[c][0], P.ep[c][1], P.ep[c][2], P.ep[c][3]);
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
+    __shared__ float red[64 * WG_MAXNB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int ntiles = (a.n_points + TP - 1) / TP;
-    const int nrounds = (ntiles + 1) / 2;
-    const int nnt = (a.nb0 + a.nb1) / 16;
-    f32x4 acc[7];
+    const int nt0 = a.nb0 / 16, nt1 = a.nb1 / 16, nnt = nt0 + nt1;
+    for (int e = tid; e < 64 * WG_MAXNB; e += 256) red[e] = 0.f;
+    f32x4 acc[NT][7];
 #pragma unroll
-    for (int n = 0; n < 7; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
+        for (int n = 0; n < 7; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bool need_pe = false, need_eps = false;
+    for (int t = 0; t < a.nterms; ++t) {
+        need_pe |= a.t[t].bop0 == OP_PE || a.t[t].bop1 == OP_PE || a.t[t].bop0 == OP_EPS || a.t[t].bop1 == OP_EPS;
+        need_eps |= a.t[t].bop0 == OP_EPS || a.t[t].bop1 == OP_EPS;
+    }
 
-    for (int round = blockIdx.x; round < nrounds; round += gridDim.x) {
-        const int tile0 = round * 2;
-        __syncthreads();
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+        const bool valid = tile * TP + 4 * g + (i & 3) < a.n_points;   // the point this lane LOADS
+        PeLane P;
+        if (need_pe) pe_lane_setup(P, a.points, a.g_grad, need_eps, tile, i, g, a.n_points, a.symmetric != 0);
         for (int t = 0; t < a.nterms; ++t) {
             const WgradTerm& T = a.t[t];
-            wg_stage_tbl(Al[t], T.aop, T.a0, T.a1, a.w5row, tile0, ntiles, a.n_points, tid);
-            if (T.bop0 == OP_PE || T.bop0 == OP_EPS)
-                wg_stage_pe(Bl[t], T.bop0, a.points, a.g_grad, tile0 * TP, a.n_points, a.symmetric != 0, tid);
-            else
-                wg_stage_tbl(Bl[t], T.bop0, T.b0, nullptr, nullptr, tile0, ntiles, a.n_points, tid);
-            if (a.nb1 > 0) {
-                float* dst = Bl[t] + a.nb0 * WG_LDP;
-                if (T.bop1 == OP_PE || T.bop1 == OP_EPS)
-                    wg_stage_pe(dst, T.bop1, a.points, a.g_grad, tile0 * TP, a.n_points, a.symmetric != 0, tid);
-                else
-                    wg_stage_tbl(dst, T.bop1, T.b1, nullptr, nullptr, tile0, ntiles, a.n_points, tid);
-            }
-        }
-        __syncthreads();
-        for (int t = 0; t < a.nterms; ++t) {
-            const float* ap = Al[t] + (16 * wave + i) * WG_LDP + g;
-            const float* bp = Bl[t] + i * WG_LDP + g;
+            float4 af[NT], bf[7];
 #pragma unroll
-            for (int s = 0; s < WG_PT / 4; ++s) {
-                const float av = ap[4 * s];
+            for (int m = 0; m < NT; ++m) af[m] = wg_frag(T.aop, T.a0, T.a1, a.w5row, tile, m, i, g, valid);
 #pragma unroll
-                for (int n = 0; n < 7; ++n)
-                    if (n < nnt) acc[n] = mfma16(av, bp[n * 16 * WG_LDP + 4 * s], acc[n]);
+            for (int n = 0; n < 7; ++n) {
+                if (n < nnt) {
+                    const bool seg1 = n >= nt0;
+                    const int op = seg1 ? T.bop1 : T.bop0;
+                    const int ln = seg1 ? n - nt0 : n;
+                    if (op == OP_PE || op == OP_EPS) bf[n] = pe_frag(P, op, ln);
+                    else bf[n] = wg_frag(op, seg1 ? T.b1 : T.b0, nullptr, nullptr, tile, ln, i, g, valid);
+                }
             }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int m = 0; m < NT; ++m)
+#pragma unroll
+                    for (int n = 0; n < 7; ++n)
+                        if (n < nnt) {
+                            const float av = s == 0 ? af[m].x : (s == 1 ? af[m].y : (s == 2 ? af[m].z : af[m].w));
+                            const float bv = s == 0 ? bf[n].x : (s == 1 ? bf[n].y : (s == 2 ? bf[n].z : bf[n].w));
+                            acc[m][n] = mfma16(av, bv, acc[m][n]);
+                        }
         }
     }
+    // combine the four waves of the workgroup in LDS, then one partial image per workgroup
+    __syncthreads();
+    const int ld = 16 * nnt;
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
+        for (int n = 0; n < 7; ++n)
+            if (n < nnt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicAdd(&red[(16 * m + 4 * g + r) * ld + 16 * n + i], acc[m][n][r]);
+            }
+    __syncthreads();
     float* out = a.partial + (size_t)blockIdx.x * a.partial_stride + a.out_offset;
-#pragma unroll
-    for (int n = 0; n < 7; ++n)
-        if (n < nnt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) out[(16 * wave + 4 * g + r) * a.out_ld + 16 * n + i] = acc[n][r];
-        }
+    for (int e = tid; e < 64 * ld; e += 256) out[(e / ld) * a.out_ld + (e % ld)] = red[e];
 }
 
 // out[i] = sum_b partial[b][i], fixed order

@@ -67,7 +67,7 @@ def rgb_composite_forward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, db
 
 # operand transform codes of sc_wgrad (csrc/wgrad.hip)
 OP_NONE, OP_PLAIN, OP_SP, OP_Q, OP_Q4, OP_PE, OP_EPS = range(7)
-WGRAD_PARTS = 256
+WGRAD_PARTS = 512
 
 
 def _wgrad(lib, terms, points, g_grad, w5row, n_points, symmetric, nb0, nb1, partial, stride, out_offset, out_ld):
