@@ -58,6 +58,59 @@ int sc_sdf_forward(const float* points, const float* w_pack, const float* cbias,
                    int n_per_image, int n_images, int symmetric, float* sdf, float* grad,
                    float* feat, float* stash_a, float* stash_p, void* stream);
 
+/* Reverse pass of sc_sdf_forward incl. the second-order terms of d/dtheta[d sdf/dx] (what autograd's
+ * double backward does for model/implicit.py:180-186 + model/renderer.py:101-107).
+ * stash_a / stash_p: as written by sc_sdf_forward.  g_sdf [n], g_grad [n][3], g_feat (TBL64): upstream
+ * gradients, any may be NULL (= zero).  Outputs: g_points [n][3] (may be NULL); ga (5 x TBL64), gp (4 x
+ * TBL64, only written when g_grad != NULL), r0 (TBL64): operands of the weight-gradient GEMMs (sc_wgrad). */
+int sc_sdf_backward(const float* points, const float* w_pack, int n_points, int symmetric,
+                    const float* stash_a, const float* stash_p, const float* g_sdf, const float* g_grad,
+                    const float* g_feat, float* g_points, float* ga, float* gp, float* r0, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * RGB MLP + Laplace density + alpha compositing, one wavefront per ray of 64 samples
+ * (RGBNetwork.forward model/implicit.py:220-239, LaplaceDensity :65-83, Renderer.volume_rendering
+ * model/renderer.py:187-209 and the per-ray reductions :117-152).
+ * points [n_rays*64][3], z_vals [n_rays][64], depth_fac [n_rays], sdf [P], grad [P][3] (= d sdf/dx),
+ * feat TBL64 (from sc_sdf_forward), v_pack (SC_RGB_PACK_FLOATS, packing.pack_rgb), dbias
+ * [n_images][3][64], beta_param: the raw scalar parameter renderer.density.beta in device memory.
+ * Outputs: rgb [n_rays][3], mask/mask_hard/depth [n_rays], normal [n_rays][3]; optional weights/alpha
+ * [n_rays][64] and rgb_flat [P][3] (rgb_flat is required by the backward).                          */
+int sc_rgb_composite_forward(const float* points, const float* z_vals, const float* depth_fac,
+                             const float* sdf, const float* grad, const float* feat,
+                             const float* v_pack, const float* dbias, const float* beta_param,
+                             int n_rays, int rays_per_image, int n_images, int symmetric,
+                             float beta_min, float bgcolor, float normal_pow,
+                             float* rgb, float* mask, float* mask_hard, float* depth, float* normal,
+                             float* weights, float* alpha, float* rgb_flat, void* stream);
+
+/* Reverse pass.  G_* are the upstream per-ray gradients (NULL = zero).  g_beta [1] must be zero-filled
+ * (atomicAdd).  gy (3 x TBL64), rr (3 x TBL64), gy3 [P][3]: operands for the RGB weight gradients.      */
+int sc_rgb_composite_backward(
+    const float* points, const float* z_vals, const float* depth_fac, const float* sdf, const float* grad,
+    const float* feat, const float* v_pack, const float* dbias, const float* beta_param, const float* rgb_flat,
+    int n_rays, int rays_per_image, int n_images, int symmetric, float beta_min, float bgcolor, float normal_pow,
+    const float* G_rgb, const float* G_mask, const float* G_depth, const float* G_normal,
+    float* g_sdf, float* g_grad, float* g_feat, float* g_points, float* g_z, float* g_depth_fac, float* g_beta,
+    float* gy, float* rr, float* gy3, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight-gradient GEMM  dW[64][nb0+nb1] = sum_points A(p) (x) [B0(p) | B1(p)]  over one or two terms.
+ * Operand transform codes: 1 plain TBL64, 2 softplus(a), 3 p*softplus'(a), 4 w5row*softplus'(a),
+ * 5 positional encoding of the point (48 columns), 6 g_grad-weighted PE Jacobian (48 columns).
+ * Every one of the `nparts` workgroups writes its partial result at
+ * partial[part*partial_stride + out_offset + row*out_ld + col]; sc_partial_reduce sums the parts.       */
+int sc_wgrad(int nterms,
+             const float* a0_0, const float* a1_0, int aop_0, const float* b0_0, int bop0_0, const float* b1_0, int bop1_0,
+             const float* a0_1, const float* a1_1, int aop_1, const float* b0_1, int bop0_1, const float* b1_1, int bop1_1,
+             const float* points, const float* g_grad, const float* w5row, int n_points, int symmetric,
+             int nb0, int nb1, float* partial, int nparts, int partial_stride, int out_offset, int out_ld, void* stream);
+int sc_partial_reduce(const float* partial, int nparts, int stride, int n, float* out, void* stream);
+
+/* out[img][k][ch] += sum_{p in img} coef[p][k] * x[ch][p]  (coef NULL: K = 1, coefficient 1; else K = 3).
+ * out must be zero-filled.  Used for bias / latent gradients and the 3-row output layer of the RGB net. */
+int sc_tbl_sum(const float* x, const float* coef, int n_points, int n_per_image, int n_images, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

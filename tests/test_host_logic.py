@@ -1,0 +1,192 @@
+"""Host-side logic that needs no GPU: options/EasyDict semantics, weight packing, TBL layout helpers,
+camera algebra and loss terms of the product vs the oracle, batch schema, checkpoint ABI."""
+import copy
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import reference_ops as R
+from shapeclipper_amd import packing, synthetic
+from shapeclipper_amd.utils import camera, options
+from shapeclipper_amd.utils.util import EasyDict as edict
+
+
+def _opt(extra=()):
+    return options.set(options.parse_arguments(["--yaml=options/pix3d/config.yaml", "--name=pytest",
+                                                "--output_root=/tmp/sc_pytest"] + list(extra)), verbose=False)
+
+
+def test_options_cli_semantics():
+    o = _opt(["--eval.vox_res=100", "--tb!", "--resume", "--optim.lr=3.e-4", "--data.pix3d.cat=table"])
+    assert o.eval.vox_res == 100 and o.tb is False and o.resume is True and o.optim.lr == 3e-4
+    assert o.data.pix3d.cat == "table" and o.batch_size == 12 and o.render.rand_sample == 512
+    assert (o.H, o.W) == (224, 224) and o.output_path == "/tmp/sc_pytest/pix3d_output/pytest"
+    assert o.hip.deterministic_conv is False
+    with pytest.raises(AssertionError):
+        options.parse_arguments(["--a.b=1", "--a.b=2"])          # duplicate key
+    with pytest.raises(AssertionError):
+        options.parse_arguments(["a=1"])                          # must start with --
+    c = copy.deepcopy(o)                                          # Loss(opt) deep-copies the options
+    c.arch.impl_sdf.n_channels = 3
+    assert o.arch.impl_sdf.n_channels == 64 and isinstance(c.arch, edict)
+
+
+def test_reference_yaml_keys_are_all_present():
+    import yaml
+    keys = {"group", "name", "load", "batch_size", "max_epoch", "yaml", "seed", "gpu", "cpu", "output_root", "image_size",
+            "resume", "pretrain", "pre", "arch", "eval", "data", "render", "reg", "loss_weight", "optim", "camera", "tb", "freq"}
+    cfg = yaml.safe_load(open("options/pix3d/config.yaml"))
+    assert keys <= set(cfg)
+    assert set(cfg["loss_weight"]) == {"eikonal", "render", "mask", "normal", "nearest_img", "nearest_mask",
+                                       "nearest_normal", "cam_uniform", "cam_margin", "category_reg", "cam_sym"}
+    assert cfg["render"] == dict(sampler="uniform", n_samples_uniform=64, rand_sample=512, ray_uniform_fac=5, normal_model="volume")
+
+
+def test_pe_slot_order_is_a_permutation_with_pads():
+    cols = [packing.pe_slot_col(c) for c in range(48)]
+    real = sorted(c for c in cols if c >= 0)
+    assert real == list(range(39)) and cols.count(-1) == 9
+    # the 13 slots that depend on coordinate c are exactly packed columns 16c..16c+15
+    for c in range(3):
+        for col in range(16 * c, 16 * c + 16):
+            r = cols[col]
+            assert r < 0 or r == c or (r - 3) % 3 == c
+
+
+def test_pack_sdf_reproduces_the_reference_mlp(golden):
+    g = golden("g2_networks")
+    W = {k[len("pert.sdf."):]: torch.tensor(g[k]) for k in g.files if k.startswith("pert.sdf.")}
+    z, pts = torch.tensor(g["z_sdf"]), torch.tensor(g["pts"])
+    pack, cb = packing.pack_sdf(W, z)
+    assert pack.numel() == packing.SDF_PACK_FLOATS and cb.shape == (2, 5, 64)
+    xs = pts.clone(); xs[:, 0] = xs[:, 0].abs()
+    e = torch.cat([R.posenc(xs, 6), torch.zeros(len(pts), 1)], 1)[:, packing._SLOT_IDX]
+    o = packing.SDF_OFF
+    m = lambda key, r, c: pack[o[key]:o[key] + r * c].view(r, c)
+    sp = lambda a: torch.nn.functional.softplus(a, beta=100)
+    img = torch.arange(256) // 128
+    h = sp(e @ m("W0", 64, 48).t() + cb[img, 0])
+    h = sp(torch.cat([h, e], 1) @ m("W1", 64, 112).t() + cb[img, 1])
+    h = sp(torch.cat([h, e], 1) @ m("W2", 64, 112).t() + cb[img, 2])
+    h = sp(h @ m("W3", 64, 64).t() + cb[img, 3])
+    h = sp(h @ m("W4", 64, 64).t() + cb[img, 4])
+    out = h @ m("W5", 65, 64).t() + pack[o["B5"]:o["B5"] + 65]
+    assert (out[:, :1] - torch.tensor(g["sdf"])).abs().max() < 1e-5
+    assert (out[:, 1:] - torch.tensor(g["feat"])).abs().max() < 1e-5
+
+
+def test_pack_rgb_reproduces_the_reference_mlp(golden):
+    g = golden("g2_networks")
+    W = {k[len("pert.rgb."):]: torch.tensor(g[k]) for k in g.files if k.startswith("pert.rgb.")}
+    z, pts, feat = torch.tensor(g["z_rgb"]), torch.tensor(g["pts"]), torch.tensor(g["feat"])
+    pack, db = packing.pack_rgb(W, z)
+    xs = pts.clone(); xs[:, 0] = xs[:, 0].abs()
+    e = torch.cat([R.posenc(xs, 6), torch.zeros(len(pts), 1)], 1)[:, packing._SLOT_IDX]
+    o = packing.RGB_OFF
+    img = torch.arange(256) // 128
+    r = torch.relu(torch.cat([e, feat], 1) @ pack[o["V0"]:o["V0"] + 64 * 112].view(64, 112).t() + db[img, 0])
+    r = torch.relu(r @ pack[o["V1"]:o["V1"] + 4096].view(64, 64).t() + db[img, 1])
+    r = torch.relu(r @ pack[o["V2"]:o["V2"] + 4096].view(64, 64).t() + db[img, 2])
+    c = torch.sigmoid(r @ pack[o["V3"]:o["V3"] + 192].view(3, 64).t() + pack[o["B3"]:o["B3"] + 3])
+    assert (c - torch.tensor(g["rgb"])).abs().max() < 1e-5
+
+
+def test_packing_is_differentiable_to_every_original_parameter():
+    cfg = R.Cfg()
+    W = {k: v.requires_grad_(True) for k, v in R.init_sdf_weights(cfg, 0).items()}
+    z = torch.randn(3, 64, requires_grad=True)
+    pack, cb = packing.pack_sdf(W, z)
+    (pack.sum() + cb.sum()).backward()
+    assert all(v.grad is not None for v in W.values()) and z.grad is not None
+    # latent columns receive gradient only through cbias, PE/hidden columns only through the pack
+    assert torch.all(W["lin0.weight"].grad[:, :39] == 1) and torch.allclose(W["lin1.weight"].grad[:, :64], torch.full((64, 64), 1 / math.sqrt(2)))
+
+
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 100])
+def test_tbl_roundtrip(n):
+    x = torch.randn(n, 64)
+    t = packing.rows_to_tbl(x)
+    assert t.numel() == packing.n_tiles(n) * 1024
+    assert torch.equal(packing.tbl_to_rows(t, n), x)
+    # element (point p, channel c) lives at float4 block [tile][c//4][p%16], lane c%4
+    p, c = n - 1, 37
+    assert t.view(-1, 16, 16, 4)[p // 16, c // 4, p % 16, c % 4] == x[p, c]
+
+
+def test_camera_matches_oracle_on_selected_pixels(golden):
+    g = golden("g8_camera")
+    o = _opt(); o.H, o.W = 8, 8
+    pose, intr = torch.tensor(g["pose"]), torch.tensor(g["intr"])
+    c, r = camera.get_center_and_ray(o, pose, intr=intr)
+    assert torch.allclose(c, torch.tensor(g["center"]), atol=1e-6) and torch.allclose(r, torch.tensor(g["ray"]), atol=2e-6)
+    idx = torch.tensor([[3, 60, 17], [0, 63, 32]])
+    c2, r2 = camera.get_center_and_ray(o, pose, intr=intr, ray_idx=idx)
+    assert torch.allclose(r2, torch.tensor(g["ray"]).gather(1, idx[..., None].expand(-1, -1, 3)), atol=2e-6)
+    assert torch.allclose(camera.get_intr(o, torch.tensor(g["scale_focal"])), intr)
+    assert torch.allclose(camera.transform_normal(torch.tensor(g["normals"]), pose), torch.tensor(g["normals_transformed"]), atol=1e-6)
+    M = torch.randn(5, 3, 3) + 3 * torch.eye(3)
+    assert torch.allclose(camera.inverse3x3(M) @ M, torch.eye(3).expand(5, 3, 3), atol=1e-5)
+    from shapeclipper_amd.model.graph import rotation_from_trig
+    Rm = rotation_from_trig(torch.tensor(g["trig_azim"]), torch.tensor(g["trig_elev"]), torch.tensor(g["trig_theta"]))
+    assert torch.allclose(Rm, pose[..., :3], atol=1e-6)
+
+
+def test_product_losses_match_golden(golden):
+    from shapeclipper_amd.model.loss import Loss
+    g = golden("g7_losses")
+    o = _opt()
+    L = Loss(o)
+    t = lambda k: torch.tensor(g[k])
+    val = lambda k: float(g["val." + k])
+    assert abs(L.MSE_loss(t("pred3"), t("tgt3")).item() - val("mse")) < 1e-6
+    assert abs(L.MSE_loss(t("pred3"), t("tgt3"), tolerance=0.2).item() - val("mse_tol")) < 1e-6
+    assert abs(L.MSE_loss(t("eik"), 1).item() - val("mse_eik")) < 1e-6
+    assert abs(L.L1_loss(t("pred3"), t("tgt3")).item() - val("l1")) < 1e-6
+    assert abs(L.iou_loss(t("pm"), t("tm")).item() - val("iou")) < 1e-6
+    assert abs(L.iou_loss(t("pm").clone(), t("tm"), tolerance=0.1).item() - val("iou_tol")) < 1e-6
+    assert abs(L.mask_loss(t("pm"), t("tm")).item() - val("mask")) < 1e-6
+    assert abs(L.normal_loss(t("npred"), t("ngt"), t("nmask"), tolerance=0.2).item() - val("normal")) < 1e-5
+    assert abs(L.normal_loss(t("npred"), t("ngt"), t("nmask")).item() - val("normal_notol")) < 1e-5
+    assert abs(L.cam_uniform_loss(o, t("trig")).item() - val("cam_uniform")) < 1e-6
+    assert abs(L.cam_margin(o, t("trig_e"), [-90 + 1e-3, 90 - 1e-3]).item() - val("cam_margin")) < 1e-5
+
+
+def test_synthetic_batch_schema_and_graph_abi():
+    o = _opt(["--arch.enc_pretrained!"])
+    b = synthetic.make_batch(o, 2)
+    assert b.rgb_input_map.shape == (2, 3, 224, 224) and b.ray_idx.shape == (2, 512) and b.ray_idx.dtype == torch.int64
+    assert b.rgb_input.shape == (2, 512, 3) and b.mask_input.shape == (2, 512, 1) and b.normal_input.shape == (2, 512, 3)
+    assert b.rgb_input_NN.shape == (2, 512, 3, 5) and b.rgb_input_map_NN.shape == (2, 3, 224, 224, 5)
+    assert b.ray_idx_NN.shape == (2, 512, 5) and b.pose_gt_NN.shape == (2, 3, 4, 5) and b.pose_gt.shape == (2, 3, 4)
+    assert torch.equal(b.rgb_input[0, 5], b.rgb_input_map[0, :, b.ray_idx[0, 5] // 224, b.ray_idx[0, 5] % 224])
+    from shapeclipper_amd.model.graph import Graph
+    graph = Graph(o)
+    assert [n for n, _ in graph.named_children()] == ["estimator", "sdf_network", "rgb_network", "renderer", "encoder",
+                                                      "latent_proj_shape", "latent_proj_rgb", "loss_fns"]
+    sd = graph.state_dict()
+    for k in ("sdf_network.lin0.weight", "renderer.sdf_network.lin5.bias", "renderer.density.beta", "rgb_network.lin3.weight",
+              "encoder.layer4.2.bn2.running_var", "estimator.feature_extractor.layer1.0.conv1.weight", "estimator.extr_fc.bias",
+              "latent_proj_shape.0.linear1.weight", "latent_proj_rgb.2.bias"):
+        assert k in sd, k
+    assert abs(sum(p.numel() for p in graph.parameters()) / 1e6 - 36.8) < 0.05
+    assert graph.sdf_network.lin0.weight.shape == (64, 103) and graph.sdf_network.lin1.weight.shape == (64, 167)
+    assert graph.rgb_network.lin0.weight.shape == (64, 167) and graph.sdf_network.lin5.weight.shape == (65, 64)
+    # same RNG stream as the reference's SDFNetwork init (oracle reproduces it, golden pins the oracle)
+    from shapeclipper_amd.model.implicit import SDFNetwork
+    torch.manual_seed(0)
+    net = SDFNetwork(o)
+    W0 = R.init_sdf_weights(R.Cfg(), 0)
+    assert all(torch.equal(net.state_dict()[k], v) for k, v in W0.items())
+
+
+def test_uniform_sampler_consumes_the_reference_rng_stream(golden):
+    from shapeclipper_amd.model.renderer import UniformSampler
+    g = golden("g6_render_train")
+    o = _opt()
+    torch.manual_seed(78)
+    z, z_eik = UniformSampler(o).get_z_vals(o, torch.zeros(64, 3), torch.tensor(g["scale_dist"]), training=True)
+    zr, zer = R.get_z_vals(R.Cfg(), 64, torch.tensor(g["scale_dist"]), True, torch.tensor(g["t_rand"]), torch.tensor(g["eik_idx"]))
+    assert torch.allclose(z, zr, atol=1e-6) and torch.allclose(z_eik, zer, atol=1e-6)
+    assert torch.equal(torch.empty(64, 3).uniform_(-1, 1), torch.tensor(g["eik_pts"]))    # third draw of the stream

@@ -1,0 +1,134 @@
+"""The CPU oracle (oracle/reference_ops.py, oracle/chamfer_ref.c) against the golden vectors captured
+from the reference's own modules (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import torch
+
+from oracle import chamfer_ref
+from oracle import reference_ops as R
+
+T = torch.tensor
+
+
+def _W(g, prefix):
+    return {k[len(prefix):]: T(g[k]) for k in g.files if k.startswith(prefix)}
+
+
+def test_g1_posenc(golden):
+    g = golden("g1_posenc")
+    assert torch.equal(R.posenc(T(g["x"]), 6), T(g["pe"]))
+
+
+def test_g2_networks_and_init(golden):
+    g = golden("g2_networks")
+    cfg = R.Cfg()
+    W0 = R.init_sdf_weights(cfg, 0)
+    for k, v in W0.items():
+        assert torch.equal(v, T(g["sdf." + k])), k            # same RNG stream as SDFNetwork.__init__
+    Ws, Wr = _W(g, "pert.sdf."), _W(g, "pert.rgb.")
+    pts = T(g["pts"])
+    sdf, feat, grad = R.sdf_conditional(cfg, Ws, 2, pts.clone(), T(g["z_sdf"]), compute_grad=True)
+    assert torch.allclose(sdf.detach(), T(g["sdf"]), atol=1e-6) and torch.allclose(feat.detach(), T(g["feat"]), atol=1e-6)
+    assert torch.allclose(grad.detach(), T(g["grad"]), atol=1e-5)
+    lat = T(g["z_rgb"]).unsqueeze(1).repeat(1, 128, 1).view(256, -1)
+    assert torch.allclose(R.rgb_mlp(cfg, Wr, pts, lat, T(g["feat"])), T(g["rgb"]), atol=1e-6)
+    # x-mirror symmetry (force_symmetry) known answer
+    p = torch.tensor([[0.3, 0.2, 0.1], [-0.3, 0.2, 0.1]])
+    s = R.sdf_conditional(cfg, Ws, 1, p, T(g["z_sdf"])[:1], compute_grad=False)[0]
+    assert s[0].item() == s[1].item()
+
+
+def test_g3_laplace(golden):
+    g = golden("g3_laplace")
+    d = R.laplace_density(T(g["sdf"]), T(g["beta"]))
+    assert torch.allclose(d, T(g["density"]), rtol=1e-6)
+    assert abs(d[0].item() - 9.3127) < 1e-3 and abs(d[1].item() - 4.9950) < 1e-3 and abs(d[2].item() - 0.67735) < 1e-4
+
+
+def test_g4_volume_rendering(golden):
+    g = golden("g4_volume_rendering")
+    w, a = R.volume_rendering(T(g["z_vals"]), T(g["sdf"]), T(g["beta"]))
+    assert torch.allclose(w, T(g["weights"]), atol=1e-6) and torch.allclose(a, T(g["alpha"]), atol=1e-6)
+    assert torch.all(a[:, -1] == 0) and torch.all(w.sum(1) <= 1 + 1e-5)
+
+
+def test_g5_g6_render(golden):
+    g2 = golden("g2_networks")
+    Ws, Wr = _W(g2, "pert.sdf."), _W(g2, "pert.rgb.")
+    cfg = R.Cfg(H=8, W=8)
+    g = golden("g5_render_eval")
+    t = lambda k: T(g[k])
+    _, eik_idx, _ = R.draw_render_randoms(128, 64, False)
+    o = R.render(cfg, Ws, Wr, t("beta"), t("pose"), t("intr"), t("scale_dist"), t("z_sdf"), t("z_rgb"), None, False, None, eik_idx, None)
+    for k in ("rgb", "mask", "mask_hard", "depth", "normal"):
+        assert torch.allclose(o[k].detach(), t(k), atol=2e-6), k
+    g = golden("g6_render_train")
+    t = lambda k: T(g[k])
+    o = R.render(cfg, Ws, Wr, t("beta"), t("pose"), t("intr"), t("scale_dist"), t("z_sdf"), t("z_rgb"), t("ray_idx"), True,
+                 t("t_rand"), t("eik_idx"), t("eik_pts"))
+    for k in ("rgb", "mask", "depth", "normal", "grad_eikonal"):
+        assert torch.allclose(o[k].detach(), t(k), atol=2e-6), k
+    assert o["grad_eikonal"].shape[0] == 2 * 2 * 32
+
+
+def test_g7_losses(golden):
+    g = golden("g7_losses")
+    cfg = R.Cfg()
+    t = lambda k: T(g[k])
+    val = lambda k: float(g["val." + k])
+    assert abs(R.mse_loss(t("pred3"), t("tgt3")).item() - val("mse")) < 1e-6
+    assert abs(R.mse_loss(t("pred3"), t("tgt3"), tolerance=0.2).item() - val("mse_tol")) < 1e-6
+    assert abs(R.mask_loss(cfg, t("pm"), t("tm")).item() - val("mask")) < 1e-6
+    assert abs(R.iou_loss(t("pm").clone(), t("tm"), tolerance=0.1).item() - val("iou_tol")) < 1e-6
+    assert abs(R.normal_loss(cfg, t("npred"), t("ngt"), t("nmask"), tolerance=0.2).item() - val("normal")) < 1e-5
+    assert abs(R.cam_uniform_loss(cfg, t("trig")).item() - val("cam_uniform")) < 1e-6
+    assert abs(R.cam_margin(t("trig_e"), [-90 + 1e-3, 90 - 1e-3]).item() - val("cam_margin")) < 1e-5
+    assert torch.allclose(R.nn_view_scores(t("tm"), t("mask_NN"), 4), t("nn_probs"), atol=1e-6)
+
+
+def test_g8_camera(golden):
+    g = golden("g8_camera")
+    cfg = R.Cfg(H=8, W=8)
+    t = lambda k: T(g[k])
+    pose = R.pose_from_trig(cfg, t("trig_azim"), t("trig_elev"), t("trig_theta"), t("scale_dist"))
+    assert torch.allclose(pose, t("pose"), atol=1e-6)
+    c, r = R.get_center_and_ray(cfg, pose, R.get_intr(cfg, t("scale_focal")))
+    assert torch.allclose(c, t("center"), atol=1e-6) and torch.allclose(r, t("ray"), atol=1e-6)
+    # identity-R, t=(0,0,5): origin (0,0,-5), first ray (-0.12256,-0.12256,0.98486) before normalisation -> normalised
+    assert np.allclose(g["center224"][0, 0], [0, 0, -5], atol=1e-6)
+    r0 = g["ray224_first"][0] / np.linalg.norm(g["ray224_first"][0])
+    assert np.allclose(r0, [-0.12256, -0.12256, 0.98486], atol=1e-4)
+    assert torch.allclose(R.transform_normal(t("normals"), t("pose")), t("normals_transformed"), atol=1e-6)
+
+
+def test_g9_chamfer_c_oracle(golden):
+    g = golden("g9_chamfer")
+    d1, d2, i1, i2 = chamfer_ref.chamfer_forward(g["xyz1"], g["xyz2"])
+    assert np.array_equal(i1, g["idx1"]) and np.array_equal(i2, g["idx2"])
+    assert np.array_equal(d1, g["dist1"]) and np.array_equal(d2, g["dist2"])
+    # independent float64 brute force: the C oracle's index is a true minimiser; duplicates -> lowest index
+    a, b = g["xyz1"].astype(np.float64), g["xyz2"].astype(np.float64)
+    D = ((a[:, :, None] - b[:, None]) ** 2).sum(-1)
+    assert np.abs(D.min(2) - d1).max() < 1e-6
+    dup = np.where((g["xyz2"][0] == g["xyz2"][0, 7]).all(-1))[0]
+    assert np.all(i1[0][np.isin(i1[0], dup)] == 7)
+    g1, g2 = chamfer_ref.chamfer_backward(g["xyz1"], g["xyz2"], g["gd1"], g["gd2"], g["idx1"], g["idx2"])
+    assert np.allclose(g1, g["g1"], atol=1e-6) and np.allclose(g2, g["g2"], atol=1e-6)
+    # self distance: 0 with identity index
+    s1, s2, j1, j2 = chamfer_ref.chamfer_forward(g["xyz1"][:, :64], g["xyz1"][:, :64])
+    assert np.all(s1 == 0) and np.array_equal(j1[0], np.arange(64))
+    # numpy fp32 brute force agrees on the index away from near-ties
+    n1, _, ni1, _ = R.chamfer_forward_f32(g["xyz1"][:, :200], g["xyz2"][:, :300])
+    c1, _, ci1, _ = chamfer_ref.chamfer_forward(g["xyz1"][:, :200], g["xyz2"][:, :300])
+    assert (ni1 == ci1).mean() > 0.99 and np.abs(n1 - c1).max() < 1e-6
+
+
+def test_g10_eval3d(golden):
+    g = golden("g10_eval3d")
+    t = lambda k: T(g[k])
+    assert torch.allclose(R.compute_fscore(t("dist1"), t("dist2")), t("fscore"))
+    assert torch.allclose(R.normalize_pc(t("pc")), t("pc_normalized"), atol=1e-6)
+    assert torch.equal(R.dense_grid(-0.6, 0.6, 6, 2), t("grid"))
+    assert float(R.compute_fscore(t("dist1") * 0, t("dist1") * 0).min()) == 1.0     # identical clouds -> F = 1
+    g2 = golden("g2_networks")
+    lvl = R.level_grid(R.Cfg(), _W(g2, "pert.sdf."), t("z_sdf"), t("grid"))
+    assert torch.allclose(lvl, t("level"), atol=1e-6)
