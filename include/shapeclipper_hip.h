@@ -111,6 +111,19 @@ int sc_partial_reduce(const float* partial, int nparts, int stride, int n, float
  * out must be zero-filled.  Used for bias / latent gradients and the 3-row output layer of the RGB net. */
 int sc_tbl_sum(const float* x, const float* coef, int n_points, int n_per_image, int n_images, float* out, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Loss reductions of one render in one launch (Loss.MSE_loss / mask_loss / normal_loss, model/loss.py:19-97
+ * as called from Graph.compute_loss, model/graph.py:224-236, 252-264).
+ * rgb, rgb_t, normal, normal_t [B][R][3]; mask, mask_t [B][R]; eik [B][E] or NULL.
+ * normal mask = (mask_t > 0.5) & (mask > 0.5); keep_frac = 1 - reg.normal_tol (double: the cut is
+ * int(n * keep_frac) as in loss.py:62).  out4 (zero-filled by the caller) receives
+ * (render MSE, IoU + mask_mse*MSE, robust normal loss, eikonal MSE); g_* receive d loss_k / d prediction.
+ * ang_ws: [B*R] floats of workspace.                                                               */
+int sc_loss_fused_forward(const float* rgb, const float* rgb_t, const float* mask, const float* mask_t,
+                          const float* normal, const float* normal_t, const float* eik, int B, int R, int E,
+                          float normal_l1, float mask_mse, double keep_frac, float* out4, float* g_rgb,
+                          float* g_mask, float* g_normal, float* g_eik, float* ang_ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,210 @@
+// loss.hip -- the per-step loss reductions of one render in ONE launch (values + input gradients).
+//
+// Replaces, for the [B,R,*] tensors a render produces (reference model/graph.py:220-265 -> model/loss.py):
+//   render  : Loss.MSE_loss(rgb, rgb_target)                                   loss.py:19-32
+//   mask    : Loss.mask_loss = iou_loss + reg.mask_mse * MSE_loss              loss.py:75-97
+//   normal  : Loss.normal_loss (mask compaction, 5*L1 + angular, keep the int(n*(1-tol)) smallest
+//             angular errors, mean)                                            loss.py:52-67
+//   eikonal : Loss.MSE_loss(|grad sdf|, 1)                                     loss.py:19-32
+// The reference spends ~60 launch-bound torch kernels (+ a full sort and two boolean-index syncs)
+// on this per render; here blocks 0..B-1 do the per-image sums (IoU needs per-image numerators) and
+// block B does the robust normal selection with a 4-pass radix select instead of a sort.
+// Loss values are accumulated with atomicAdd into out[4] (pre-zeroed); the gradients of each loss
+// w.r.t. its prediction are written alongside (the backward is then 4 scalings).
+// Bound: latency (tensors are tens of KB); the metric is microseconds and launch count.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sc {
+
+struct LossArgs {
+    const float* rgb; const float* rgb_t;        // [B][R][3]
+    const float* mask; const float* mask_t;      // [B][R]
+    const float* normal; const float* normal_t;  // [B][R][3]
+    const float* eik;                            // [B][E] or null
+    int B, R, E;
+    float normal_l1, mask_mse;
+    double keep_frac;                            // 1 - reg.normal_tol
+    float* out;                                  // [4]: render, mask, normal, eikonal (pre-zeroed)
+    float* g_rgb; float* g_mask; float* g_normal; float* g_eik;
+    float* ang_ws;                               // [B*R] workspace (angular error of masked rays)
+};
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int k = 0; k < nw; ++k) s += red[k];
+    return s;
+}
+
+__device__ __forceinline__ uint32_t order_key(float f) {   // monotone float -> uint map
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(1024) void loss_fused_kernel(LossArgs a) {
+    __shared__ float red[16];
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned int sh_prefix, sh_remaining, sh_n;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if ((int)blockIdx.x < a.B) {
+        // ---------------- per-image sums: MSE partials + IoU ----------------
+        const int b = blockIdx.x;
+        const float inv_rgb = 1.f / ((float)a.B * a.R * 3), inv_m = 1.f / ((float)a.B * a.R);
+        float s_rgb = 0.f, s_mm = 0.f, s_i = 0.f, s_u = 0.f, s_e = 0.f;
+        for (int i = tid; i < a.R * 3; i += nt) {
+            const float d = a.rgb[(size_t)b * a.R * 3 + i] - a.rgb_t[(size_t)b * a.R * 3 + i];
+            s_rgb += d * d;
+            a.g_rgb[(size_t)b * a.R * 3 + i] = 2.f * d * inv_rgb;
+        }
+        for (int i = tid; i < a.R; i += nt) {
+            const float p = a.mask[(size_t)b * a.R + i], t = a.mask_t[(size_t)b * a.R + i];
+            s_mm += (p - t) * (p - t);
+            s_i += p * t;
+            s_u += p + t - p * t + 1.e-8f;
+        }
+        if (a.eik) {
+            const float inv_e = 1.f / ((float)a.B * a.E);
+            for (int i = tid; i < a.E; i += nt) {
+                const float d = a.eik[(size_t)b * a.E + i] - 1.f;
+                s_e += d * d;
+                a.g_eik[(size_t)b * a.E + i] = 2.f * d * inv_e;
+            }
+            s_e = block_sum(s_e, red);
+        }
+        s_rgb = block_sum(s_rgb, red);
+        s_mm = block_sum(s_mm, red);
+        const float I = block_sum(s_i, red), U = block_sum(s_u, red);
+        // d/dp [1 - I/U] = -(t*U - I*(1-t)) / U^2 ; mean over the B images
+        for (int i = tid; i < a.R; i += nt) {
+            const float p = a.mask[(size_t)b * a.R + i], t = a.mask_t[(size_t)b * a.R + i];
+            a.g_mask[(size_t)b * a.R + i] = -(t * U - I * (1.f - t)) / (U * U) / (float)a.B
+                                            + a.mask_mse * 2.f * (p - t) * inv_m;
+        }
+        if (tid == 0) {
+            atomicAdd(&a.out[0], s_rgb * inv_rgb);
+            atomicAdd(&a.out[1], (1.f - I / U) / (float)a.B + a.mask_mse * s_mm * inv_m);
+            if (a.eik) atomicAdd(&a.out[3], s_e / ((float)a.B * a.E));
+        }
+        return;
+    }
+    // ---------------- block B: robust masked normal loss over the whole batch ----------------
+    const int N = a.B * a.R;
+    unsigned int n_local = 0;
+    for (int i = tid; i < N; i += nt) {
+        const bool m = a.mask_t[i] > 0.5f && a.mask[i] > 0.5f;
+        float ang = 0.f;
+        if (m) {
+            ang = 1.f - (a.normal[i * 3] * a.normal_t[i * 3] + a.normal[i * 3 + 1] * a.normal_t[i * 3 + 1]
+                         + a.normal[i * 3 + 2] * a.normal_t[i * 3 + 2]);
+            ++n_local;
+        }
+        a.ang_ws[i] = m ? ang : __builtin_nanf("");    // NaN marks "not in the mask"
+    }
+    if (tid == 0) sh_n = 0;
+    __syncthreads();
+    atomicAdd(&sh_n, n_local);
+    __syncthreads();
+    const unsigned int n = sh_n;
+    const unsigned int n_keep = (unsigned int)((double)n * a.keep_frac);
+    // radix select: key of the n_keep-th smallest angular error (1-based rank n_keep)
+    uint32_t prefix = 0, kth_key = 0;
+    unsigned int remaining = n_keep;      // rank (1-based) inside the current candidate set
+    if (n_keep > 0) {
+        for (int pass = 3; pass >= 0; --pass) {
+            for (int k = tid; k < 256; k += nt) hist[k] = 0;
+            __syncthreads();
+            const uint32_t hi_mask = pass == 3 ? 0u : (0xFFFFFFFFu << (8 * (pass + 1)));
+            for (int i = tid; i < N; i += nt) {
+                const float v = a.ang_ws[i];
+                if (v == v) {
+                    const uint32_t key = order_key(v);
+                    if ((key & hi_mask) == (prefix & hi_mask)) atomicAdd(&hist[(key >> (8 * pass)) & 255u], 1u);
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned int acc = 0, r = remaining;
+                int d = 0;
+                for (; d < 256; ++d) {
+                    if (acc + hist[d] >= r) break;
+                    acc += hist[d];
+                }
+                sh_prefix = prefix | ((uint32_t)d << (8 * pass));
+                sh_remaining = r - acc;
+            }
+            __syncthreads();
+            prefix = sh_prefix;
+            remaining = sh_remaining;
+            __syncthreads();
+        }
+        kth_key = prefix;       // `remaining` = how many elements equal to the k-th value are kept (by index order)
+    }
+    // keep: key < kth, plus the first `remaining` ties in index order (ties are exact float duplicates)
+    __shared__ unsigned int tie_taken;
+    if (tid == 0) tie_taken = 0;
+    __syncthreads();
+    float s_loss = 0.f;
+    const float inv_keep = n_keep > 0 ? 1.f / (float)n_keep : 0.f;
+    // ties: process in index order with a serialised counter only when needed (rare)
+    for (int base = 0; base < N; base += nt) {
+        const int i = base + tid;
+        bool keep = false, tie = false;
+        float v = 0.f;
+        if (i < N) {
+            v = a.ang_ws[i];
+            if (v == v && n_keep > 0) {
+                const uint32_t key = order_key(v);
+                keep = key < kth_key;
+                tie = key == kth_key;
+            }
+        }
+        if (__syncthreads_or(tie)) {
+            // rank ties inside this chunk by thread index (chunks are visited in index order)
+            for (int w = 0; w < nt; w += 64) {
+                if ((tid & ~63) == w) {
+                    const unsigned long long bal = __ballot(tie);
+                    if (tie) {
+                        const unsigned int before = __popcll(bal & ((1ull << (tid & 63)) - 1ull));
+                        if (tie_taken + before < remaining) keep = true;
+                    }
+                    if ((tid & 63) == 0 && bal) tie_taken += __popcll(bal);
+                }
+                __syncthreads();
+            }
+        }
+        if (i < N) {
+            float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+            if (keep) {
+                const float p0 = a.normal[i * 3], p1 = a.normal[i * 3 + 1], p2 = a.normal[i * 3 + 2];
+                const float t0 = a.normal_t[i * 3], t1 = a.normal_t[i * 3 + 1], t2 = a.normal_t[i * 3 + 2];
+                const float l1 = fabsf(p0 - t0) + fabsf(p1 - t1) + fabsf(p2 - t2);
+                s_loss += a.normal_l1 * l1 + v;
+                auto sgn = [](float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); };
+                g0 = (a.normal_l1 * sgn(p0 - t0) - t0) * inv_keep;
+                g1 = (a.normal_l1 * sgn(p1 - t1) - t1) * inv_keep;
+                g2 = (a.normal_l1 * sgn(p2 - t2) - t2) * inv_keep;
+            }
+            a.g_normal[i * 3] = g0; a.g_normal[i * 3 + 1] = g1; a.g_normal[i * 3 + 2] = g2;
+        }
+    }
+    s_loss = block_sum(s_loss, red);
+    if (tid == 0) a.out[2] = n_keep > 0 ? s_loss * inv_keep : __builtin_nanf("");   // mean of an empty set is NaN (torch)
+}
+
+}  // namespace sc
+
+extern "C" int sc_loss_fused_forward(const float* rgb, const float* rgb_t, const float* mask, const float* mask_t,
+                                     const float* normal, const float* normal_t, const float* eik, int B, int R, int E,
+                                     float normal_l1, float mask_mse, double keep_frac, float* out4, float* g_rgb,
+                                     float* g_mask, float* g_normal, float* g_eik, float* ang_ws, void* stream_) {
+    if (B <= 0 || R <= 0) return 0;
+    sc::LossArgs a{rgb, rgb_t, mask, mask_t, normal, normal_t, eik, B, R, E, normal_l1, mask_mse, keep_frac,
+                   out4, g_rgb, g_mask, g_normal, g_eik, ang_ws};
+    hipLaunchKernelGGL(sc::loss_fused_kernel, dim3(B + 1), dim3(1024), 0, (hipStream_t)stream_, a);
+    return (int)hipGetLastError();
+}

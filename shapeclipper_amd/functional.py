@@ -78,3 +78,25 @@ class RgbCompositeFunction(torch.autograd.Function):
                                        c(G_rgb), c(G_mask), c(G_depth), c(G_normal))
         return (g["points"], g["z_vals"], g["depth_fac"], g["sdf"], g["grad"], g["feat"], g["v_pack"], g["dbias"],
                 g["beta"].reshape(beta_shape), None, None, None, None, None, None)
+
+
+class FusedRenderLoss(torch.autograd.Function):
+    """render MSE, mask (IoU + mask_mse*MSE), robust masked normal loss and eikonal MSE of one render in a
+    single HIP launch (csrc/loss.hip).  Returns a [4] tensor (render, mask, normal, eikonal)."""
+
+    @staticmethod
+    def forward(ctx, rgb, rgb_t, mask, mask_t, normal, normal_t, eik, normal_l1, mask_mse, keep_frac):
+        out, grads = ops.loss_fused_forward(rgb, rgb_t, mask, mask_t, normal, normal_t, eik, normal_l1, mask_mse, keep_frac)
+        ctx.shapes = (rgb.shape, mask.shape, normal.shape, eik.shape if eik is not None else None)
+        ctx.save_for_backward(*[g for g in grads if g is not None])
+        ctx.has_eik = eik is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        saved = ctx.saved_tensors
+        g_rgb, g_mask, g_normal = saved[0], saved[1], saved[2]
+        s_rgb, s_mask, s_normal, s_eik = ctx.shapes
+        g_eik = (saved[3] * G[3]).view(s_eik) if ctx.has_eik else None
+        return ((g_rgb * G[0]).view(s_rgb), None, (g_mask * G[1]).view(s_mask), None, (g_normal * G[2]).view(s_normal),
+                None, g_eik, None, None, None)

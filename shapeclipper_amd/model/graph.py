@@ -161,6 +161,10 @@ class Graph(nn.Module):
         w2 = var.category_weight.view(B, 1) if "category_weight" in var else None
         lw, fns = opt.loss_weight, self.loss_fns
         mask_gt = var.mask_gt if "mask_gt" in var else var.mask_input
+        fused = (w3 is None and var.rgb_recon.is_cuda and lw.render is not None and lw.mask is not None
+                 and lw.normal is not None and var.rgb_recon.dim() == 3 and opt.get("hip", {}).get("fused_loss", True))
+        if fused:
+            return self.compute_loss_fused(opt, var, training, mask_gt)
         if lw.render is not None:
             out.render = fns.MSE_loss(var.rgb_recon, var.rgb_gt if "rgb_gt" in var else var.rgb_input, weight=w3)
         if lw.mask is not None:
@@ -191,6 +195,45 @@ class Graph(nn.Module):
                     total = total + fns.normal_loss(var["normal_recon_NN_{}".format(v)], target, valid, weight=w3,
                                                     tolerance=opt.reg.normal_tol)
                 out.nearest_normal = total
+        return out
+
+    def compute_loss_fused(self, opt, var, training, mask_gt):
+        """Same dictionary as compute_loss, with the [B,R,*] reductions of each render done by ONE HIP launch
+        (csrc/loss.hip) instead of ~60 small torch kernels, a sort and two boolean-index syncs."""
+        from ..functional import FusedRenderLoss
+        out = edict()
+        B = len(var.idx)
+        lw, fns = opt.loss_weight, self.loss_fns
+        keep = 1 - opt.reg.normal_tol
+        rgb_gt = var.rgb_gt if "rgb_gt" in var else var.rgb_input
+        eik = var.grad_eikonal.view(B, -1) if (training and lw.eikonal is not None) else None
+        main = FusedRenderLoss.apply(var.rgb_recon, rgb_gt, var.mask_recon, mask_gt, var.normal_recon,
+                                     var.normal_transformed, eik, float(opt.reg.normal_l1), float(opt.reg.mask_mse), keep)
+        out.render, out.mask, out.normal = main[0], main[1], main[2]
+        if training:
+            if eik is not None:
+                out.eikonal = main[3]
+            if lw.cam_margin is not None:
+                out.cam_margin = fns.cam_margin_loss(opt, var)
+            if lw.cam_uniform is not None:
+                out.cam_uniform = fns.cam_uniform_loss(opt, var.trig_azim)
+            if lw.cam_sym is not None:
+                out.cam_sym = fns.cam_sym_loss(opt, var, self.estimator)
+            if lw.nearest_img is not None or lw.nearest_mask is not None or lw.nearest_normal is not None:
+                tot = None
+                for v in range(opt.reg.n_views):
+                    nn_in = var["input_NN_{}".format(v)]
+                    target = camera.transform_normal(nn_in.normal_input, var["pose_NN_{}".format(v)])
+                    r = FusedRenderLoss.apply(var["rgb_recon_NN_{}".format(v)], nn_in.rgb_input, var["mask_recon_NN_{}".format(v)],
+                                              nn_in.mask_input, var["normal_recon_NN_{}".format(v)], target, None,
+                                              float(opt.reg.normal_l1), float(opt.reg.mask_mse), keep)
+                    tot = r if tot is None else tot + r
+                if lw.nearest_img is not None:
+                    out.nearest_img = tot[0]
+                if lw.nearest_mask is not None:
+                    out.nearest_mask = tot[1]
+                if lw.nearest_normal is not None:
+                    out.nearest_normal = tot[2]
         return out
 
     # ------------------------------------------------------------------------------------------------

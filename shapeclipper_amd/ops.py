@@ -206,3 +206,29 @@ def rgb_composite_backward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, d
     g["v_pack"] = g_v
     g["dbias"] = torch.stack([tbl_sum(GY(l), P, rays_per_image * 64, n_images).view(n_images, 64) for l in range(3)], dim=1)
     return g
+
+
+def loss_fused_forward(rgb, rgb_t, mask, mask_t, normal, normal_t, eik, normal_l1, mask_mse, keep_frac):
+    """-> (out [4] = (render, mask, normal, eikonal) losses, (g_rgb, g_mask, g_normal, g_eik|None))."""
+    lib = _lib.load()
+    B, R = rgb.shape[0], rgb.shape[1]
+    dev = rgb.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    c = lambda t: t.detach().contiguous().float()
+    rgb, rgb_t, normal, normal_t = c(rgb), c(rgb_t), c(normal), c(normal_t)
+    mask, mask_t = c(mask).view(B, R), c(mask_t).view(B, R)
+    E = 0
+    if eik is not None:
+        eik = c(eik).view(B, -1)
+        E = eik.shape[1]
+    out = torch.zeros(4, **f32)
+    g_rgb, g_mask, g_normal = torch.empty(B, R, 3, **f32), torch.empty(B, R, **f32), torch.empty(B, R, 3, **f32)
+    g_eik = torch.empty(B, E, **f32) if eik is not None else None
+    ws = torch.empty(B * R, **f32)
+    code = lib.sc_loss_fused_forward(_lib.ptr(rgb), _lib.ptr(rgb_t), _lib.ptr(mask), _lib.ptr(mask_t), _lib.ptr(normal),
+                                     _lib.ptr(normal_t), _lib.ptr(eik), c_int(B), c_int(R), c_int(E),
+                                     ctypes.c_float(normal_l1), ctypes.c_float(mask_mse), ctypes.c_double(keep_frac),
+                                     _lib.ptr(out), _lib.ptr(g_rgb), _lib.ptr(g_mask), _lib.ptr(g_normal),
+                                     _lib.ptr(g_eik), _lib.ptr(ws), _lib.stream())
+    _lib.check(code, "sc_loss_fused_forward")
+    return out, (g_rgb, g_mask, g_normal, g_eik)
