@@ -50,13 +50,14 @@ int sc_chamfer3d_backward(const float* xyz1, const float* xyz2, float* gradxyz1,
  * Outputs (any may be NULL):  sdf [n_points];  grad [n_points][3] = d sdf / d point (its presence
  * selects the gradient kernel);  feat / stash_a / stash_p: tile-blocked 64-channel tensors
  * (TBL64: [ceil(n/16)][16][16][4] floats), stash_a holds 5 and stash_p 4 such tensors back to back
- * (pre-activations a_0..a_4 and adjoints p_0..p_3 kept for sc_sdf_backward).                    */
+ * (pre-activations a_0..a_4 and adjoints p_0..p_3 kept for sc_sdf_backward).
+ * scratch: required when grad != NULL and stash_a == NULL: 256*8*5*1024 floats of per-wave scratch.  */
 #define SC_SDF_PACK_FLOATS (64*48 + 2*64*112 + 2*64*64 + 65*64 + 65)
 #define SC_RGB_PACK_FLOATS (64*112 + 2*64*64 + 3*64 + 4)
 #define SC_TILE_POINTS 16
 int sc_sdf_forward(const float* points, const float* w_pack, const float* cbias, int n_points,
                    int n_per_image, int n_images, int symmetric, float* sdf, float* grad,
-                   float* feat, float* stash_a, float* stash_p, void* stream);
+                   float* feat, float* stash_a, float* stash_p, float* scratch, void* stream);
 
 /* Reverse pass of sc_sdf_forward incl. the second-order terms of d/dtheta[d sdf/dx] (what autograd's
  * double backward does for model/implicit.py:180-186 + model/renderer.py:101-107).

@@ -36,10 +36,12 @@ struct SdfBwdArgs {
     float* r0;             // TBL64 out
 };
 
+constexpr int SDFB_WAVES = 8;   // 2 waves per SIMD: this kernel is dominated by stash loads (64 % wave-cycles in s_waitcnt at 1 wave/SIMD)
+
 template <bool HAS_GG>
-__global__ __launch_bounds__(256) void sdf_bwd_kernel(SdfBwdArgs a) {
+__global__ __launch_bounds__(64 * SDFB_WAVES) void sdf_bwd_kernel(SdfBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    stage_sdf_weights(lds, a.w, threadIdx.x, 256);
+    stage_sdf_weights(lds, a.w, threadIdx.x, 64 * SDFB_WAVES);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = lane & 15, g = lane >> 4;
@@ -60,23 +62,7 @@ __global__ __launch_bounds__(256) void sdf_bwd_kernel(SdfBwdArgs a) {
     const float* w2t = lds + SdfLds::W2 + 4 * g * SdfLds::LD1 + p;
     const float* w1t = lds + SdfLds::W1 + 4 * g * SdfLds::LD1 + p;
 
-    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
-        const int pt = tile * TP + p;
-        const bool valid = pt < a.n_points;
-        const int ptc = valid ? pt : a.n_points - 1;
-        const float x0 = a.points[(size_t)ptc * 3 + 0], x1 = a.points[(size_t)ptc * 3 + 1], x2 = a.points[(size_t)ptc * 3 + 2];
-        float e[PE_STEPS], d1[PE_STEPS], d2[PE_STEPS];
-        pe_slots<true, HAS_GG>(x0, x1, x2, g, a.symmetric != 0, e, d1, d2);
-        const float Gs = (valid && a.g_sdf) ? a.g_sdf[pt] : 0.f;
-        float gam[3] = {0.f, 0.f, 0.f};
-        if (HAS_GG && valid) { gam[0] = a.g_grad[(size_t)pt * 3]; gam[1] = a.g_grad[(size_t)pt * 3 + 1]; gam[2] = a.g_grad[(size_t)pt * 3 + 2]; }
-        float gx[3] = {0.f, 0.f, 0.f};
-        float pend4[ACT_STEPS];   // pend_0..3 are parked in the Ga output buffers (L2-hot) to save 64 VGPRs
-        float u4[ACT_STEPS];
-        f32x4 acc[NT];
-        float av[ACT_STEPS], pv[ACT_STEPS], gq[ACT_STEPS], gpv[ACT_STEPS];
-
-// d(gx_c)/.. helper: gx_c += scale_c * sum_s V[s] * (W_le * DV[4c..4c+3])[s]
+// gx_c += scale_c * sum_s V[s] * (W_le * DV[4c..4c+3])[s]
 #define SC_PE_DOT(WE, LD, V, DV, SCALE)                                                     \
         _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                      \
             f32x4 tacc[NT];                                                                  \
@@ -90,11 +76,26 @@ __global__ __launch_bounds__(256) void sdf_bwd_kernel(SdfBwdArgs a) {
             gx[c] = __builtin_fmaf(SCALE, dsum, gx[c]);                                      \
         }
 
-        if (HAS_GG) {
+    // ================= R pass over all tiles of this wave (only when d/d(grad) is given) =================
+    // Parks pend_0..3 in Ga_0..3, pend_4 in Ga_4, u4 in r0 and the second-order part of G point in g_points;
+    // the V pass below picks them up (same wave, L2-hot).  Two loops instead of one keep each loop body
+    // under 256 VGPRs (2 waves per SIMD) -- a single fused body needed ~500 and spilled.
+    if (HAS_GG) {
+        for (int tile = blockIdx.x * SDFB_WAVES + wave; tile < ntiles; tile += gridDim.x * SDFB_WAVES) {
+            const int pt = tile * TP + p;
+            const bool valid = pt < a.n_points;
+            const int ptc = valid ? pt : a.n_points - 1;
+            const float x0 = a.points[(size_t)ptc * 3 + 0], x1 = a.points[(size_t)ptc * 3 + 1], x2 = a.points[(size_t)ptc * 3 + 2];
+            float e[PE_STEPS], d1[PE_STEPS], d2[PE_STEPS];
+            pe_slots<true, true>(x0, x1, x2, g, a.symmetric != 0, e, d1, d2);
+            float gam[3] = {0.f, 0.f, 0.f};
+            if (valid) { gam[0] = a.g_grad[(size_t)pt * 3]; gam[1] = a.g_grad[(size_t)pt * 3 + 1]; gam[2] = a.g_grad[(size_t)pt * 3 + 2]; }
+            float gx[3] = {0.f, 0.f, 0.f};
+            f32x4 acc[NT];
+            float av[ACT_STEPS], pv[ACT_STEPS], gq[ACT_STEPS], gpv[ACT_STEPS];
             float eps[PE_STEPS];
 #pragma unroll
             for (int j = 0; j < PE_STEPS; ++j) eps[j] = gam[j >> 2] * d1[j];
-// one reverse-adjoint step for a layer with a PE skip input (l = 0,1,2)
 #define SC_R_STEP(L, WE, LD)                                                                \
             acc_to_regs(acc, gq);                                                            \
             tbl_load(a.stash_a + (size_t)(L) * tbl, tile, p, g, av);                         \
@@ -132,20 +133,41 @@ __global__ __launch_bounds__(256) void sdf_bwd_kernel(SdfBwdArgs a) {
             mm_act<SdfLds::LD3, NT>(w4, gpv, acc);                             // Gq4
             acc_to_regs(acc, gq);
             tbl_load(a.stash_a + 4 * tbl, tile, p, g, av);
+            {
+                float pend4[ACT_STEPS], u4[ACT_STEPS];
 #pragma unroll
-            for (int s = 0; s < ACT_STEPS; ++s) {
-                float t, r;
-                softplus_parts(av[s], t, r);
-                pend4[s] = gq[s] * w5s[kp(s)] * softplus_d2(t, r);
-                u4[s] = gq[s] * softplus_d1(av[s], t, r);
+                for (int s = 0; s < ACT_STEPS; ++s) {
+                    float t, r;
+                    softplus_parts(av[s], t, r);
+                    pend4[s] = gq[s] * w5s[kp(s)] * softplus_d2(t, r);
+                    u4[s] = gq[s] * softplus_d1(av[s], t, r);
+                }
+                tbl_store(a.ga + 4 * tbl, tile, p, g, pend4);
+                tbl_store(a.r0, tile, p, g, u4);
             }
-        } else {
-#pragma unroll
-            for (int s = 0; s < ACT_STEPS; ++s) { u4[s] = 0.f; pend4[s] = 0.f; }
+            if (a.g_points) {
+                const float o0 = group_sum(gx[0]), o1 = group_sum(gx[1]), o2 = group_sum(gx[2]);
+                if (valid && g == 0) {
+                    a.g_points[(size_t)pt * 3 + 0] = o0;
+                    a.g_points[(size_t)pt * 3 + 1] = o1;
+                    a.g_points[(size_t)pt * 3 + 2] = o2;
+                }
+            }
         }
+    }
 
-        // ---- V pass ----
-        float gav[ACT_STEPS];
+    // ================= V pass =================
+    for (int tile = blockIdx.x * SDFB_WAVES + wave; tile < ntiles; tile += gridDim.x * SDFB_WAVES) {
+        const int pt = tile * TP + p;
+        const bool valid = pt < a.n_points;
+        const int ptc = valid ? pt : a.n_points - 1;
+        const float x0 = a.points[(size_t)ptc * 3 + 0], x1 = a.points[(size_t)ptc * 3 + 1], x2 = a.points[(size_t)ptc * 3 + 2];
+        float e[PE_STEPS], d1[PE_STEPS], d2[PE_STEPS];
+        pe_slots<true, false>(x0, x1, x2, g, a.symmetric != 0, e, d1, d2);
+        const float Gs = (valid && a.g_sdf) ? a.g_sdf[pt] : 0.f;
+        float gx[3] = {0.f, 0.f, 0.f};
+        f32x4 acc[NT];
+        float av[ACT_STEPS], pv[ACT_STEPS], gav[ACT_STEPS];
         acc_zero(acc);
         if (a.g_feat) {
             float gf[ACT_STEPS];
@@ -155,13 +177,17 @@ __global__ __launch_bounds__(256) void sdf_bwd_kernel(SdfBwdArgs a) {
         tbl_load(a.stash_a + 4 * tbl, tile, p, g, av);
         {
             float r0v[ACT_STEPS];
+            if (HAS_GG) {
+                tbl_load(a.ga + 4 * tbl, tile, p, g, pv);      // pend4
+                tbl_load(a.r0, tile, p, g, r0v);               // u4
+            }
 #pragma unroll
             for (int s = 0; s < ACT_STEPS; ++s) {
                 float t, r;
                 softplus_parts(av[s], t, r);
                 const float gh = acc[s >> 2][s & 3] + w5s[kp(s)] * Gs;
-                r0v[s] = Gs * softplus_val(av[s], t) + u4[s];
-                gav[s] = gh * softplus_d1(av[s], t, r) + pend4[s];
+                r0v[s] = Gs * softplus_val(av[s], t) + (HAS_GG ? r0v[s] : 0.f);
+                gav[s] = gh * softplus_d1(av[s], t, r) + (HAS_GG ? pv[s] : 0.f);
             }
             tbl_store(a.r0, tile, p, g, r0v);
             tbl_store(a.ga + 4 * tbl, tile, p, g, gav);
@@ -189,9 +215,12 @@ __global__ __launch_bounds__(256) void sdf_bwd_kernel(SdfBwdArgs a) {
         if (a.g_points) {
             const float o0 = group_sum(gx[0]), o1 = group_sum(gx[1]), o2 = group_sum(gx[2]);
             if (valid && g == 0) {
-                a.g_points[(size_t)pt * 3 + 0] = o0;
-                a.g_points[(size_t)pt * 3 + 1] = o1;
-                a.g_points[(size_t)pt * 3 + 2] = o2;
+                const float b0 = HAS_GG ? a.g_points[(size_t)pt * 3 + 0] : 0.f;
+                const float b1 = HAS_GG ? a.g_points[(size_t)pt * 3 + 1] : 0.f;
+                const float b2 = HAS_GG ? a.g_points[(size_t)pt * 3 + 2] : 0.f;
+                a.g_points[(size_t)pt * 3 + 0] = o0 + b0;
+                a.g_points[(size_t)pt * 3 + 1] = o1 + b1;
+                a.g_points[(size_t)pt * 3 + 2] = o2 + b2;
             }
         }
     }
@@ -206,18 +235,18 @@ extern "C" int sc_sdf_backward(const float* points, const float* w_pack, int n_p
     if (n_points <= 0) return 0;
     sc::SdfBwdArgs a{points, w_pack, n_points, symmetric, stash_a, stash_p, g_sdf, g_grad, g_feat, g_points, ga, gp, r0};
     const int ntiles = (n_points + sc::TP - 1) / sc::TP;
-    int blocks = (ntiles + 3) / 4;
+    int blocks = (ntiles + sc::SDFB_WAVES - 1) / sc::SDFB_WAVES;
     if (blocks > 256) blocks = 256;
     const size_t lds_bytes = sc::SdfLds::TOTAL * sizeof(float);
     hipStream_t stream = (hipStream_t)stream_;
     if (g_grad) {
         static bool attr_g = false;
         if (!attr_g) { (void)hipFuncSetAttribute((const void*)sc::sdf_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_g = true; }
-        hipLaunchKernelGGL(sc::sdf_bwd_kernel<true>, dim3(blocks), dim3(256), lds_bytes, stream, a);
+        hipLaunchKernelGGL(sc::sdf_bwd_kernel<true>, dim3(blocks), dim3(64 * sc::SDFB_WAVES), lds_bytes, stream, a);
     } else {
         static bool attr_v = false;
         if (!attr_v) { (void)hipFuncSetAttribute((const void*)sc::sdf_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_v = true; }
-        hipLaunchKernelGGL(sc::sdf_bwd_kernel<false>, dim3(blocks), dim3(256), lds_bytes, stream, a);
+        hipLaunchKernelGGL(sc::sdf_bwd_kernel<false>, dim3(blocks), dim3(64 * sc::SDFB_WAVES), lds_bytes, stream, a);
     }
     return (int)hipGetLastError();
 }

@@ -31,12 +31,15 @@ struct SdfFwdArgs {
     float* feat;           // TBL64 [ntiles] or null
     float* stash_a;        // [5] x TBL64 (layer-major) or null: pre-activations a_l  (training)
     float* stash_p;        // [4] x TBL64 or null: adjoint p_0..p_3               (training)
+    float* scratch;        // GRAD without stash_a: [gridDim.x * WAVES][5][1024] floats of L2-resident per-wave scratch
 };
 
+constexpr int SDF_WAVES = 8;   // 2 waves per SIMD: the VALU phases of one wave overlap the MFMA phases of the other
+
 template <bool GRAD>
-__global__ __launch_bounds__(256) void sdf_fwd_kernel(SdfFwdArgs a) {
+__global__ __launch_bounds__(64 * SDF_WAVES) void sdf_fwd_kernel(SdfFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    stage_sdf_weights(lds, a.w, threadIdx.x, 256);
+    stage_sdf_weights(lds, a.w, threadIdx.x, 64 * SDF_WAVES);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -60,7 +63,14 @@ __global__ __launch_bounds__(256) void sdf_fwd_kernel(SdfFwdArgs a) {
     const float* w1t = lds + SdfLds::W1 + 4 * g * SdfLds::LD1 + p;
     const float* b5 = lds + SdfLds::B5;
 
-    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    // pre-activations a_l are parked in memory between the value chain and the gradient sweep (keeping
+    // sp'(a_l) of five layers in registers costs 80 VGPRs and forced 1 wave/SIMD): the training stash if
+    // there is one, otherwise a per-wave scratch slot that never leaves L2.
+    float* park = a.stash_a;
+    size_t park_stride = tbl;
+    if (GRAD && !park) { park = a.scratch + (size_t)(blockIdx.x * SDF_WAVES + wave) * 5 * 1024; park_stride = 1024; }
+    for (int tile = blockIdx.x * SDF_WAVES + wave; tile < ntiles; tile += gridDim.x * SDF_WAVES) {
+        const int ptile = a.stash_a ? tile : 0;
         const int pt = tile * TP + p;
         const bool valid = pt < a.n_points;
         const int ptc = valid ? pt : a.n_points - 1;
@@ -71,7 +81,6 @@ __global__ __launch_bounds__(256) void sdf_fwd_kernel(SdfFwdArgs a) {
         float e[PE_STEPS], d1[PE_STEPS], d2[PE_STEPS];
         pe_slots<GRAD, false>(x0, x1, x2, g, a.symmetric != 0, e, d1, d2);
 
-        float dsp[GRAD ? 5 : 1][ACT_STEPS];
         float h[ACT_STEPS];
         f32x4 acc[NT];
 
@@ -79,12 +88,11 @@ __global__ __launch_bounds__(256) void sdf_fwd_kernel(SdfFwdArgs a) {
         {                                                                                  \
             float av[ACT_STEPS];                                                           \
             acc_to_regs(acc, av);                                                          \
-            if (a.stash_a) tbl_store(a.stash_a + (size_t)(L) * tbl, tile, p, g, av);      \
+            if (park) tbl_store(park + (size_t)(L) * park_stride, ptile, p, g, av);        \
             _Pragma("unroll") for (int s = 0; s < ACT_STEPS; ++s) {                         \
                 float t, r;                                                                \
                 softplus_parts(av[s], t, r);                                               \
                 h[s] = softplus_val(av[s], t);                                             \
-                if (GRAD) dsp[GRAD ? (L) : 0][s] = softplus_d1(av[s], t, r);               \
             }                                                                              \
         }
 
@@ -139,34 +147,41 @@ __global__ __launch_bounds__(256) void sdf_fwd_kernel(SdfFwdArgs a) {
                     g2 = __builtin_fmaf(q[s], t2[s >> 2][s & 3], g2);                      \
                 }                                                                          \
             }
-#pragma unroll
-            for (int s = 0; s < ACT_STEPS; ++s) q[s] = w5s[kp(s)] * dsp[GRAD ? 4 : 0][s];
+#define SC_DSP(L, EXPR)                                                                     \
+            {                                                                              \
+                float av[ACT_STEPS];                                                       \
+                tbl_load(park + (size_t)(L) * park_stride, ptile, p, g, av);               \
+                _Pragma("unroll") for (int s = 0; s < ACT_STEPS; ++s) {                     \
+                    float t, r;                                                            \
+                    softplus_parts(av[s], t, r);                                           \
+                    const float ds = softplus_d1(av[s], t, r);                             \
+                    q[s] = (EXPR) * ds;                                                    \
+                }                                                                          \
+            }
+            SC_DSP(4, w5s[kp(s)])
             acc_zero(acc);
             mm_act_t<SdfLds::LD3, NT>(w4t, q, acc);                 // p3 = W4^T q4
             acc_to_regs(acc, pv);
             if (a.stash_p) tbl_store(a.stash_p + 3 * tbl, tile, p, g, pv);
-#pragma unroll
-            for (int s = 0; s < ACT_STEPS; ++s) q[s] = pv[s] * dsp[GRAD ? 3 : 0][s];
+            SC_DSP(3, pv[s])
             acc_zero(acc);
             mm_act_t<SdfLds::LD3, NT>(w3t, q, acc);                 // p2 = W3^T q3
             acc_to_regs(acc, pv);
             if (a.stash_p) tbl_store(a.stash_p + 2 * tbl, tile, p, g, pv);
-#pragma unroll
-            for (int s = 0; s < ACT_STEPS; ++s) q[s] = pv[s] * dsp[GRAD ? 2 : 0][s];
+            SC_DSP(2, pv[s])
             SC_PE_JAC(w2e, SdfLds::LD1)
             acc_zero(acc);
             mm_act_t<SdfLds::LD1, NT>(w2t, q, acc);                 // p1 = W2h^T q2
             acc_to_regs(acc, pv);
             if (a.stash_p) tbl_store(a.stash_p + 1 * tbl, tile, p, g, pv);
-#pragma unroll
-            for (int s = 0; s < ACT_STEPS; ++s) q[s] = pv[s] * dsp[GRAD ? 1 : 0][s];
+            SC_DSP(1, pv[s])
             SC_PE_JAC(w1e, SdfLds::LD1)
             acc_zero(acc);
             mm_act_t<SdfLds::LD1, NT>(w1t, q, acc);                 // p0 = W1h^T q1
             acc_to_regs(acc, pv);
             if (a.stash_p) tbl_store(a.stash_p + 0 * tbl, tile, p, g, pv);
-#pragma unroll
-            for (int s = 0; s < ACT_STEPS; ++s) q[s] = pv[s] * dsp[0][s];
+            SC_DSP(0, pv[s])
+#undef SC_DSP
             SC_PE_JAC(w0, SdfLds::LD0)
 #undef SC_PE_JAC
             g0 = group_sum(g0); g1 = group_sum(g1); g2 = group_sum(g2);
@@ -183,22 +198,23 @@ __global__ __launch_bounds__(256) void sdf_fwd_kernel(SdfFwdArgs a) {
 
 extern "C" int sc_sdf_forward(const float* points, const float* w_pack, const float* cbias, int n_points,
                               int n_per_image, int n_images, int symmetric, float* sdf, float* grad,
-                              float* feat, float* stash_a, float* stash_p, void* stream_) {
+                              float* feat, float* stash_a, float* stash_p, float* scratch, void* stream_) {
     if (n_points <= 0) return 0;
-    sc::SdfFwdArgs a{points, w_pack, cbias, n_points, n_per_image, n_images, symmetric, sdf, grad, feat, stash_a, stash_p};
+    sc::SdfFwdArgs a{points, w_pack, cbias, n_points, n_per_image, n_images, symmetric, sdf, grad, feat, stash_a, stash_p, scratch};
     const int ntiles = (n_points + sc::TP - 1) / sc::TP;
-    int blocks = (ntiles + 3) / 4;
-    if (blocks > 256) blocks = 256;   // one persistent workgroup per CU (LDS-resident weights)
+    int blocks = (ntiles + sc::SDF_WAVES - 1) / sc::SDF_WAVES;
+    if (blocks > 256) blocks = 256;   // one persistent 8-wave workgroup per CU (LDS-resident weights)
+    if (grad && !stash_a && !scratch) return (int)hipErrorInvalidValue;
     const size_t lds_bytes = sc::SdfLds::TOTAL * sizeof(float);
     hipStream_t stream = (hipStream_t)stream_;
     if (grad) {
         static bool attr_g = false;
         if (!attr_g) { (void)hipFuncSetAttribute((const void*)sc::sdf_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_g = true; }
-        hipLaunchKernelGGL(sc::sdf_fwd_kernel<true>, dim3(blocks), dim3(256), lds_bytes, stream, a);
+        hipLaunchKernelGGL(sc::sdf_fwd_kernel<true>, dim3(blocks), dim3(64 * sc::SDF_WAVES), lds_bytes, stream, a);
     } else {
         static bool attr_v = false;
         if (!attr_v) { (void)hipFuncSetAttribute((const void*)sc::sdf_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_v = true; }
-        hipLaunchKernelGGL(sc::sdf_fwd_kernel<false>, dim3(blocks), dim3(256), lds_bytes, stream, a);
+        hipLaunchKernelGGL(sc::sdf_fwd_kernel<false>, dim3(blocks), dim3(64 * sc::SDF_WAVES), lds_bytes, stream, a);
     }
     return (int)hipGetLastError();
 }

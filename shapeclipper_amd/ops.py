@@ -12,6 +12,17 @@ from .packing import n_tiles
 c_int = ctypes.c_int
 
 
+_SCRATCH = {}
+
+
+def _sdf_scratch(dev):
+    """[256 workgroups x 8 waves][5][1024] floats (42 MB), one per device, reused by every call on a stream."""
+    key = (dev.type, dev.index)
+    if key not in _SCRATCH:
+        _SCRATCH[key] = torch.empty(256 * 8 * 5 * 1024, device=dev, dtype=torch.float32)
+    return _SCRATCH[key]
+
+
 def sdf_forward(points: torch.Tensor, w_pack: torch.Tensor, cbias: torch.Tensor, n_per_image: int,
                 symmetric: bool = True, want_grad: bool = True, want_feat: bool = True,
                 stash: bool = False):
@@ -25,9 +36,11 @@ def sdf_forward(points: torch.Tensor, w_pack: torch.Tensor, cbias: torch.Tensor,
     feat = torch.empty(nt * 1024, device=dev, dtype=torch.float32) if want_feat else None
     sa = torch.empty(5 * nt * 1024, device=dev, dtype=torch.float32) if stash else None
     sp = torch.empty(4 * nt * 1024, device=dev, dtype=torch.float32) if (stash and want_grad) else None
+    # gradient kernel without a training stash: per-wave scratch for the parked pre-activations (L2-resident)
+    scratch = _sdf_scratch(dev) if (want_grad and not stash) else None
     code = lib.sc_sdf_forward(_lib.ptr(points), _lib.ptr(w_pack), _lib.ptr(cbias), c_int(n), c_int(n_per_image),
                               c_int(cbias.shape[0]), c_int(1 if symmetric else 0), _lib.ptr(sdf), _lib.ptr(grad),
-                              _lib.ptr(feat), _lib.ptr(sa), _lib.ptr(sp), _lib.stream())
+                              _lib.ptr(feat), _lib.ptr(sa), _lib.ptr(sp), _lib.ptr(scratch), _lib.stream())
     _lib.check(code, "sc_sdf_forward")
     if stash:
         return sdf, grad, feat, sa, sp
