@@ -106,11 +106,14 @@ int sc_wgrad(int nterms,
              const float* a0_1, const float* a1_1, int aop_1, const float* b0_1, int bop0_1, const float* b1_1, int bop1_1,
              const float* points, const float* g_grad, const float* w5row, int n_points, int symmetric,
              int nb0, int nb1, float* partial, int nparts, int partial_stride, int out_offset, int out_ld, void* stream);
+/* out[i] += sum_part partial[part*stride + i], i < n.  out must be zero-filled (16 atomic chunks per element). */
 int sc_partial_reduce(const float* partial, int nparts, int stride, int n, float* out, void* stream);
 
-/* out[img][k][ch] += sum_{p in img} coef[p][k] * x[ch][p]  (coef NULL: K = 1, coefficient 1; else K = 3).
+/* out_t[img][k][ch] += sum_{p in img} coef[p][k] * x_t[ch][p] for t < n_tensors (<= 8) TBL64 tensors in ONE
+ * launch (coef NULL: K = 1, coefficient 1; else K = 3).  xs / outs are HOST arrays of device pointers; every
  * out must be zero-filled.  Used for bias / latent gradients and the 3-row output layer of the RGB net. */
-int sc_tbl_sum(const float* x, const float* coef, int n_points, int n_per_image, int n_images, float* out, void* stream);
+int sc_tbl_sum(const float* const* xs, int n_tensors, const float* coef, int n_points, int n_per_image,
+               int n_images, float* const* outs, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Loss reductions of one render in one launch (Loss.MSE_loss / mask_loss / normal_loss, model/loss.py:19-97

@@ -58,33 +58,42 @@ __device__ __forceinline__ float sp_val(float a) { float t, r; softplus_parts(a,
 // (i>>2) at point 4g + (i&3): the four lanes of a quad now hold a 4x4 (channel x point) block, and a
 // 4x4 transpose inside the quad (two DPP-able xor-shuffle stages) leaves every lane with its channel
 // at points 4g..4g+3.  The wave's 64 loads are one fully coalesced 1 KiB request; no LDS, no barrier.
+// lane ^ 1 / lane ^ 2 inside a quad as DPP quad_perm moves (VALU, no LDS crossbar round trip)
+__device__ __forceinline__ float quad_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // [1,0,3,2]
+}
+__device__ __forceinline__ float quad_xor2(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // [2,3,0,1]
+}
+
 __device__ __forceinline__ void quad_transpose(float4& v, int j) {
     const bool odd = j & 1;
     float s0 = odd ? v.x : v.y, s1 = odd ? v.z : v.w;
-    float t0 = __shfl_xor(s0, 1), t1 = __shfl_xor(s1, 1);
+    float t0 = quad_xor1(s0), t1 = quad_xor1(s1);
     if (odd) { v.x = t0; v.z = t1; } else { v.y = t0; v.w = t1; }
     const bool hi = j & 2;
     s0 = hi ? v.x : v.z; s1 = hi ? v.y : v.w;
-    t0 = __shfl_xor(s0, 2); t1 = __shfl_xor(s1, 2);
+    t0 = quad_xor2(s0); t1 = quad_xor2(s1);
     if (hi) { v.x = t0; v.y = t1; } else { v.z = t0; v.w = t1; }
 }
 
 // channel tile T (16 channels) of a TBL operand for this lane: x..w = K-steps 0..3
-__device__ __forceinline__ float4 wg_frag(int op, const float* x0, const float* x1, const float* w5row,
+template <int op>
+__device__ __forceinline__ float4 wg_frag(const float* x0, const float* x1, const float* w5row,
                                           int tile, int T, int i, int g, bool valid) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     const int grp = 4 * T + (i >> 2), pt = 4 * g + (i & 3);
     if (valid) {
-        if (op == OP_PLAIN) {
+        if constexpr (op == OP_PLAIN) {
             v = wg_load4(x0, tile, grp, pt);
-        } else if (op == OP_SP) {
+        } else if constexpr (op == OP_SP) {
             const float4 a = wg_load4(x0, tile, grp, pt);
             v = make_float4(sp_val(a.x), sp_val(a.y), sp_val(a.z), sp_val(a.w));
-        } else if (op == OP_Q) {
+        } else if constexpr (op == OP_Q) {
             const float4 pz = wg_load4(x0, tile, grp, pt);
             const float4 a = wg_load4(x1, tile, grp, pt);
             v = make_float4(pz.x * sp_d1(a.x), pz.y * sp_d1(a.y), pz.z * sp_d1(a.z), pz.w * sp_d1(a.w));
-        } else if (op == OP_Q4) {
+        } else if constexpr (op == OP_Q4) {
             const float4 a = wg_load4(x1, tile, grp, pt);
             const float4 w = reinterpret_cast<const float4*>(w5row)[grp];
             v = make_float4(w.x * sp_d1(a.x), w.y * sp_d1(a.y), w.z * sp_d1(a.z), w.w * sp_d1(a.w));
@@ -130,60 +139,68 @@ __device__ __forceinline__ void pe_lane_setup(PeLane& P, const float* points, co
 }
 
 // B fragment of PE coordinate tile c (x..w = K-steps = points 4g..4g+3)
-__device__ __forceinline__ float4 pe_frag(const PeLane& P, int op, int c) {
+template <int op>
+__device__ __forceinline__ float4 pe_frag(const PeLane& P, int c) {
     return op == OP_PE ? make_float4(P.pe[c][0], P.pe[c][1], P.pe[c][2], P.pe[c][3])
                        : make_float4(P.ep[c][0], P.ep[c][1], P.ep[c][2], P.ep[c][3]);
 }
 
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
-    __shared__ float red[64 * WG_MAXNB];
+// B fragment n of a term whose two segments have compile-time transforms B0 (first NT0 tiles) and B1
+template <int B0, int B1, int NT0>
+__device__ __forceinline__ float4 b_frag(const WgradTerm& T, const PeLane& P, int tile, int n, int i, int g, bool valid) {
+    if (n < NT0) {
+        if constexpr (B0 == OP_PE || B0 == OP_EPS) return pe_frag<B0>(P, n);
+        else return wg_frag<B0>(T.b0, nullptr, nullptr, tile, n, i, g, valid);
+    } else {
+        if constexpr (B1 == OP_PE || B1 == OP_EPS) return pe_frag<B1>(P, n - NT0);
+        else if constexpr (B1 == OP_NONE) return make_float4(0.f, 0.f, 0.f, 0.f);
+        else return wg_frag<B1>(T.b1, nullptr, nullptr, tile, n - NT0, i, g, valid);
+    }
+}
+
+template <int A, int B0, int B1, int NT0, int NNT>
+__device__ __forceinline__ void wgrad_term(const WgradTerm& T, const PeLane& P, const float* w5row, int tile, int i, int g,
+                                           bool valid, f32x4 (&acc)[NT][NNT]) {
+    float4 af[NT], bf[NNT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m) af[m] = wg_frag<A>(T.a0, T.a1, w5row, tile, m, i, g, valid);
+#pragma unroll
+    for (int n = 0; n < NNT; ++n) bf[n] = b_frag<B0, B1, NT0>(T, P, tile, n, i, g, valid);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int m = 0; m < NT; ++m)
+#pragma unroll
+            for (int n = 0; n < NNT; ++n) {
+                const float av = s == 0 ? af[m].x : (s == 1 ? af[m].y : (s == 2 ? af[m].z : af[m].w));
+                const float bv = s == 0 ? bf[n].x : (s == 1 ? bf[n].y : (s == 2 ? bf[n].z : bf[n].w));
+                acc[m][n] = mfma16(av, bv, acc[m][n]);
+            }
+}
+
+// NT0: N tiles of B segment 0.  Term 0 = (A0; B00 | B10), optional term 1 = (A1; B01 | B11) (A1 == OP_NONE: absent).
+template <int NNT, int NT0, int WPS, int A0, int B00, int B10, int A1, int B01, int B11>
+__global__ __launch_bounds__(256, WPS) void wgrad_kernel(WgradArgs a) {
+    __shared__ float red[64 * 16 * NNT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int ntiles = (a.n_points + TP - 1) / TP;
-    const int nt0 = a.nb0 / 16, nt1 = a.nb1 / 16, nnt = nt0 + nt1;
-    for (int e = tid; e < 64 * WG_MAXNB; e += 256) red[e] = 0.f;
-    f32x4 acc[NT][7];
+    constexpr int nnt = NNT;
+    for (int e = tid; e < 64 * 16 * NNT; e += 256) red[e] = 0.f;
+    f32x4 acc[NT][NNT];
 #pragma unroll
     for (int m = 0; m < NT; ++m)
 #pragma unroll
-        for (int n = 0; n < 7; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bool need_pe = false, need_eps = false;
-    for (int t = 0; t < a.nterms; ++t) {
-        need_pe |= a.t[t].bop0 == OP_PE || a.t[t].bop1 == OP_PE || a.t[t].bop0 == OP_EPS || a.t[t].bop1 == OP_EPS;
-        need_eps |= a.t[t].bop0 == OP_EPS || a.t[t].bop1 == OP_EPS;
-    }
+        for (int n = 0; n < NNT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr bool need_pe = B00 == OP_PE || B10 == OP_PE || B01 == OP_EPS || B11 == OP_EPS || B00 == OP_EPS || B10 == OP_EPS;
+    constexpr bool need_eps = B01 == OP_EPS || B11 == OP_EPS || B00 == OP_EPS || B10 == OP_EPS;
 
     for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
         const bool valid = tile * TP + 4 * g + (i & 3) < a.n_points;   // the point this lane LOADS
         PeLane P;
-        if (need_pe) pe_lane_setup(P, a.points, a.g_grad, need_eps, tile, i, g, a.n_points, a.symmetric != 0);
-        for (int t = 0; t < a.nterms; ++t) {
-            const WgradTerm& T = a.t[t];
-            float4 af[NT], bf[7];
-#pragma unroll
-            for (int m = 0; m < NT; ++m) af[m] = wg_frag(T.aop, T.a0, T.a1, a.w5row, tile, m, i, g, valid);
-#pragma unroll
-            for (int n = 0; n < 7; ++n) {
-                if (n < nnt) {
-                    const bool seg1 = n >= nt0;
-                    const int op = seg1 ? T.bop1 : T.bop0;
-                    const int ln = seg1 ? n - nt0 : n;
-                    if (op == OP_PE || op == OP_EPS) bf[n] = pe_frag(P, op, ln);
-                    else bf[n] = wg_frag(op, seg1 ? T.b1 : T.b0, nullptr, nullptr, tile, ln, i, g, valid);
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int m = 0; m < NT; ++m)
-#pragma unroll
-                    for (int n = 0; n < 7; ++n)
-                        if (n < nnt) {
-                            const float av = s == 0 ? af[m].x : (s == 1 ? af[m].y : (s == 2 ? af[m].z : af[m].w));
-                            const float bv = s == 0 ? bf[n].x : (s == 1 ? bf[n].y : (s == 2 ? bf[n].z : bf[n].w));
-                            acc[m][n] = mfma16(av, bv, acc[m][n]);
-                        }
-        }
+        if constexpr (need_pe) pe_lane_setup(P, a.points, a.g_grad, need_eps, tile, i, g, a.n_points, a.symmetric != 0);
+        wgrad_term<A0, B00, B10, NT0, NNT>(a.t[0], P, a.w5row, tile, i, g, valid, acc);
+        if constexpr (A1 != OP_NONE) wgrad_term<A1, B01, B11, NT0, NNT>(a.t[1], P, a.w5row, tile, i, g, valid, acc);
     }
     // combine the four waves of the workgroup in LDS, then one partial image per workgroup
     __syncthreads();
@@ -191,8 +208,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int m = 0; m < NT; ++m)
 #pragma unroll
-        for (int n = 0; n < 7; ++n)
-            if (n < nnt) {
+        for (int n = 0; n < NNT; ++n)
+            {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) atomicAdd(&red[(16 * m + 4 * g + r) * ld + 16 * n + i], acc[m][n][r]);
             }
@@ -201,27 +218,32 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     for (int e = tid; e < 64 * ld; e += 256) out[(e / ld) * a.out_ld + (e % ld)] = red[e];
 }
 
-// out[i] = sum_b partial[b][i], fixed order
+// out[i] = sum_b partial[b][i].  blockIdx.y splits the parts into 16 chunks (each summed in a fixed order) that
+// are combined with one atomicAdd each: out must be zero-filled by the caller.
 __global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ partial, int nparts, int stride,
                                                              int n, float* __restrict__ out) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= n) return;
+    const int per = (nparts + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = min(nparts, b0 + per);
     float s = 0.f;
-    for (int b = 0; b < nparts; ++b) s += partial[(size_t)b * stride + idx];
-    out[idx] = s;
+    for (int b = b0; b < b1; ++b) s += partial[(size_t)b * stride + idx];
+    if (b1 > b0) atomicAdd(&out[idx], s);
 }
 
 // out[img][k][ch] += sum_{p in img} coef_k(p) * X[ch][p]     (K = 1: coef = 1;  K = 3: coef = cw[p][k])
 struct TblSumArgs {
-    const float* x;      // TBL64
+    const float* xs[8];  // up to 8 TBL64 tensors, one per blockIdx.y
     const float* coef;   // [n_points][3] or null
     int n_points, n_per_image, n_images;
-    float* out;          // [n_images][K][64], pre-zeroed, atomicAdd
+    float* outs[8];      // each [n_images][K][64], pre-zeroed, atomicAdd
 };
 
 template <int K>
 __global__ __launch_bounds__(256) void tbl_sum_kernel(TblSumArgs a) {
     const int tid = threadIdx.x, grp = tid >> 4, pt = tid & 15;
+    const float* __restrict__ x = a.xs[blockIdx.y];
+    float* __restrict__ out = a.outs[blockIdx.y];
     const int ntiles = (a.n_points + TP - 1) / TP;
     const int tiles_per_block = (ntiles + gridDim.x - 1) / gridDim.x;
     const int t0 = blockIdx.x * tiles_per_block, t1 = min(ntiles, t0 + tiles_per_block);
@@ -242,9 +264,9 @@ __global__ __launch_bounds__(256) void tbl_sum_kernel(TblSumArgs a) {
                 float v = have ? acc[k][r] : 0.f;
                 if (uniform) {
                     v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-                    if (pt == 0 && have) atomicAdd(&a.out[((size_t)cur * K + k) * 64 + 4 * grp + r], v);
+                    if (pt == 0 && have) atomicAdd(&out[((size_t)cur * K + k) * 64 + 4 * grp + r], v);
                 } else if (have) {
-                    atomicAdd(&a.out[((size_t)cur * K + k) * 64 + 4 * grp + r], v);
+                    atomicAdd(&out[((size_t)cur * K + k) * 64 + 4 * grp + r], v);
                 }
                 acc[k][r] = 0.f;
             }
@@ -258,7 +280,7 @@ __global__ __launch_bounds__(256) void tbl_sum_kernel(TblSumArgs a) {
             cur = img;
         }
         if (valid) {
-            const float4 v = wg_load4(a.x, tile, grp, pt);
+            const float4 v = wg_load4(x, tile, grp, pt);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const float c = K == 1 ? 1.f : a.coef[(size_t)gp * 3 + k];
@@ -290,25 +312,49 @@ int sc_wgrad(int nterms,
     a.nterms = nterms; a.points = points; a.g_grad = g_grad; a.w5row = w5row; a.n_points = n_points;
     a.symmetric = symmetric; a.nb0 = nb0; a.nb1 = nb1; a.partial = partial; a.partial_stride = partial_stride;
     a.out_offset = out_offset; a.out_ld = out_ld;
-    hipLaunchKernelGGL(sc::wgrad_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream_, a);
-    return (int)hipGetLastError();
+    hipStream_t st = (hipStream_t)stream_;
+    using namespace sc;
+    const int key0 = aop_0 * 100 + bop0_0 * 10 + bop1_0;
+    const int key1 = nterms > 1 ? aop_1 * 100 + bop0_1 * 10 + bop1_1 : 0;
+#define SC_WG(NNT, NT0, WPS, A0, B00, B10, A1, B01, B11)                                                         \
+    if (nb0 == 16 * NT0 && nb0 + nb1 == 16 * NNT && key0 == A0 * 100 + B00 * 10 + B10 &&                         \
+        key1 == (A1 == OP_NONE ? 0 : A1 * 100 + B01 * 10 + B11)) {                                               \
+        hipLaunchKernelGGL((wgrad_kernel<NNT, NT0, WPS, A0, B00, B10, A1, B01, B11>), dim3(nparts), dim3(256), 0, st, a); \
+        return (int)hipGetLastError();                                                                           \
+    }
+    SC_WG(3, 3, 3, OP_PLAIN, OP_PE, OP_NONE, OP_Q, OP_EPS, OP_NONE)         // dW0e
+    SC_WG(3, 3, 3, OP_PLAIN, OP_PE, OP_NONE, OP_NONE, OP_NONE, OP_NONE)
+    SC_WG(7, 4, 2, OP_PLAIN, OP_SP, OP_PE, OP_Q, OP_PLAIN, OP_EPS)          // dW1, dW2
+    SC_WG(7, 4, 2, OP_PLAIN, OP_SP, OP_PE, OP_NONE, OP_NONE, OP_NONE)
+    SC_WG(4, 4, 3, OP_PLAIN, OP_SP, OP_NONE, OP_Q, OP_PLAIN, OP_NONE)       // dW3
+    SC_WG(4, 4, 3, OP_PLAIN, OP_SP, OP_NONE, OP_Q4, OP_PLAIN, OP_NONE)      // dW4
+    SC_WG(4, 4, 3, OP_PLAIN, OP_SP, OP_NONE, OP_NONE, OP_NONE, OP_NONE)     // dW5 feature rows, no-Gg variants
+    SC_WG(7, 3, 2, OP_PLAIN, OP_PE, OP_PLAIN, OP_NONE, OP_NONE, OP_NONE)    // dV0
+    SC_WG(4, 4, 3, OP_PLAIN, OP_PLAIN, OP_NONE, OP_NONE, OP_NONE, OP_NONE)  // dV1, dV2
+#undef SC_WG
+    return (int)hipErrorInvalidValue;   // operand combination not instantiated
 }
 
 int sc_partial_reduce(const float* partial, int nparts, int stride, int n, float* out, void* stream_) {
-    hipLaunchKernelGGL(sc::partial_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream_,
+    hipLaunchKernelGGL(sc::partial_reduce_kernel, dim3((n + 255) / 256, 16), dim3(256), 0, (hipStream_t)stream_,
                        partial, nparts, stride, n, out);
     return (int)hipGetLastError();
 }
 
-// out [n_images][K][64] must be zero-filled by the caller; K = 3 when coef != NULL else 1.
-int sc_tbl_sum(const float* x, const float* coef, int n_points, int n_per_image, int n_images, float* out, void* stream_) {
-    if (n_points <= 0) return 0;
-    sc::TblSumArgs a{x, coef, n_points, n_per_image, n_images, out};
+// xs / outs: HOST arrays of n_tensors (<= 8) device pointers; every out [n_images][K][64] must be zero-filled
+// by the caller; K = 3 when coef != NULL else 1.  One launch for all tensors (blockIdx.y).
+int sc_tbl_sum(const float* const* xs, int n_tensors, const float* coef, int n_points, int n_per_image, int n_images,
+               float* const* outs, void* stream_) {
+    if (n_points <= 0 || n_tensors <= 0) return 0;
+    if (n_tensors > 8) return (int)hipErrorInvalidValue;
+    sc::TblSumArgs a;
+    for (int t = 0; t < 8; ++t) { a.xs[t] = t < n_tensors ? xs[t] : nullptr; a.outs[t] = t < n_tensors ? outs[t] : nullptr; }
+    a.coef = coef; a.n_points = n_points; a.n_per_image = n_per_image; a.n_images = n_images;
     const int ntiles = (n_points + sc::TP - 1) / sc::TP;
     int blocks = (ntiles + 63) / 64;
     if (blocks > 1024) blocks = 1024;
-    if (coef) hipLaunchKernelGGL(sc::tbl_sum_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, a);
-    else hipLaunchKernelGGL(sc::tbl_sum_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, a);
+    if (coef) hipLaunchKernelGGL(sc::tbl_sum_kernel<3>, dim3(blocks, n_tensors), dim3(256), 0, (hipStream_t)stream_, a);
+    else hipLaunchKernelGGL(sc::tbl_sum_kernel<1>, dim3(blocks, n_tensors), dim3(256), 0, (hipStream_t)stream_, a);
     return (int)hipGetLastError();
 }
 

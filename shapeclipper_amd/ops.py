@@ -80,7 +80,7 @@ def rgb_composite_forward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, db
 
 # operand transform codes of sc_wgrad (csrc/wgrad.hip)
 OP_NONE, OP_PLAIN, OP_SP, OP_Q, OP_Q4, OP_PE, OP_EPS = range(7)
-WGRAD_PARTS = 512
+WGRAD_PARTS = 768
 
 
 def _wgrad(lib, terms, points, g_grad, w5row, n_points, symmetric, nb0, nb1, partial, stride, out_offset, out_ld):
@@ -95,15 +95,24 @@ def _wgrad(lib, terms, points, g_grad, w5row, n_points, symmetric, nb0, nb1, par
     _lib.check(code, "sc_wgrad")
 
 
-def tbl_sum(x, n_points, n_per_image, n_images, coef=None):
-    """sum over the points of each image of a TBL64 tensor -> [n_images, K, 64] (K = 3 with coef [N,3])."""
+def tbl_sum_multi(xs, n_points, n_per_image, n_images, coef=None):
+    """Per-image sums over the points of several TBL64 tensors in ONE launch
+    -> [len(xs), n_images, K, 64] (K = 3 with coef [N,3], else 1)."""
     lib = _lib.load()
     K = 3 if coef is not None else 1
-    out = torch.zeros(n_images, K, 64, device=x.device, dtype=torch.float32)
-    code = lib.sc_tbl_sum(_lib.ptr(x), _lib.ptr(coef), c_int(n_points), c_int(n_per_image), c_int(n_images),
-                          _lib.ptr(out), _lib.stream())
+    n = len(xs)
+    out = torch.zeros(n, n_images, K, 64, device=xs[0].device, dtype=torch.float32)
+    PtrArr = ctypes.c_void_p * n
+    xp = PtrArr(*[x.data_ptr() for x in xs])
+    op = PtrArr(*[out[i].data_ptr() for i in range(n)])
+    code = lib.sc_tbl_sum(xp, c_int(n), _lib.ptr(coef), c_int(n_points), c_int(n_per_image), c_int(n_images), op,
+                          _lib.stream())
     _lib.check(code, "sc_tbl_sum")
     return out
+
+
+def tbl_sum(x, n_points, n_per_image, n_images, coef=None):
+    return tbl_sum_multi([x], n_points, n_per_image, n_images, coef)[0]
 
 
 def sdf_backward(points, w_pack, n_per_image, n_images, symmetric, stash_a, stash_p, g_sdf, g_grad, g_feat,
@@ -132,7 +141,7 @@ def sdf_backward(points, w_pack, n_per_image, n_images, symmetric, stash_a, stas
     GP = lambda l: gp[l * T:(l + 1) * T]
     gg = g_grad is not None
     stride = SDF_PACK_FLOATS
-    partial = torch.zeros(WGRAD_PARTS * stride, **f32)
+    partial = torch.empty(WGRAD_PARTS * stride, **f32)     # every workgroup of every launch writes its whole region
     w5row = w_pack[SDF_OFF["W5"]:SDF_OFF["W5"] + 64]
     common = (points, g_grad, w5row, n, symmetric)
 
@@ -159,16 +168,20 @@ def sdf_backward(points, w_pack, n_per_image, n_images, symmetric, stash_a, stas
     if g_feat is not None:
         launch([(g_feat, None, OP_PLAIN, A(4), OP_SP, None, OP_NONE)], 64, 0, SDF_OFF["W5"] + 64, 64)
 
-    g_w = torch.empty(stride, **f32)
+    g_w = torch.zeros(stride, **f32)
     code = lib.sc_partial_reduce(_lib.ptr(partial), c_int(WGRAD_PARTS), c_int(stride), c_int(stride), _lib.ptr(g_w),
                                  _lib.stream())
     _lib.check(code, "sc_partial_reduce")
     # W5 row 0 (sdf row):  sum_p (Gs * h4 + Gq4 * sp'(a4))   and the output bias
-    g_w[SDF_OFF["W5"]:SDF_OFF["W5"] + 64] = tbl_sum(r0, n, n, 1).view(64)
+    tot = tbl_sum_multi([r0] + ([g_feat] if g_feat is not None else []), n, n, 1)
+    g_w[SDF_OFF["W5"]:SDF_OFF["W5"] + 64] = tot[0].view(64)
     g_w[SDF_OFF["B5"]] = g_sdf.sum() if g_sdf is not None else 0.0
     if g_feat is not None:
-        g_w[SDF_OFF["B5"] + 1:SDF_OFF["B5"] + 65] = tbl_sum(g_feat, n, n, 1).view(64)
-    g_c = torch.stack([tbl_sum(GA(l), n, n_per_image, n_images).view(n_images, 64) for l in range(5)], dim=1)
+        g_w[SDF_OFF["B5"] + 1:SDF_OFF["B5"] + 65] = tot[1].view(64)
+    else:   # regions no launch wrote (the partial buffer is not zero-initialised)
+        g_w[SDF_OFF["W5"] + 64:SDF_OFF["B5"]] = 0.0
+        g_w[SDF_OFF["B5"] + 1:] = 0.0
+    g_c = tbl_sum_multi([GA(l) for l in range(5)], n, n_per_image, n_images).view(5, n_images, 64).permute(1, 0, 2).contiguous()
     return g_points, g_w, g_c
 
 
@@ -204,12 +217,12 @@ def rgb_composite_backward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, d
     GY = lambda l: gy[l * T:(l + 1) * T]
     RR = lambda l: rr[l * T:(l + 1) * T]
     stride = RGB_PACK_FLOATS
-    partial = torch.zeros(WGRAD_PARTS * stride, **f32)
+    partial = torch.empty(WGRAD_PARTS * stride, **f32)
     common = (points, None, None, P, symmetric)
     _wgrad(lib, [(GY(0), None, OP_PLAIN, None, OP_PE, feat, OP_PLAIN)], *common, 48, 64, partial, stride, RGB_OFF["V0"], 112)
     _wgrad(lib, [(GY(1), None, OP_PLAIN, RR(0), OP_PLAIN, None, OP_NONE)], *common, 64, 0, partial, stride, RGB_OFF["V1"], 64)
     _wgrad(lib, [(GY(2), None, OP_PLAIN, RR(1), OP_PLAIN, None, OP_NONE)], *common, 64, 0, partial, stride, RGB_OFF["V2"], 64)
-    g_v = torch.empty(stride, **f32)
+    g_v = torch.zeros(stride, **f32)
     code = lib.sc_partial_reduce(_lib.ptr(partial), c_int(WGRAD_PARTS), c_int(stride), c_int(stride), _lib.ptr(g_v),
                                  _lib.stream())
     _lib.check(code, "sc_partial_reduce")
@@ -217,7 +230,7 @@ def rgb_composite_backward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, d
     g_v[RGB_OFF["B3"]:RGB_OFF["B3"] + 3] = gy3.sum(dim=0)
     g_v[RGB_OFF["B3"] + 3] = 0.0
     g["v_pack"] = g_v
-    g["dbias"] = torch.stack([tbl_sum(GY(l), P, rays_per_image * 64, n_images).view(n_images, 64) for l in range(3)], dim=1)
+    g["dbias"] = tbl_sum_multi([GY(l) for l in range(3)], P, rays_per_image * 64, n_images).view(3, n_images, 64).permute(1, 0, 2).contiguous()
     return g
 
 
