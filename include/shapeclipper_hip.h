@@ -128,6 +128,24 @@ int sc_loss_fused_forward(const float* rgb, const float* rgb_t, const float* mas
                           float normal_l1, float mask_mse, double keep_frac, float* out4, float* g_rgb,
                           float* g_mask, float* g_normal, float* g_eik, float* ang_ws, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * CLIP ViT image tower forward (replaces clip_encoder.encode_image, CLIP_anno.py:166; third-party
+ * openai/CLIP, parity unpinned).  image [B][C][H][W] fp32 (already CLIP-normalised) -> out [B][proj_dim]
+ * fp32 (NOT L2-normalised).  Requirements: head dim 64, D % 64 == 0, mlp % 64 == 0, (H/patch)*(W/patch)+1 <= 64.
+ * w_bf16: bf16 matrices, row-major [out][in], in this order: patch [D][C*patch*patch]; per layer
+ *   qkv [3D][D] (q rows, k rows, v rows), out_proj [D][D], fc1 [mlp][D], fc2 [D][mlp]; then proj [proj_dim][D].
+ * w_f32: fp32 vectors in this order: class_embedding [D], position_embedding [T][D], ln_pre gamma, beta;
+ *   per layer ln_1 gamma, beta, qkv bias [3D], out_proj bias, ln_2 gamma, beta, fc1 bias [mlp], fc2 bias;
+ *   then ln_post gamma, beta.
+ * workspace: >= sc_clip_vit_workspace_bytes(...) bytes of device memory.                               */
+int sc_clip_vit_forward(const float* image, int B, int C, int H, int W, int patch, int D, int mlp, int layers,
+                        int heads, int proj_dim, const uint16_t* w_bf16, const float* w_f32, float ln_eps,
+                        float* out, void* workspace, long long workspace_bytes, void* stream);
+/* out[M][N] = A[M][K] (bf16) * Wt[N][K]^T (bf16) + bias; epi 0: fp32 store, 1: fp32 +=, 2: quick_gelu -> bf16,
+ * 3: bf16.  K % 64 == 0.                                                                               */
+int sc_gemm_bf16(int epi, const uint16_t* A, const uint16_t* Wt, const float* bias, void* out, int M, int N, int K, void* stream);
+int sc_f32_to_bf16(const float* x, uint16_t* y, long long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,320 @@
+// clip_vit.hip -- CLIP ViT image-tower forward for gfx950 (bf16 MFMA GEMMs, fp32 LayerNorm / softmax /
+// residual stream).
+//
+// Replaces the call `clip_encoder.encode_image(image)` of the reference's offline annotator
+// (CLIP_anno.py:166; model loaded at :16 from the un-vendored openai/CLIP package).  Architecture
+// (openai/CLIP VisionTransformer == transformers.CLIPVisionModelWithProjection):
+//   patch conv (stride = patch, no bias) -> [cls; patches] + pos -> ln_pre -> L x {x += attn(ln_1 x);
+//   x += fc2(quick_gelu(fc1(ln_2 x)))} -> ln_post(x[:,0]) -> @ proj
+// Parity: unpinned against the reference (third-party, no weights offline); checked against the
+// transformers implementation with seeded random weights (tests/test_gpu_clip.py).
+//
+// Kernels:
+//   patchify        image fp32 NCHW -> bf16 [B*np, 3*P*P]  (im2col of non-overlapping patches)
+//   gemm_bf16<EPI>  C[M,N] = A[M,K] * W[N,K]^T + bias, 128x128x64 tiles, 4 waves x (2x2) 32x32x16 MFMA,
+//                   XOR-swizzled LDS (conflict-free ds_read_b128), register-prefetched next K tile;
+//                   epilogues: fp32 store / fp32 residual add / quick_gelu->bf16 / bf16
+//   layernorm       fp32 row -> bf16 (GEMM input) or fp32, one wave per token
+//   embed           [cls; patch tokens] + positional embedding -> fp32 residual stream
+//   attention       one wave per (image, head): K,V in LDS, fp32 scores/softmax, <= 64 tokens
+// Bound: the four GEMMs per layer -> bf16 MFMA (dense peak 2.5 PFLOP/s).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sc {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef uint16_t bf16_t;
+
+__device__ __forceinline__ bf16_t f2bf(float f) {      // round-to-nearest-even
+    uint32_t u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, bf16_t* __restrict__ out,
+                                                       int B, int C, int H, int W, int P) {
+    const int gw = W / P, gh = H / P, np = gw * gh, K = C * P * P;
+    const size_t total = (size_t)B * np * K;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int k = (int)(idx % K);
+        const size_t row = idx / K;
+        const int pidx = (int)(row % np), b = (int)(row / np);
+        const int c = k / (P * P), ky = (k / P) % P, kx = k % P;
+        const int py = pidx / gw, px = pidx % gw;
+        out[idx] = f2bf(img[(((size_t)b * C + c) * H + py * P + ky) * W + px * P + kx]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+enum { EPI_F32 = 0, EPI_RESID = 1, EPI_GELU_BF16 = 2, EPI_BF16 = 3 };
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
+                                                        const float* __restrict__ bias, void* __restrict__ out,
+                                                        int M, int N, int K) {
+    __shared__ uint4 As[128 * 8];
+    __shared__ uint4 Bs[128 * 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int bm = blockIdx.y * 128, bn = blockIdx.x * 128;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint4 ra[4], rb[4];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = tid + 256 * q, row = c >> 3, kc = c & 7;
+            const int gm = bm + row, gn = bn + row;
+            ra[q] = gm < M ? *reinterpret_cast<const uint4*>(A + (size_t)gm * K + kt * 64 + kc * 8) : make_uint4(0, 0, 0, 0);
+            rb[q] = gn < N ? *reinterpret_cast<const uint4*>(Wt + (size_t)gn * K + kt * 64 + kc * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    const int nk = K / 64;
+    gload(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();                      // previous tile fully consumed
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = tid + 256 * q, row = c >> 3, kc = c & 7;
+            As[row * 8 + (kc ^ (row & 7))] = ra[q];
+            Bs[row * 8 + (kc ^ (row & 7))] = rb[q];
+        }
+        __syncthreads();
+        if (kt + 1 < nk) gload(kt + 1);       // in flight while the MFMAs below run
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 af[2], bf[2];
+            const int kc = 2 * kk + (lane >> 5);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = 64 * wr + 32 * i + (lane & 31);
+                const uint4 v = As[row * 8 + (kc ^ (row & 7))];
+                af[i] = __builtin_bit_cast(bf16x8, v);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = 64 * wc + 32 * j + (lane & 31);
+                const uint4 v = Bs[row * 8 + (kc ^ (row & 7))];
+                bf[j] = __builtin_bit_cast(bf16x8, v);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = bn + 64 * wc + 32 * j + (lane & 31);
+            if (col >= N) continue;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = bm + 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row >= M) continue;
+                const float v = acc[i][j][r] + bv;
+                const size_t o = (size_t)row * N + col;
+                if (EPI == EPI_F32) reinterpret_cast<float*>(out)[o] = v;
+                else if (EPI == EPI_RESID) reinterpret_cast<float*>(out)[o] += v;
+                else if (EPI == EPI_GELU_BF16) reinterpret_cast<bf16_t*>(out)[o] = f2bf(v / (1.f + __expf(-1.702f * v)));
+                else reinterpret_cast<bf16_t*>(out)[o] = f2bf(v);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm over D (multiple of 64, <= 1024 here) per row; x rows are `stride` floats apart.
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int stride, const float* __restrict__ g,
+                                                        const float* __restrict__ b, void* __restrict__ out, int rows, int D,
+                                                        float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * stride;
+    float s = 0.f, ss = 0.f;
+    for (int d = lane; d < D; d += 64) { const float v = xr[d]; s += v; ss += v * v; }
+    for (int o = 32; o >= 1; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+    const float mean = s / D;
+    const float var = fmaxf(ss / D - mean * mean, 0.f);
+    const float inv = rsqrtf(var + eps);
+    for (int d = lane; d < D; d += 64) {
+        const float v = (xr[d] - mean) * inv * g[d] + b[d];
+        if (OUT_BF16) reinterpret_cast<bf16_t*>(out)[(size_t)row * D + d] = f2bf(v);
+        else reinterpret_cast<float*>(out)[(size_t)row * D + d] = v;
+    }
+}
+
+// tokens: x[b,0] = cls + pos[0]; x[b,1+i] = patch[b,i] + pos[1+i]
+__global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ patch, const float* __restrict__ cls,
+                                                    const float* __restrict__ pos, float* __restrict__ x, int B, int T, int D) {
+    const size_t total = (size_t)B * T * D;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int d = (int)(idx % D);
+        const int t = (int)((idx / D) % T);
+        const int b = (int)(idx / ((size_t)D * T));
+        const float v = t == 0 ? cls[d] : patch[((size_t)b * (T - 1) + (t - 1)) * D + d];
+        x[idx] = v + pos[(size_t)t * D + d];
+    }
+}
+
+// One wave per (image, head).  qkv: bf16 [B*T, 3*D] (q | k | v), head dim 64, T <= 64.  out bf16 [B*T, D].
+__global__ __launch_bounds__(64) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int T, int D,
+                                                       int heads, float scale) {
+    __shared__ float Ks[64 * 65];
+    __shared__ float Vs[64 * 64];
+    __shared__ float Ss[64 * 65];     // one score row per lane (dynamic indexing -> LDS, not scratch)
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads, lane = threadIdx.x;
+    const size_t rs = (size_t)3 * D;
+    for (int e = lane; e < T * 64; e += 64) {
+        const int t = e >> 6, d = e & 63;
+        const bf16_t* base = qkv + ((size_t)b * T + t) * rs + h * 64 + d;
+        Ks[t * 65 + d] = bf2f(base[D]);
+        Vs[t * 64 + d] = bf2f(base[2 * D]);
+    }
+    __syncthreads();
+    if (lane >= T) return;
+    float q[64];
+    const bf16_t* qp = qkv + ((size_t)b * T + lane) * rs + h * 64;
+#pragma unroll
+    for (int d = 0; d < 64; ++d) q[d] = bf2f(qp[d]) * scale;
+    float* sc = Ss + lane * 65;
+    float mx = -3.0e38f;
+    for (int t = 0; t < T; ++t) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < 64; ++d) s = __builtin_fmaf(q[d], Ks[t * 65 + d], s);
+        sc[t] = s;
+        mx = fmaxf(mx, s);
+    }
+    float den = 0.f;
+    for (int t = 0; t < T; ++t) { const float ev = __expf(sc[t] - mx); sc[t] = ev; den += ev; }
+    const float inv = 1.f / den;
+    float o[64];
+#pragma unroll
+    for (int d = 0; d < 64; ++d) o[d] = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const float p = sc[t] * inv;
+#pragma unroll
+        for (int d = 0; d < 64; ++d) o[d] = __builtin_fmaf(p, Vs[t * 64 + d], o[d]);
+    }
+    bf16_t* op = out + ((size_t)b * T + lane) * D + h * 64;
+#pragma unroll
+    for (int d = 0; d < 64; ++d) op[d] = f2bf(o[d]);
+}
+
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = f2bf(x[i]);
+}
+
+static int launch_gemm(int epi, const bf16_t* A, const bf16_t* Wt, const float* bias, void* out, int M, int N, int K,
+                       hipStream_t st) {
+    if (K % 64) return (int)hipErrorInvalidValue;
+    dim3 grid((N + 127) / 128, (M + 127) / 128);
+    switch (epi) {
+        case EPI_F32: hipLaunchKernelGGL(gemm_bf16_kernel<EPI_F32>, grid, dim3(256), 0, st, A, Wt, bias, out, M, N, K); break;
+        case EPI_RESID: hipLaunchKernelGGL(gemm_bf16_kernel<EPI_RESID>, grid, dim3(256), 0, st, A, Wt, bias, out, M, N, K); break;
+        case EPI_GELU_BF16: hipLaunchKernelGGL(gemm_bf16_kernel<EPI_GELU_BF16>, grid, dim3(256), 0, st, A, Wt, bias, out, M, N, K); break;
+        default: hipLaunchKernelGGL(gemm_bf16_kernel<EPI_BF16>, grid, dim3(256), 0, st, A, Wt, bias, out, M, N, K); break;
+    }
+    return (int)hipGetLastError();
+}
+
+}  // namespace sc
+
+extern "C" {
+
+// y[n] = bf16(x[n])  (weight preparation, once per model)
+int sc_f32_to_bf16(const float* x, uint16_t* y, long long n, void* stream_) {
+    if (n <= 0) return 0;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sc::f32_to_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, x, y, (size_t)n);
+    return (int)hipGetLastError();
+}
+
+// Generic bf16 GEMM used by the tower (exported for tests): out[M,N] (epi 0 fp32 / 1 fp32 += / 2 quick_gelu bf16 / 3 bf16)
+int sc_gemm_bf16(int epi, const uint16_t* A, const uint16_t* Wt, const float* bias, void* out, int M, int N, int K, void* stream_) {
+    return sc::launch_gemm(epi, A, Wt, bias, out, M, N, K, (hipStream_t)stream_);
+}
+
+// Full image tower.  See include/shapeclipper_hip.h for the weight image layout.
+int sc_clip_vit_forward(const float* image, int B, int C, int H, int W, int patch, int D, int mlp, int layers, int heads,
+                        int proj_dim, const uint16_t* w_bf16, const float* w_f32, float ln_eps, float* out,
+                        void* workspace, long long workspace_bytes, void* stream_) {
+    using namespace sc;
+    hipStream_t st = (hipStream_t)stream_;
+    if (D % 64 || D / heads != 64 || mlp % 64 || (C * patch * patch) % 64) return (int)hipErrorInvalidValue;
+    const int np = (H / patch) * (W / patch), T = np + 1, M = B * T, Kp = C * patch * patch;
+    if (T > 64) return (int)hipErrorInvalidValue;
+    // workspace carve (all 256-byte aligned)
+    char* ws = (char*)workspace;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { char* p = ws + off; off += (bytes + 255) & ~(size_t)255; return p; };
+    bf16_t* a_patch = (bf16_t*)carve((size_t)B * np * Kp * 2);
+    float* patch_out = (float*)carve((size_t)B * np * D * 4);
+    float* x = (float*)carve((size_t)M * D * 4);
+    bf16_t* xn = (bf16_t*)carve((size_t)M * D * 2);
+    bf16_t* qkv = (bf16_t*)carve((size_t)M * 3 * D * 2);
+    bf16_t* att = (bf16_t*)carve((size_t)M * D * 2);
+    bf16_t* hbuf = (bf16_t*)carve((size_t)M * mlp * 2);
+    bf16_t* pooled = (bf16_t*)carve((size_t)B * D * 2);
+    if ((long long)off > workspace_bytes) return (int)hipErrorInvalidValue;
+    // weight images: bf16 matrices then fp32 vectors, in this fixed order
+    const bf16_t* wb = w_bf16;
+    const float* wf = w_f32;
+    const bf16_t* w_patch = wb; wb += (size_t)D * Kp;
+    const float* cls = wf; wf += D;
+    const float* pos = wf; wf += (size_t)T * D;
+    const float* lnpre_g = wf; wf += D;
+    const float* lnpre_b = wf; wf += D;
+
+    hipLaunchKernelGGL(patchify_kernel, dim3(2048), dim3(256), 0, st, image, a_patch, B, C, H, W, patch);
+    int rc = launch_gemm(EPI_F32, a_patch, w_patch, nullptr, patch_out, B * np, D, Kp, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(embed_kernel, dim3(1024), dim3(256), 0, st, patch_out, cls, pos, x, B, T, D);
+    hipLaunchKernelGGL(layernorm_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, x, D, lnpre_g, lnpre_b, (void*)x, M, D, ln_eps);
+    for (int l = 0; l < layers; ++l) {
+        const bf16_t* w_qkv = wb; wb += (size_t)3 * D * D;
+        const bf16_t* w_o = wb; wb += (size_t)D * D;
+        const bf16_t* w_fc1 = wb; wb += (size_t)mlp * D;
+        const bf16_t* w_fc2 = wb; wb += (size_t)D * mlp;
+        const float* ln1_g = wf; wf += D;
+        const float* ln1_b = wf; wf += D;
+        const float* b_qkv = wf; wf += 3 * D;
+        const float* b_o = wf; wf += D;
+        const float* ln2_g = wf; wf += D;
+        const float* ln2_b = wf; wf += D;
+        const float* b_fc1 = wf; wf += mlp;
+        const float* b_fc2 = wf; wf += D;
+        hipLaunchKernelGGL(layernorm_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, x, D, ln1_g, ln1_b, (void*)xn, M, D, ln_eps);
+        if ((rc = launch_gemm(EPI_BF16, xn, w_qkv, b_qkv, qkv, M, 3 * D, D, st))) return rc;
+        hipLaunchKernelGGL(attention_kernel, dim3(B * heads), dim3(64), 0, st, qkv, att, T, D, heads, 0.125f);
+        if ((rc = launch_gemm(EPI_RESID, att, w_o, b_o, x, M, D, D, st))) return rc;
+        hipLaunchKernelGGL(layernorm_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, x, D, ln2_g, ln2_b, (void*)xn, M, D, ln_eps);
+        if ((rc = launch_gemm(EPI_GELU_BF16, xn, w_fc1, b_fc1, hbuf, M, mlp, D, st))) return rc;
+        if ((rc = launch_gemm(EPI_RESID, hbuf, w_fc2, b_fc2, x, M, D, mlp, st))) return rc;
+    }
+    const bf16_t* w_proj = wb;
+    const float* lnpost_g = wf; wf += D;
+    const float* lnpost_b = wf; wf += D;
+    // ln_post on the class token of every image (row stride T*D), then the projection (no bias)
+    hipLaunchKernelGGL(layernorm_kernel<true>, dim3((B + 3) / 4), dim3(256), 0, st, x, T * D, lnpost_g, lnpost_b, (void*)pooled, B, D, ln_eps);
+    return launch_gemm(EPI_F32, pooled, w_proj, nullptr, out, B, proj_dim, D, st);
+}
+
+}  // extern "C"

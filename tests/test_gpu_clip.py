@@ -1,0 +1,61 @@
+"""CLIP ViT image tower (csrc/clip_vit.hip) vs transformers.CLIPVisionModelWithProjection (fp32, CPU) with
+seeded random weights -- architecture-level oracle; parity with the reference is unpinned (openai/CLIP is an
+un-vendored dependency of CLIP_anno.py:16 and no weights are available offline).
+
+Bar: bf16 GEMM inputs, fp32 accumulate: cosine similarity of embeddings > 0.999, max abs error < 3 % of max |ref|."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _hf(width, layers, heads, mlp, patch, image, proj, seed):
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    torch.manual_seed(seed)
+    cfg = CLIPVisionConfig(hidden_size=width, intermediate_size=mlp, num_hidden_layers=layers, num_attention_heads=heads,
+                           patch_size=patch, image_size=image, projection_dim=proj, hidden_act="quick_gelu")
+    m = CLIPVisionModelWithProjection(cfg).eval()
+    with torch.no_grad():      # make biases / LN params non-trivial
+        for n, p in m.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+            else:
+                p.mul_(3.0)
+    return m
+
+
+@pytest.mark.parametrize("width,layers,heads,mlp,patch,image,proj,B", [(128, 2, 2, 256, 32, 64, 64, 3), (768, 12, 12, 3072, 32, 224, 512, 4)])
+def test_clip_tower_vs_transformers(width, layers, heads, mlp, patch, image, proj, B):
+    from shapeclipper_amd.model.clip_vit import ClipVisionTower
+    hf = _hf(width, layers, heads, mlp, patch, image, proj, seed=width)
+    x = torch.randn(B, 3, image, image)
+    with torch.no_grad():
+        ref = hf(pixel_values=x).image_embeds
+    tower = ClipVisionTower(image_size=image, patch=patch, width=width, layers=layers, heads=heads, mlp=mlp, proj=proj)
+    tower.load_state_dict(hf.state_dict())
+    tower = tower.cuda()
+    got = tower.encode_image(x.cuda()).cpu()
+    cos = torch.nn.functional.cosine_similarity(got, ref, dim=-1)
+    assert cos.min().item() > 0.999, cos
+    assert (got - ref).abs().max().item() < 0.03 * ref.abs().max().item()
+
+
+def test_gemm_bf16_transpose_detecting():
+    """C = A W^T with asymmetric operands (catches swapped row/col in the MFMA C/D mapping)."""
+    import ctypes
+    from shapeclipper_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    M, N, K = 200, 192, 128
+    A = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=dev) + torch.arange(N, device=dev)[:, None] * 0.01).to(torch.bfloat16)
+    bias = torch.randn(N, device=dev)
+    out = torch.zeros(M, N, device=dev)
+    rc = lib.sc_gemm_bf16(ctypes.c_int(0), _lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(out), ctypes.c_int(M),
+                          ctypes.c_int(N), ctypes.c_int(K), _lib.stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref = A.float() @ W.float().t() + bias
+    assert (out - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
