@@ -146,6 +146,40 @@ int sc_clip_vit_forward(const float* image, int B, int C, int H, int W, int patc
 int sc_gemm_bf16(int epi, const uint16_t* A, const uint16_t* Wt, const float* bias, void* out, int M, int N, int K, void* stream);
 int sc_f32_to_bf16(const float* x, uint16_t* y, long long n, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Ray sampling (UniformSampler.get_z_vals + point generation, model/renderer.py:13-37,84-86).
+ * cam_loc, ray_dirs [n_rays][3]; scale_dist [n_images]; u [n_rays][64] stratified jitter in [0,1) or NULL
+ * (evaluation: plain linspace).  Outputs z_vals [n_rays][64], points [n_rays*64][3].  Arithmetic follows the
+ * reference's fp32 op order (no fma contraction) so z_vals / points are bit-identical to the torch ops.   */
+int sc_ray_sample_forward(const float* cam_loc, const float* ray_dirs, const float* scale_dist, const float* u,
+                          int n_rays, int rays_per_image, int n_images, float cam_dist, float* z_vals,
+                          float* points, void* stream);
+/* adjoint: g_points [P][3] (+ g_z_extra [n_rays][64] from the compositing, may be NULL) -> g_cam_loc,
+ * g_ray_dirs [n_rays][3], g_scale_dist [n_images] (zero-filled by the caller; atomicAdd).               */
+int sc_ray_sample_backward(const float* ray_dirs, const float* z_vals, const float* g_points,
+                           const float* g_z_extra, int n_rays, int rays_per_image, int n_images, float cam_dist,
+                           float* g_cam_loc, float* g_ray_dirs, float* g_scale_dist, void* stream);
+
+/* One render without gradients in a single call (Renderer.forward, model/renderer.py:57-152):
+ * sc_ray_sample_forward -> sc_sdf_forward -> sc_rgb_composite_forward.  z_vals, points, sdf, grad, feat and
+ * scratch are caller-provided work buffers (sizes as in the three entry points).                         */
+int sc_render_forward(const float* cam_loc, const float* ray_dirs, const float* depth_fac, const float* scale_dist,
+                      const float* u, const float* sdf_pack, const float* sdf_cbias, const float* rgb_pack,
+                      const float* rgb_dbias, const float* beta_param, int n_rays, int rays_per_image, int n_images,
+                      int symmetric, float cam_dist, float beta_min, float bgcolor, float normal_pow,
+                      float* rgb, float* mask, float* mask_hard, float* depth, float* normal,
+                      float* z_vals, float* points, float* sdf, float* grad, float* feat, float* scratch, void* stream);
+
+/* compute_level_grid (utils/eval_3D.py:9-38): SDF on linspace(lo,hi,n_axis)^3 ('ij' order) for every image.
+ * points_ws: [n_images*n_axis^3][3] floats of workspace; level: [n_images][n_axis][n_axis][n_axis].       */
+int sc_sdf_grid_forward(const float* sdf_pack, const float* sdf_cbias, float lo, float hi, int n_axis, int n_images,
+                        int symmetric, float* points_ws, float* level, void* stream);
+
+/* backward of sc_loss_fused_forward: scales the stored gradients in place by the upstream dL/dloss_k (G4[4],
+ * device memory).  g_eik may be NULL.                                                                  */
+int sc_loss_fused_backward(const float* G4, float* g_rgb, long long n_rgb, float* g_mask, long long n_mask,
+                           float* g_normal, long long n_normal, float* g_eik, long long n_eik, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,3 +100,26 @@ class FusedRenderLoss(torch.autograd.Function):
         g_eik = (saved[3] * G[3]).view(s_eik) if ctx.has_eik else None
         return ((g_rgb * G[0]).view(s_rgb), None, (g_mask * G[1]).view(s_mask), None, (g_normal * G[2]).view(s_normal),
                 None, g_eik, None, None, None)
+
+
+class RaySampleFunction(torch.autograd.Function):
+    """cam_loc, ray_dirs [n_rays,3], scale_dist [B], u [n_rays,64] | None -> z_vals [n_rays,64], points [n_rays*64,3]
+    (UniformSampler.get_z_vals + point generation, reference model/renderer.py:13-37,84-86) with a hand-written adjoint."""
+
+    @staticmethod
+    def forward(ctx, cam_loc, ray_dirs, scale_dist, u, rays_per_image, cam_dist):
+        cam_loc, ray_dirs, scale_dist = cam_loc.contiguous(), ray_dirs.contiguous(), scale_dist.contiguous()
+        z, pts = ops.ray_sample_forward(cam_loc, ray_dirs, scale_dist, u, rays_per_image, cam_dist)
+        ctx.save_for_backward(ray_dirs, z)
+        ctx.meta = (rays_per_image, scale_dist.shape[0], cam_dist)
+        return z, pts
+
+    @staticmethod
+    def backward(ctx, g_z, g_points):
+        ray_dirs, z = ctx.saved_tensors
+        rpi, n_images, cam_dist = ctx.meta
+        if g_points is None:
+            g_points = torch.zeros(z.numel(), 3, device=z.device)
+        g_o, g_d, g_sd = ops.ray_sample_backward(ray_dirs, z, g_points.contiguous(), g_z.contiguous() if g_z is not None else None,
+                                                 rpi, n_images, cam_dist)
+        return g_o, g_d, g_sd, None, None, None

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as torch_F
 
-from ..functional import RgbCompositeFunction, SdfFunction
+from ..functional import RaySampleFunction, RgbCompositeFunction, SdfFunction
 from ..utils import camera
 from .implicit import LaplaceDensity
 
@@ -82,16 +82,18 @@ class Renderer(nn.Module):
         ray_dirs = ray_dirs.reshape(-1, 3)
         depth_fac = depth_fac.reshape(-1)
 
-        z_vals, z_eik = self.ray_sampler.get_z_vals(opt, ray_dirs, scale_dist, training)
-        assert z_vals.shape[1] == S
-        points_flat = (cam_loc.unsqueeze(1) + z_vals.unsqueeze(2) * ray_dirs.unsqueeze(1)).reshape(-1, 3)
+        # reference CPU-generator draws, in its order (renderer.py:29,33): jitter then the eikonal sample index
+        t_rand = torch.rand(B * R, S).to(ray_dirs.device) if training else None
+        eik_idx = torch.randint(S, (B * R,)).to(ray_dirs.device)
+        z_vals, points_flat = RaySampleFunction.apply(cam_loc, ray_dirs, scale_dist, t_rand, R, float(opt.camera.dist))
+        z_eik = torch.gather(z_vals, 1, eik_idx.unsqueeze(-1))
         assert proj_latent_rgb.shape[1] == opt.arch.impl_rgb.proj_latent_dim
 
         # fused SDF value + feature + d(sdf)/dx, then RGB MLP + density + compositing
         w_pack, cbias = self.sdf_network.packed(proj_latent_sdf)
         sdf, grad, feat = SdfFunction.apply(points_flat, w_pack, cbias, R * S, sym, True, True)
         v_pack, dbias = self.rgb_network.packed(proj_latent_rgb)
-        outs = RgbCompositeFunction.apply(points_flat, z_vals.contiguous(), depth_fac.contiguous(), sdf, grad, feat,
+        outs = RgbCompositeFunction.apply(points_flat, z_vals, depth_fac.contiguous(), sdf, grad, feat,
                                           v_pack, dbias, self.density.beta, R, sym, float(self.density.beta_min),
                                           self.bg_color, float(opt.reg.normal_pow), bool(visualize))
         rgb, mask, mask_hard, depth, normal = outs[:5]

@@ -258,3 +258,67 @@ def loss_fused_forward(rgb, rgb_t, mask, mask_t, normal, normal_t, eik, normal_l
                                      _lib.ptr(g_eik), _lib.ptr(ws), _lib.stream())
     _lib.check(code, "sc_loss_fused_forward")
     return out, (g_rgb, g_mask, g_normal, g_eik)
+
+
+def ray_sample_forward(cam_loc, ray_dirs, scale_dist, u, rays_per_image, cam_dist):
+    """-> z_vals [n_rays,64], points [n_rays*64,3]  (u = None: evaluation linspace)."""
+    lib = _lib.load()
+    n_rays = ray_dirs.shape[0]
+    z = torch.empty(n_rays, 64, device=ray_dirs.device, dtype=torch.float32)
+    pts = torch.empty(n_rays * 64, 3, device=ray_dirs.device, dtype=torch.float32)
+    code = lib.sc_ray_sample_forward(_lib.ptr(cam_loc), _lib.ptr(ray_dirs), _lib.ptr(scale_dist), _lib.ptr(u), c_int(n_rays),
+                                     c_int(rays_per_image), c_int(scale_dist.shape[0]), ctypes.c_float(cam_dist),
+                                     _lib.ptr(z), _lib.ptr(pts), _lib.stream())
+    _lib.check(code, "sc_ray_sample_forward")
+    return z, pts
+
+
+def ray_sample_backward(ray_dirs, z_vals, g_points, g_z, rays_per_image, n_images, cam_dist):
+    lib = _lib.load()
+    n_rays = ray_dirs.shape[0]
+    dev = ray_dirs.device
+    g_o = torch.empty(n_rays, 3, device=dev, dtype=torch.float32)
+    g_d = torch.empty(n_rays, 3, device=dev, dtype=torch.float32)
+    g_sd = torch.zeros(n_images, device=dev, dtype=torch.float32)
+    code = lib.sc_ray_sample_backward(_lib.ptr(ray_dirs), _lib.ptr(z_vals), _lib.ptr(g_points), _lib.ptr(g_z), c_int(n_rays),
+                                      c_int(rays_per_image), c_int(n_images), ctypes.c_float(cam_dist), _lib.ptr(g_o),
+                                      _lib.ptr(g_d), _lib.ptr(g_sd), _lib.stream())
+    _lib.check(code, "sc_ray_sample_backward")
+    return g_o, g_d, g_sd
+
+
+def sdf_grid_forward(w_pack, cbias, lo, hi, n_axis, symmetric=True):
+    """compute_level_grid in one call: -> level [n_images, n_axis, n_axis, n_axis]."""
+    lib = _lib.load()
+    B = cbias.shape[0]
+    dev = cbias.device
+    ws = torch.empty(B * n_axis ** 3, 3, device=dev, dtype=torch.float32)
+    level = torch.empty(B, n_axis, n_axis, n_axis, device=dev, dtype=torch.float32)
+    code = lib.sc_sdf_grid_forward(_lib.ptr(w_pack), _lib.ptr(cbias), ctypes.c_float(lo), ctypes.c_float(hi), c_int(n_axis),
+                                   c_int(B), c_int(1 if symmetric else 0), _lib.ptr(ws), _lib.ptr(level), _lib.stream())
+    _lib.check(code, "sc_sdf_grid_forward")
+    return level
+
+
+def render_forward(cam_loc, ray_dirs, depth_fac, scale_dist, u, sdf_pack, sdf_cbias, rgb_pack, rgb_dbias, beta_param,
+                   rays_per_image, symmetric, cam_dist, beta_min, bgcolor, normal_pow):
+    """One gradient-free render through the single C entry point sc_render_forward."""
+    lib = _lib.load()
+    n_rays = ray_dirs.shape[0]
+    dev = ray_dirs.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    P = n_rays * 64
+    out = dict(rgb=torch.empty(n_rays, 3, **f32), mask=torch.empty(n_rays, **f32), mask_hard=torch.empty(n_rays, **f32),
+               depth=torch.empty(n_rays, **f32), normal=torch.empty(n_rays, 3, **f32))
+    z = torch.empty(n_rays, 64, **f32); pts = torch.empty(P, 3, **f32); sdf = torch.empty(P, **f32)
+    grad = torch.empty(P, 3, **f32); feat = torch.empty(n_tiles(P) * 1024, **f32)
+    code = lib.sc_render_forward(
+        _lib.ptr(cam_loc), _lib.ptr(ray_dirs), _lib.ptr(depth_fac), _lib.ptr(scale_dist), _lib.ptr(u), _lib.ptr(sdf_pack),
+        _lib.ptr(sdf_cbias), _lib.ptr(rgb_pack), _lib.ptr(rgb_dbias), _lib.ptr(beta_param), c_int(n_rays), c_int(rays_per_image),
+        c_int(scale_dist.shape[0]), c_int(1 if symmetric else 0), ctypes.c_float(cam_dist), ctypes.c_float(beta_min),
+        ctypes.c_float(bgcolor), ctypes.c_float(normal_pow), _lib.ptr(out["rgb"]), _lib.ptr(out["mask"]), _lib.ptr(out["mask_hard"]),
+        _lib.ptr(out["depth"]), _lib.ptr(out["normal"]), _lib.ptr(z), _lib.ptr(pts), _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(feat),
+        _lib.ptr(_sdf_scratch(dev)), _lib.stream())
+    _lib.check(code, "sc_render_forward")
+    out.update(z_vals=z, points=pts)
+    return out
