@@ -78,27 +78,31 @@ __device__ __forceinline__ void quad_transpose(float4& v, int j) {
 }
 
 // channel tile T (16 channels) of a TBL operand for this lane: x..w = K-steps 0..3
+// ---- operand fragments: raw loads (issued one tile ahead) and the transform + transpose applied at use ----
+// channel tile T (16 channels) of a TBL operand, raw float4 of this lane: 4 consecutive channels of ONE point
 template <int op>
-__device__ __forceinline__ float4 wg_frag(const float* x0, const float* x1, const float* w5row,
-                                          int tile, int T, int i, int g, bool valid) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+__device__ __forceinline__ void wg_raw(const float* x0, const float* x1, int tile, int T, int i, int g, bool valid,
+                                       float4& r0, float4& r1) {
+    r0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    r1 = r0;
     const int grp = 4 * T + (i >> 2), pt = 4 * g + (i & 3);
     if (valid) {
-        if constexpr (op == OP_PLAIN) {
-            v = wg_load4(x0, tile, grp, pt);
-        } else if constexpr (op == OP_SP) {
-            const float4 a = wg_load4(x0, tile, grp, pt);
-            v = make_float4(sp_val(a.x), sp_val(a.y), sp_val(a.z), sp_val(a.w));
-        } else if constexpr (op == OP_Q) {
-            const float4 pz = wg_load4(x0, tile, grp, pt);
-            const float4 a = wg_load4(x1, tile, grp, pt);
-            v = make_float4(pz.x * sp_d1(a.x), pz.y * sp_d1(a.y), pz.z * sp_d1(a.z), pz.w * sp_d1(a.w));
-        } else if constexpr (op == OP_Q4) {
-            const float4 a = wg_load4(x1, tile, grp, pt);
-            const float4 w = reinterpret_cast<const float4*>(w5row)[grp];
-            v = make_float4(w.x * sp_d1(a.x), w.y * sp_d1(a.y), w.z * sp_d1(a.z), w.w * sp_d1(a.w));
-        }
+        if constexpr (op == OP_PLAIN || op == OP_SP) r0 = wg_load4(x0, tile, grp, pt);
+        if constexpr (op == OP_Q) { r0 = wg_load4(x0, tile, grp, pt); r1 = wg_load4(x1, tile, grp, pt); }
+        if constexpr (op == OP_Q4) r1 = wg_load4(x1, tile, grp, pt);
     }
+}
+// transform + quad transpose: x..w = K-steps 0..3 (points 4g..4g+3) of channel 16T + i
+template <int op>
+__device__ __forceinline__ float4 wg_cook(float4 r0, float4 r1, const float* w5row, int T, int i, bool valid) {
+    float4 v = r0;
+    if constexpr (op == OP_SP) v = make_float4(sp_val(r0.x), sp_val(r0.y), sp_val(r0.z), sp_val(r0.w));
+    if constexpr (op == OP_Q) v = make_float4(r0.x * sp_d1(r1.x), r0.y * sp_d1(r1.y), r0.z * sp_d1(r1.z), r0.w * sp_d1(r1.w));
+    if constexpr (op == OP_Q4) {
+        const float4 w = reinterpret_cast<const float4*>(w5row)[4 * T + (i >> 2)];
+        v = make_float4(w.x * sp_d1(r1.x), w.y * sp_d1(r1.y), w.z * sp_d1(r1.z), w.w * sp_d1(r1.w));
+    }
+    if (!valid) v = make_float4(0.f, 0.f, 0.f, 0.f);     // softplus(0) != 0: re-mask out-of-range points
     quad_transpose(v, i & 3);
     return v;
 }
@@ -145,27 +149,43 @@ __device__ __forceinline__ float4 pe_frag(const PeLane& P, int c) {
                        : make_float4(P.ep[c][0], P.ep[c][1], P.ep[c][2], P.ep[c][3]);
 }
 
-// B fragment n of a term whose two segments have compile-time transforms B0 (first NT0 tiles) and B1
-template <int B0, int B1, int NT0>
-__device__ __forceinline__ float4 b_frag(const WgradTerm& T, const PeLane& P, int tile, int n, int i, int g, bool valid) {
-    if (n < NT0) {
-        if constexpr (B0 == OP_PE || B0 == OP_EPS) return pe_frag<B0>(P, n);
-        else return wg_frag<B0>(T.b0, nullptr, nullptr, tile, n, i, g, valid);
-    } else {
-        if constexpr (B1 == OP_PE || B1 == OP_EPS) return pe_frag<B1>(P, n - NT0);
-        else if constexpr (B1 == OP_NONE) return make_float4(0.f, 0.f, 0.f, 0.f);
-        else return wg_frag<B1>(T.b1, nullptr, nullptr, tile, n - NT0, i, g, valid);
+template <int A, int B0, int B1, int NT0, int NNT>
+struct TermRaw {
+    float4 a0[NT], a1[NT], b[NNT];
+};
+
+template <int A, int B0, int B1, int NT0, int NNT>
+__device__ __forceinline__ void term_load(const WgradTerm& T, int tile, int i, int g, bool valid, TermRaw<A, B0, B1, NT0, NNT>& R) {
+    float4 dummy;
+#pragma unroll
+    for (int m = 0; m < NT; ++m) wg_raw<A>(T.a0, T.a1, tile, m, i, g, valid, R.a0[m], R.a1[m]);
+#pragma unroll
+    for (int n = 0; n < NNT; ++n) {
+        if (n < NT0) {
+            if constexpr (B0 == OP_PLAIN || B0 == OP_SP) wg_raw<B0>(T.b0, nullptr, tile, n, i, g, valid, R.b[n], dummy);
+        } else {
+            if constexpr (B1 == OP_PLAIN || B1 == OP_SP) wg_raw<B1>(T.b1, nullptr, tile, n - NT0, i, g, valid, R.b[n], dummy);
+        }
     }
 }
 
 template <int A, int B0, int B1, int NT0, int NNT>
-__device__ __forceinline__ void wgrad_term(const WgradTerm& T, const PeLane& P, const float* w5row, int tile, int i, int g,
-                                           bool valid, f32x4 (&acc)[NT][NNT]) {
+__device__ __forceinline__ void term_compute(const TermRaw<A, B0, B1, NT0, NNT>& R, const PeLane& P, const float* w5row, int i,
+                                             bool valid, f32x4 (&acc)[NT][NNT]) {
     float4 af[NT], bf[NNT];
 #pragma unroll
-    for (int m = 0; m < NT; ++m) af[m] = wg_frag<A>(T.a0, T.a1, w5row, tile, m, i, g, valid);
+    for (int m = 0; m < NT; ++m) af[m] = wg_cook<A>(R.a0[m], R.a1[m], w5row, m, i, valid);
 #pragma unroll
-    for (int n = 0; n < NNT; ++n) bf[n] = b_frag<B0, B1, NT0>(T, P, tile, n, i, g, valid);
+    for (int n = 0; n < NNT; ++n) {
+        if (n < NT0) {
+            if constexpr (B0 == OP_PE || B0 == OP_EPS) bf[n] = pe_frag<B0>(P, n);
+            else bf[n] = wg_cook<B0>(R.b[n], R.b[n], nullptr, n, i, valid);
+        } else {
+            if constexpr (B1 == OP_PE || B1 == OP_EPS) bf[n] = pe_frag<B1>(P, n - NT0);
+            else if constexpr (B1 == OP_NONE) bf[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+            else bf[n] = wg_cook<B1>(R.b[n], R.b[n], nullptr, n - NT0, i, valid);
+        }
+    }
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -195,12 +215,31 @@ __global__ __launch_bounds__(256, WPS) void wgrad_kernel(WgradArgs a) {
     constexpr bool need_pe = B00 == OP_PE || B10 == OP_PE || B01 == OP_EPS || B11 == OP_EPS || B00 == OP_EPS || B10 == OP_EPS;
     constexpr bool need_eps = B01 == OP_EPS || B11 == OP_EPS || B00 == OP_EPS || B10 == OP_EPS;
 
-    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
-        const bool valid = tile * TP + 4 * g + (i & 3) < a.n_points;   // the point this lane LOADS
+    // software pipeline: the raw operand loads of the NEXT tile are issued before the transforms + MFMAs of
+    // the current one, so every wave always has ~20 KB of HBM reads in flight
+    TermRaw<A0, B00, B10, NT0, NNT> c0, n0;
+    TermRaw<A1, B01, B11, NT0, NNT> c1, n1;
+    const int stride = gridDim.x * 4;
+    int tile = blockIdx.x * 4 + wave;
+    bool nvalid = tile * TP + 4 * g + (i & 3) < a.n_points;   // validity of the point this lane LOADS
+    if (tile < ntiles) {
+        term_load(a.t[0], tile, i, g, nvalid, n0);
+        if constexpr (A1 != OP_NONE) term_load(a.t[1], tile, i, g, nvalid, n1);
+    }
+    for (; tile < ntiles; tile += stride) {
+        c0 = n0;
+        if constexpr (A1 != OP_NONE) c1 = n1;
+        const bool valid = nvalid;
+        const int next = tile + stride;
+        if (next < ntiles) {
+            nvalid = next * TP + 4 * g + (i & 3) < a.n_points;
+            term_load(a.t[0], next, i, g, nvalid, n0);
+            if constexpr (A1 != OP_NONE) term_load(a.t[1], next, i, g, nvalid, n1);
+        }
         PeLane P;
         if constexpr (need_pe) pe_lane_setup(P, a.points, a.g_grad, need_eps, tile, i, g, a.n_points, a.symmetric != 0);
-        wgrad_term<A0, B00, B10, NT0, NNT>(a.t[0], P, a.w5row, tile, i, g, valid, acc);
-        if constexpr (A1 != OP_NONE) wgrad_term<A1, B01, B11, NT0, NNT>(a.t[1], P, a.w5row, tile, i, g, valid, acc);
+        term_compute(c0, P, a.w5row, i, valid, acc);
+        if constexpr (A1 != OP_NONE) term_compute(c1, P, a.w5row, i, valid, acc);
     }
     // combine the four waves of the workgroup in LDS, then one partial image per workgroup
     __syncthreads();
@@ -322,15 +361,12 @@ int sc_wgrad(int nterms,
         hipLaunchKernelGGL((wgrad_kernel<NNT, NT0, WPS, A0, B00, B10, A1, B01, B11>), dim3(nparts), dim3(256), 0, st, a); \
         return (int)hipGetLastError();                                                                           \
     }
-    SC_WG(3, 3, 3, OP_PLAIN, OP_PE, OP_NONE, OP_Q, OP_EPS, OP_NONE)         // dW0e
-    SC_WG(3, 3, 3, OP_PLAIN, OP_PE, OP_NONE, OP_NONE, OP_NONE, OP_NONE)
-    SC_WG(7, 4, 2, OP_PLAIN, OP_SP, OP_PE, OP_Q, OP_PLAIN, OP_EPS)          // dW1, dW2
-    SC_WG(7, 4, 2, OP_PLAIN, OP_SP, OP_PE, OP_NONE, OP_NONE, OP_NONE)
-    SC_WG(4, 4, 3, OP_PLAIN, OP_SP, OP_NONE, OP_Q, OP_PLAIN, OP_NONE)       // dW3
-    SC_WG(4, 4, 3, OP_PLAIN, OP_SP, OP_NONE, OP_Q4, OP_PLAIN, OP_NONE)      // dW4
-    SC_WG(4, 4, 3, OP_PLAIN, OP_SP, OP_NONE, OP_NONE, OP_NONE, OP_NONE)     // dW5 feature rows, no-Gg variants
-    SC_WG(7, 3, 2, OP_PLAIN, OP_PE, OP_PLAIN, OP_NONE, OP_NONE, OP_NONE)    // dV0
-    SC_WG(4, 4, 3, OP_PLAIN, OP_PLAIN, OP_NONE, OP_NONE, OP_NONE, OP_NONE)  // dV1, dV2
+    SC_WG(3, 3, 2, OP_PLAIN, OP_PE, OP_NONE, OP_Q, OP_EPS, OP_NONE)         // dW0e, dW1e, dW2e
+    SC_WG(3, 3, 2, OP_PLAIN, OP_PE, OP_NONE, OP_NONE, OP_NONE, OP_NONE)     // ... without d/d(grad); dV0e
+    SC_WG(4, 4, 2, OP_PLAIN, OP_SP, OP_NONE, OP_Q, OP_PLAIN, OP_NONE)       // dW1h, dW2h, dW3
+    SC_WG(4, 4, 2, OP_PLAIN, OP_SP, OP_NONE, OP_Q4, OP_PLAIN, OP_NONE)      // dW4
+    SC_WG(4, 4, 2, OP_PLAIN, OP_SP, OP_NONE, OP_NONE, OP_NONE, OP_NONE)     // dW5 feature rows, no-Gg variants
+    SC_WG(4, 4, 2, OP_PLAIN, OP_PLAIN, OP_NONE, OP_NONE, OP_NONE, OP_NONE)  // dV0f, dV1, dV2
 #undef SC_WG
     return (int)hipErrorInvalidValue;   // operand combination not instantiated
 }

@@ -80,7 +80,7 @@ def rgb_composite_forward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, db
 
 # operand transform codes of sc_wgrad (csrc/wgrad.hip)
 OP_NONE, OP_PLAIN, OP_SP, OP_Q, OP_Q4, OP_PE, OP_EPS = range(7)
-WGRAD_PARTS = 768
+WGRAD_PARTS = 512
 
 
 def _wgrad(lib, terms, points, g_grad, w5row, n_points, symmetric, nb0, nb1, partial, stride, out_offset, out_ld):
@@ -152,11 +152,15 @@ def sdf_backward(points, w_pack, n_per_image, n_images, symmetric, stash_a, stas
     if gg:
         t.append((P(0), A(0), OP_Q, None, OP_EPS, None, OP_NONE))
     launch(t, 48, 0, SDF_OFF["W0"], 48)
-    for l, key in ((1, "W1"), (2, "W2")):
-        t = [(GA(l), None, OP_PLAIN, A(l - 1), OP_SP, None, OP_PE)]
+    for l, key in ((1, "W1"), (2, "W2")):      # [64][112] = [hidden 64 | PE 48]: two launches of <= 4 N tiles each
+        t = [(GA(l), None, OP_PLAIN, A(l - 1), OP_SP, None, OP_NONE)]
         if gg:
-            t.append((P(l), A(l), OP_Q, GP(l - 1), OP_PLAIN, None, OP_EPS))
-        launch(t, 64, 48, SDF_OFF[key], 112)
+            t.append((P(l), A(l), OP_Q, GP(l - 1), OP_PLAIN, None, OP_NONE))
+        launch(t, 64, 0, SDF_OFF[key], 112)
+        t = [(GA(l), None, OP_PLAIN, None, OP_PE, None, OP_NONE)]
+        if gg:
+            t.append((P(l), A(l), OP_Q, None, OP_EPS, None, OP_NONE))
+        launch(t, 48, 0, SDF_OFF[key] + 64, 112)
     t = [(GA(3), None, OP_PLAIN, A(2), OP_SP, None, OP_NONE)]
     if gg:
         t.append((P(3), A(3), OP_Q, GP(2), OP_PLAIN, None, OP_NONE))
@@ -219,7 +223,8 @@ def rgb_composite_backward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, d
     stride = RGB_PACK_FLOATS
     partial = torch.empty(WGRAD_PARTS * stride, **f32)
     common = (points, None, None, P, symmetric)
-    _wgrad(lib, [(GY(0), None, OP_PLAIN, None, OP_PE, feat, OP_PLAIN)], *common, 48, 64, partial, stride, RGB_OFF["V0"], 112)
+    _wgrad(lib, [(GY(0), None, OP_PLAIN, None, OP_PE, None, OP_NONE)], *common, 48, 0, partial, stride, RGB_OFF["V0"], 112)
+    _wgrad(lib, [(GY(0), None, OP_PLAIN, feat, OP_PLAIN, None, OP_NONE)], *common, 64, 0, partial, stride, RGB_OFF["V0"] + 48, 112)
     _wgrad(lib, [(GY(1), None, OP_PLAIN, RR(0), OP_PLAIN, None, OP_NONE)], *common, 64, 0, partial, stride, RGB_OFF["V1"], 64)
     _wgrad(lib, [(GY(2), None, OP_PLAIN, RR(1), OP_PLAIN, None, OP_NONE)], *common, 64, 0, partial, stride, RGB_OFF["V2"], 64)
     g_v = torch.zeros(stride, **f32)
