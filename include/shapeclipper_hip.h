@@ -155,7 +155,8 @@ int sc_ray_sample_forward(const float* cam_loc, const float* ray_dirs, const flo
                           int n_rays, int rays_per_image, int n_images, float cam_dist, float* z_vals,
                           float* points, void* stream);
 /* adjoint: g_points [P][3] (+ g_z_extra [n_rays][64] from the compositing, may be NULL) -> g_cam_loc,
- * g_ray_dirs [n_rays][3], g_scale_dist [n_images] (zero-filled by the caller; atomicAdd).               */
+ * g_ray_dirs [n_rays][3], g_scale_dist [n_rays]: per-RAY contribution; d/d scale_dist[b] is its sum over the
+ * rays of image b (left to the caller: one tiny reduction instead of 16K contended atomics).            */
 int sc_ray_sample_backward(const float* ray_dirs, const float* z_vals, const float* g_points,
                            const float* g_z_extra, int n_rays, int rays_per_image, int n_images, float cam_dist,
                            float* g_cam_loc, float* g_ray_dirs, float* g_scale_dist, void* stream);

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void ray_sample_kernel(const float* __restrict
 }
 
 // adjoint: g_points [P][3], g_z_extra [n_rays][64] (from compositing, may be null)
-//   -> g_cam_loc [n_rays][3], g_ray_dirs [n_rays][3], g_scale_dist [n_images] (atomicAdd, pre-zeroed)
+//   -> g_cam_loc [n_rays][3], g_ray_dirs [n_rays][3], g_scale_dist_ray [n_rays] (sum over the rays of an image = d/d scale_dist)
 __global__ __launch_bounds__(256) void ray_sample_bwd_kernel(const float* __restrict__ ray_dirs, const float* __restrict__ z_vals,
                                                              const float* __restrict__ g_points, const float* __restrict__ g_z_extra,
                                                              int n_rays, int rays_per_image, int n_images, float cam_dist,
@@ -69,8 +69,9 @@ __global__ __launch_bounds__(256) void ray_sample_bwd_kernel(const float* __rest
         if (lane == 0) {
             g_cam_loc[(size_t)ray * 3] = s0; g_cam_loc[(size_t)ray * 3 + 1] = s1; g_cam_loc[(size_t)ray * 3 + 2] = s2;
             g_ray_dirs[(size_t)ray * 3] = t0; g_ray_dirs[(size_t)ray * 3 + 1] = t1; g_ray_dirs[(size_t)ray * 3 + 2] = t2;
-            // every z of the ray shifts by cam_dist * d(scale_dist): near and far move together
-            atomicAdd(&g_scale_dist[min(ray / rays_per_image, n_images - 1)], cam_dist * gz);
+            // every z of the ray shifts by cam_dist * d(scale_dist): near and far move together.  Per-ray value;
+            // the caller sums the rays of an image (32 addresses would serialise 16K atomics).
+            g_scale_dist[ray] = cam_dist * gz;
         }
     }
 }

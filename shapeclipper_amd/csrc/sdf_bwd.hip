@@ -76,12 +76,17 @@ __global__ __launch_bounds__(64 * SDFB_WAVES) void sdf_bwd_kernel(SdfBwdArgs a) 
             gx[c] = __builtin_fmaf(SCALE, dsum, gx[c]);                                      \
         }
 
-    // ================= R pass over all tiles of this wave (only when d/d(grad) is given) =================
-    // Parks pend_0..3 in Ga_0..3, pend_4 in Ga_4, u4 in r0 and the second-order part of G point in g_points;
-    // the V pass below picks them up (same wave, L2-hot).  Two loops instead of one keep each loop body
+    // ================= R sweep (only when d/d(grad) is given), then V sweep, per chunk of CH tiles =================
+    // R parks pend_0..3 in Ga_0..3, pend_4 in Ga_4, u4 in r0 and the second-order part of G point in g_points; the V
+    // sweep of the same chunk picks them up a few microseconds later (same wave, still in L2 / Infinity Cache, so the
+    // round trip and the second read of a_l cost no HBM traffic).  Two loops instead of one fused body keep each body
     // under 256 VGPRs (2 waves per SIMD) -- a single fused body needed ~500 and spilled.
+    constexpr int CH = 2;   // tiles per wave between the R and the V sweep: the parked tensors stay in L2 / Infinity Cache
+    const int wave_gid = blockIdx.x * SDFB_WAVES + wave, nwaves = gridDim.x * SDFB_WAVES;
+    for (int chunk = wave_gid * CH; chunk < ntiles; chunk += nwaves * CH) {
     if (HAS_GG) {
-        for (int tile = blockIdx.x * SDFB_WAVES + wave; tile < ntiles; tile += gridDim.x * SDFB_WAVES) {
+#pragma unroll 1
+        for (int tile = chunk; tile < min(chunk + CH, ntiles); ++tile) {
             const int pt = tile * TP + p;
             const bool valid = pt < a.n_points;
             const int ptc = valid ? pt : a.n_points - 1;
@@ -157,7 +162,8 @@ __global__ __launch_bounds__(64 * SDFB_WAVES) void sdf_bwd_kernel(SdfBwdArgs a) 
     }
 
     // ================= V pass =================
-    for (int tile = blockIdx.x * SDFB_WAVES + wave; tile < ntiles; tile += gridDim.x * SDFB_WAVES) {
+#pragma unroll 1
+    for (int tile = chunk; tile < min(chunk + CH, ntiles); ++tile) {
         const int pt = tile * TP + p;
         const bool valid = pt < a.n_points;
         const int ptc = valid ? pt : a.n_points - 1;
@@ -224,6 +230,7 @@ __global__ __launch_bounds__(64 * SDFB_WAVES) void sdf_bwd_kernel(SdfBwdArgs a) 
             }
         }
     }
+    }   // chunk
 }
 
 }  // namespace sc

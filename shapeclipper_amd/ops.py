@@ -284,12 +284,12 @@ def ray_sample_backward(ray_dirs, z_vals, g_points, g_z, rays_per_image, n_image
     dev = ray_dirs.device
     g_o = torch.empty(n_rays, 3, device=dev, dtype=torch.float32)
     g_d = torch.empty(n_rays, 3, device=dev, dtype=torch.float32)
-    g_sd = torch.zeros(n_images, device=dev, dtype=torch.float32)
+    g_sd = torch.empty(n_rays, device=dev, dtype=torch.float32)
     code = lib.sc_ray_sample_backward(_lib.ptr(ray_dirs), _lib.ptr(z_vals), _lib.ptr(g_points), _lib.ptr(g_z), c_int(n_rays),
                                       c_int(rays_per_image), c_int(n_images), ctypes.c_float(cam_dist), _lib.ptr(g_o),
                                       _lib.ptr(g_d), _lib.ptr(g_sd), _lib.stream())
     _lib.check(code, "sc_ray_sample_backward")
-    return g_o, g_d, g_sd
+    return g_o, g_d, g_sd.view(n_images, rays_per_image).sum(dim=1)
 
 
 def sdf_grid_forward(w_pack, cbias, lo, hi, n_axis, symmetric=True):
