@@ -156,8 +156,14 @@ def main():
         big = sorted([s.elapsed_time(e) for s, e, _ in timing[dom]], reverse=True)[:2 * a.steps]
         mean_big = sum(big) / len(big)
         achieved = FLOPS_PER_POINT[dom] * n_pts_main / (mean_big * 1e-3) / 1e12
+        traffic = None
+        try:   # HBM-side bytes per launch measured with rocprofv3 --pmc on this workload (profiles/, see its _comment)
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                traffic = json.load(f)["kernels"][dom]["traffic_bytes"] if a.batch == 32 else None
+        except Exception:
+            pass
         roofline = dict(kernel=dom, bound="mfma", achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS,
-                        unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                        unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
                         launch_ms=round(mean_big, 4), points_per_launch=n_pts_main,
                         flops_per_point=FLOPS_PER_POINT[dom])
         out = dict(metric="train-step images/sec (Pix3D cfg, bs32/GPU)", value=round(a.batch * world / (dt / a.steps), 2),
