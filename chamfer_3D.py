@@ -26,6 +26,17 @@ def _dims(xyz1, xyz2):
 def forward(xyz1, xyz2, dist1, dist2, idx1, idx2):
     lib = _lib.load()
     b, n, m = _dims(xyz1, xyz2)
+    blocks = b * ((min(n, m) + 1023) // 1024)
+    if 0 < blocks < 1024 and max(n, m) >= 4096:
+        # too few workgroups to fill 256 CUs (evaluation: b = 1): split the target cloud over workgroup slices
+        import torch
+        nsplit = max(1, min(32, 2048 // blocks))
+        ws = torch.empty(b * (n + m), dtype=torch.int64, device=xyz1.device)
+        code = lib.sc_chamfer3d_forward_split(_lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(dist1), _lib.ptr(dist2),
+                                              _lib.ptr(idx1), _lib.ptr(idx2), ctypes.c_int(b), ctypes.c_int(n),
+                                              ctypes.c_int(m), ctypes.c_int(nsplit), _lib.ptr(ws), _lib.stream())
+        _lib.check(code, "sc_chamfer3d_forward_split")
+        return 1
     code = lib.sc_chamfer3d_forward(_lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(dist1), _lib.ptr(dist2),
                                     _lib.ptr(idx1), _lib.ptr(idx2), ctypes.c_int(b), ctypes.c_int(n),
                                     ctypes.c_int(m), _lib.stream())

@@ -32,6 +32,12 @@ extern "C" {
 int sc_chamfer3d_forward(const float* xyz1, const float* xyz2, float* dist1, float* dist2,
                          int32_t* idx1, int32_t* idx2, int b, int n, int m, void* stream);
 
+/* Same results (bit for bit), for small batches: the targets are split over `nsplit` workgroup slices and merged
+ * with 64-bit atomicMin on (distance bits, index) keys.  workspace: (b*n + b*m) * 8 bytes of device scratch.   */
+int sc_chamfer3d_forward_split(const float* xyz1, const float* xyz2, float* dist1, float* dist2,
+                               int32_t* idx1, int32_t* idx2, int b, int n, int m, int nsplit,
+                               void* workspace, void* stream);
+
 /* gradxyz1 [b,n,3], gradxyz2 [b,m,3] must be ZERO-FILLED by the caller (atomicAdd accumulation,
  * chamfer3D.cu:166-171,177-178).                                                                */
 int sc_chamfer3d_backward(const float* xyz1, const float* xyz2, float* gradxyz1, float* gradxyz2,

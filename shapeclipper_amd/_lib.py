@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libshapeclipper_hip.so")
 
 SYMBOLS = (
-    "sc_chamfer3d_forward", "sc_chamfer3d_backward", "sc_sdf_forward", "sc_rgb_composite_forward",
+    "sc_chamfer3d_forward", "sc_chamfer3d_forward_split", "sc_chamfer3d_backward", "sc_sdf_forward", "sc_rgb_composite_forward",
     "sc_rgb_composite_backward", "sc_sdf_backward", "sc_wgrad", "sc_partial_reduce", "sc_tbl_sum", "sc_loss_fused_forward",
     "sc_clip_vit_forward", "sc_gemm_bf16", "sc_f32_to_bf16",
     "sc_ray_sample_forward", "sc_ray_sample_backward", "sc_render_forward", "sc_sdf_grid_forward", "sc_loss_fused_backward",

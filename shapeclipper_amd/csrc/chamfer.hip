@@ -82,7 +82,7 @@ __global__ __launch_bounds__(CH_THREADS) void chamfer_nn_kernel(
 #pragma unroll
                 for (int q = 0; q < CH_Q; ++q) {
                     const float d = dist2(T.x, T.y, T.z, qx[q], qy[q], qz[q]);
-                    mn[q] = d < mn[q] ? d : mn[q];
+                    mn[q] = __builtin_fminf(mn[q], d);     // one v_min_f32 per pair (inputs are finite: no NaN semantics needed)
                 }
             }
             const int blk = (k0 + sb) / CH_SUB;
@@ -102,6 +102,84 @@ __global__ __launch_bounds__(CH_THREADS) void chamfer_nn_kernel(
             result_blk[(size_t)b * n + j] = bblk[q];
         }
     }
+}
+
+// Target-split variant for small batches (B*N/1024 workgroups cannot fill 256 CUs): blockIdx.z walks a slice
+// of the targets; every (query, slice) resolves its exact first-minimum index inside the slice and publishes
+// key = (float bits of d) << 32 | index with a 64-bit atomicMin.  d >= 0, so unsigned order of the float bits is
+// numeric order, and for equal d the smaller index wins -- exactly the reference's global lowest-index tie rule.
+__global__ __launch_bounds__(CH_THREADS) void chamfer_nn_split_kernel(
+    int n, const float* __restrict__ xyz, int m, const float* __restrict__ xyz2, int slice_len,
+    unsigned long long* __restrict__ keys) {
+    __shared__ float4 tgt[CH_TCHUNK];
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int qbase = blockIdx.x * (CH_THREADS * CH_Q);
+    const int t_begin = blockIdx.z * slice_len, t_end = min(m, t_begin + slice_len);
+    const float* q_ptr = xyz + (size_t)b * n * 3;
+    const float* t_ptr = xyz2 + (size_t)b * m * 3;
+    float qx[CH_Q], qy[CH_Q], qz[CH_Q], best[CH_Q];
+    int bblk[CH_Q];
+#pragma unroll
+    for (int q = 0; q < CH_Q; ++q) {
+        int j = qbase + q * CH_THREADS + tid;
+        j = j < n ? j : n - 1;
+        qx[q] = q_ptr[j * 3 + 0]; qy[q] = q_ptr[j * 3 + 1]; qz[q] = q_ptr[j * 3 + 2];
+        best[q] = __builtin_inff();
+        bblk[q] = t_begin / CH_SUB;
+    }
+    for (int k0 = t_begin; k0 < t_end; k0 += CH_TCHUNK) {
+        const int cnt = min(CH_TCHUNK, t_end - k0);
+        const int cnt_pad = (cnt + CH_SUB - 1) & ~(CH_SUB - 1);
+        __syncthreads();
+        for (int j = tid; j < cnt_pad; j += CH_THREADS) {
+            float4 t = make_float4(CH_FAR, CH_FAR, CH_FAR, 0.f);
+            if (j < cnt) { const float* p = t_ptr + (size_t)(k0 + j) * 3; t.x = p[0]; t.y = p[1]; t.z = p[2]; }
+            tgt[j] = t;
+        }
+        __syncthreads();
+        for (int sb = 0; sb < cnt_pad; sb += CH_SUB) {
+            float mn[CH_Q];
+#pragma unroll
+            for (int q = 0; q < CH_Q; ++q) mn[q] = __builtin_inff();
+#pragma unroll
+            for (int t = 0; t < CH_SUB; ++t) {
+                const float4 T = tgt[sb + t];
+#pragma unroll
+                for (int q = 0; q < CH_Q; ++q) mn[q] = __builtin_fminf(mn[q], dist2(T.x, T.y, T.z, qx[q], qy[q], qz[q]));
+            }
+            const int blk = (k0 + sb) / CH_SUB;      // slices start at multiples of CH_SUB
+#pragma unroll
+            for (int q = 0; q < CH_Q; ++q) {
+                const bool better = mn[q] < best[q];
+                best[q] = better ? mn[q] : best[q];
+                bblk[q] = better ? blk : bblk[q];
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < CH_Q; ++q) {
+        const int j = qbase + q * CH_THREADS + tid;
+        if (j < n && t_begin < t_end) {
+            const int kb = bblk[q] * CH_SUB;
+            int idx = kb;
+            for (int t = CH_SUB - 1; t >= 0; --t) {
+                const int k = kb + t;
+                if (k < t_end && dist2(t_ptr[k * 3 + 0], t_ptr[k * 3 + 1], t_ptr[k * 3 + 2], qx[q], qy[q], qz[q]) == best[q]) idx = k;
+            }
+            const unsigned long long key = ((unsigned long long)__float_as_uint(best[q]) << 32) | (unsigned int)idx;
+            atomicMin(&keys[(size_t)b * n + j], key);
+        }
+    }
+}
+
+__global__ __launch_bounds__(CH_THREADS) void chamfer_unpack_kernel(size_t total, const unsigned long long* __restrict__ keys,
+                                                                   float* __restrict__ result, int* __restrict__ result_i) {
+    const size_t gid = (size_t)blockIdx.x * CH_THREADS + threadIdx.x;
+    if (gid >= total) return;
+    const unsigned long long k = keys[gid];
+    result[gid] = __uint_as_float((unsigned int)(k >> 32));
+    result_i[gid] = (int)(unsigned int)(k & 0xFFFFFFFFull);
 }
 
 // Second pass: turn the winning sub-block id into the exact first index (same arithmetic).
@@ -168,6 +246,35 @@ int sc_chamfer3d_forward(const float* xyz1, const float* xyz2, float* dist1, flo
         size_t t2 = (size_t)b * m;
         hipLaunchKernelGGL(sc::chamfer_nn_index_kernel, dim3((unsigned)((t2 + sc::CH_THREADS - 1) / sc::CH_THREADS)),
                            dim3(sc::CH_THREADS), 0, stream, b, m, xyz2, n, xyz1, dist2, idx2);
+    }
+    return (int)hipGetLastError();
+}
+
+// Same contract as sc_chamfer3d_forward, plus `workspace`: (b*n + b*m) uint64 of scratch.  Splits the target
+// cloud over `nsplit` workgroup slices (use when b*ceil(n/1024) workgroups cannot fill the chip, e.g. evaluation b=1).
+int sc_chamfer3d_forward_split(const float* xyz1, const float* xyz2, float* dist1, float* dist2, int32_t* idx1,
+                               int32_t* idx2, int b, int n, int m, int nsplit, void* workspace, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (b <= 0 || n <= 0 || m <= 0) return 0;
+    if (nsplit < 1) nsplit = 1;
+    unsigned long long* k1 = (unsigned long long*)workspace;
+    unsigned long long* k2 = k1 + (size_t)b * n;
+    (void)hipMemsetAsync(workspace, 0xFF, ((size_t)b * n + (size_t)b * m) * sizeof(unsigned long long), stream);
+    auto slice = [&](int cnt) { int s = (cnt + nsplit - 1) / nsplit; return (s + sc::CH_SUB - 1) / sc::CH_SUB * sc::CH_SUB; };
+    const int per = sc::CH_THREADS * sc::CH_Q;
+    {
+        const int sl = slice(m);
+        dim3 g((n + per - 1) / per, b, (m + sl - 1) / sl);
+        hipLaunchKernelGGL(sc::chamfer_nn_split_kernel, g, dim3(sc::CH_THREADS), 0, stream, n, xyz1, m, xyz2, sl, k1);
+        const size_t t = (size_t)b * n;
+        hipLaunchKernelGGL(sc::chamfer_unpack_kernel, dim3((unsigned)((t + sc::CH_THREADS - 1) / sc::CH_THREADS)), dim3(sc::CH_THREADS), 0, stream, t, k1, dist1, idx1);
+    }
+    {
+        const int sl = slice(n);
+        dim3 g((m + per - 1) / per, b, (n + sl - 1) / sl);
+        hipLaunchKernelGGL(sc::chamfer_nn_split_kernel, g, dim3(sc::CH_THREADS), 0, stream, m, xyz2, n, xyz1, sl, k2);
+        const size_t t = (size_t)b * m;
+        hipLaunchKernelGGL(sc::chamfer_unpack_kernel, dim3((unsigned)((t + sc::CH_THREADS - 1) / sc::CH_THREADS)), dim3(sc::CH_THREADS), 0, stream, t, k2, dist2, idx2);
     }
     return (int)hipGetLastError();
 }

@@ -92,3 +92,27 @@ def test_full_size_properties():
     # symmetry: chamfer(a,b).dist1 == chamfer(b,a).dist2
     e1, e2, j1, j2 = run_hip(b, a)
     assert np.array_equal(e2, d1) and np.array_equal(j2, i1)
+
+
+@pytest.mark.parametrize("B,N,M,nsplit", [(1, 5000, 7001, 8), (2, 4099, 4100, 3), (1, 100, 50, 4)])
+def test_split_entry_point_is_bit_identical(B, N, M, nsplit):
+    import ctypes
+    from oracle import chamfer_ref
+    from shapeclipper_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    rng = np.random.RandomState(N)
+    a = rng.uniform(-0.5, 0.5, (B, N, 3)).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, (B, M, 3)).astype(np.float32)
+    b[:, M // 2] = b[:, 3]; b[:, M - 1] = b[:, 3]                     # duplicates in different slices
+    x1, x2 = torch.tensor(a, device=dev), torch.tensor(b, device=dev)
+    d1 = torch.zeros(B, N, device=dev); d2 = torch.zeros(B, M, device=dev)
+    i1 = torch.zeros(B, N, dtype=torch.int32, device=dev); i2 = torch.zeros(B, M, dtype=torch.int32, device=dev)
+    ws = torch.empty(B * (N + M), dtype=torch.int64, device=dev)
+    rc = lib.sc_chamfer3d_forward_split(_lib.ptr(x1), _lib.ptr(x2), _lib.ptr(d1), _lib.ptr(d2), _lib.ptr(i1), _lib.ptr(i2),
+                                        ctypes.c_int(B), ctypes.c_int(N), ctypes.c_int(M), ctypes.c_int(nsplit), _lib.ptr(ws), _lib.stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    r = chamfer_ref.chamfer_forward(a, b)
+    for x, y in zip((d1, d2, i1, i2), r):
+        assert np.array_equal(x.cpu().numpy(), y)
