@@ -107,6 +107,8 @@ def process_options(opt):
     assert isinstance(opt.gpu, int)
     opt.device = "cpu" if opt.cpu or not torch.cuda.is_available() else "cuda:{}".format(opt.gpu)
     opt.H, opt.W = opt.image_size
+    if "data" in opt and "dataset" in opt.data and opt.data.dataset not in opt.data and "pix3d" in opt.data:
+        opt.data[opt.data.dataset] = opt.data.pix3d      # e.g. --data.dataset=synthetic reuses the Pix3D camera ranges
     torch.backends.cudnn.deterministic = bool(opt.get("hip", {}).get("deterministic_conv", False))
 
 
