@@ -256,6 +256,47 @@ class Runner:
         opt.H, opt.W = opt.image_size
         return float((metric["dist_acc"] + metric["dist_cov"]) / 2)
 
+    @torch.no_grad()
+    def evaluate_sharded(self, opt, ep=0):
+        """Evaluation over all ranks (BASELINE config[4]; the reference evaluates on one GPU, evaluate.py:16-18):
+        rank r takes the test samples with index % world == r (eval.batch_size = 1), per-sample records are
+        gathered once, rank 0 writes chamfer.txt / cd_cat.txt / f_score.txt in sample order."""
+        from ..parallel import gather_eval_records
+        self.graph.eval()
+        opt.H, opt.W = opt.eval.image_size
+        rank = opt.device if isinstance(opt.device, int) else 0
+        recs = []
+        for it in range(rank, len(self.test_data), opt.world_size):
+            sample = self.test_data[it]
+            batch = {k: ({kk: vv[None] for kk, vv in v.items()} if isinstance(v, dict) else torch.as_tensor(v)[None]) for k, v in sample.items()}
+            var = self.evaluate_batch(opt, edict(batch), ep, it, single_gpu=True)
+            eval_3D.eval_metrics(opt, var, self.graph.module.sdf_network)
+            recs.append(torch.cat([var.idx.float().view(1), var.cd_acc.view(1), var.cd_comp.view(1), var.f_score.view(-1),
+                                   var.category_label.float().view(1)]))
+        dev = next(self.graph.parameters()).device
+        records = torch.stack(recs) if recs else torch.zeros(0, 10, device=dev)
+        allr = gather_eval_records(records.to(dev), opt.world_size).cpu()
+        opt.H, opt.W = opt.image_size
+        if _rank0(opt):
+            with open("{}/chamfer.txt".format(opt.output_path), "w") as f:
+                for r in allr:
+                    f.write("{} {:.8f} {:.8f}\n".format(int(r[0]), r[1], r[2]))
+            C = opt.data.num_classes
+            names = getattr(self.test_data, "label2cat", {i: str(i) for i in range(C)})
+            with open(os.path.join(opt.output_path, "cd_cat.txt"), "w") as f:
+                f.write("CD     Acc    Comp   Count Cat\n")
+                for c in range(C):
+                    sel = allr[allr[:, 9] == c]
+                    n = sel.shape[0] + 0.001
+                    a_, c_ = float(sel[:, 1].sum()) / n, float(sel[:, 2].sum()) / n
+                    f.write("%.4f %.4f %.4f %5d %s\n" % ((a_ + c_) / 2, a_, c_, n, names[c]))
+            fs = allr[:, 3:9].mean(dim=0)
+            with open(os.path.join(opt.output_path, "f_score.txt"), "w") as f:
+                for i, th in enumerate(opt.eval.f_thresholds):
+                    f.write("F-score @ %.2f: %.4f\n" % (th * 100, fs[i].item()))
+            log.loss_eval(opt, loss=None, chamfer=(allr[:, 1].mean(), allr[:, 2].mean()))
+        return float((allr[:, 1].mean() + allr[:, 2].mean()) / 2) if allr.shape[0] else float("nan")
+
     def evaluate_batch(self, opt, var, ep=None, it=None, single_gpu=False, visualize=False):
         var = util.move_to_device(var, opt.device)
         return self.graph.module(opt, var, training=False, visualize=visualize, get_loss=False)

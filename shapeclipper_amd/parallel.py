@@ -80,3 +80,23 @@ class FlatGradAllReduce:
         if self.world > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.mul_(1.0 / self.world)
+
+
+def gather_eval_records(records: torch.Tensor, world_size: int) -> torch.Tensor:
+    """Sharded evaluation (BASELINE config[4]): every rank evaluated the samples idx % world == rank and holds
+    `records` [n_local, 10] = (idx, cd_acc, cd_comp, f_score[6], category).  Returns on every rank the records of
+    all ranks sorted by sample index ([N, 10]); rank 0 writes chamfer.txt / cd_cat.txt / f_score.txt from them.
+    One small all_gather (ranks may hold different counts: padded with idx = -1)."""
+    if world_size <= 1:
+        return records[records[:, 0].argsort()]
+    n_local = torch.tensor([records.shape[0]], device=records.device)
+    counts = [torch.zeros_like(n_local) for _ in range(world_size)]
+    dist.all_gather(counts, n_local)
+    n_max = int(max(c.item() for c in counts))
+    padded = records.new_full((n_max, records.shape[1]), -1.0)
+    padded[:records.shape[0]] = records
+    out = [torch.empty_like(padded) for _ in range(world_size)]
+    dist.all_gather(out, padded)
+    allr = torch.cat(out, 0)
+    allr = allr[allr[:, 0] >= 0]
+    return allr[allr[:, 0].argsort()]

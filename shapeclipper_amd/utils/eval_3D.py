@@ -76,6 +76,37 @@ def _edge_crossing_points(level, lo, hi, num_points, rng):
     return pts[pick] / S * (hi - lo) + lo
 
 
+@torch.no_grad()
+def edge_crossing_points_device(level, lo, hi, num_points, seed=0):
+    """Device-side version of _edge_crossing_points: level [B,S,S,S] on the GPU -> points [B,num_points,3] on the GPU
+    (no D2H of the (N+1)^3 grid, no Python threads).  Used when PyMCubes/trimesh are not importable."""
+    B, S = level.shape[0], level.shape[1]
+    dev = level.device
+    ar = torch.arange(S, device=dev, dtype=torch.float32)
+    out = torch.zeros(B, num_points, 3, device=dev)
+    gen = torch.Generator(device=dev)
+    for b in range(B):
+        pts = []
+        for ax in range(3):
+            a = level[b].narrow(ax, 0, S - 1)
+            c = level[b].narrow(ax, 1, S - 1)
+            cross = (a * c) < 0
+            idx = cross.nonzero()                                  # [n,3] integer grid coordinates of the edge start
+            if idx.numel() == 0:
+                continue
+            t = a[cross] / (a[cross] - c[cross])
+            p = idx.float()
+            p[:, ax] += t
+            pts.append(p)
+        if not pts:
+            continue
+        pts = torch.cat(pts, 0)
+        gen.manual_seed(seed + b)
+        pick = torch.randint(0, pts.shape[0], (num_points,), device=dev, generator=gen)
+        out[b] = pts[pick] / S * (hi - lo) + lo                    # same 1/S rescale as the reference's mesh vertices
+    return out
+
+
 def convert_to_explicit_worker(opt, i, level_vox_i, isoval, meshes, pointclouds=None):
     lo, hi = opt.eval.range
     S = level_vox_i.shape[0]
@@ -134,11 +165,17 @@ def eval_metrics(opt, var, sdf_network, vis_only=False):
     B = points_3D.shape[0]
     level_vox = compute_level_grid(opt, sdf_network, var.proj_latent_sdf, points_3D)
     var.eval_vox = points_3D.view(B, -1, 3)
-    *level_grids, = level_vox.cpu().numpy()
-    meshes, pointclouds = convert_to_explicit(opt, level_grids, isoval=0., to_pointcloud=True)
-    var.mesh_pred = meshes
     dev = var.idx.device
-    var.dpc_pred = torch.tensor(pointclouds, dtype=torch.float32, device=dev)
+    if HAVE_MESHING:
+        *level_grids, = level_vox.cpu().numpy()
+        meshes, pointclouds = convert_to_explicit(opt, level_grids, isoval=0., to_pointcloud=True)
+        var.mesh_pred = meshes
+        var.dpc_pred = torch.tensor(pointclouds, dtype=torch.float32, device=dev)
+    else:   # stay on the device: surface samples from grid-edge sign changes
+        var.mesh_pred = [None] * B
+        lo, hi = opt.eval.range
+        var.dpc_pred = edge_crossing_points_device(level_vox, lo, hi, opt.eval.num_points,
+                                                   seed=int(var.idx[0]) if len(var.idx) else 0).to(dev)
     if opt.data.dataset in ["openimage"]:
         var.f_score = torch.zeros(B, len(opt.eval.f_thresholds)).to(dev)
         var.cd_acc = torch.zeros(B).to(dev); var.cd_comp = torch.zeros(B).to(dev)

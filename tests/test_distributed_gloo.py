@@ -43,6 +43,11 @@ def _worker(rank, world, port, out):
         p.grad = None
     red.zero_grad()
     ok &= all(p.grad is not None and float(p.grad.abs().sum()) == 0 for p in net.parameters())
+    # sharded-eval record gather: uneven shards, result sorted by sample index on every rank
+    from shapeclipper_amd.parallel import gather_eval_records
+    mine = torch.tensor([[float(i)] + [float(i) * 0.5] * 9 for i in range(7) if i % world == rank])
+    allr = gather_eval_records(mine, world)
+    ok &= allr.shape == (7, 10) and torch.equal(allr[:, 0], torch.arange(7.0)) and torch.allclose(allr[:, 1], torch.arange(7.0) * 0.5)
     out[rank] = bool(ok)
     dist.destroy_process_group()
 

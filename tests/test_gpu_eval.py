@@ -78,3 +78,27 @@ def test_pretrain_step_reduces_sphere_loss():
         optim.step()
         losses.append(float(loss.all))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+
+
+def test_sharded_evaluation_equals_single_process_evaluation():
+    """evaluate_sharded (world 1 here; the gather itself is covered by the 2-rank gloo test) writes the same
+    chamfer.txt as the reference-style Runner.evaluate."""
+    import os
+    os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+    from shapeclipper_amd.model.runner import Runner
+    o = _opt(["--data.dataset=synthetic", "--eval.vox_res=16", "--eval.num_points=1000", "--tb!", "--name=pytest_eval"])
+    o.device, o.world_size, o.port = 0, 1, 0
+    torch.manual_seed(0)
+    r = Runner(o)
+    r.load_dataset(o, eval_split="test")
+    r.build_networks(o)
+    r.evaluate(o, ep=0)
+    a = open(os.path.join(o.output_path, "chamfer.txt")).read()
+    fa = open(os.path.join(o.output_path, "f_score.txt")).read()
+    r.evaluate_sharded(o, ep=0)
+    b = open(os.path.join(o.output_path, "chamfer.txt")).read()
+    fb = open(os.path.join(o.output_path, "f_score.txt")).read()
+    assert len(a.strip().splitlines()) == 4
+    va = [[float(x) for x in l.split()] for l in a.strip().splitlines()]
+    vb = [[float(x) for x in l.split()] for l in b.strip().splitlines()]
+    assert torch.allclose(torch.tensor(va), torch.tensor(vb), atol=1e-6) and fa == fb
