@@ -86,7 +86,7 @@ def test_sharded_evaluation_equals_single_process_evaluation():
     import os
     os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
     from shapeclipper_amd.model.runner import Runner
-    o = _opt(["--data.dataset=synthetic", "--eval.vox_res=16", "--eval.num_points=1000", "--tb!", "--name=pytest_eval"])
+    o = _opt(["--data.dataset=synthetic", "--eval.vox_res=16", "--eval.num_points=1000", "--tb!"])
     o.device, o.world_size, o.port = 0, 1, 0
     torch.manual_seed(0)
     r = Runner(o)
