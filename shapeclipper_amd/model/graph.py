@@ -65,6 +65,8 @@ class Graph(nn.Module):
         B = len(var.idx)
         sampled = bool(opt.render.rand_sample and training)
         ray_idx = var.ray_idx if sampled else None
+        self.sdf_network.begin_step()       # one packed weight image per forward pass, shared by all renders
+        self.rgb_network.begin_step()
 
         var.latent_raw = var.latent if "latent" in var else self.encoder(var.rgb_input_map)
         var.latent_shape = var.latent_raw[:, :opt.arch.latent_dim_shape]

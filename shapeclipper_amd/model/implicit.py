@@ -117,8 +117,20 @@ class SDFNetwork(nn.Module):
                 for l in range(self.num_layers - 1) for n in ("weight", "bias")}
 
     def packed(self, proj_latent):
-        """(w_pack, cbias [B,5,64]) for the HIP kernels; differentiable w.r.t. parameters and latent."""
-        return packing.pack_sdf(self.weight_dict(), proj_latent)
+        """(w_pack, cbias [B,5,64]) for the HIP kernels; differentiable w.r.t. parameters and latent.
+        The weight image does not depend on the latent: inside one Graph.forward (between begin_step() calls) it is
+        built once and shared by the main render, the NN-view render and the eikonal calls (4 uses per step)."""
+        cache = getattr(self, "_pack_cache", None)
+        if cache is not None and cache[0] == torch.is_grad_enabled():
+            return cache[1], packing.sdf_cbias(self.weight_dict(), proj_latent)
+        w_pack, cbias = packing.pack_sdf(self.weight_dict(), proj_latent)
+        if getattr(self, "_pack_cache_on", False):
+            self._pack_cache = (torch.is_grad_enabled(), w_pack)
+        return w_pack, cbias
+
+    def begin_step(self, enable=True):
+        """Start (or stop) sharing the packed weight image; call once per forward pass, before the first render."""
+        self._pack_cache_on, self._pack_cache = enable, None
 
     def forward(self, points_raw, proj_latent):
         """Per-point latent form of the reference ([N,3], [N,Z] -> [N,1+C]); every point is its own 'image'."""
@@ -164,7 +176,16 @@ class RGBNetwork(nn.Module):
                 for l in range(self.num_layers - 1) for n in ("weight", "bias")}
 
     def packed(self, proj_latent):
-        return packing.pack_rgb(self.weight_dict(), proj_latent)
+        cache = getattr(self, "_pack_cache", None)
+        if cache is not None and cache[0] == torch.is_grad_enabled():
+            return cache[1], packing.rgb_dbias(self.weight_dict(), proj_latent)
+        v_pack, dbias = packing.pack_rgb(self.weight_dict(), proj_latent)
+        if getattr(self, "_pack_cache_on", False):
+            self._pack_cache = (torch.is_grad_enabled(), v_pack)
+        return v_pack, dbias
+
+    def begin_step(self, enable=True):
+        self._pack_cache_on, self._pack_cache = enable, None
 
     def forward(self, points_raw, proj_latent, sdf_feature):
         pts = points_raw

@@ -58,6 +58,19 @@ def check_arch(opt) -> None:
             "(impl_sdf: 5x64, pos_enc 6, skip [1,2]; impl_rgb: 3x64, pos_enc 6; no weight_norm)")
 
 
+def sdf_cbias(W: Dict[str, torch.Tensor], z: torch.Tensor) -> torch.Tensor:
+    """Per-image biases c_l = b_l + W_l[:, latent] @ z (skip layers scaled by 1/sqrt2) -> [B, 5, 64]."""
+    r = 1.0 / math.sqrt(2.0)
+    w0, w1, w2 = W["lin0.weight"], W["lin1.weight"], W["lin2.weight"]
+    B = z.shape[0]
+    c0 = W["lin0.bias"] + z @ w0[:, 39:].t()
+    c1 = W["lin1.bias"] + (z @ w1[:, 103:].t()) * r
+    c2 = W["lin2.bias"] + (z @ w2[:, 103:].t()) * r
+    c3 = W["lin3.bias"].unsqueeze(0).expand(B, 64)
+    c4 = W["lin4.bias"].unsqueeze(0).expand(B, 64)
+    return torch.stack([c0, c1, c2, c3, c4], dim=1).contiguous()
+
+
 def pack_sdf(W: Dict[str, torch.Tensor], z: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """SDFNetwork parameters (state-dict names lin{l}.weight/.bias) + latent z [B, Z]
     -> (w_pack [SDF_PACK_FLOATS], cbias [B, 5, 64])."""
@@ -65,13 +78,7 @@ def pack_sdf(W: Dict[str, torch.Tensor], z: torch.Tensor) -> Tuple[torch.Tensor,
     w0, w1, w2 = W["lin0.weight"], W["lin1.weight"], W["lin2.weight"]
     Z = z.shape[1]
     assert w0.shape == (64, 39 + Z) and w1.shape == (64, 64 + 39 + Z)
-    B = z.shape[0]
-    c0 = W["lin0.bias"] + z @ w0[:, 39:].t()
-    c1 = W["lin1.bias"] + (z @ w1[:, 103:].t()) * r
-    c2 = W["lin2.bias"] + (z @ w2[:, 103:].t()) * r
-    c3 = W["lin3.bias"].unsqueeze(0).expand(B, 64)
-    c4 = W["lin4.bias"].unsqueeze(0).expand(B, 64)
-    cbias = torch.stack([c0, c1, c2, c3, c4], dim=1).contiguous()
+    cbias = sdf_cbias(W, z)
     pack = torch.cat([
         _slots(w0[:, :39]).reshape(-1),
         torch.cat([w1[:, :64] * r, _slots(w1[:, 64:103]) * r], dim=1).reshape(-1),
@@ -83,17 +90,22 @@ def pack_sdf(W: Dict[str, torch.Tensor], z: torch.Tensor) -> Tuple[torch.Tensor,
     return pack, cbias
 
 
+def rgb_dbias(W: Dict[str, torch.Tensor], z: torch.Tensor) -> torch.Tensor:
+    v0 = W["lin0.weight"]
+    Z, B = z.shape[1], z.shape[0]
+    d0 = W["lin0.bias"] + z @ v0[:, 39:39 + Z].t()
+    d1 = W["lin1.bias"].unsqueeze(0).expand(B, 64)
+    d2 = W["lin2.bias"].unsqueeze(0).expand(B, 64)
+    return torch.stack([d0, d1, d2], dim=1).contiguous()
+
+
 def pack_rgb(W: Dict[str, torch.Tensor], z: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """RGBNetwork parameters + latent z_rgb [B, Z] -> (v_pack [RGB_PACK_FLOATS], dbias [B, 3, 64]).
     lin0 input order is [PE(39), z_rgb(Z), sdf_feature(64)] (model/implicit.py:231)."""
     v0 = W["lin0.weight"]
     Z = z.shape[1]
     assert v0.shape == (64, 39 + Z + 64)
-    B = z.shape[0]
-    d0 = W["lin0.bias"] + z @ v0[:, 39:39 + Z].t()
-    d1 = W["lin1.bias"].unsqueeze(0).expand(B, 64)
-    d2 = W["lin2.bias"].unsqueeze(0).expand(B, 64)
-    dbias = torch.stack([d0, d1, d2], dim=1).contiguous()
+    dbias = rgb_dbias(W, z)
     pack = torch.cat([
         torch.cat([_slots(v0[:, :39]), v0[:, 39 + Z:]], dim=1).reshape(-1),
         W["lin1.weight"].reshape(-1), W["lin2.weight"].reshape(-1),
