@@ -93,6 +93,29 @@ def cpu_baseline(batch, rays=512):
                        "B=%d, %d timed steps, no encoders/optimizer" % (B, n))
 
 
+def build_runner(batch_per_gpu, rank=0, local=0, world=1):
+    """Runner + options + HBM-resident synthetic batch for the Pix3D training configuration."""
+    from shapeclipper_amd import synthetic
+    from shapeclipper_amd.model.runner import Runner
+    from shapeclipper_amd.utils import options, util
+    from shapeclipper_amd.utils.util import EasyDict as edict
+
+    opt = options.set(options.parse_arguments([
+        "--yaml=%s/options/pix3d/config.yaml" % ROOT, "--name=bench", "--output_root=/tmp/sc_bench_%d" % rank,
+        "--batch_size=%d" % (batch_per_gpu * world), "--tb!", "--arch.enc_pretrained!"]), verbose=False)
+    opt.device, opt.world_size, opt.port = local, world, 0
+    opt.freq.scalar, opt.freq.ckpt_latest = 0, 10 ** 9
+    torch.manual_seed(rank)
+    runner = Runner(opt)                       # divides batch_size by world_size
+    runner.build_networks(opt)
+    runner.setup_optimizer(opt)
+    runner.graph.train()
+    runner.it, runner.ep, runner.best_val = 1, 0, 0.0
+    runner.timer = edict(start=time.time(), it_mean=None)
+    batch = util.move_to_device(synthetic.make_batch(opt, batch_per_gpu, seed=rank, training=True), "cuda:%d" % local)
+    return runner, opt, batch
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -104,24 +127,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl")
 
-    from shapeclipper_amd import _lib, synthetic
-    from shapeclipper_amd.model.runner import Runner
-    from shapeclipper_amd.utils import options, util
+    from shapeclipper_amd import _lib
     from shapeclipper_amd.utils.util import EasyDict as edict
-
-    opt = options.set(options.parse_arguments([
-        "--yaml=%s/options/pix3d/config.yaml" % ROOT, "--name=bench", "--output_root=/tmp/sc_bench_%d" % rank,
-        "--batch_size=%d" % (a.batch * world), "--tb!", "--arch.enc_pretrained!"]), verbose=False)
-    opt.device, opt.world_size, opt.port = local, world, 0
-    opt.freq.scalar, opt.freq.ckpt_latest = 0, 10 ** 9
-    torch.manual_seed(rank)
-    runner = Runner(opt)                       # divides batch_size by world_size
-    runner.build_networks(opt)
-    runner.setup_optimizer(opt)
-    runner.graph.train()
-    runner.it, runner.ep, runner.best_val = 1, 0, 0.0
-    runner.timer = edict(start=time.time(), it_mean=None)
-    batch = util.move_to_device(synthetic.make_batch(opt, a.batch, seed=rank, training=True), "cuda:%d" % local)
+    runner, opt, batch = build_runner(a.batch, rank, local, world)
 
     def step():
         opt.H, opt.W = opt.image_size

@@ -38,8 +38,18 @@ def rotation_from_trig(trig_azim, trig_elev, trig_theta):
     Ry = camera.azim_to_rotation_matrix(trig_azim, representation="trig")
     Rx = camera.elev_to_rotation_matrix(trig_elev, representation="trig")
     Rz = camera.roll_to_rotation_matrix(trig_theta, representation="trig")
-    perm = torch.tensor(_AXIS_PERMUTE, device=Ry.device).unsqueeze(0).expand_as(Ry)
-    return Rz @ Rx @ Ry @ perm
+    return Rz @ Rx @ Ry @ _axis_permute(Ry.device).unsqueeze(0).expand_as(Ry)
+
+
+_PERM_CACHE = {}
+
+
+def _axis_permute(device):
+    """The constant lives on the device once (building it per call is a synchronising pageable H2D copy)."""
+    key = str(device)
+    if key not in _PERM_CACHE:
+        _PERM_CACHE[key] = torch.tensor(_AXIS_PERMUTE, device=device)
+    return _PERM_CACHE[key]
 
 
 def _latent_projector(dim_in, dim_out):
@@ -67,6 +77,10 @@ class Graph(nn.Module):
         ray_idx = var.ray_idx if sampled else None
         self.sdf_network.begin_step()       # one packed weight image per forward pass, shared by all renders
         self.rgb_network.begin_step()
+        use_NN = (opt.loss_weight.nearest_img is not None or opt.loss_weight.nearest_mask is not None) and training
+        # The neighbour choice depends only on the input masks; it needs one device->host read (numpy RNG, as the
+        # reference).  Done first, while the stream is empty, the host never has to wait for the main render.
+        idx_NN = self.select_neighbours(opt, var) if use_NN else None
 
         var.latent_raw = var.latent if "latent" in var else self.encoder(var.rgb_input_map)
         var.latent_shape = var.latent_raw[:, :opt.arch.latent_dim_shape]
@@ -91,8 +105,8 @@ class Graph(nn.Module):
             var.normal_recon_map = as_map(var.normal_recon, 3, opt.H, opt.W)
             var.normal_transformed_map = as_map(var.normal_transformed, 3, opt.image_size[0], opt.image_size[1])
 
-        if (opt.loss_weight.nearest_img is not None or opt.loss_weight.nearest_mask is not None) and training:
-            self.forward_NN(opt, var)
+        if use_NN:
+            self.forward_NN(opt, var, idx_NN=idx_NN)
 
         if get_loss:
             return var, self.compute_loss(opt, var, training)
@@ -115,11 +129,12 @@ class Graph(nn.Module):
             picks.append(np.random.choice(K, size=(opt.reg.n_views,), replace=False, p=p))
         return torch.tensor(np.stack(picks, axis=0)).long().to(var.rgb_input_map.device)
 
-    def forward_NN(self, opt, var, training=True):
+    def forward_NN(self, opt, var, training=True, idx_NN=None):
         B = len(var.idx)
         assert opt.reg.n_views <= opt.data.k_nearest
         sampled = bool(opt.render.rand_sample and training)
-        idx_NN = self.select_neighbours(opt, var)                       # [B, V]
+        if idx_NN is None:
+            idx_NN = self.select_neighbours(opt, var)                   # [B, V]
         if sampled:
             assert len(var.ray_idx.shape) == 2
         rows = torch.arange(B, device=idx_NN.device)

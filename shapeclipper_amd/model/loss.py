@@ -102,7 +102,7 @@ class Loss(nn.Module):
 
     def cam_uniform_loss(self, opt, trig):
         B = trig.shape[0]
-        grid = torch.arange(1., 2 * B, 2., requires_grad=False).float().to(trig.device) * np.pi / B
+        grid = torch.arange(1., 2 * B, 2., device=trig.device).float() * np.pi / B
         empirical = (trig[:, 0], trig[:, 1], trig[:, 0] * trig[:, 1])
         prior = (torch.cos(grid), torch.sin(grid), torch.cos(grid) * torch.sin(grid))
         dists = [p.sort(dim=0, descending=False)[0] - e.sort(dim=0, descending=False)[0] for p, e in zip(prior, empirical)]

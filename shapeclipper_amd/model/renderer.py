@@ -85,8 +85,12 @@ class Renderer(nn.Module):
         # reference CPU-generator draws, in its order (renderer.py:29,33): jitter then the eikonal sample index
         dev_rng = bool(opt.get("hip", {}).get("device_rng", False))   # True: draw on the GPU (no 4 MB H2D copy per render,
         rdev = ray_dirs.device if dev_rng else "cpu"                   # but a different random stream than the reference)
-        t_rand = torch.rand(B * R, S, device=rdev).to(ray_dirs.device) if training else None
-        eik_idx = torch.randint(S, (B * R,), device=rdev).to(ray_dirs.device)
+        # CPU draws land in pinned memory and are copied asynchronously: a pageable H2D copy would drain the stream
+        # (one host sync per draw, three per render) and let the GPU idle while the host catches up.
+        pin = (not dev_rng) and ray_dirs.is_cuda
+        up = lambda x: x.to(ray_dirs.device, non_blocking=True)
+        t_rand = up(torch.rand(B * R, S, device=rdev, pin_memory=pin)) if training else None
+        eik_idx = up(torch.randint(S, (B * R,), device=rdev, pin_memory=pin))
         z_vals, points_flat = RaySampleFunction.apply(cam_loc, ray_dirs, scale_dist, t_rand, R, float(opt.camera.dist))
         z_eik = torch.gather(z_vals, 1, eik_idx.unsqueeze(-1))
         assert proj_latent_rgb.shape[1] == opt.arch.impl_rgb.proj_latent_dim
@@ -109,7 +113,7 @@ class Renderer(nn.Module):
         if training:
             # uniform points (CPU generator, as the reference) + one near-surface point per ray
             n_eik = B * R
-            eik = torch.empty(n_eik, 3, device=rdev).uniform_(self.eik_range[0], self.eik_range[1]).to(rgb.device).reshape(B, R, 3)
+            eik = up(torch.empty(n_eik, 3, device=rdev, pin_memory=pin).uniform_(self.eik_range[0], self.eik_range[1])).reshape(B, R, 3)
             near = (cam_loc + z_eik * ray_dirs).reshape(B, R, 3)
             eik_points = torch.cat([eik, near], 1).reshape(-1, 3)
             _, _, g_eik = self.sdf_network.get_conditional_output(opt, B, eik_points, proj_latent_sdf, compute_grad=True)

@@ -175,10 +175,11 @@ class Runner:
         else:
             optim.zero_grad()
         var, loss = self.graph.forward(opt, var, training=True, get_loss=True)
-        loss = self.summarize_loss(opt, var, loss, non_act_loss_key=frozen_keys)
+        loss = self.summarize_loss(opt, var, loss, non_act_loss_key=frozen_keys, defer_check=True)
         loss.all.backward()
         if self.reducer is not None:
             self.reducer.all_reduce()
+        self.check_finite(loss)               # the flag was copied to the host asynchronously: no stream drain
         optim.step()
 
         if _rank0(opt):
@@ -194,9 +195,11 @@ class Runner:
         util.update_timer(opt, self.timer, self.ep if hasattr(self, "ep") else 0, len(loader) if loader is not None else 1)
         return loss
 
-    def summarize_loss(self, opt, var, loss, non_act_loss_key=[]):
+    def summarize_loss(self, opt, var, loss, non_act_loss_key=[], defer_check=False):
         """all = sum_k float(w_k) * loss_k (keys in non_act_loss_key weigh 0).  NaN/Inf are checked with ONE
-        host read of a device flag instead of two syncs per key (reference runner.py:296-302)."""
+        host read of a device flag instead of two syncs per key (reference runner.py:296-302).  With defer_check the
+        flag travels to pinned host memory asynchronously and `check_finite(loss)` raises the same assertions later
+        (train_iteration calls it after the backward pass is queued and before the optimizer step)."""
         assert "all" not in loss
         total, bad = 0., None
         for key in loss:
@@ -207,13 +210,35 @@ class Runner:
             flag = ~torch.isfinite(value)
             bad = flag if bad is None else (bad | flag)
             total = total + (0.0 if key in non_act_loss_key else float(opt.loss_weight[key])) * value
-        if bad is not None and opt.get("check_finite", True) and bool(bad):
-            for key in loss:
-                v = loss[key].mean()
-                assert not torch.isinf(v), "loss {} is Inf".format(key)
-                assert not torch.isnan(v), "loss {} is NaN".format(key)
+        self._pending_check = None
+        if bad is not None and opt.get("check_finite", True):
+            if defer_check and bad.is_cuda:
+                host = torch.empty((), dtype=torch.bool, pin_memory=True)
+                host.copy_(bad, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record()
+                self._pending_check = (host, done)
+            elif bool(bad):
+                self._raise_not_finite(loss)
         loss.update(all=total)
         return loss
+
+    @staticmethod
+    def _raise_not_finite(loss):
+        for key in loss:
+            if key == "all":
+                continue
+            v = loss[key].mean()
+            assert not torch.isinf(v), "loss {} is Inf".format(key)
+            assert not torch.isnan(v), "loss {} is NaN".format(key)
+
+    def check_finite(self, loss):
+        pending, self._pending_check = getattr(self, "_pending_check", None), None
+        if pending is not None:
+            host, done = pending
+            done.synchronize()
+            if bool(host):
+                self._raise_not_finite(loss)
 
     # ---- evaluation -----------------------------------------------------------------------------------
     @torch.no_grad()

@@ -233,7 +233,7 @@ def rgb_composite_backward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, d
     _lib.check(code, "sc_partial_reduce")
     g_v[RGB_OFF["V3"]:RGB_OFF["V3"] + 192] = tbl_sum(RR(2), P, P, 1, coef=gy3).view(192)
     g_v[RGB_OFF["B3"]:RGB_OFF["B3"] + 3] = gy3.sum(dim=0)
-    g_v[RGB_OFF["B3"] + 3] = 0.0
+    g_v[RGB_OFF["B3"] + 3:RGB_OFF["B3"] + 4].zero_()       # (indexing with a python scalar would synchronise)
     g["v_pack"] = g_v
     g["dbias"] = tbl_sum_multi([GY(l) for l in range(3)], P, rays_per_image * 64, n_images).view(3, n_images, 64).permute(1, 0, 2).contiguous()
     return g

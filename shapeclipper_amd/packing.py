@@ -40,10 +40,16 @@ def pe_slot_col(col: int) -> int:
 _SLOT_IDX = [pe_slot_col(c) if pe_slot_col(c) >= 0 else 39 for c in range(PE_COLS)]
 
 
+_SLOT_IDX_DEV = {}
+
+
 def _slots(w_pe: torch.Tensor) -> torch.Tensor:
     """[out, 39] -> [out, 48] in slot order (pads are exact zeros)."""
     ext = torch.cat([w_pe, w_pe.new_zeros(w_pe.shape[0], 1)], dim=1)
-    return ext[:, torch.as_tensor(_SLOT_IDX, device=w_pe.device)]
+    key = str(w_pe.device)
+    if key not in _SLOT_IDX_DEV:           # built once per device: a list -> device tensor copy synchronises
+        _SLOT_IDX_DEV[key] = torch.as_tensor(_SLOT_IDX, device=w_pe.device)
+    return ext[:, _SLOT_IDX_DEV[key]]
 
 
 def check_arch(opt) -> None:
