@@ -187,6 +187,38 @@ int sc_sdf_grid_forward(const float* sdf_pack, const float* sdf_cbias, float lo,
 int sc_loss_fused_backward(const float* G4, float* g_rgb, long long n_rgb, float* g_mask, long long n_mask,
                            float* g_normal, long long n_normal, float* g_eik, long long n_eik, void* stream);
 
+/* ---- encoder glue: BatchNorm2d fused with the residual add / ReLU / stem max-pool around it --------
+ * Replaces, between the MIOpen convolutions of the reference's torchvision ResNet-18/34 (model/graph.py:52-54,
+ * model/view_estimator.py:40-42; torchvision BasicBlock.forward), nn.BatchNorm2d + `out += identity` + ReLU.
+ * All tensors NCHW fp32, contiguous, 16-byte aligned.  N images, C channels, HW = H*W.
+ * sc_bn_splits: number S of per-channel partial blocks the kernels use; `partial` must hold C*S*2 floats.   */
+int sc_bn_splits(int N, int C);
+
+/* y = [relu]( gamma*(x-mean)*rstd + beta [+ res] ).  training != 0: batch statistics (biased variance), running
+ * statistics updated with `momentum` (unbiased variance) and *n_tracked += 1 (both may be NULL); training == 0: the
+ * running statistics are used.  save_mean / save_rstd [C] are written for the backward.                      */
+int sc_bn_act_forward(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                      float* save_mean, float* save_rstd, float* run_mean, float* run_var, int64_t* n_tracked,
+                      float* partial, int N, int C, int HW, int relu, int training, float eps, float momentum,
+                      void* stream);
+
+/* Backward of sc_bn_act_forward.  y (the forward output) is needed only when a residual was added AND relu != 0
+ * (pass NULL otherwise: the ReLU mask is then recomputed from x).  dres (may be NULL) receives the gradient of the
+ * residual input (= the ReLU-masked dy); dx may be NULL; dgamma / dbeta [C] are always written.               */
+int sc_bn_act_backward(const float* dy, const float* x, const float* y, const float* gamma, const float* beta,
+                       const float* mean, const float* rstd, float* partial, float* dx, float* dres, float* dgamma,
+                       float* dbeta, int N, int C, int HW, int relu, int training, void* stream);
+
+/* ResNet stem: y = maxpool3x3/stride2/pad1( relu( bn(x) ) ), x [N,C,H,W] -> y [N,C,Ho,Wo], Ho = (H-1)/2+1.
+ * idx [N,C,Ho,Wo] int32: argmax position h*W+w (first maximum in scan order, as torch.nn.MaxPool2d).          */
+int sc_bn_relu_pool_forward(const float* x, const float* gamma, const float* beta, float* y, int* idx,
+                            float* save_mean, float* save_rstd, float* run_mean, float* run_var, int64_t* n_tracked,
+                            float* partial, int N, int C, int H, int W, int training, float eps, float momentum,
+                            void* stream);
+int sc_bn_relu_pool_backward(const float* dy, const int* idx, const float* x, const float* gamma, const float* beta,
+                             const float* mean, const float* rstd, float* partial, float* dx, float* dgamma,
+                             float* dbeta, int N, int C, int H, int W, int training, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

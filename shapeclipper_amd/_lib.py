@@ -20,6 +20,7 @@ SYMBOLS = (
     "sc_rgb_composite_backward", "sc_sdf_backward", "sc_wgrad", "sc_partial_reduce", "sc_tbl_sum", "sc_loss_fused_forward",
     "sc_clip_vit_forward", "sc_gemm_bf16", "sc_f32_to_bf16",
     "sc_ray_sample_forward", "sc_ray_sample_backward", "sc_render_forward", "sc_sdf_grid_forward", "sc_loss_fused_backward",
+    "sc_bn_splits", "sc_bn_act_forward", "sc_bn_act_backward", "sc_bn_relu_pool_forward", "sc_bn_relu_pool_backward",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -27,6 +28,8 @@ _lib: Optional[ctypes.CDLL] = None
 # Optional per-entry-point GPU timing (bench.py): when TIMING is a dict every C-ABI call is bracketed by
 # two events on torch's current stream (the stream the kernels are enqueued on).
 TIMING = None
+TIMING_SKIP = ("sc_bn_splits", "sc_bn_act_forward", "sc_bn_act_backward", "sc_bn_relu_pool_forward",
+               "sc_bn_relu_pool_backward")       # ~500 tiny calls per step: not worth two events each
 
 
 class _Timed:
@@ -36,7 +39,7 @@ class _Timed:
         self.name, self.fn = name, fn
 
     def __call__(self, *args):
-        if TIMING is None:
+        if TIMING is None or self.name in TIMING_SKIP:
             return self.fn(*args)
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()

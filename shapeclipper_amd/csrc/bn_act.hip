@@ -1,0 +1,437 @@
+// bn_act.hip -- BatchNorm2d fused with the residual add and ReLU that surround it in a ResNet basic block, and with
+// the 3x3/2 max-pool of the stem (NCHW fp32, forward + hand-written backward).
+//
+// after the renderer kernels the encoders dominate the step (reference model/graph.py:16-65,
+// model/view_estimator.py:35-103: torchvision ResNet-18/34).  Convolutions stay on MIOpen; everything between them is
+// HBM-bound streaming that the stock path spreads over BN (read x twice, write), add (2R+1W), ReLU (1R+1W) forward
+// and threshold_backward + BN backward on the way back.  Here per BN:
+//   forward  : stats pass (1R) + apply pass  y = relu(gamma*(x-mean)*rstd + beta [+ res])   (1-2R, 1W)
+//   backward : stats pass  g = dy*[y>0]; sum g, sum g*xhat [; dres = g]                     (2-3R, 0-1W)
+//              apply pass  dx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat))                (2R, 1W)
+// The ReLU mask of the no-residual form is recomputed from x (same fma as the forward, bit-identical), so y is not read.
+// Statistics: one block per (channel, image subset); partial sums of (x-K), (x-K)^2 with K = first element of the
+// channel (shifted-data variance), combined in a fixed order -> deterministic.  Running statistics (momentum update,
+// unbiased variance) and num_batches_tracked are updated in the apply kernel, as nn.BatchNorm2d does in training.
+// Bound: HBM (8 TB/s).  Algorithmic bytes per element: forward 12-16 B, backward 20-28 B.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+namespace sc {
+
+constexpr int BN_T = 256;
+
+template <int W> struct Vec;
+template <> struct Vec<4> {
+    float v[4];
+    __device__ __forceinline__ static Vec ld(const float* p) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        return Vec{{t.x, t.y, t.z, t.w}};
+    }
+    __device__ __forceinline__ void st(float* p) const { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Vec<1> {
+    float v[1];
+    __device__ __forceinline__ static Vec ld(const float* p) { return Vec{{*p}}; }
+    __device__ __forceinline__ void st(float* p) const { *p = v[0]; }
+};
+
+// Visit the elements of channel c in images n = s, s+S, s+2S, ... (this block's share), float4-wide when HW % 4 == 0.
+template <class F>
+__device__ __forceinline__ void bn_iterate(int N, int C, int HW, int c, int s, int S, F&& f) {
+    const int cnt = (N - s + S - 1) / S;
+    if ((HW & 3) == 0) {
+        const int hw4 = HW >> 2, total = cnt * hw4;
+#pragma unroll 2
+        for (int idx = threadIdx.x; idx < total; idx += BN_T) {
+            const int nl = idx / hw4, i = idx - nl * hw4;
+            f(((size_t)(s + nl * S) * C + c) * HW + 4 * i, std::integral_constant<int, 4>{});
+        }
+    } else {
+        const int total = cnt * HW;
+        for (int idx = threadIdx.x; idx < total; idx += BN_T) {
+            const int nl = idx / HW, i = idx - nl * HW;
+            f(((size_t)(s + nl * S) * C + c) * HW + i, std::integral_constant<int, 1>{});
+        }
+    }
+}
+
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {   // red: 2 * (BN_T / 64) floats
+    for (int d = 32; d >= 1; d >>= 1) {
+        a += __shfl_xor(a, d);
+        b += __shfl_xor(b, d);
+    }
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        red[w] = a;
+        red[BN_T / 64 + w] = b;
+    }
+    __syncthreads();
+    a = 0.f;
+    b = 0.f;
+    for (int k = 0; k < BN_T / 64; ++k) {
+        a += red[k];
+        b += red[BN_T / 64 + k];
+    }
+}
+
+// Combine the S per-block partial pairs of channel c (fixed order); every thread gets the totals.
+__device__ __forceinline__ void combine_partials(const float* partial, int c, int S, float& a, float& b) {
+    a = 0.f;
+    b = 0.f;
+    for (int k = 0; k < S; ++k) {          // S <= 32: a short uniform (scalar-cached) loop
+        a += partial[((size_t)c * S + k) * 2];
+        b += partial[((size_t)c * S + k) * 2 + 1];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BN_T) void bn_stats_kernel(const float* __restrict__ x, int N, int C, int HW,
+                                                        float* __restrict__ partial) {
+    __shared__ float red[2 * BN_T / 64];
+    const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+    const float K = x[(size_t)c * HW];
+    float s1 = 0.f, s2 = 0.f;
+    bn_iterate(N, C, HW, c, s, S, [&](size_t off, auto w) {
+        const auto v = Vec<decltype(w)::value>::ld(x + off);
+#pragma unroll
+        for (int k = 0; k < decltype(w)::value; ++k) {
+            const float d = v.v[k] - K;
+            s1 += d;
+            s2 += d * d;
+        }
+    });
+    block_sum2(s1, s2, red);
+    if (threadIdx.x == 0) {
+        partial[((size_t)c * S + s) * 2] = s1;
+        partial[((size_t)c * S + s) * 2 + 1] = s2;
+    }
+}
+
+struct BnFwdArgs {
+    const float* x; const float* res; const float* gamma; const float* beta; const float* partial;
+    float* y; float* save_mean; float* save_rstd; float* run_mean; float* run_var; int64_t* n_tracked;
+    int N, C, HW, relu, training;
+    float eps, momentum;
+};
+
+__global__ __launch_bounds__(BN_T) void bn_apply_fwd_kernel(BnFwdArgs a) {
+    const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+    float mean, rstd;
+    if (a.training) {
+        float s1, s2;
+        combine_partials(a.partial, c, S, s1, s2);
+        const float n = (float)a.N * (float)a.HW;
+        const float dm = s1 / n;
+        const float var = fmaxf(s2 / n - dm * dm, 0.f);
+        mean = a.x[(size_t)c * a.HW] + dm;
+        rstd = rsqrtf(var + a.eps);
+        if (s == 0 && threadIdx.x == 0) {
+            if (a.run_mean) {
+                a.run_mean[c] = (1.f - a.momentum) * a.run_mean[c] + a.momentum * mean;
+                a.run_var[c] = (1.f - a.momentum) * a.run_var[c] + a.momentum * (n > 1.f ? var * n / (n - 1.f) : var);
+            }
+            if (a.n_tracked && c == 0) *a.n_tracked += 1;
+        }
+    } else {
+        mean = a.run_mean[c];
+        rstd = rsqrtf(a.run_var[c] + a.eps);
+    }
+    if (s == 0 && threadIdx.x == 0) {
+        a.save_mean[c] = mean;
+        a.save_rstd[c] = rstd;
+    }
+    const float scale = a.gamma[c] * rstd, shift = a.beta[c] - mean * scale;
+    bn_iterate(a.N, a.C, a.HW, c, s, S, [&](size_t off, auto w) {
+        constexpr int W = decltype(w)::value;
+        auto v = Vec<W>::ld(a.x + off);
+        if (a.res) {
+            const auto r = Vec<W>::ld(a.res + off);
+#pragma unroll
+            for (int k = 0; k < W; ++k) v.v[k] = fmaf(v.v[k], scale, shift) + r.v[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < W; ++k) v.v[k] = fmaf(v.v[k], scale, shift);
+        }
+        if (a.relu) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) v.v[k] = fmaxf(v.v[k], 0.f);
+        }
+        v.st(a.y + off);
+    });
+}
+
+struct BnBwdArgs {
+    const float* dy; const float* x; const float* y;      // y: forward output, needed for the mask only when res was added
+    const float* gamma; const float* beta; const float* mean; const float* rstd;
+    float* partial; float* dx; float* dres; float* dgamma; float* dbeta;
+    int N, C, HW, relu, training, has_res;
+};
+
+// g = dy * [output > 0]; the no-residual mask is recomputed from x with the forward's own fma.
+template <int W>
+__device__ __forceinline__ Vec<W> bn_masked_grad(const BnBwdArgs& a, size_t off, const Vec<W>& xv, float scale, float shift) {
+    auto g = Vec<W>::ld(a.dy + off);
+    if (a.relu) {
+        if (a.has_res) {
+            const auto yv = Vec<W>::ld(a.y + off);
+#pragma unroll
+            for (int k = 0; k < W; ++k) g.v[k] = yv.v[k] > 0.f ? g.v[k] : 0.f;
+        } else {
+#pragma unroll
+            for (int k = 0; k < W; ++k) g.v[k] = fmaf(xv.v[k], scale, shift) > 0.f ? g.v[k] : 0.f;
+        }
+    }
+    return g;
+}
+
+__global__ __launch_bounds__(BN_T) void bn_bwd_stats_kernel(BnBwdArgs a) {
+    __shared__ float red[2 * BN_T / 64];
+    const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+    const float mean = a.mean[c], rstd = a.rstd[c];
+    const float scale = a.gamma[c] * rstd, shift = a.beta[c] - mean * scale;
+    float s1 = 0.f, s2 = 0.f;
+    bn_iterate(a.N, a.C, a.HW, c, s, S, [&](size_t off, auto w) {
+        constexpr int W = decltype(w)::value;
+        const auto xv = Vec<W>::ld(a.x + off);
+        const auto g = bn_masked_grad<W>(a, off, xv, scale, shift);
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            s1 += g.v[k];
+            s2 += g.v[k] * ((xv.v[k] - mean) * rstd);
+        }
+        if (a.dres) g.st(a.dres + off);
+    });
+    block_sum2(s1, s2, red);
+    if (threadIdx.x == 0) {
+        a.partial[((size_t)c * S + s) * 2] = s1;
+        a.partial[((size_t)c * S + s) * 2 + 1] = s2;
+    }
+}
+
+__global__ __launch_bounds__(BN_T) void bn_bwd_apply_kernel(BnBwdArgs a) {
+    const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+    const float mean = a.mean[c], rstd = a.rstd[c], gamma = a.gamma[c];
+    const float scale = gamma * rstd, shift = a.beta[c] - mean * scale;
+    float sg, sgx;
+    combine_partials(a.partial, c, S, sg, sgx);
+    if (s == 0 && threadIdx.x == 0) {
+        a.dgamma[c] = sgx;
+        a.dbeta[c] = sg;
+    }
+    if (!a.dx) return;
+    const float n = (float)a.N * (float)a.HW;
+    const float mg = a.training ? sg / n : 0.f, mgx = a.training ? sgx / n : 0.f;
+    bn_iterate(a.N, a.C, a.HW, c, s, S, [&](size_t off, auto w) {
+        constexpr int W = decltype(w)::value;
+        const auto xv = Vec<W>::ld(a.x + off);
+        // with a residual the masked gradient was already written to dres by the stats pass
+        const auto g = a.dres ? Vec<W>::ld(a.dres + off) : bn_masked_grad<W>(a, off, xv, scale, shift);
+        Vec<W> o;
+#pragma unroll
+        for (int k = 0; k < W; ++k) o.v[k] = scale * (g.v[k] - mg - (xv.v[k] - mean) * rstd * mgx);
+        o.st(a.dx + off);
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Stem: y = maxpool3x3/s2/p1( relu( bn(x) ) ), x [N,C,H,W] -> y [N,C,Ho,Wo]; idx = argmax position (h*W+w, first max
+// in scan order like torch) kept as int32 for the backward.  BN+ReLU is monotone per channel when scale >= 0, but the
+// general form is evaluated (scale may be negative).
+struct PoolFwdArgs {
+    const float* x; const float* gamma; const float* beta; const float* partial; int S_stats;
+    float* y; int* idx; float* save_mean; float* save_rstd; float* run_mean; float* run_var; int64_t* n_tracked;
+    int N, C, H, W, Ho, Wo, training;
+    float eps, momentum;
+};
+
+__global__ __launch_bounds__(BN_T) void bn_relu_pool_fwd_kernel(PoolFwdArgs a) {
+    const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+    const int HW = a.H * a.W;
+    float mean, rstd;
+    if (a.training) {
+        float s1, s2;
+        combine_partials(a.partial, c, a.S_stats, s1, s2);
+        const float n = (float)a.N * (float)HW;
+        const float dm = s1 / n;
+        const float var = fmaxf(s2 / n - dm * dm, 0.f);
+        mean = a.x[(size_t)c * HW] + dm;
+        rstd = rsqrtf(var + a.eps);
+        if (s == 0 && threadIdx.x == 0) {
+            if (a.run_mean) {
+                a.run_mean[c] = (1.f - a.momentum) * a.run_mean[c] + a.momentum * mean;
+                a.run_var[c] = (1.f - a.momentum) * a.run_var[c] + a.momentum * (n > 1.f ? var * n / (n - 1.f) : var);
+            }
+            if (a.n_tracked && c == 0) *a.n_tracked += 1;
+        }
+    } else {
+        mean = a.run_mean[c];
+        rstd = rsqrtf(a.run_var[c] + a.eps);
+    }
+    if (s == 0 && threadIdx.x == 0) {
+        a.save_mean[c] = mean;
+        a.save_rstd[c] = rstd;
+    }
+    const float scale = a.gamma[c] * rstd, shift = a.beta[c] - mean * scale;
+    const int HoWo = a.Ho * a.Wo;
+    const int cnt = (a.N - s + S - 1) / S, total = cnt * HoWo;
+    for (int t = threadIdx.x; t < total; t += BN_T) {
+        const int nl = t / HoWo, o = t - nl * HoWo;
+        const int ho = o / a.Wo, wo = o - ho * a.Wo;
+        const size_t plane = ((size_t)(s + nl * S) * a.C + c);
+        const float* xp = a.x + plane * HW;
+        float best = -__builtin_inff();
+        int bi = -1;
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+            const int h = 2 * ho - 1 + dh;
+            if (h < 0 || h >= a.H) continue;
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const int w = 2 * wo - 1 + dw;
+                if (w < 0 || w >= a.W) continue;
+                const float v = fmaxf(fmaf(xp[h * a.W + w], scale, shift), 0.f);
+                if (v > best || bi < 0) {          // strict >: first maximum in scan order
+                    best = v;
+                    bi = h * a.W + w;
+                }
+            }
+        }
+        a.y[plane * HoWo + o] = best;
+        a.idx[plane * HoWo + o] = bi;
+    }
+}
+
+struct PoolBwdArgs {
+    const float* dy; const int* idx; const float* x; const float* gamma; const float* beta; const float* mean;
+    const float* rstd; float* partial; float* dx; float* dgamma; float* dbeta;
+    int N, C, H, W, Ho, Wo, training;
+};
+
+// Gradient that reaches BN-output position (h,w): sum of dy over the (at most 4) pooling windows whose argmax is
+// (h,w), gated by the ReLU.  Gathered (no atomics): every input position looks at the windows that cover it.
+__device__ __forceinline__ float pool_gather(const PoolBwdArgs& a, size_t plane, int h, int w) {
+    const int HoWo = a.Ho * a.Wo, pos = h * a.W + w;
+    float g = 0.f;
+    const int ho_lo = max((h - 1 + 1) / 2, 0), ho_hi = min((h + 1) / 2, a.Ho - 1);     // windows with 2ho-1 <= h <= 2ho+1
+    const int wo_lo = max(w / 2, 0), wo_hi = min((w + 1) / 2, a.Wo - 1);
+    for (int ho = ho_lo; ho <= ho_hi; ++ho)
+        for (int wo = wo_lo; wo <= wo_hi; ++wo)
+            if (a.idx[plane * HoWo + ho * a.Wo + wo] == pos) g += a.dy[plane * HoWo + ho * a.Wo + wo];
+    return g;
+}
+
+template <bool APPLY>
+__global__ __launch_bounds__(BN_T) void bn_relu_pool_bwd_kernel(PoolBwdArgs a, int S_stats) {
+    __shared__ float red[2 * BN_T / 64];
+    const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+    const int HW = a.H * a.W;
+    const float mean = a.mean[c], rstd = a.rstd[c];
+    const float scale = a.gamma[c] * rstd, shift = a.beta[c] - mean * scale;
+    float sg = 0.f, sgx = 0.f, mg = 0.f, mgx = 0.f;
+    if (APPLY) {
+        combine_partials(a.partial, c, S_stats, sg, sgx);
+        if (s == 0 && threadIdx.x == 0) {
+            a.dgamma[c] = sgx;
+            a.dbeta[c] = sg;
+        }
+        const float n = (float)a.N * (float)HW;
+        mg = a.training ? sg / n : 0.f;
+        mgx = a.training ? sgx / n : 0.f;
+        sg = 0.f;
+        sgx = 0.f;
+    }
+    const int cnt = (a.N - s + S - 1) / S, total = cnt * HW;
+    for (int t = threadIdx.x; t < total; t += BN_T) {
+        const int nl = t / HW, p = t - nl * HW;
+        const int h = p / a.W, w = p - h * a.W;
+        const size_t plane = ((size_t)(s + nl * S) * a.C + c);
+        const float xv = a.x[plane * HW + p];
+        float g = 0.f;
+        if (fmaf(xv, scale, shift) > 0.f) g = pool_gather(a, plane, h, w);   // ReLU gate (a max of 0 carries no gradient)
+        const float xh = (xv - mean) * rstd;
+        if (APPLY) {
+            a.dx[plane * HW + p] = scale * (g - mg - xh * mgx);
+        } else {
+            sg += g;
+            sgx += g * xh;
+        }
+    }
+    if (!APPLY) {
+        block_sum2(sg, sgx, red);
+        if (threadIdx.x == 0) {
+            a.partial[((size_t)c * S + s) * 2] = sg;
+            a.partial[((size_t)c * S + s) * 2 + 1] = sgx;
+        }
+    }
+}
+
+static inline int bn_splits(int N, int C) {
+    int S = (2048 + C - 1) / C;
+    if (S > N) S = N;
+    if (S > 32) S = 32;
+    return S < 1 ? 1 : S;
+}
+
+}  // namespace sc
+
+extern "C" int sc_bn_splits(int N, int C) { return sc::bn_splits(N, C); }
+
+extern "C" int sc_bn_act_forward(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                                 float* save_mean, float* save_rstd, float* run_mean, float* run_var,
+                                 int64_t* n_tracked, float* partial, int N, int C, int HW, int relu, int training,
+                                 float eps, float momentum, void* stream_) {
+    if (N <= 0 || C <= 0 || HW <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream_;
+    const dim3 grid(C, sc::bn_splits(N, C));
+    if (training) hipLaunchKernelGGL(sc::bn_stats_kernel, grid, dim3(sc::BN_T), 0, st, x, N, C, HW, partial);
+    sc::BnFwdArgs a{x, res, gamma, beta, partial, y, save_mean, save_rstd, run_mean, run_var, n_tracked,
+                    N, C, HW, relu, training, eps, momentum};
+    hipLaunchKernelGGL(sc::bn_apply_fwd_kernel, grid, dim3(sc::BN_T), 0, st, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int sc_bn_act_backward(const float* dy, const float* x, const float* y, const float* gamma,
+                                  const float* beta, const float* mean, const float* rstd, float* partial, float* dx,
+                                  float* dres, float* dgamma, float* dbeta, int N, int C, int HW, int relu,
+                                  int training, void* stream_) {
+    if (N <= 0 || C <= 0 || HW <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream_;
+    const dim3 grid(C, sc::bn_splits(N, C));
+    sc::BnBwdArgs a{dy, x, y, gamma, beta, mean, rstd, partial, dx, dres, dgamma, dbeta, N, C, HW, relu, training,
+                    (y != nullptr) ? 1 : 0};
+    hipLaunchKernelGGL(sc::bn_bwd_stats_kernel, grid, dim3(sc::BN_T), 0, st, a);
+    hipLaunchKernelGGL(sc::bn_bwd_apply_kernel, grid, dim3(sc::BN_T), 0, st, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int sc_bn_relu_pool_forward(const float* x, const float* gamma, const float* beta, float* y, int* idx,
+                                       float* save_mean, float* save_rstd, float* run_mean, float* run_var,
+                                       int64_t* n_tracked, float* partial, int N, int C, int H, int W, int training,
+                                       float eps, float momentum, void* stream_) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream_;
+    const int S = sc::bn_splits(N, C);
+    const dim3 grid(C, S);
+    if (training) hipLaunchKernelGGL(sc::bn_stats_kernel, grid, dim3(sc::BN_T), 0, st, x, N, C, H * W, partial);
+    sc::PoolFwdArgs a{x, gamma, beta, partial, S, y, idx, save_mean, save_rstd, run_mean, run_var, n_tracked,
+                      N, C, H, W, (H + 2 - 3) / 2 + 1, (W + 2 - 3) / 2 + 1, training, eps, momentum};
+    hipLaunchKernelGGL(sc::bn_relu_pool_fwd_kernel, grid, dim3(sc::BN_T), 0, st, a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int sc_bn_relu_pool_backward(const float* dy, const int* idx, const float* x, const float* gamma,
+                                        const float* beta, const float* mean, const float* rstd, float* partial,
+                                        float* dx, float* dgamma, float* dbeta, int N, int C, int H, int W,
+                                        int training, void* stream_) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream_;
+    const int S = sc::bn_splits(N, C);
+    const dim3 grid(C, S);
+    sc::PoolBwdArgs a{dy, idx, x, gamma, beta, mean, rstd, partial, dx, dgamma, dbeta,
+                      N, C, H, W, (H + 2 - 3) / 2 + 1, (W + 2 - 3) / 2 + 1, training};
+    hipLaunchKernelGGL(sc::bn_relu_pool_bwd_kernel<false>, grid, dim3(sc::BN_T), 0, st, a, S);
+    hipLaunchKernelGGL(sc::bn_relu_pool_bwd_kernel<true>, grid, dim3(sc::BN_T), 0, st, a, S);
+    return (int)hipGetLastError();
+}

@@ -123,3 +123,79 @@ class RaySampleFunction(torch.autograd.Function):
         g_o, g_d, g_sd = ops.ray_sample_backward(ray_dirs, z, g_points.contiguous(), g_z.contiguous() if g_z is not None else None,
                                                  rpi, n_images, cam_dist)
         return g_o, g_d, g_sd, None, None, None
+
+
+class BnActFunction(torch.autograd.Function):
+    """y = [relu]( batch_norm(x) [+ res] ) in two HIP launches (csrc/bn_act.hip); nn.BatchNorm2d semantics for the
+    running statistics (updated in place; num_batches_tracked incremented by the kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, res, weight, bias, running_mean, running_var, n_tracked, training, momentum, eps, relu):
+        x = ops._aligned(x)
+        res = ops._aligned(res) if res is not None else None
+        y, mean, rstd = ops.bn_act_forward(x, res, weight, bias, running_mean, running_var, n_tracked, training,
+                                           momentum, eps, relu)
+        ctx.meta = (training, relu, res is not None)
+        ctx.save_for_backward(x, weight, bias, mean, rstd, y if (res is not None and relu) else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        training, relu, has_res = ctx.meta
+        x, weight, bias, mean, rstd, y = ctx.saved_tensors
+        dx, dres, dg, db = ops.bn_act_backward(ops._aligned(dy), x, y, weight, bias, mean, rstd, training, relu,
+                                               want_dx=ctx.needs_input_grad[0],
+                                               want_dres=has_res and ctx.needs_input_grad[1])
+        return dx, dres, dg, db, None, None, None, None, None, None, None
+
+
+class BnReluPoolFunction(torch.autograd.Function):
+    """ResNet stem tail: maxpool3x3/2( relu( batch_norm(x) ) ) without materialising the full-resolution BN output."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, n_tracked, training, momentum, eps):
+        x = ops._aligned(x)
+        y, idx, mean, rstd = ops.bn_relu_pool_forward(x, weight, bias, running_mean, running_var, n_tracked, training,
+                                                      momentum, eps)
+        ctx.training = training
+        ctx.save_for_backward(x, weight, bias, mean, rstd, idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias, mean, rstd, idx = ctx.saved_tensors
+        dx, dg, db = ops.bn_relu_pool_backward(ops._aligned(dy), idx, x, weight, bias, mean, rstd, ctx.training)
+        return dx, dg, db, None, None, None, None, None, None
+
+
+def _bn_fusable(bn, x):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and bn.affine and bn.momentum is not None
+            and (bn.training or bn.track_running_stats))
+
+
+def bn_act(bn, x, residual=None, relu=True):
+    """nn.BatchNorm2d `bn` applied to x, then `+ residual`, then ReLU.  Device tensors take the fused HIP path (raises
+    if the library is missing); host tensors use the stock torch operators (pretrain plumbing on CPU, config[0])."""
+    if not _bn_fusable(bn, x):
+        out = bn(x)
+        if residual is not None:
+            out = out + residual
+        return torch.relu_(out) if relu else out
+    training = bn.training or not bn.track_running_stats
+    track = bn.track_running_stats
+    return BnActFunction.apply(x, residual, bn.weight, bn.bias, bn.running_mean if track else None,
+                               bn.running_var if track else None,
+                               bn.num_batches_tracked if (track and training) else None,
+                               training, float(bn.momentum), float(bn.eps), relu)
+
+
+def bn_relu_maxpool(bn, x):
+    """maxpool3x3/2/1(relu(bn(x))) (ResNet stem)."""
+    if not _bn_fusable(bn, x):
+        return torch.nn.functional.max_pool2d(torch.relu_(bn(x)), 3, 2, 1)
+    training = bn.training or not bn.track_running_stats
+    track = bn.track_running_stats
+    return BnReluPoolFunction.apply(x, bn.weight, bn.bias, bn.running_mean if track else None,
+                                    bn.running_var if track else None,
+                                    bn.num_batches_tracked if (track and training) else None,
+                                    training, float(bn.momentum), float(bn.eps))

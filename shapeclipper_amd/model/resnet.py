@@ -1,11 +1,17 @@
 """ResNet-18/34 trunks in plain torch.nn with torchvision's state-dict key names
 (conv1, bn1, layer{1..4}.{i}.conv{1,2}/bn{1,2}/downsample.{0,1}, fc) so that reference
-checkpoints load.  torchvision itself is not a dependency of this build.  These encoders are
-OUT of the hand-written hot path: they run on MIOpen through stock PyTorch-ROCm."""
+checkpoints load.  torchvision itself is not a dependency of this build.  SURVEY 8f-1: the convolutions
+run on MIOpen through stock PyTorch-ROCm; everything between them (BatchNorm + residual add + ReLU, and the
+stem's BN + ReLU + max-pool) is the fused HIP path of csrc/bn_act.hip (`FUSED_BN = False` restores the
+stock operators, e.g. for A/B timing)."""
 from __future__ import annotations
 
 import torch
 import torch.nn as nn
+
+from ..functional import bn_act, bn_relu_maxpool
+
+FUSED_BN = True
 
 
 class BasicBlock(nn.Module):
@@ -21,10 +27,14 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        identity = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
-        return self.relu(out + identity)
+        if not FUSED_BN:
+            identity = x if self.downsample is None else self.downsample(x)
+            out = self.relu(self.bn1(self.conv1(x)))
+            out = self.bn2(self.conv2(out))
+            return self.relu(out + identity)
+        identity = x if self.downsample is None else bn_act(self.downsample[1], self.downsample[0](x), relu=False)
+        out = bn_act(self.bn1, self.conv1(x))
+        return bn_act(self.bn2, self.conv2(out), residual=identity)
 
 
 class ResNet(nn.Module):
@@ -58,7 +68,10 @@ class ResNet(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        if FUSED_BN:
+            x = bn_relu_maxpool(self.bn1, self.conv1(x))
+        else:
+            x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         return self.fc(torch.flatten(self.avgpool(x), 1))
 

@@ -327,3 +327,84 @@ def render_forward(cam_loc, ray_dirs, depth_fac, scale_dist, u, sdf_pack, sdf_cb
     _lib.check(code, "sc_render_forward")
     out.update(z_vals=z, points=pts)
     return out
+
+
+# ---- encoder glue: fused BatchNorm2d (+ residual, ReLU, stem max-pool) -------------------------------------------
+_BN_SPLITS = {}
+
+
+def _bn_partial(N, C, like):
+    key = (N, C)
+    if key not in _BN_SPLITS:
+        _BN_SPLITS[key] = int(_lib.load().sc_bn_splits(c_int(N), c_int(C)))
+    return torch.empty(C * _BN_SPLITS[key] * 2, device=like.device, dtype=torch.float32)
+
+
+def _aligned(t):
+    t = t.contiguous()
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
+def bn_act_forward(x, res, gamma, beta, running_mean, running_var, n_tracked, training, momentum, eps, relu):
+    """x [N,C,H,W] (+ res) -> y, save_mean [C], save_rstd [C]; running statistics updated in place when training."""
+    lib = _lib.load()
+    N, C, H, W = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(C, device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    partial = _bn_partial(N, C, x)
+    code = lib.sc_bn_act_forward(_lib.ptr(x), _lib.ptr(res), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(y), _lib.ptr(mean),
+                                 _lib.ptr(rstd), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(n_tracked),
+                                 _lib.ptr(partial), c_int(N), c_int(C), c_int(H * W), c_int(1 if relu else 0),
+                                 c_int(1 if training else 0), ctypes.c_float(eps), ctypes.c_float(momentum), _lib.stream())
+    _lib.check(code, "sc_bn_act_forward")
+    return y, mean, rstd
+
+
+def bn_act_backward(dy, x, y, gamma, beta, mean, rstd, training, relu, want_dx, want_dres):
+    lib = _lib.load()
+    N, C, H, W = x.shape
+    dx = torch.empty_like(x) if want_dx else None
+    dres = torch.empty_like(x) if want_dres else None
+    dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
+    dbeta = torch.empty_like(dgamma)
+    partial = _bn_partial(N, C, x)
+    code = lib.sc_bn_act_backward(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean),
+                                  _lib.ptr(rstd), _lib.ptr(partial), _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dgamma),
+                                  _lib.ptr(dbeta), c_int(N), c_int(C), c_int(H * W), c_int(1 if relu else 0),
+                                  c_int(1 if training else 0), _lib.stream())
+    _lib.check(code, "sc_bn_act_backward")
+    return dx, dres, dgamma, dbeta
+
+
+def bn_relu_pool_forward(x, gamma, beta, running_mean, running_var, n_tracked, training, momentum, eps):
+    lib = _lib.load()
+    N, C, H, W = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty(N, C, Ho, Wo, device=x.device, dtype=torch.float32)
+    idx = torch.empty(N, C, Ho, Wo, device=x.device, dtype=torch.int32)
+    mean = torch.empty(C, device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    partial = _bn_partial(N, C, x)
+    code = lib.sc_bn_relu_pool_forward(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(y), _lib.ptr(idx),
+                                       _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(running_mean), _lib.ptr(running_var),
+                                       _lib.ptr(n_tracked), _lib.ptr(partial), c_int(N), c_int(C), c_int(H), c_int(W),
+                                       c_int(1 if training else 0), ctypes.c_float(eps), ctypes.c_float(momentum),
+                                       _lib.stream())
+    _lib.check(code, "sc_bn_relu_pool_forward")
+    return y, idx, mean, rstd
+
+
+def bn_relu_pool_backward(dy, idx, x, gamma, beta, mean, rstd, training):
+    lib = _lib.load()
+    N, C, H, W = x.shape
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
+    dbeta = torch.empty_like(dgamma)
+    partial = _bn_partial(N, C, x)
+    code = lib.sc_bn_relu_pool_backward(_lib.ptr(dy), _lib.ptr(idx), _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta),
+                                        _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(partial), _lib.ptr(dx), _lib.ptr(dgamma),
+                                        _lib.ptr(dbeta), c_int(N), c_int(C), c_int(H), c_int(W),
+                                        c_int(1 if training else 0), _lib.stream())
+    _lib.check(code, "sc_bn_relu_pool_backward")
+    return dx, dgamma, dbeta

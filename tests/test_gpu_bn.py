@@ -1,0 +1,135 @@
+"""Fused BatchNorm (+ residual add, ReLU, stem max-pool) kernels of csrc/bn_act.hip against the stock torch operators
+they replace inside the ResNet encoders (torchvision BasicBlock / stem semantics).
+Tolerance: fp32, 2e-5 of the tensor's scale for outputs and input gradients (different summation order only)."""
+import copy
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, tol=2e-5, what="", where=None):
+    scale = max(float(b.abs().max()), 1e-6)
+    diff = (a - b).abs()
+    if where is not None:
+        diff = diff * where
+    err = float(diff.max())
+    assert err <= tol * scale + 1e-7, "%s: max err %.3e (scale %.3e)" % (what, err, scale)
+
+
+def _stock(bn, x, res, relu):
+    out = bn(x)
+    if res is not None:
+        out = out + res
+    return torch.relu(out) if relu else out
+
+
+@pytest.mark.parametrize("shape", [(8, 64, 56, 56), (4, 16, 7, 7), (3, 5, 6, 10), (32, 512, 7, 7), (1, 8, 4, 4)])
+@pytest.mark.parametrize("relu,with_res", [(True, False), (True, True), (False, False), (False, True)])
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_act_matches_torch(shape, relu, with_res, training):
+    from shapeclipper_amd.functional import bn_act
+    torch.manual_seed(0)
+    N, C, H, W = shape
+    dev = "cuda"
+    x0 = (torch.randn(shape, device=dev) * 1.7 + 0.4)
+    r0 = torch.randn(shape, device=dev) if with_res else None
+    cot = torch.randn(shape, device=dev)
+    bn_a = nn.BatchNorm2d(C).to(dev)
+    with torch.no_grad():
+        bn_a.weight.copy_(torch.randn(C) * 0.5 + 1.0)       # includes negative scales
+        bn_a.bias.copy_(torch.randn(C) * 0.3)
+        bn_a.running_mean.copy_(torch.randn(C) * 0.2)
+        bn_a.running_var.copy_(torch.rand(C) + 0.5)
+    bn_a.train(training)
+    if relu:
+        # keep every pre-activation away from the ReLU kink: an element within rounding of 0 may legitimately land on
+        # either side of it in two fp32 implementations, which would flip its gradient (and move dgamma/dbeta)
+        probe = copy.deepcopy(bn_a)
+        for _ in range(4):
+            with torch.no_grad():
+                z = probe(x0) + (r0 if with_res else 0)
+                near = z.abs() < 1e-3
+                if not bool(near.any()):
+                    break
+                x0[near] += 0.25
+    bn_b = copy.deepcopy(bn_a)
+    bn_b.train(training)
+    outs = []
+    for bn, fn in ((bn_a, _stock), (bn_b, lambda bn, x, r, relu: bn_act(bn, x, residual=r, relu=relu))):
+        x = x0.clone().requires_grad_(True)
+        r = r0.clone().requires_grad_(True) if with_res else None
+        y = fn(bn, x, r, relu)
+        (y * cot).sum().backward()
+        outs.append((y.detach(), x.grad, r.grad if with_res else None, bn.weight.grad, bn.bias.grad,
+                     bn.running_mean.clone(), bn.running_var.clone(), int(bn.num_batches_tracked)))
+    ref, got = outs
+    _close(got[0], ref[0], what="y")
+    # an output within rounding of the ReLU kink may land on either side of it: such elements (a handful per million)
+    # are left out of the element-wise gradient comparison
+    away = (ref[0].abs() > 1e-5).float() if relu else None
+    _close(got[1], ref[1], tol=5e-5, what="dx", where=away)
+    if with_res:
+        _close(got[2], ref[2], what="dres", where=away)
+    _close(got[3], ref[3], tol=1e-4, what="dgamma")
+    _close(got[4], ref[4], tol=1e-4, what="dbeta")
+    _close(got[5], ref[5], what="running_mean")
+    _close(got[6], ref[6], what="running_var")
+    assert got[7] == ref[7]
+
+
+@pytest.mark.parametrize("shape", [(4, 8, 30, 30), (2, 4, 17, 23), (8, 64, 112, 112)])
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_relu_maxpool_matches_torch(shape, training):
+    from shapeclipper_amd.functional import bn_relu_maxpool
+    torch.manual_seed(1)
+    N, C, H, W = shape
+    dev = "cuda"
+    x0 = torch.randn(shape, device=dev) * 1.3 - 0.2
+    bn_a = nn.BatchNorm2d(C).to(dev)
+    with torch.no_grad():
+        bn_a.weight.copy_(torch.randn(C) * 0.5 + 1.0)
+        bn_a.bias.copy_(torch.randn(C) * 0.3)
+    bn_b = copy.deepcopy(bn_a)
+    bn_a.train(training)
+    bn_b.train(training)
+    xa = x0.clone().requires_grad_(True)
+    ya = F.max_pool2d(torch.relu(bn_a(xa)), 3, 2, 1)
+    cot = torch.randn_like(ya)
+    (ya * cot).sum().backward()
+    xb = x0.clone().requires_grad_(True)
+    yb = bn_relu_maxpool(bn_b, xb)
+    assert yb.shape == ya.shape
+    (yb * cot).sum().backward()
+    _close(yb.detach(), ya.detach(), what="y")
+    _close(xb.grad, xa.grad, tol=5e-5, what="dx")
+    _close(bn_b.weight.grad, bn_a.weight.grad, tol=1e-4, what="dgamma")
+    _close(bn_b.bias.grad, bn_a.bias.grad, tol=1e-4, what="dbeta")
+    _close(bn_b.running_mean, bn_a.running_mean, what="running_mean")
+    _close(bn_b.running_var, bn_a.running_var, what="running_var")
+    assert int(bn_b.num_batches_tracked) == int(bn_a.num_batches_tracked)
+
+
+def test_resnet18_fused_equals_stock_operators():
+    from shapeclipper_amd.model import resnet
+    torch.manual_seed(2)
+    net = resnet.build("resnet18").cuda().train()
+    x = torch.randn(4, 3, 224, 224, device="cuda")
+    res = []
+    for fused in (False, True):
+        resnet.FUSED_BN = fused
+        try:
+            m = copy.deepcopy(net)
+            y = m(x)
+            y.square().mean().backward()
+            res.append((y.detach(), m.conv1.weight.grad.clone(), m.layer4[1].bn2.weight.grad.clone(),
+                        m.layer1[0].bn1.running_var.clone()))
+        finally:
+            resnet.FUSED_BN = True
+    # 17 BN layers deep: rounding differences (and the odd ReLU-kink flip) are amplified -> relative L2 error
+    for a, b, name in zip(res[1], res[0], ("logits", "d conv1.weight", "d layer4.1.bn2.weight", "running_var")):
+        rel = float((a - b).norm() / b.norm().clamp_min(1e-12))
+        assert rel < 5e-3, "%s: relative L2 error %.3e" % (name, rel)
