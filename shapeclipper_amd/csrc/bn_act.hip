@@ -309,61 +309,62 @@ struct PoolBwdArgs {
     int N, C, H, W, Ho, Wo, training;
 };
 
-// Gradient that reaches BN-output position (h,w): sum of dy over the (at most 4) pooling windows whose argmax is
-// (h,w), gated by the ReLU.  Gathered (no atomics): every input position looks at the windows that cover it.
-__device__ __forceinline__ float pool_gather(const PoolBwdArgs& a, size_t plane, int h, int w) {
-    const int HoWo = a.Ho * a.Wo, pos = h * a.W + w;
-    float g = 0.f;
-    const int ho_lo = max((h - 1 + 1) / 2, 0), ho_hi = min((h + 1) / 2, a.Ho - 1);     // windows with 2ho-1 <= h <= 2ho+1
-    const int wo_lo = max(w / 2, 0), wo_hi = min((w + 1) / 2, a.Wo - 1);
-    for (int ho = ho_lo; ho <= ho_hi; ++ho)
-        for (int wo = wo_lo; wo <= wo_hi; ++wo)
-            if (a.idx[plane * HoWo + ho * a.Wo + wo] == pos) g += a.dy[plane * HoWo + ho * a.Wo + wo];
-    return g;
-}
-
-template <bool APPLY>
-__global__ __launch_bounds__(BN_T) void bn_relu_pool_bwd_kernel(PoolBwdArgs a, int S_stats) {
+// Pass 1 of the stem backward.  One thread owns a 2x2 block of BN-output positions (rows 2i,2i+1, cols 2j,2j+1): the
+// only pooling windows that can have their argmax there are (i..i+1) x (j..j+1), so 4 idx/dy reads serve 4 inputs
+// (gather form, no atomics).  The gradient is gated by the ReLU (recomputed from x), written to dx as a temporary and
+// reduced into the per-channel sums; pass 2 (bn_bwd_apply_kernel with dres == dx) finishes dx in place.
+__global__ __launch_bounds__(BN_T) void bn_relu_pool_bwd_gather_kernel(PoolBwdArgs a) {
     __shared__ float red[2 * BN_T / 64];
     const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
-    const int HW = a.H * a.W;
+    const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
+    const int Hq = (a.H + 1) >> 1, Wq = (a.W + 1) >> 1, Q = Hq * Wq;
     const float mean = a.mean[c], rstd = a.rstd[c];
     const float scale = a.gamma[c] * rstd, shift = a.beta[c] - mean * scale;
-    float sg = 0.f, sgx = 0.f, mg = 0.f, mgx = 0.f;
-    if (APPLY) {
-        combine_partials(a.partial, c, S_stats, sg, sgx);
-        if (s == 0 && threadIdx.x == 0) {
-            a.dgamma[c] = sgx;
-            a.dbeta[c] = sg;
-        }
-        const float n = (float)a.N * (float)HW;
-        mg = a.training ? sg / n : 0.f;
-        mgx = a.training ? sgx / n : 0.f;
-        sg = 0.f;
-        sgx = 0.f;
-    }
-    const int cnt = (a.N - s + S - 1) / S, total = cnt * HW;
+    float sg = 0.f, sgx = 0.f;
+    const int cnt = (a.N - s + S - 1) / S, total = cnt * Q;
     for (int t = threadIdx.x; t < total; t += BN_T) {
-        const int nl = t / HW, p = t - nl * HW;
-        const int h = p / a.W, w = p - h * a.W;
+        const int nl = t / Q, q = t - nl * Q;
+        const int i = q / Wq, j = q - i * Wq;
         const size_t plane = ((size_t)(s + nl * S) * a.C + c);
-        const float xv = a.x[plane * HW + p];
-        float g = 0.f;
-        if (fmaf(xv, scale, shift) > 0.f) g = pool_gather(a, plane, h, w);   // ReLU gate (a max of 0 carries no gradient)
-        const float xh = (xv - mean) * rstd;
-        if (APPLY) {
-            a.dx[plane * HW + p] = scale * (g - mg - xh * mgx);
-        } else {
-            sg += g;
-            sgx += g * xh;
+        int wi[2][2];
+        float wd[2][2];
+#pragma unroll
+        for (int di = 0; di < 2; ++di)
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj) {
+                const bool ok = (i + di) < a.Ho && (j + dj) < a.Wo;
+                const size_t o = plane * HoWo + (size_t)(i + di) * a.Wo + (j + dj);
+                wi[di][dj] = ok ? a.idx[o] : -1;
+                wd[di][dj] = ok ? a.dy[o] : 0.f;
+            }
+#pragma unroll
+        for (int eh = 0; eh < 2; ++eh) {
+            const int h = 2 * i + eh;
+            if (h >= a.H) continue;
+#pragma unroll
+            for (int ew = 0; ew < 2; ++ew) {
+                const int w = 2 * j + ew;
+                if (w >= a.W) continue;
+                const int pos = h * a.W + w;
+                const float xv = a.x[plane * HW + pos];
+                float g = 0.f;
+                // even row/col: covered only by window i (j); odd: by windows i and i+1 (j and j+1)
+#pragma unroll
+                for (int di = 0; di <= eh; ++di)
+#pragma unroll
+                    for (int dj = 0; dj <= ew; ++dj)
+                        if (wi[di][dj] == pos) g += wd[di][dj];
+                if (!(fmaf(xv, scale, shift) > 0.f)) g = 0.f;        // ReLU gate (a max of 0 carries no gradient)
+                a.dx[plane * HW + pos] = g;
+                sg += g;
+                sgx += g * ((xv - mean) * rstd);
+            }
         }
     }
-    if (!APPLY) {
-        block_sum2(sg, sgx, red);
-        if (threadIdx.x == 0) {
-            a.partial[((size_t)c * S + s) * 2] = sg;
-            a.partial[((size_t)c * S + s) * 2 + 1] = sgx;
-        }
+    block_sum2(sg, sgx, red);
+    if (threadIdx.x == 0) {
+        a.partial[((size_t)c * S + s) * 2] = sg;
+        a.partial[((size_t)c * S + s) * 2 + 1] = sgx;
     }
 }
 
@@ -431,7 +432,9 @@ extern "C" int sc_bn_relu_pool_backward(const float* dy, const int* idx, const f
     const dim3 grid(C, S);
     sc::PoolBwdArgs a{dy, idx, x, gamma, beta, mean, rstd, partial, dx, dgamma, dbeta,
                       N, C, H, W, (H + 2 - 3) / 2 + 1, (W + 2 - 3) / 2 + 1, training};
-    hipLaunchKernelGGL(sc::bn_relu_pool_bwd_kernel<false>, grid, dim3(sc::BN_T), 0, st, a, S);
-    hipLaunchKernelGGL(sc::bn_relu_pool_bwd_kernel<true>, grid, dim3(sc::BN_T), 0, st, a, S);
+    hipLaunchKernelGGL(sc::bn_relu_pool_bwd_gather_kernel, grid, dim3(sc::BN_T), 0, st, a);
+    // pass 2: dx = scale * (g - mean(g) - xhat * mean(g xhat)) in place (g was left in dx)
+    sc::BnBwdArgs b{nullptr, x, nullptr, gamma, beta, mean, rstd, partial, dx, dx, dgamma, dbeta, N, C, H * W, 0, training, 0};
+    hipLaunchKernelGGL(sc::bn_bwd_apply_kernel, grid, dim3(sc::BN_T), 0, st, b);
     return (int)hipGetLastError();
 }
