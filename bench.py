@@ -144,6 +144,7 @@ def main():
     t0 = time.time()
     for _ in range(a.steps):
         loss = step()
+    host_dt = time.time() - t0          # host time to enqueue the K steps (the GPU is still working)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -185,7 +186,7 @@ def main():
                                         "(input + CLIP-NN view) + eikonal, ResNet-34 encoder + ResNet-18 estimator, Adam",
                                global_batch=a.batch * world, rays_per_image=opt.render.rand_sample, samples_per_ray=64,
                                parallelism="dp%d" % world),
-                   roofline=roofline,
+                   roofline=roofline, host_enqueue_ms_per_step=round(host_dt / a.steps * 1e3, 3),
                    hip_ms_per_step={k: round(v["total_ms"] / a.steps, 3) for k, v in sorted(per.items())})
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_batch)

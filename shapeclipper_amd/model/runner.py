@@ -80,6 +80,9 @@ class Runner:
     def setup_optimizer(self, opt):
         if _rank0(opt): log.info("setting up optimizers...")
         kwargs = {k: (tuple(v) if k == "betas" else v) for k, v in opt.optim.params.items()}
+        on_gpu = next(self.graph.parameters()).is_cuda
+        if on_gpu and self.optimizer in (torch.optim.Adam, torch.optim.AdamW) and opt.get("hip", {}).get("fused_adam", True):
+            kwargs.setdefault("fused", True)       # one multi-tensor kernel instead of ~90 foreach launches per step
         full, view = [], []
         for k, v in self.graph.named_parameters():
             full.append(v)

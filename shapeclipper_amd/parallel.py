@@ -26,6 +26,10 @@ class ModuleHolder(nn.Module):
 
 
 class FlatGradAllReduce:
+    """Gradients are produced by autograd as usual (`.grad` starts as None each step, so the first accumulation of a
+    parameter is a pointer move, not an add kernel), then packed with one multi-tensor copy into the flat buffer,
+    all-reduced with ONE collective, averaged, and handed back to the optimizer as views of the flat buffer."""
+
     def __init__(self, module: nn.Module, world_size: int, broadcast_buffers: bool = True):
         self.module = module
         self.world = world_size
@@ -34,9 +38,9 @@ class FlatGradAllReduce:
         total = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
-        off = 0
+        self.views, off = [], 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
         self.buffers = [b for b in module.buffers() if b.dtype.is_floating_point] if broadcast_buffers else []
         if self.world > 1:
@@ -47,14 +51,19 @@ class FlatGradAllReduce:
         return self.flat.numel() * 4
 
     def zero_grad(self):
-        self.flat.zero_()
-        # re-attach views if an optimizer's zero_grad(set_to_none=True) dropped them
-        off = 0
         for p in self.params:
-            n = p.numel()
-            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + off * 4:
-                p.grad = self.flat[off:off + n].view_as(p)
-            off += n
+            p.grad = None
+
+    def pack(self):
+        """Copy every produced gradient into its slot of the flat buffer (parameters that received none contribute
+        zeros, the semantics of find_unused_parameters=True) and point `.grad` at the slots."""
+        have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+        if len(have) != len(self.params):
+            self.flat.zero_()
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        for v, p in zip(self.views, self.params):
+            p.grad = v
 
     def broadcast_parameters(self, src=0):
         flat = torch.cat([p.data.reshape(-1) for p in self.params])
@@ -70,13 +79,15 @@ class FlatGradAllReduce:
             return
         flat = torch.cat([b.reshape(-1) for b in self.buffers])
         dist.broadcast(flat, src)
-        off = 0
+        views, off = [], 0
         for b in self.buffers:
-            b.copy_(flat[off:off + b.numel()].view_as(b))
+            views.append(flat[off:off + b.numel()].view_as(b))
             off += b.numel()
+        torch._foreach_copy_(self.buffers, views)
 
     def all_reduce(self):
         """Call after backward(): mean of the gradients over all ranks, one collective."""
+        self.pack()
         if self.world > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.mul_(1.0 / self.world)

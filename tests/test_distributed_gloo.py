@@ -25,11 +25,12 @@ def _worker(rank, world, port, out):
     red.zero_grad()
     y = net["bn"](net["b"](x))
     y.sum().backward()
-    local = red.flat.clone()
+    ok = all(p.grad is None for p in net["unused"].parameters())                        # autograd produced nothing there
+    local = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in red.params])
     red.all_reduce()
     gathered = [torch.zeros_like(local) for _ in range(world)]
     dist.all_gather(gathered, local)
-    ok = torch.allclose(red.flat, sum(gathered) / world, atol=1e-6)
+    ok &= torch.allclose(red.flat, sum(gathered) / world, atol=1e-6)
     ok &= all(p.grad.data_ptr() >= red.flat.data_ptr() for p in net.parameters())      # grads are views of the flat buffer
     ok &= bool(torch.all(net["unused"].weight.grad == 0))                               # unused params contribute zeros
     net["bn"].running_mean.fill_(float(rank))
@@ -38,11 +39,17 @@ def _worker(rank, world, port, out):
     ws = [torch.zeros_like(w0[0]) for _ in range(world)]
     dist.all_gather(ws, w0[0])
     ok &= torch.equal(ws[0], ws[1])                                                     # parameters start identical
-    # a second step must start from zeroed grads even if the optimizer dropped them
-    for p in net.parameters():
-        p.grad = None
+    # a second step starts from dropped grads (first accumulation = pointer move) and ends in the flat views again,
+    # with no residue of the first step
     red.zero_grad()
-    ok &= all(p.grad is not None and float(p.grad.abs().sum()) == 0 for p in net.parameters())
+    ok &= all(p.grad is None for p in net.parameters())
+    net["bn"](net["b"](x)).sum().backward()
+    local2 = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in red.params])
+    red.all_reduce()
+    gathered2 = [torch.zeros_like(local2) for _ in range(world)]
+    dist.all_gather(gathered2, local2)
+    ok &= torch.allclose(red.flat, sum(gathered2) / world, atol=1e-6)
+    ok &= all(p.grad.data_ptr() >= red.flat.data_ptr() for p in net.parameters())
     # sharded-eval record gather: uneven shards, result sorted by sample index on every rank
     from shapeclipper_amd.parallel import gather_eval_records
     mine = torch.tensor([[float(i)] + [float(i) * 0.5] * 9 for i in range(7) if i % world == rank])
