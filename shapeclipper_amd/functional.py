@@ -132,20 +132,20 @@ class BnActFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, weight, bias, running_mean, running_var, n_tracked, training, momentum, eps, relu):
         x = ops._aligned(x)
-        res = ops._aligned(res) if res is not None else None
-        y, mean, rstd = ops.bn_act_forward(x, res, weight, bias, running_mean, running_var, n_tracked, training,
-                                           momentum, eps, relu)
+        if res is not None:
+            res = ops._aligned(res)
+        y, stats = ops.bn_act_forward(x, res, weight, bias, running_mean, running_var, n_tracked, training,
+                                      momentum, eps, relu)
         ctx.meta = (training, relu, res is not None)
-        ctx.save_for_backward(x, weight, bias, mean, rstd, y if (res is not None and relu) else None)
+        ctx.save_for_backward(x, weight, bias, stats, y if (res is not None and relu) else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         training, relu, has_res = ctx.meta
-        x, weight, bias, mean, rstd, y = ctx.saved_tensors
-        dx, dres, dg, db = ops.bn_act_backward(ops._aligned(dy), x, y, weight, bias, mean, rstd, training, relu,
-                                               want_dx=ctx.needs_input_grad[0],
-                                               want_dres=has_res and ctx.needs_input_grad[1])
+        x, weight, bias, stats, y = ctx.saved_tensors
+        dx, dres, dg, db = ops.bn_act_backward(ops._aligned(dy), x, y, weight, bias, stats, training, relu,
+                                               ctx.needs_input_grad[0], has_res and ctx.needs_input_grad[1])
         return dx, dres, dg, db, None, None, None, None, None, None, None
 
 
@@ -155,16 +155,16 @@ class BnReluPoolFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, n_tracked, training, momentum, eps):
         x = ops._aligned(x)
-        y, idx, mean, rstd = ops.bn_relu_pool_forward(x, weight, bias, running_mean, running_var, n_tracked, training,
-                                                      momentum, eps)
+        y, idx, stats = ops.bn_relu_pool_forward(x, weight, bias, running_mean, running_var, n_tracked, training,
+                                                 momentum, eps)
         ctx.training = training
-        ctx.save_for_backward(x, weight, bias, mean, rstd, idx)
+        ctx.save_for_backward(x, weight, bias, stats, idx)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight, bias, mean, rstd, idx = ctx.saved_tensors
-        dx, dg, db = ops.bn_relu_pool_backward(ops._aligned(dy), idx, x, weight, bias, mean, rstd, ctx.training)
+        x, weight, bias, stats, idx = ctx.saved_tensors
+        dx, dg, db = ops.bn_relu_pool_backward(ops._aligned(dy), idx, x, weight, bias, stats, ctx.training)
         return dx, dg, db, None, None, None, None, None, None
 
 

@@ -330,81 +330,105 @@ def render_forward(cam_loc, ray_dirs, depth_fac, scale_dist, u, sdf_pack, sdf_cb
 
 
 # ---- encoder glue: fused BatchNorm2d (+ residual, ReLU, stem max-pool) -------------------------------------------
-_BN_SPLITS = {}
+# ~270 of these calls per step: the binding is kept lean (argtypes declared once so plain ints go through ctypes,
+# one persistent partial-sum buffer per device -- calls on a stream are ordered, so it can be shared).
+_VP, _CI, _CF = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+_BN_SIG = dict(
+    sc_bn_act_forward=[_VP] * 11 + [_CI] * 5 + [_CF, _CF, _VP],
+    sc_bn_act_backward=[_VP] * 12 + [_CI] * 5 + [_VP],
+    sc_bn_relu_pool_forward=[_VP] * 11 + [_CI] * 5 + [_CF, _CF, _VP],
+    sc_bn_relu_pool_backward=[_VP] * 11 + [_CI] * 5 + [_VP],
+)
+_bn_fn = {}
+_bn_ws = {}
 
 
-def _bn_partial(N, C, like):
-    key = (N, C)
-    if key not in _BN_SPLITS:
-        _BN_SPLITS[key] = int(_lib.load().sc_bn_splits(c_int(N), c_int(C)))
-    return torch.empty(C * _BN_SPLITS[key] * 2, device=like.device, dtype=torch.float32)
+def _bn(name):
+    fn = _bn_fn.get(name)
+    if fn is None:
+        fn = getattr(_lib.load()._cdll, name)
+        fn.argtypes, fn.restype = _BN_SIG[name], ctypes.c_int
+        _bn_fn[name] = fn
+    return fn
+
+
+def _bn_partial(x):
+    """Workspace for the per-channel partial sums: C * S * 2 floats with S <= 32 (see sc_bn_splits)."""
+    dev = x.device.index
+    need = x.shape[1] * 64
+    ws = _bn_ws.get(dev)
+    if ws is None or ws.numel() < need:
+        ws = _bn_ws[dev] = torch.empty(max(need, 1 << 16), device=x.device, dtype=torch.float32)
+    return ws.data_ptr()
 
 
 def _aligned(t):
-    t = t.contiguous()
-    return t if t.data_ptr() % 16 == 0 else t.clone()
+    if not t.is_cuda:
+        raise RuntimeError("shapeclipper_amd: HIP kernels need device tensors (got a CPU tensor); the product path has no CPU fallback")
+    if not t.is_contiguous():
+        t = t.contiguous()
+    return t if (t.storage_offset() & 3) == 0 else t.clone()
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
 
 
 def bn_act_forward(x, res, gamma, beta, running_mean, running_var, n_tracked, training, momentum, eps, relu):
-    """x [N,C,H,W] (+ res) -> y, save_mean [C], save_rstd [C]; running statistics updated in place when training."""
-    lib = _lib.load()
+    """x [N,C,H,W] (+ res) -> y, stats [2,C] (save_mean, save_rstd); running statistics updated in place when training."""
     N, C, H, W = x.shape
     y = torch.empty_like(x)
-    mean = torch.empty(C, device=x.device, dtype=torch.float32)
-    rstd = torch.empty_like(mean)
-    partial = _bn_partial(N, C, x)
-    code = lib.sc_bn_act_forward(_lib.ptr(x), _lib.ptr(res), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(y), _lib.ptr(mean),
-                                 _lib.ptr(rstd), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(n_tracked),
-                                 _lib.ptr(partial), c_int(N), c_int(C), c_int(H * W), c_int(1 if relu else 0),
-                                 c_int(1 if training else 0), ctypes.c_float(eps), ctypes.c_float(momentum), _lib.stream())
-    _lib.check(code, "sc_bn_act_forward")
-    return y, mean, rstd
+    stats = torch.empty(2, C, device=x.device, dtype=torch.float32)
+    sp = stats.data_ptr()
+    code = _bn("sc_bn_act_forward")(x.data_ptr(), _p(res), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), sp, sp + 4 * C,
+                                    _p(running_mean), _p(running_var), _p(n_tracked), _bn_partial(x), N, C, H * W,
+                                    1 if relu else 0, 1 if training else 0, eps, momentum, _stream())
+    if code:
+        _lib.check(code, "sc_bn_act_forward")
+    return y, stats
 
 
-def bn_act_backward(dy, x, y, gamma, beta, mean, rstd, training, relu, want_dx, want_dres):
-    lib = _lib.load()
+def bn_act_backward(dy, x, y, gamma, beta, stats, training, relu, want_dx, want_dres):
     N, C, H, W = x.shape
     dx = torch.empty_like(x) if want_dx else None
     dres = torch.empty_like(x) if want_dres else None
-    dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
-    dbeta = torch.empty_like(dgamma)
-    partial = _bn_partial(N, C, x)
-    code = lib.sc_bn_act_backward(_lib.ptr(dy), _lib.ptr(x), _lib.ptr(y), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(mean),
-                                  _lib.ptr(rstd), _lib.ptr(partial), _lib.ptr(dx), _lib.ptr(dres), _lib.ptr(dgamma),
-                                  _lib.ptr(dbeta), c_int(N), c_int(C), c_int(H * W), c_int(1 if relu else 0),
-                                  c_int(1 if training else 0), _lib.stream())
-    _lib.check(code, "sc_bn_act_backward")
-    return dx, dres, dgamma, dbeta
+    dgb = torch.empty(2, C, device=x.device, dtype=torch.float32)
+    sp, gp = stats.data_ptr(), dgb.data_ptr()
+    code = _bn("sc_bn_act_backward")(dy.data_ptr(), x.data_ptr(), _p(y), gamma.data_ptr(), beta.data_ptr(), sp, sp + 4 * C,
+                                     _bn_partial(x), _p(dx), _p(dres), gp, gp + 4 * C, N, C, H * W, 1 if relu else 0,
+                                     1 if training else 0, _stream())
+    if code:
+        _lib.check(code, "sc_bn_act_backward")
+    return dx, dres, dgb[0], dgb[1]
 
 
 def bn_relu_pool_forward(x, gamma, beta, running_mean, running_var, n_tracked, training, momentum, eps):
-    lib = _lib.load()
     N, C, H, W = x.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     y = torch.empty(N, C, Ho, Wo, device=x.device, dtype=torch.float32)
     idx = torch.empty(N, C, Ho, Wo, device=x.device, dtype=torch.int32)
-    mean = torch.empty(C, device=x.device, dtype=torch.float32)
-    rstd = torch.empty_like(mean)
-    partial = _bn_partial(N, C, x)
-    code = lib.sc_bn_relu_pool_forward(_lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(y), _lib.ptr(idx),
-                                       _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(running_mean), _lib.ptr(running_var),
-                                       _lib.ptr(n_tracked), _lib.ptr(partial), c_int(N), c_int(C), c_int(H), c_int(W),
-                                       c_int(1 if training else 0), ctypes.c_float(eps), ctypes.c_float(momentum),
-                                       _lib.stream())
-    _lib.check(code, "sc_bn_relu_pool_forward")
-    return y, idx, mean, rstd
+    stats = torch.empty(2, C, device=x.device, dtype=torch.float32)
+    sp = stats.data_ptr()
+    code = _bn("sc_bn_relu_pool_forward")(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), idx.data_ptr(),
+                                          sp, sp + 4 * C, _p(running_mean), _p(running_var), _p(n_tracked),
+                                          _bn_partial(x), N, C, H, W, 1 if training else 0, eps, momentum, _stream())
+    if code:
+        _lib.check(code, "sc_bn_relu_pool_forward")
+    return y, idx, stats
 
 
-def bn_relu_pool_backward(dy, idx, x, gamma, beta, mean, rstd, training):
-    lib = _lib.load()
+def bn_relu_pool_backward(dy, idx, x, gamma, beta, stats, training):
     N, C, H, W = x.shape
     dx = torch.empty_like(x)
-    dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
-    dbeta = torch.empty_like(dgamma)
-    partial = _bn_partial(N, C, x)
-    code = lib.sc_bn_relu_pool_backward(_lib.ptr(dy), _lib.ptr(idx), _lib.ptr(x), _lib.ptr(gamma), _lib.ptr(beta),
-                                        _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(partial), _lib.ptr(dx), _lib.ptr(dgamma),
-                                        _lib.ptr(dbeta), c_int(N), c_int(C), c_int(H), c_int(W),
-                                        c_int(1 if training else 0), _lib.stream())
-    _lib.check(code, "sc_bn_relu_pool_backward")
-    return dx, dgamma, dbeta
+    dgb = torch.empty(2, C, device=x.device, dtype=torch.float32)
+    sp, gp = stats.data_ptr(), dgb.data_ptr()
+    code = _bn("sc_bn_relu_pool_backward")(dy.data_ptr(), idx.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                           sp, sp + 4 * C, _bn_partial(x), dx.data_ptr(), gp, gp + 4 * C, N, C, H, W,
+                                           1 if training else 0, _stream())
+    if code:
+        _lib.check(code, "sc_bn_relu_pool_backward")
+    return dx, dgb[0], dgb[1]
