@@ -219,6 +219,15 @@ int sc_bn_relu_pool_backward(const float* dy, const int* idx, const float* x, co
                              const float* mean, const float* rstd, float* partial, float* dx, float* dgamma,
                              float* dbeta, int N, int C, int H, int W, int training, void* stream);
 
+/* ---- iso-surface extraction for evaluation (replaces mcubes.marching_cubes, utils/eval_3D.py:125) -----
+ * level [n_images][n_axis]^3 fp32.  sc_isosurface_count writes counts[cube] (cube = ((b*Nc + x)*Nc + y)*Nc + z,
+ * Nc = n_axis-1): number of triangles of the marching-tetrahedra surface {level = iso} inside the cube (0..12).
+ * The caller turns counts into exclusive offsets (int64 prefix sum) and allocates tris [total][3][3];
+ * sc_isosurface_emit writes the triangles of every cube at its offset, vertices in grid-index units.           */
+int sc_isosurface_count(const float* level, int n_images, int n_axis, float iso, int* counts, void* stream);
+int sc_isosurface_emit(const float* level, int n_images, int n_axis, float iso, const int* counts,
+                       const long long* offsets, float* tris, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,7 @@ SYMBOLS = (
     "sc_clip_vit_forward", "sc_gemm_bf16", "sc_f32_to_bf16",
     "sc_ray_sample_forward", "sc_ray_sample_backward", "sc_render_forward", "sc_sdf_grid_forward", "sc_loss_fused_backward",
     "sc_bn_splits", "sc_bn_act_forward", "sc_bn_act_backward", "sc_bn_relu_pool_forward", "sc_bn_relu_pool_backward",
+    "sc_isosurface_count", "sc_isosurface_emit",
 )
 
 _lib: Optional[ctypes.CDLL] = None

@@ -77,34 +77,40 @@ def _edge_crossing_points(level, lo, hi, num_points, rng):
 
 
 @torch.no_grad()
-def edge_crossing_points_device(level, lo, hi, num_points, seed=0):
-    """Device-side version of _edge_crossing_points: level [B,S,S,S] on the GPU -> points [B,num_points,3] on the GPU
-    (no D2H of the (N+1)^3 grid, no Python threads).  Used when PyMCubes/trimesh are not importable."""
+def surface_points_device(level, lo, hi, num_points, seed=0, iso=0.0):
+    """level [B,S,S,S] on the GPU -> (points [B,num_points,3], tris list) sampled area-uniformly on the iso-surface.
+
+    Device-side replacement of `mcubes.marching_cubes` + `trimesh.Trimesh.sample` (reference utils/eval_3D.py:123-153)
+    when those packages are absent: triangles from the HIP marching-tetrahedra kernels (csrc/isosurface.hip), a
+    triangle per sample drawn with probability proportional to its area, a uniform point inside it (the same scheme
+    trimesh uses).  Vertices get the reference's 1/S rescale.  No D2H of the (N+1)^3 grid, no Python threads; seeded per
+    call so that sharded evaluation is independent of which rank handles a sample."""
+    from .. import ops
     B, S = level.shape[0], level.shape[1]
     dev = level.device
-    ar = torch.arange(S, device=dev, dtype=torch.float32)
+    tris, per_image = ops.isosurface_triangles(level, iso)
     out = torch.zeros(B, num_points, 3, device=dev)
+    meshes = []
     gen = torch.Generator(device=dev)
+    start = 0
     for b in range(B):
-        pts = []
-        for ax in range(3):
-            a = level[b].narrow(ax, 0, S - 1)
-            c = level[b].narrow(ax, 1, S - 1)
-            cross = (a * c) < 0
-            idx = cross.nonzero()                                  # [n,3] integer grid coordinates of the edge start
-            if idx.numel() == 0:
-                continue
-            t = a[cross] / (a[cross] - c[cross])
-            p = idx.float()
-            p[:, ax] += t
-            pts.append(p)
-        if not pts:
-            continue
-        pts = torch.cat(pts, 0)
+        n = int(per_image[b])
+        t = tris[start:start + n] / S * (hi - lo) + lo
+        start += n
+        meshes.append(t)
+        if n == 0:
+            continue                                               # the reference returns zeros for an empty mesh
         gen.manual_seed(seed + b)
-        pick = torch.randint(0, pts.shape[0], (num_points,), device=dev, generator=gen)
-        out[b] = pts[pick] / S * (hi - lo) + lo                    # same 1/S rescale as the reference's mesh vertices
-    return out
+        e1, e2 = t[:, 1] - t[:, 0], t[:, 2] - t[:, 0]
+        area = torch.linalg.cross(e1, e2).norm(dim=1)
+        if float(area.sum()) <= 0:
+            continue
+        pick = torch.multinomial(area, num_points, replacement=True, generator=gen)
+        uv = torch.rand(num_points, 2, device=dev, generator=gen)
+        flip = uv.sum(dim=1, keepdim=True) > 1
+        uv = torch.where(flip, 1 - uv, uv)
+        out[b] = t[pick, 0] + uv[:, :1] * e1[pick] + uv[:, 1:] * e2[pick]
+    return out, meshes
 
 
 def convert_to_explicit_worker(opt, i, level_vox_i, isoval, meshes, pointclouds=None):
@@ -171,11 +177,10 @@ def eval_metrics(opt, var, sdf_network, vis_only=False):
         meshes, pointclouds = convert_to_explicit(opt, level_grids, isoval=0., to_pointcloud=True)
         var.mesh_pred = meshes
         var.dpc_pred = torch.tensor(pointclouds, dtype=torch.float32, device=dev)
-    else:   # stay on the device: surface samples from grid-edge sign changes
-        var.mesh_pred = [None] * B
+    else:   # stay on the device: marching-tetrahedra triangles + area-uniform samples (csrc/isosurface.hip)
         lo, hi = opt.eval.range
-        var.dpc_pred = edge_crossing_points_device(level_vox, lo, hi, opt.eval.num_points,
-                                                   seed=int(var.idx[0]) if len(var.idx) else 0).to(dev)
+        var.dpc_pred, var.mesh_pred = surface_points_device(level_vox, lo, hi, opt.eval.num_points,
+                                                            seed=int(var.idx[0]) if len(var.idx) else 0)
     if opt.data.dataset in ["openimage"]:
         var.f_score = torch.zeros(B, len(opt.eval.f_thresholds)).to(dev)
         var.cd_acc = torch.zeros(B).to(dev); var.cd_comp = torch.zeros(B).to(dev)

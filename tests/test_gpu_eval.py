@@ -51,13 +51,13 @@ def test_graph_eval_forward_and_metrics():
     assert var.dpc_pred.shape == (1, 5000, 3) and var.f_score.shape == (1, 6)
     assert torch.isfinite(acc) and torch.isfinite(comp) and 0 <= float(var.f_score.min()) <= float(var.f_score.max()) <= 1
     # surface samples really lie on the zero level set of the network (|sdf| small at the sampled points)
-    pts = torch.tensor(np.concatenate([eval_3D._edge_crossing_points(
-        eval_3D.compute_level_grid(o, graph.sdf_network, var.proj_latent_sdf, eval_3D.get_dense_3D_grid(o, var))[0].cpu().numpy(),
-        -0.6, 0.6, 2000, np.random.RandomState(0))]), dtype=torch.float32, device="cuda:0")
+    level = eval_3D.compute_level_grid(o, graph.sdf_network, var.proj_latent_sdf, eval_3D.get_dense_3D_grid(o, var))
+    pts, meshes = eval_3D.surface_points_device(level, -0.6, 0.6, 2000, seed=0)
+    assert len(meshes) == 1 and meshes[0].shape[1:] == (3, 3)
     # the reference rescales marching-cubes vertices by 1/S with S = N+1 grid samples (eval_3D.py:143-145), i.e.
     # slightly shrunk; undo that to test against the true zero level set
     S = o.eval.vox_res + 1
-    pts = -0.6 + (pts + 0.6) * S / (S - 1)
+    pts = -0.6 + (pts[0] + 0.6) * S / (S - 1)
     sdf, _, _ = graph.sdf_network.get_conditional_output(o, 1, pts.contiguous(), var.proj_latent_sdf, compute_grad=False)
     assert sdf.abs().max().item() < 0.02
 

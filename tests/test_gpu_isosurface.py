@@ -1,0 +1,68 @@
+"""Iso-surface extraction on the GPU (csrc/isosurface.hip) against its CPU restatement (oracle/isosurface_ref.py) and
+analytic properties.  The reference's PyMCubes/trimesh step (utils/eval_3D.py:123-153) is third-party and absent:
+the triangulation is parity-unpinned; what is checked is kernel == restatement triangle by triangle (bit-exact, same
+fp32 interpolation and emission order), the area of a sphere, and area-uniform sampling."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _sphere(S, r, centre=(0.0, 0.0, 0.0)):
+    ax = np.linspace(-1, 1, S)
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
+    return (np.sqrt((X - centre[0]) ** 2 + (Y - centre[1]) ** 2 + (Z - centre[2]) ** 2) - r).astype(np.float32)
+
+
+def test_triangles_equal_cpu_restatement_bit_exact():
+    from oracle.isosurface_ref import marching_tets
+    from shapeclipper_amd import ops
+    rng = np.random.RandomState(0)
+    grids = [rng.randn(7, 7, 7).astype(np.float32),                       # noise: every case of every tetrahedron
+             _sphere(13, 0.55, (0.1, -0.05, 0.2)),
+             np.full((5, 5, 5), 1.0, np.float32),                         # no surface
+             _sphere(13, 0.5)]                                            # exact zeros on grid vertices (ties)
+    grids[3][6, 6, 1] = 0.0
+    for g in grids:
+        tris, per = ops.isosurface_triangles(torch.tensor(g[None]).cuda(), 0.0)
+        ref = marching_tets(g, 0.0)
+        assert int(per[0]) == ref.shape[0] == tris.shape[0]
+        assert np.array_equal(tris.cpu().numpy(), ref)
+
+
+def test_batched_grid_and_offsets():
+    from oracle.isosurface_ref import marching_tets
+    from shapeclipper_amd import ops
+    a, b, c = _sphere(9, 0.5), np.full((9, 9, 9), -1.0, np.float32), _sphere(9, 0.7, (0.1, 0.1, 0.0))
+    tris, per = ops.isosurface_triangles(torch.tensor(np.stack([a, b, c])).cuda(), 0.0)
+    ra, rc = marching_tets(a), marching_tets(c)
+    assert per.tolist() == [ra.shape[0], 0, rc.shape[0]]
+    assert np.array_equal(tris.cpu().numpy(), np.concatenate([ra, rc]))
+
+
+def test_sphere_area_and_uniform_samples():
+    from shapeclipper_amd.utils import eval_3D
+    S, r = 65, 0.45
+    level = torch.tensor(_sphere(S, r)[None] * 0.6).cuda()               # grid spans [-0.6, 0.6]: radius 0.27
+    pts, meshes = eval_3D.surface_points_device(level, -0.6, 0.6, 20000, seed=1)
+    t = meshes[0]
+    area = 0.5 * torch.linalg.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0]).norm(dim=1).sum().item()
+    scale = S / (S - 1)                                                  # undo the reference's 1/S vertex rescale
+    assert abs(area * scale ** 2 / (4 * math.pi * (0.6 * r) ** 2) - 1) < 0.01
+    p = (pts[0] + 0.6) * scale - 0.6
+    rad = p.norm(dim=1)
+    assert float((rad - 0.6 * r).abs().max()) < 2 * (1.2 / (S - 1)) ** 2 / (0.6 * r) + 1e-4
+    # area-uniform: each octant of the sphere gets 1/8 of the samples (binomial 4-sigma)
+    octant = ((p[:, 0] > 0).long() * 4 + (p[:, 1] > 0).long() * 2 + (p[:, 2] > 0).long()).bincount(minlength=8).float() / 20000
+    assert float((octant - 0.125).abs().max()) < 4 * math.sqrt(0.125 * 0.875 / 20000)
+    # z is uniform on a sphere (Archimedes): compare the lower-quartile mass
+    assert abs(float((p[:, 2] < -0.5 * 0.6 * r).float().mean()) - 0.25) < 0.015
+
+
+def test_empty_surface_gives_zero_points():
+    from shapeclipper_amd.utils import eval_3D
+    pts, meshes = eval_3D.surface_points_device(torch.ones(2, 9, 9, 9).cuda(), -0.6, 0.6, 100)
+    assert meshes[0].shape[0] == 0 and float(pts.abs().max()) == 0.0

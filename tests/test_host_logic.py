@@ -190,3 +190,24 @@ def test_uniform_sampler_consumes_the_reference_rng_stream(golden):
     zr, zer = R.get_z_vals(R.Cfg(), 64, torch.tensor(g["scale_dist"]), True, torch.tensor(g["t_rand"]), torch.tensor(g["eik_idx"]))
     assert torch.allclose(z, zr, atol=1e-6) and torch.allclose(z_eik, zer, atol=1e-6)
     assert torch.equal(torch.empty(64, 3).uniform_(-1, 1), torch.tensor(g["eik_pts"]))    # third draw of the stream
+
+
+def test_isosurface_restatement_on_a_sphere():
+    """oracle/isosurface_ref.py (the checker of csrc/isosurface.hip): closed surface of the right area, on the sphere."""
+    import numpy as np
+    from oracle.isosurface_ref import marching_tets, triangle_areas
+    S, r = 17, 0.6
+    ax = np.linspace(-1, 1, S)
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
+    tris = marching_tets((np.sqrt(X * X + Y * Y + Z * Z) - r).astype(np.float32))
+    h = 2.0 / (S - 1)
+    assert abs(triangle_areas(tris).sum() * h * h / (4 * np.pi * r * r) - 1) < 0.02
+    p = tris.reshape(-1, 3) * h - 1
+    assert np.abs(np.linalg.norm(p, axis=1) - r).max() < h * h
+    # watertight: every edge of the soup is shared by exactly two triangles
+    from collections import Counter
+    edges = Counter()
+    for t in tris:
+        for a, b in ((0, 1), (1, 2), (2, 0)):
+            edges[tuple(sorted((tuple(t[a]), tuple(t[b]))))] += 1
+    assert set(edges.values()) == {2}
