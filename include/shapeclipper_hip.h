@@ -191,33 +191,36 @@ int sc_loss_fused_backward(const float* G4, float* g_rgb, long long n_rgb, float
  * Replaces, between the MIOpen convolutions of the reference's torchvision ResNet-18/34 (model/graph.py:52-54,
  * model/view_estimator.py:40-42; torchvision BasicBlock.forward), nn.BatchNorm2d + `out += identity` + ReLU.
  * All tensors NCHW fp32, contiguous, 16-byte aligned.  N images, C channels, HW = H*W.
- * sc_bn_splits: number S of per-channel partial blocks the kernels use; `partial` must hold C*S*2 floats.   */
+ * sc_bn_splits: number S of per-channel partial blocks the kernels use for one group.                       */
 int sc_bn_splits(int N, int C);
 
 /* y = [relu]( gamma*(x-mean)*rstd + beta [+ res] ).  training != 0: batch statistics (biased variance), running
- * statistics updated with `momentum` (unbiased variance) and *n_tracked += 1 (both may be NULL); training == 0: the
- * running statistics are used.  save_mean / save_rstd [C] are written for the backward.                      */
+ * statistics updated with `momentum` (unbiased variance) and *n_tracked += groups (both may be NULL); training == 0:
+ * the running statistics are used.  groups = G >= 1 (N % G == 0): the batch is G independent sub-batches of N/G
+ * images (what the reference feeds through the network in G consecutive calls): statistics per sub-batch, running
+ * statistics updated G times in order.  save_mean / save_rstd [G][C] are written for the backward.
+ * `partial` must hold 2*(2048 + C*G) floats.                                                                  */
 int sc_bn_act_forward(const float* x, const float* res, const float* gamma, const float* beta, float* y,
                       float* save_mean, float* save_rstd, float* run_mean, float* run_var, int64_t* n_tracked,
-                      float* partial, int N, int C, int HW, int relu, int training, float eps, float momentum,
-                      void* stream);
+                      float* partial, int N, int C, int HW, int relu, int training, int groups, float eps,
+                      float momentum, void* stream);
 
 /* Backward of sc_bn_act_forward.  y (the forward output) is needed only when a residual was added AND relu != 0
  * (pass NULL otherwise: the ReLU mask is then recomputed from x).  dres (may be NULL) receives the gradient of the
  * residual input (= the ReLU-masked dy); dx may be NULL; dgamma / dbeta [C] are always written.               */
 int sc_bn_act_backward(const float* dy, const float* x, const float* y, const float* gamma, const float* beta,
                        const float* mean, const float* rstd, float* partial, float* dx, float* dres, float* dgamma,
-                       float* dbeta, int N, int C, int HW, int relu, int training, void* stream);
+                       float* dbeta, int N, int C, int HW, int relu, int training, int groups, void* stream);
 
 /* ResNet stem: y = maxpool3x3/stride2/pad1( relu( bn(x) ) ), x [N,C,H,W] -> y [N,C,Ho,Wo], Ho = (H-1)/2+1.
  * idx [N,C,Ho,Wo] int32: argmax position h*W+w (first maximum in scan order, as torch.nn.MaxPool2d).          */
 int sc_bn_relu_pool_forward(const float* x, const float* gamma, const float* beta, float* y, int* idx,
                             float* save_mean, float* save_rstd, float* run_mean, float* run_var, int64_t* n_tracked,
-                            float* partial, int N, int C, int H, int W, int training, float eps, float momentum,
-                            void* stream);
+                            float* partial, int N, int C, int H, int W, int training, int groups, float eps,
+                            float momentum, void* stream);
 int sc_bn_relu_pool_backward(const float* dy, const int* idx, const float* x, const float* gamma, const float* beta,
                              const float* mean, const float* rstd, float* partial, float* dx, float* dgamma,
-                             float* dbeta, int N, int C, int H, int W, int training, void* stream);
+                             float* dbeta, int N, int C, int H, int W, int training, int groups, void* stream);
 
 /* ---- iso-surface extraction for evaluation (replaces mcubes.marching_cubes, utils/eval_3D.py:125) -----
  * level [n_images][n_axis]^3 fp32.  sc_isosurface_count writes counts[cube] (cube = ((b*Nc + x)*Nc + y)*Nc + z,

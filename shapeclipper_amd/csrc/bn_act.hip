@@ -12,6 +12,10 @@
 // Statistics: one block per (channel, image subset); partial sums of (x-K), (x-K)^2 with K = first element of the
 // channel (shifted-data variance), combined in a fixed order -> deterministic.  Running statistics (momentum update,
 // unbiased variance) and num_batches_tracked are updated in the apply kernel, as nn.BatchNorm2d does in training.
+// Groups: the batch may hold G independent sub-batches of N/G images (the passes the reference runs one after the
+// other through the same network: input view, CLIP neighbour, mirrored image).  Statistics, normalisation and the
+// backward means are per group; the running statistics receive the G momentum updates in group order, exactly as G
+// sequential forward calls would apply them; dgamma/dbeta are summed over the groups (shared parameters).
 // Bound: HBM (8 TB/s).  Algorithmic bytes per element: forward 12-16 B, backward 20-28 B.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -36,22 +40,36 @@ template <> struct Vec<1> {
     __device__ __forceinline__ void st(float* p) const { *p = v[0]; }
 };
 
-// Visit the elements of channel c in images n = s, s+S, s+2S, ... (this block's share), float4-wide when HW % 4 == 0.
+// This block's share of the batch: group g (images n0 .. n0+Ng-1), split s of S inside the group.
+struct BnShare {
+    int g, s, S, n0, Ng;
+};
+__device__ __forceinline__ BnShare bn_share(int N, int G) {
+    BnShare sh;
+    sh.S = gridDim.y / G;
+    sh.g = blockIdx.y / sh.S;
+    sh.s = blockIdx.y - sh.g * sh.S;
+    sh.Ng = N / G;
+    sh.n0 = sh.g * sh.Ng;
+    return sh;
+}
+
+// Visit the elements of channel c in images n0+s, n0+s+S, ... of the group, float4-wide when HW % 4 == 0.
 template <class F>
-__device__ __forceinline__ void bn_iterate(int N, int C, int HW, int c, int s, int S, F&& f) {
-    const int cnt = (N - s + S - 1) / S;
+__device__ __forceinline__ void bn_iterate(const BnShare& sh, int C, int HW, int c, F&& f) {
+    const int cnt = (sh.Ng - sh.s + sh.S - 1) / sh.S;
     if ((HW & 3) == 0) {
         const int hw4 = HW >> 2, total = cnt * hw4;
 #pragma unroll 2
         for (int idx = threadIdx.x; idx < total; idx += BN_T) {
             const int nl = idx / hw4, i = idx - nl * hw4;
-            f(((size_t)(s + nl * S) * C + c) * HW + 4 * i, std::integral_constant<int, 4>{});
+            f(((size_t)(sh.n0 + sh.s + nl * sh.S) * C + c) * HW + 4 * i, std::integral_constant<int, 4>{});
         }
     } else {
         const int total = cnt * HW;
         for (int idx = threadIdx.x; idx < total; idx += BN_T) {
             const int nl = idx / HW, i = idx - nl * HW;
-            f(((size_t)(s + nl * S) * C + c) * HW + i, std::integral_constant<int, 1>{});
+            f(((size_t)(sh.n0 + sh.s + nl * sh.S) * C + c) * HW + i, std::integral_constant<int, 1>{});
         }
     }
 }
@@ -76,24 +94,32 @@ __device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {   /
     }
 }
 
-// Combine the S per-block partial pairs of channel c (fixed order); every thread gets the totals.
-__device__ __forceinline__ void combine_partials(const float* partial, int c, int S, float& a, float& b) {
+// partial layout: [C][G*S][2].  Sum of the S pairs of (channel c, group g), fixed order; every thread gets the totals.
+__device__ __forceinline__ void combine_partials(const float* partial, int c, int g, int S, int G, float& a, float& b) {
     a = 0.f;
     b = 0.f;
-    for (int k = 0; k < S; ++k) {          // S <= 32: a short uniform (scalar-cached) loop
-        a += partial[((size_t)c * S + k) * 2];
-        b += partial[((size_t)c * S + k) * 2 + 1];
+    const float* p = partial + ((size_t)c * G * S + (size_t)g * S) * 2;
+    for (int k = 0; k < S; ++k) {          // S <= 32: a short uniform loop
+        a += p[2 * k];
+        b += p[2 * k + 1];
     }
 }
 
+__device__ __forceinline__ void store_partial(float* partial, int c, const BnShare& sh, int G, float a, float b) {
+    float* p = partial + ((size_t)c * G * sh.S + (size_t)sh.g * sh.S + sh.s) * 2;
+    p[0] = a;
+    p[1] = b;
+}
+
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BN_T) void bn_stats_kernel(const float* __restrict__ x, int N, int C, int HW,
+__global__ __launch_bounds__(BN_T) void bn_stats_kernel(const float* __restrict__ x, int N, int C, int HW, int G,
                                                         float* __restrict__ partial) {
     __shared__ float red[2 * BN_T / 64];
-    const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
-    const float K = x[(size_t)c * HW];
+    const int c = blockIdx.x;
+    const BnShare sh = bn_share(N, G);
+    const float K = x[((size_t)sh.n0 * C + c) * HW];
     float s1 = 0.f, s2 = 0.f;
-    bn_iterate(N, C, HW, c, s, S, [&](size_t off, auto w) {
+    bn_iterate(sh, C, HW, c, [&](size_t off, auto w) {
         const auto v = Vec<decltype(w)::value>::ld(x + off);
 #pragma unroll
         for (int k = 0; k < decltype(w)::value; ++k) {
@@ -103,49 +129,71 @@ __global__ __launch_bounds__(BN_T) void bn_stats_kernel(const float* __restrict_
         }
     });
     block_sum2(s1, s2, red);
-    if (threadIdx.x == 0) {
-        partial[((size_t)c * S + s) * 2] = s1;
-        partial[((size_t)c * S + s) * 2 + 1] = s2;
-    }
+    if (threadIdx.x == 0) store_partial(partial, c, sh, G, s1, s2);
 }
 
-struct BnFwdArgs {
-    const float* x; const float* res; const float* gamma; const float* beta; const float* partial;
-    float* y; float* save_mean; float* save_rstd; float* run_mean; float* run_var; int64_t* n_tracked;
-    int N, C, HW, relu, training;
+struct BnStatArgs {      // what the forward needs to turn partial sums into (mean, rstd) and running statistics
+    const float* x; const float* partial;
+    float* save_mean; float* save_rstd;      // [G][C]
+    float* run_mean; float* run_var; int64_t* n_tracked;
+    int N, C, HW, G, training;
     float eps, momentum;
 };
 
-__global__ __launch_bounds__(BN_T) void bn_apply_fwd_kernel(BnFwdArgs a) {
-    const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
-    float mean, rstd;
-    if (a.training) {
+// (mean, rstd) of channel c for this block's group; block (blockIdx.y == 0) also records the statistics of every
+// group for the backward and applies the G running-statistics updates in group order.
+__device__ __forceinline__ void bn_forward_stats(const BnStatArgs& a, int c, const BnShare& sh, float& mean, float& rstd) {
+    const float n = (float)sh.Ng * (float)a.HW;
+    auto group_stats = [&](int g, float& m, float& var) {
         float s1, s2;
-        combine_partials(a.partial, c, S, s1, s2);
-        const float n = (float)a.N * (float)a.HW;
+        combine_partials(a.partial, c, g, sh.S, a.G, s1, s2);
         const float dm = s1 / n;
-        const float var = fmaxf(s2 / n - dm * dm, 0.f);
-        mean = a.x[(size_t)c * a.HW] + dm;
+        var = fmaxf(s2 / n - dm * dm, 0.f);
+        m = a.x[((size_t)g * sh.Ng * a.C + c) * a.HW] + dm;
+    };
+    if (a.training) {
+        float var;
+        group_stats(sh.g, mean, var);
         rstd = rsqrtf(var + a.eps);
-        if (s == 0 && threadIdx.x == 0) {
-            if (a.run_mean) {
-                a.run_mean[c] = (1.f - a.momentum) * a.run_mean[c] + a.momentum * mean;
-                a.run_var[c] = (1.f - a.momentum) * a.run_var[c] + a.momentum * (n > 1.f ? var * n / (n - 1.f) : var);
-            }
-            if (a.n_tracked && c == 0) *a.n_tracked += 1;
-        }
     } else {
         mean = a.run_mean[c];
         rstd = rsqrtf(a.run_var[c] + a.eps);
     }
-    if (s == 0 && threadIdx.x == 0) {
-        a.save_mean[c] = mean;
-        a.save_rstd[c] = rstd;
+    if (blockIdx.y == 0 && threadIdx.x == 0) {
+        for (int g = 0; g < a.G; ++g) {
+            float m = mean, r = rstd;
+            if (a.training) {
+                float var;
+                group_stats(g, m, var);
+                r = rsqrtf(var + a.eps);
+                if (a.run_mean) {
+                    a.run_mean[c] = (1.f - a.momentum) * a.run_mean[c] + a.momentum * m;
+                    a.run_var[c] = (1.f - a.momentum) * a.run_var[c] + a.momentum * (n > 1.f ? var * n / (n - 1.f) : var);
+                }
+            }
+            a.save_mean[(size_t)g * a.C + c] = m;
+            a.save_rstd[(size_t)g * a.C + c] = r;
+        }
+        if (a.training && a.n_tracked && c == 0) *a.n_tracked += a.G;
     }
+}
+
+struct BnFwdArgs {
+    BnStatArgs st;
+    const float* res; const float* gamma; const float* beta; float* y;
+    int relu;
+};
+
+__global__ __launch_bounds__(BN_T) void bn_apply_fwd_kernel(BnFwdArgs a) {
+    const int c = blockIdx.x;
+    const BnShare sh = bn_share(a.st.N, a.st.G);
+    float mean, rstd;
+    bn_forward_stats(a.st, c, sh, mean, rstd);
     const float scale = a.gamma[c] * rstd, shift = a.beta[c] - mean * scale;
-    bn_iterate(a.N, a.C, a.HW, c, s, S, [&](size_t off, auto w) {
+    const float* x = a.st.x;
+    bn_iterate(sh, a.st.C, a.st.HW, c, [&](size_t off, auto w) {
         constexpr int W = decltype(w)::value;
-        auto v = Vec<W>::ld(a.x + off);
+        auto v = Vec<W>::ld(x + off);
         if (a.res) {
             const auto r = Vec<W>::ld(a.res + off);
 #pragma unroll
@@ -164,9 +212,9 @@ __global__ __launch_bounds__(BN_T) void bn_apply_fwd_kernel(BnFwdArgs a) {
 
 struct BnBwdArgs {
     const float* dy; const float* x; const float* y;      // y: forward output, needed for the mask only when res was added
-    const float* gamma; const float* beta; const float* mean; const float* rstd;
+    const float* gamma; const float* beta; const float* mean; const float* rstd;     // mean, rstd: [G][C]
     float* partial; float* dx; float* dres; float* dgamma; float* dbeta;
-    int N, C, HW, relu, training, has_res;
+    int N, C, HW, G, relu, training, has_res;
 };
 
 // g = dy * [output > 0]; the no-residual mask is recomputed from x with the forward's own fma.
@@ -188,11 +236,12 @@ __device__ __forceinline__ Vec<W> bn_masked_grad(const BnBwdArgs& a, size_t off,
 
 __global__ __launch_bounds__(BN_T) void bn_bwd_stats_kernel(BnBwdArgs a) {
     __shared__ float red[2 * BN_T / 64];
-    const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
-    const float mean = a.mean[c], rstd = a.rstd[c];
+    const int c = blockIdx.x;
+    const BnShare sh = bn_share(a.N, a.G);
+    const float mean = a.mean[(size_t)sh.g * a.C + c], rstd = a.rstd[(size_t)sh.g * a.C + c];
     const float scale = a.gamma[c] * rstd, shift = a.beta[c] - mean * scale;
     float s1 = 0.f, s2 = 0.f;
-    bn_iterate(a.N, a.C, a.HW, c, s, S, [&](size_t off, auto w) {
+    bn_iterate(sh, a.C, a.HW, c, [&](size_t off, auto w) {
         constexpr int W = decltype(w)::value;
         const auto xv = Vec<W>::ld(a.x + off);
         const auto g = bn_masked_grad<W>(a, off, xv, scale, shift);
@@ -204,26 +253,31 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_stats_kernel(BnBwdArgs a) {
         if (a.dres) g.st(a.dres + off);
     });
     block_sum2(s1, s2, red);
-    if (threadIdx.x == 0) {
-        a.partial[((size_t)c * S + s) * 2] = s1;
-        a.partial[((size_t)c * S + s) * 2 + 1] = s2;
-    }
+    if (threadIdx.x == 0) store_partial(a.partial, c, sh, a.G, s1, s2);
 }
 
 __global__ __launch_bounds__(BN_T) void bn_bwd_apply_kernel(BnBwdArgs a) {
-    const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
-    const float mean = a.mean[c], rstd = a.rstd[c], gamma = a.gamma[c];
+    const int c = blockIdx.x;
+    const BnShare sh = bn_share(a.N, a.G);
+    const float mean = a.mean[(size_t)sh.g * a.C + c], rstd = a.rstd[(size_t)sh.g * a.C + c], gamma = a.gamma[c];
     const float scale = gamma * rstd, shift = a.beta[c] - mean * scale;
     float sg, sgx;
-    combine_partials(a.partial, c, S, sg, sgx);
-    if (s == 0 && threadIdx.x == 0) {
-        a.dgamma[c] = sgx;
-        a.dbeta[c] = sg;
+    combine_partials(a.partial, c, sh.g, sh.S, a.G, sg, sgx);
+    if (blockIdx.y == 0 && threadIdx.x == 0) {      // parameters are shared by the groups: sum over all of them
+        float tg = 0.f, tgx = 0.f;
+        for (int g = 0; g < a.G; ++g) {
+            float u, v;
+            combine_partials(a.partial, c, g, sh.S, a.G, u, v);
+            tg += u;
+            tgx += v;
+        }
+        a.dgamma[c] = tgx;
+        a.dbeta[c] = tg;
     }
     if (!a.dx) return;
-    const float n = (float)a.N * (float)a.HW;
+    const float n = (float)sh.Ng * (float)a.HW;
     const float mg = a.training ? sg / n : 0.f, mgx = a.training ? sgx / n : 0.f;
-    bn_iterate(a.N, a.C, a.HW, c, s, S, [&](size_t off, auto w) {
+    bn_iterate(sh, a.C, a.HW, c, [&](size_t off, auto w) {
         constexpr int W = decltype(w)::value;
         const auto xv = Vec<W>::ld(a.x + off);
         // with a residual the masked gradient was already written to dres by the stats pass
@@ -240,47 +294,25 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_apply_kernel(BnBwdArgs a) {
 // in scan order like torch) kept as int32 for the backward.  BN+ReLU is monotone per channel when scale >= 0, but the
 // general form is evaluated (scale may be negative).
 struct PoolFwdArgs {
-    const float* x; const float* gamma; const float* beta; const float* partial; int S_stats;
-    float* y; int* idx; float* save_mean; float* save_rstd; float* run_mean; float* run_var; int64_t* n_tracked;
-    int N, C, H, W, Ho, Wo, training;
-    float eps, momentum;
+    BnStatArgs st;
+    const float* gamma; const float* beta; float* y; int* idx;
+    int H, W, Ho, Wo;
 };
 
 __global__ __launch_bounds__(BN_T) void bn_relu_pool_fwd_kernel(PoolFwdArgs a) {
-    const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
-    const int HW = a.H * a.W;
+    const int c = blockIdx.x;
+    const BnShare sh = bn_share(a.st.N, a.st.G);
+    const int HW = a.H * a.W, C = a.st.C;
     float mean, rstd;
-    if (a.training) {
-        float s1, s2;
-        combine_partials(a.partial, c, a.S_stats, s1, s2);
-        const float n = (float)a.N * (float)HW;
-        const float dm = s1 / n;
-        const float var = fmaxf(s2 / n - dm * dm, 0.f);
-        mean = a.x[(size_t)c * HW] + dm;
-        rstd = rsqrtf(var + a.eps);
-        if (s == 0 && threadIdx.x == 0) {
-            if (a.run_mean) {
-                a.run_mean[c] = (1.f - a.momentum) * a.run_mean[c] + a.momentum * mean;
-                a.run_var[c] = (1.f - a.momentum) * a.run_var[c] + a.momentum * (n > 1.f ? var * n / (n - 1.f) : var);
-            }
-            if (a.n_tracked && c == 0) *a.n_tracked += 1;
-        }
-    } else {
-        mean = a.run_mean[c];
-        rstd = rsqrtf(a.run_var[c] + a.eps);
-    }
-    if (s == 0 && threadIdx.x == 0) {
-        a.save_mean[c] = mean;
-        a.save_rstd[c] = rstd;
-    }
+    bn_forward_stats(a.st, c, sh, mean, rstd);
     const float scale = a.gamma[c] * rstd, shift = a.beta[c] - mean * scale;
     const int HoWo = a.Ho * a.Wo;
-    const int cnt = (a.N - s + S - 1) / S, total = cnt * HoWo;
+    const int cnt = (sh.Ng - sh.s + sh.S - 1) / sh.S, total = cnt * HoWo;
     for (int t = threadIdx.x; t < total; t += BN_T) {
         const int nl = t / HoWo, o = t - nl * HoWo;
         const int ho = o / a.Wo, wo = o - ho * a.Wo;
-        const size_t plane = ((size_t)(s + nl * S) * a.C + c);
-        const float* xp = a.x + plane * HW;
+        const size_t plane = ((size_t)(sh.n0 + sh.s + nl * sh.S) * C + c);
+        const float* xp = a.st.x + plane * HW;
         float best = -__builtin_inff();
         int bi = -1;
 #pragma unroll
@@ -305,8 +337,8 @@ __global__ __launch_bounds__(BN_T) void bn_relu_pool_fwd_kernel(PoolFwdArgs a) {
 
 struct PoolBwdArgs {
     const float* dy; const int* idx; const float* x; const float* gamma; const float* beta; const float* mean;
-    const float* rstd; float* partial; float* dx; float* dgamma; float* dbeta;
-    int N, C, H, W, Ho, Wo, training;
+    const float* rstd; float* partial; float* dx;
+    int N, C, H, W, Ho, Wo, G;
 };
 
 // Pass 1 of the stem backward.  One thread owns a 2x2 block of BN-output positions (rows 2i,2i+1, cols 2j,2j+1): the
@@ -315,17 +347,18 @@ struct PoolBwdArgs {
 // reduced into the per-channel sums; pass 2 (bn_bwd_apply_kernel with dres == dx) finishes dx in place.
 __global__ __launch_bounds__(BN_T) void bn_relu_pool_bwd_gather_kernel(PoolBwdArgs a) {
     __shared__ float red[2 * BN_T / 64];
-    const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+    const int c = blockIdx.x;
+    const BnShare sh = bn_share(a.N, a.G);
     const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
     const int Hq = (a.H + 1) >> 1, Wq = (a.W + 1) >> 1, Q = Hq * Wq;
-    const float mean = a.mean[c], rstd = a.rstd[c];
+    const float mean = a.mean[(size_t)sh.g * a.C + c], rstd = a.rstd[(size_t)sh.g * a.C + c];
     const float scale = a.gamma[c] * rstd, shift = a.beta[c] - mean * scale;
     float sg = 0.f, sgx = 0.f;
-    const int cnt = (a.N - s + S - 1) / S, total = cnt * Q;
+    const int cnt = (sh.Ng - sh.s + sh.S - 1) / sh.S, total = cnt * Q;
     for (int t = threadIdx.x; t < total; t += BN_T) {
         const int nl = t / Q, q = t - nl * Q;
         const int i = q / Wq, j = q - i * Wq;
-        const size_t plane = ((size_t)(s + nl * S) * a.C + c);
+        const size_t plane = ((size_t)(sh.n0 + sh.s + nl * sh.S) * a.C + c);
         int wi[2][2];
         float wd[2][2];
 #pragma unroll
@@ -362,33 +395,33 @@ __global__ __launch_bounds__(BN_T) void bn_relu_pool_bwd_gather_kernel(PoolBwdAr
         }
     }
     block_sum2(sg, sgx, red);
-    if (threadIdx.x == 0) {
-        a.partial[((size_t)c * S + s) * 2] = sg;
-        a.partial[((size_t)c * S + s) * 2 + 1] = sgx;
-    }
+    if (threadIdx.x == 0) store_partial(a.partial, c, sh, a.G, sg, sgx);
 }
 
-static inline int bn_splits(int N, int C) {
-    int S = (2048 + C - 1) / C;
-    if (S > N) S = N;
+static inline int bn_splits(int Ng, int C, int G) {      // blocks per (channel, group); C * G * S ~ 2048 blocks
+    int S = (2048 + C * G - 1) / (C * G);
+    if (S > Ng) S = Ng;
     if (S > 32) S = 32;
     return S < 1 ? 1 : S;
 }
 
 }  // namespace sc
 
-extern "C" int sc_bn_splits(int N, int C) { return sc::bn_splits(N, C); }
+static inline bool bn_bad(int N, int C, int HW, int G) { return G < 1 || N % G != 0; }
+
+extern "C" int sc_bn_splits(int N, int C) { return sc::bn_splits(N, C, 1); }
 
 extern "C" int sc_bn_act_forward(const float* x, const float* res, const float* gamma, const float* beta, float* y,
                                  float* save_mean, float* save_rstd, float* run_mean, float* run_var,
                                  int64_t* n_tracked, float* partial, int N, int C, int HW, int relu, int training,
-                                 float eps, float momentum, void* stream_) {
+                                 int groups, float eps, float momentum, void* stream_) {
     if (N <= 0 || C <= 0 || HW <= 0) return 0;
+    if (bn_bad(N, C, HW, groups)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream_;
-    const dim3 grid(C, sc::bn_splits(N, C));
-    if (training) hipLaunchKernelGGL(sc::bn_stats_kernel, grid, dim3(sc::BN_T), 0, st, x, N, C, HW, partial);
-    sc::BnFwdArgs a{x, res, gamma, beta, partial, y, save_mean, save_rstd, run_mean, run_var, n_tracked,
-                    N, C, HW, relu, training, eps, momentum};
+    const dim3 grid(C, groups * sc::bn_splits(N / groups, C, groups));
+    if (training) hipLaunchKernelGGL(sc::bn_stats_kernel, grid, dim3(sc::BN_T), 0, st, x, N, C, HW, groups, partial);
+    sc::BnFwdArgs a{{x, partial, save_mean, save_rstd, run_mean, run_var, n_tracked, N, C, HW, groups, training, eps, momentum},
+                    res, gamma, beta, y, relu};
     hipLaunchKernelGGL(sc::bn_apply_fwd_kernel, grid, dim3(sc::BN_T), 0, st, a);
     return (int)hipGetLastError();
 }
@@ -396,11 +429,12 @@ extern "C" int sc_bn_act_forward(const float* x, const float* res, const float* 
 extern "C" int sc_bn_act_backward(const float* dy, const float* x, const float* y, const float* gamma,
                                   const float* beta, const float* mean, const float* rstd, float* partial, float* dx,
                                   float* dres, float* dgamma, float* dbeta, int N, int C, int HW, int relu,
-                                  int training, void* stream_) {
+                                  int training, int groups, void* stream_) {
     if (N <= 0 || C <= 0 || HW <= 0) return 0;
+    if (bn_bad(N, C, HW, groups)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream_;
-    const dim3 grid(C, sc::bn_splits(N, C));
-    sc::BnBwdArgs a{dy, x, y, gamma, beta, mean, rstd, partial, dx, dres, dgamma, dbeta, N, C, HW, relu, training,
+    const dim3 grid(C, groups * sc::bn_splits(N / groups, C, groups));
+    sc::BnBwdArgs a{dy, x, y, gamma, beta, mean, rstd, partial, dx, dres, dgamma, dbeta, N, C, HW, groups, relu, training,
                     (y != nullptr) ? 1 : 0};
     hipLaunchKernelGGL(sc::bn_bwd_stats_kernel, grid, dim3(sc::BN_T), 0, st, a);
     hipLaunchKernelGGL(sc::bn_bwd_apply_kernel, grid, dim3(sc::BN_T), 0, st, a);
@@ -410,14 +444,14 @@ extern "C" int sc_bn_act_backward(const float* dy, const float* x, const float* 
 extern "C" int sc_bn_relu_pool_forward(const float* x, const float* gamma, const float* beta, float* y, int* idx,
                                        float* save_mean, float* save_rstd, float* run_mean, float* run_var,
                                        int64_t* n_tracked, float* partial, int N, int C, int H, int W, int training,
-                                       float eps, float momentum, void* stream_) {
+                                       int groups, float eps, float momentum, void* stream_) {
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+    if (bn_bad(N, C, H * W, groups)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream_;
-    const int S = sc::bn_splits(N, C);
-    const dim3 grid(C, S);
-    if (training) hipLaunchKernelGGL(sc::bn_stats_kernel, grid, dim3(sc::BN_T), 0, st, x, N, C, H * W, partial);
-    sc::PoolFwdArgs a{x, gamma, beta, partial, S, y, idx, save_mean, save_rstd, run_mean, run_var, n_tracked,
-                      N, C, H, W, (H + 2 - 3) / 2 + 1, (W + 2 - 3) / 2 + 1, training, eps, momentum};
+    const dim3 grid(C, groups * sc::bn_splits(N / groups, C, groups));
+    if (training) hipLaunchKernelGGL(sc::bn_stats_kernel, grid, dim3(sc::BN_T), 0, st, x, N, C, H * W, groups, partial);
+    sc::PoolFwdArgs a{{x, partial, save_mean, save_rstd, run_mean, run_var, n_tracked, N, C, H * W, groups, training, eps, momentum},
+                      gamma, beta, y, idx, H, W, (H + 2 - 3) / 2 + 1, (W + 2 - 3) / 2 + 1};
     hipLaunchKernelGGL(sc::bn_relu_pool_fwd_kernel, grid, dim3(sc::BN_T), 0, st, a);
     return (int)hipGetLastError();
 }
@@ -425,16 +459,15 @@ extern "C" int sc_bn_relu_pool_forward(const float* x, const float* gamma, const
 extern "C" int sc_bn_relu_pool_backward(const float* dy, const int* idx, const float* x, const float* gamma,
                                         const float* beta, const float* mean, const float* rstd, float* partial,
                                         float* dx, float* dgamma, float* dbeta, int N, int C, int H, int W,
-                                        int training, void* stream_) {
+                                        int training, int groups, void* stream_) {
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+    if (bn_bad(N, C, H * W, groups)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream_;
-    const int S = sc::bn_splits(N, C);
-    const dim3 grid(C, S);
-    sc::PoolBwdArgs a{dy, idx, x, gamma, beta, mean, rstd, partial, dx, dgamma, dbeta,
-                      N, C, H, W, (H + 2 - 3) / 2 + 1, (W + 2 - 3) / 2 + 1, training};
+    const dim3 grid(C, groups * sc::bn_splits(N / groups, C, groups));
+    sc::PoolBwdArgs a{dy, idx, x, gamma, beta, mean, rstd, partial, dx, N, C, H, W, (H + 2 - 3) / 2 + 1, (W + 2 - 3) / 2 + 1, groups};
     hipLaunchKernelGGL(sc::bn_relu_pool_bwd_gather_kernel, grid, dim3(sc::BN_T), 0, st, a);
     // pass 2: dx = scale * (g - mean(g) - xhat * mean(g xhat)) in place (g was left in dx)
-    sc::BnBwdArgs b{nullptr, x, nullptr, gamma, beta, mean, rstd, partial, dx, dx, dgamma, dbeta, N, C, H * W, 0, training, 0};
+    sc::BnBwdArgs b{nullptr, x, nullptr, gamma, beta, mean, rstd, partial, dx, dx, dgamma, dbeta, N, C, H * W, groups, 0, training, 0};
     hipLaunchKernelGGL(sc::bn_bwd_apply_kernel, grid, dim3(sc::BN_T), 0, st, b);
     return (int)hipGetLastError();
 }

@@ -130,42 +130,42 @@ class BnActFunction(torch.autograd.Function):
     running statistics (updated in place; num_batches_tracked incremented by the kernel)."""
 
     @staticmethod
-    def forward(ctx, x, res, weight, bias, running_mean, running_var, n_tracked, training, momentum, eps, relu):
+    def forward(ctx, x, res, weight, bias, running_mean, running_var, n_tracked, training, momentum, eps, relu, groups):
         x = ops._aligned(x)
         if res is not None:
             res = ops._aligned(res)
         y, stats = ops.bn_act_forward(x, res, weight, bias, running_mean, running_var, n_tracked, training,
-                                      momentum, eps, relu)
-        ctx.meta = (training, relu, res is not None)
+                                      momentum, eps, relu, groups)
+        ctx.meta = (training, relu, res is not None, groups)
         ctx.save_for_backward(x, weight, bias, stats, y if (res is not None and relu) else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        training, relu, has_res = ctx.meta
+        training, relu, has_res, groups = ctx.meta
         x, weight, bias, stats, y = ctx.saved_tensors
         dx, dres, dg, db = ops.bn_act_backward(ops._aligned(dy), x, y, weight, bias, stats, training, relu,
-                                               ctx.needs_input_grad[0], has_res and ctx.needs_input_grad[1])
-        return dx, dres, dg, db, None, None, None, None, None, None, None
+                                               ctx.needs_input_grad[0], has_res and ctx.needs_input_grad[1], groups)
+        return dx, dres, dg, db, None, None, None, None, None, None, None, None
 
 
 class BnReluPoolFunction(torch.autograd.Function):
     """ResNet stem tail: maxpool3x3/2( relu( batch_norm(x) ) ) without materialising the full-resolution BN output."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, n_tracked, training, momentum, eps):
+    def forward(ctx, x, weight, bias, running_mean, running_var, n_tracked, training, momentum, eps, groups):
         x = ops._aligned(x)
         y, idx, stats = ops.bn_relu_pool_forward(x, weight, bias, running_mean, running_var, n_tracked, training,
-                                                 momentum, eps)
-        ctx.training = training
+                                                 momentum, eps, groups)
+        ctx.training, ctx.groups = training, groups
         ctx.save_for_backward(x, weight, bias, stats, idx)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, weight, bias, stats, idx = ctx.saved_tensors
-        dx, dg, db = ops.bn_relu_pool_backward(ops._aligned(dy), idx, x, weight, bias, stats, ctx.training)
-        return dx, dg, db, None, None, None, None, None, None
+        dx, dg, db = ops.bn_relu_pool_backward(ops._aligned(dy), idx, x, weight, bias, stats, ctx.training, ctx.groups)
+        return dx, dg, db, None, None, None, None, None, None, None
 
 
 def _bn_fusable(bn, x):
@@ -173,11 +173,13 @@ def _bn_fusable(bn, x):
             and (bn.training or bn.track_running_stats))
 
 
-def bn_act(bn, x, residual=None, relu=True):
+def bn_act(bn, x, residual=None, relu=True, groups=1):
     """nn.BatchNorm2d `bn` applied to x, then `+ residual`, then ReLU.  Device tensors take the fused HIP path (raises
-    if the library is missing); host tensors use the stock torch operators (pretrain plumbing on CPU, config[0])."""
+    if the library is missing); host tensors use the stock torch operators (pretrain plumbing on CPU, config[0]).
+    groups > 1: x holds `groups` independent sub-batches stacked along dim 0 (statistics per sub-batch, running
+    statistics updated once per sub-batch in order -- the result of `groups` consecutive calls)."""
     if not _bn_fusable(bn, x):
-        out = bn(x)
+        out = bn(x) if groups == 1 else torch.cat([bn(c) for c in x.chunk(groups)], 0)
         if residual is not None:
             out = out + residual
         return torch.relu_(out) if relu else out
@@ -186,16 +188,17 @@ def bn_act(bn, x, residual=None, relu=True):
     return BnActFunction.apply(x, residual, bn.weight, bn.bias, bn.running_mean if track else None,
                                bn.running_var if track else None,
                                bn.num_batches_tracked if (track and training) else None,
-                               training, float(bn.momentum), float(bn.eps), relu)
+                               training, float(bn.momentum), float(bn.eps), relu, groups)
 
 
-def bn_relu_maxpool(bn, x):
+def bn_relu_maxpool(bn, x, groups=1):
     """maxpool3x3/2/1(relu(bn(x))) (ResNet stem)."""
     if not _bn_fusable(bn, x):
-        return torch.nn.functional.max_pool2d(torch.relu_(bn(x)), 3, 2, 1)
+        out = bn(x) if groups == 1 else torch.cat([bn(c) for c in x.chunk(groups)], 0)
+        return torch.nn.functional.max_pool2d(torch.relu_(out), 3, 2, 1)
     training = bn.training or not bn.track_running_stats
     track = bn.track_running_stats
     return BnReluPoolFunction.apply(x, bn.weight, bn.bias, bn.running_mean if track else None,
                                     bn.running_var if track else None,
                                     bn.num_batches_tracked if (track and training) else None,
-                                    training, float(bn.momentum), float(bn.eps))
+                                    training, float(bn.momentum), float(bn.eps), groups)

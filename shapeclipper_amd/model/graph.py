@@ -81,8 +81,12 @@ class Graph(nn.Module):
         # The neighbour choice depends only on the input masks; it needs one device->host read (numpy RNG, as the
         # reference).  Done first, while the stream is empty, the host never has to wait for the main render.
         idx_NN = self.select_neighbours(opt, var) if use_NN else None
+        views = self.gather_neighbour_views(opt, var, idx_NN, sampled) if use_NN else []
+        if use_NN and "latent" not in var and opt.get("hip", {}).get("batched_encoders", True):
+            self.encode_all_views(opt, var, views)
 
-        var.latent_raw = var.latent if "latent" in var else self.encoder(var.rgb_input_map)
+        if "latent_raw" not in var:
+            var.latent_raw = var.latent if "latent" in var else self.encoder(var.rgb_input_map)
         var.latent_shape = var.latent_raw[:, :opt.arch.latent_dim_shape]
         var.latent_rgb = var.latent_raw[:, opt.arch.latent_dim_shape:]
         var.proj_latent_sdf = self.latent_proj_shape(var.latent_shape)
@@ -106,7 +110,7 @@ class Graph(nn.Module):
             var.normal_transformed_map = as_map(var.normal_transformed, 3, opt.image_size[0], opt.image_size[1])
 
         if use_NN:
-            self.forward_NN(opt, var, idx_NN=idx_NN)
+            self.forward_NN(opt, var, views=views)
 
         if get_loss:
             return var, self.compute_loss(opt, var, training)
@@ -129,15 +133,14 @@ class Graph(nn.Module):
             picks.append(np.random.choice(K, size=(opt.reg.n_views,), replace=False, p=p))
         return torch.tensor(np.stack(picks, axis=0)).long().to(var.rgb_input_map.device)
 
-    def forward_NN(self, opt, var, training=True, idx_NN=None):
+    def gather_neighbour_views(self, opt, var, idx_NN, sampled):
+        """The n_views chosen neighbours of every image as batch dictionaries (reference graph.py:144-193)."""
         B = len(var.idx)
         assert opt.reg.n_views <= opt.data.k_nearest
-        sampled = bool(opt.render.rand_sample and training)
-        if idx_NN is None:
-            idx_NN = self.select_neighbours(opt, var)                   # [B, V]
         if sampled:
             assert len(var.ray_idx.shape) == 2
         rows = torch.arange(B, device=idx_NN.device)
+        views = []
         for v in range(opt.reg.n_views):
             pick = lambda stack: stack[rows, ..., idx_NN[:, v]]          # [B, ..., K] -> [B, ...]
             nn_in = edict()
@@ -151,12 +154,48 @@ class Graph(nn.Module):
                 nn_in.ray_idx = pick(var.ray_idx_NN)
             nn_in.pose_gt = pick(var.pose_gt_NN)
             var["input_NN_{}".format(v)] = nn_in
-            ray_idx = nn_in.ray_idx if sampled else None
+            views.append(nn_in)
+        return views
 
-            latent_NN = self.encoder(nn_in.rgb_input_map)
+    def encode_all_views(self, opt, var, views):
+        """ONE encoder pass and ONE estimator pass for everything a training step needs.
+
+        The reference calls the encoder on the input images and again on each neighbour view (graph.py:73,197), and
+        the estimator on the input, on each neighbour and on the mirrored input (graph.py:272, :204, loss.py:114): up to
+        five ResNet passes whose inputs are all known at the start of the step.  Here the image sets are stacked along
+        the batch dimension and go through each network once with `groups` = number of sets: convolutions see one
+        large batch, BatchNorm keeps per-set statistics and applies its running-statistics updates in the reference's
+        call order, so the result equals the sequential calls while the step spends 2 instead of 5 passes worth of
+        launches and every shared weight receives a single gradient."""
+        B = len(var.idx)
+        images = [var.rgb_input_map] + [nn_in.rgb_input_map for nn_in in views]
+        latent = self.encoder(torch.cat(images, 0), groups=len(images))
+        var.latent_raw = latent[:B]
+        for v, nn_in in enumerate(views):
+            nn_in.latent_raw = latent[(v + 1) * B:(v + 2) * B]
+        mirrored = [var.rgb_input_map.flip(dims=[3])] if opt.loss_weight.cam_sym is not None else []
+        est = self.estimator(torch.cat(images + mirrored, 0), groups=len(images) + len(mirrored))
+        part = lambda k: tuple(t[k * B:(k + 1) * B] for t in est)
+        var.estim_input = part(0)
+        for v, nn_in in enumerate(views):
+            nn_in.estim = part(v + 1)
+        if mirrored:
+            var.estim_flip = part(len(images))
+
+    def forward_NN(self, opt, var, training=True, idx_NN=None, views=None):
+        B = len(var.idx)
+        sampled = bool(opt.render.rand_sample and training)
+        if views is None:
+            if idx_NN is None:
+                idx_NN = self.select_neighbours(opt, var)               # [B, V]
+            views = self.gather_neighbour_views(opt, var, idx_NN, sampled)
+        for v, nn_in in enumerate(views):
+            ray_idx = nn_in.ray_idx if sampled else None
+            latent_NN = nn_in.latent_raw if "latent_raw" in nn_in else self.encoder(nn_in.rgb_input_map)
             proj_latent_rgb_NN = self.latent_proj_rgb(latent_NN[:, opt.arch.latent_dim_shape:])
             var.proj_latent_rgb_NN = proj_latent_rgb_NN
-            pose_NN, intr_NN, scale_NN = self.pred_pose(opt, var, pred_NN=True, given_input=nn_in.rgb_input_map)
+            pose_NN, intr_NN, scale_NN = self.pred_pose(opt, var, pred_NN=True, given_input=nn_in.rgb_input_map,
+                                                        estim=nn_in.get("estim"))
             var["pose_NN_{}".format(v)], var["intr_NN_{}".format(v)], var["scale_dist_NN_{}".format(v)] = pose_NN, intr_NN, scale_NN
 
             # the neighbour is rendered with the INPUT image's shape code and its own colour code
@@ -254,9 +293,11 @@ class Graph(nn.Module):
         return out
 
     # ------------------------------------------------------------------------------------------------
-    def pred_pose(self, opt, var, pred_NN=False, given_input=None):
+    def pred_pose(self, opt, var, pred_NN=False, given_input=None, estim=None):
         image = given_input if given_input is not None else var.rgb_input_map
-        trig_azim, trig_elev, trig_theta, scale_focal, scale_dist = self.estimator(image)
+        if estim is None and not pred_NN and "estim_input" in var:
+            estim = var.estim_input
+        trig_azim, trig_elev, trig_theta, scale_focal, scale_dist = estim if estim is not None else self.estimator(image)
         pose_R = camera.pose(R=rotation_from_trig(trig_azim, trig_elev, trig_theta))
         tz = scale_dist * opt.camera.dist
         pose_T = camera.pose(t=torch.stack([torch.zeros_like(tz), torch.zeros_like(tz), tz], dim=-1))

@@ -26,15 +26,16 @@ class BasicBlock(nn.Module):
         self.bn2 = nn.BatchNorm2d(planes)
         self.downsample = downsample
 
-    def forward(self, x):
+    def forward(self, x, groups=1):
         if not FUSED_BN:
+            assert groups == 1
             identity = x if self.downsample is None else self.downsample(x)
             out = self.relu(self.bn1(self.conv1(x)))
             out = self.bn2(self.conv2(out))
             return self.relu(out + identity)
-        identity = x if self.downsample is None else bn_act(self.downsample[1], self.downsample[0](x), relu=False)
-        out = bn_act(self.bn1, self.conv1(x))
-        return bn_act(self.bn2, self.conv2(out), residual=identity)
+        identity = x if self.downsample is None else bn_act(self.downsample[1], self.downsample[0](x), relu=False, groups=groups)
+        out = bn_act(self.bn1, self.conv1(x), groups=groups)
+        return bn_act(self.bn2, self.conv2(out), residual=identity, groups=groups)
 
 
 class ResNet(nn.Module):
@@ -67,12 +68,19 @@ class ResNet(nn.Module):
         layers += [BasicBlock(planes, planes) for _ in range(1, blocks)]
         return nn.Sequential(*layers)
 
-    def forward(self, x):
-        if FUSED_BN:
-            x = bn_relu_maxpool(self.bn1, self.conv1(x))
-        else:
+    def forward(self, x, groups=1):
+        """groups > 1: x stacks `groups` sub-batches that the reference feeds through the network one call after the
+        other; BatchNorm treats them separately (per-sub-batch statistics), convolutions see one large batch."""
+        if not FUSED_BN:
+            if groups > 1:
+                return torch.cat([self.forward(c) for c in x.chunk(groups)], 0)
             x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
-        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+            x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        else:
+            x = bn_relu_maxpool(self.bn1, self.conv1(x), groups=groups)
+            for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+                for block in layer:
+                    x = block(x, groups=groups)
         return self.fc(torch.flatten(self.avgpool(x), 1))
 
 

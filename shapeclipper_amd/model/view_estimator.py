@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as torch_F
 
+from ..functional import bn_act
 from . import resnet
 
 
@@ -23,11 +24,10 @@ class Bottleneck_Linear(nn.Module):
         if zero_init:
             nn.init.constant_(self.bn2.weight, 0)
 
-    def forward(self, x):
+    def forward(self, x, groups=1):
         v = x[..., None, None]
-        out = self.relu(self.bn1(self.linear1(v)))
-        out = self.bn2(self.linear2(out))
-        return self.relu(out + v)[..., 0, 0]
+        out = bn_act(self.bn1, self.linear1(v), groups=groups)                     # conv1x1 -> BN -> ReLU
+        return bn_act(self.bn2, self.linear2(out), residual=v, groups=groups)[..., 0, 0]
 
 
 class Estimator(nn.Module):
@@ -56,12 +56,14 @@ class Estimator(nn.Module):
             nn.init.constant_(fc.weight, 0.0)
             nn.init.constant_(fc.bias, 0.0)
 
-    def forward(self, inputs):
-        feat = self.feature_extractor(inputs)
-        trig = self.extr_fc(self.extr_head(feat))
+    def forward(self, inputs, groups=1):
+        """groups > 1: `inputs` stacks several image sets that the reference sends through the estimator in separate
+        calls (input view, CLIP neighbour, mirrored input); BatchNorm keeps them separate, see resnet.ResNet.forward."""
+        feat = self.feature_extractor(inputs, groups=groups)
+        trig = self.extr_fc(self.extr_head[0](feat, groups=groups))
         azim, elev, theta = (torch_F.normalize(trig[:, 2 * k:2 * k + 2], dim=1, p=2) for k in range(3))
-        size_raw = torch.tanh(self.size_fc(self.size_head(feat))).squeeze(-1)
-        persp_raw = torch.tanh(self.perspect_fc(self.perspect_head(feat))).squeeze(-1)
+        size_raw = torch.tanh(self.size_fc(self.size_head[0](feat, groups=groups))).squeeze(-1)
+        persp_raw = torch.tanh(self.perspect_fc(self.perspect_head[0](feat, groups=groups))).squeeze(-1)
         scale_size = 1 + size_raw * self.opt.camera.size_range
         scale_perspect = 1 + persp_raw * self.opt.camera.perspect_range
         return azim, elev, theta, scale_perspect, scale_size * scale_perspect

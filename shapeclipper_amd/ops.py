@@ -334,10 +334,10 @@ def render_forward(cam_loc, ray_dirs, depth_fac, scale_dist, u, sdf_pack, sdf_cb
 # one persistent partial-sum buffer per device -- calls on a stream are ordered, so it can be shared).
 _VP, _CI, _CF = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 _BN_SIG = dict(
-    sc_bn_act_forward=[_VP] * 11 + [_CI] * 5 + [_CF, _CF, _VP],
-    sc_bn_act_backward=[_VP] * 12 + [_CI] * 5 + [_VP],
-    sc_bn_relu_pool_forward=[_VP] * 11 + [_CI] * 5 + [_CF, _CF, _VP],
-    sc_bn_relu_pool_backward=[_VP] * 11 + [_CI] * 5 + [_VP],
+    sc_bn_act_forward=[_VP] * 11 + [_CI] * 6 + [_CF, _CF, _VP],
+    sc_bn_act_backward=[_VP] * 12 + [_CI] * 6 + [_VP],
+    sc_bn_relu_pool_forward=[_VP] * 11 + [_CI] * 6 + [_CF, _CF, _VP],
+    sc_bn_relu_pool_backward=[_VP] * 11 + [_CI] * 6 + [_VP],
 )
 _bn_fn = {}
 _bn_ws = {}
@@ -352,10 +352,10 @@ def _bn(name):
     return fn
 
 
-def _bn_partial(x):
-    """Workspace for the per-channel partial sums: C * S * 2 floats with S <= 32 (see sc_bn_splits)."""
+def _bn_partial(x, groups=1):
+    """Workspace for the per-(channel, group) partial sums: at most 2*(2048 + C*G) floats."""
     dev = x.device.index
-    need = x.shape[1] * 64
+    need = 2 * (2048 + x.shape[1] * groups)
     ws = _bn_ws.get(dev)
     if ws is None or ws.numel() < need:
         ws = _bn_ws[dev] = torch.empty(max(need, 1 << 16), device=x.device, dtype=torch.float32)
@@ -378,57 +378,59 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def bn_act_forward(x, res, gamma, beta, running_mean, running_var, n_tracked, training, momentum, eps, relu):
-    """x [N,C,H,W] (+ res) -> y, stats [2,C] (save_mean, save_rstd); running statistics updated in place when training."""
+def bn_act_forward(x, res, gamma, beta, running_mean, running_var, n_tracked, training, momentum, eps, relu, groups=1):
+    """x [N,C,H,W] (+ res) -> y, stats [2,G,C] (save_mean, save_rstd); running statistics updated in place when training."""
     N, C, H, W = x.shape
     y = torch.empty_like(x)
-    stats = torch.empty(2, C, device=x.device, dtype=torch.float32)
+    stats = torch.empty(2, groups, C, device=x.device, dtype=torch.float32)
     sp = stats.data_ptr()
-    code = _bn("sc_bn_act_forward")(x.data_ptr(), _p(res), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), sp, sp + 4 * C,
-                                    _p(running_mean), _p(running_var), _p(n_tracked), _bn_partial(x), N, C, H * W,
-                                    1 if relu else 0, 1 if training else 0, eps, momentum, _stream())
+    code = _bn("sc_bn_act_forward")(x.data_ptr(), _p(res), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), sp,
+                                    sp + 4 * C * groups, _p(running_mean), _p(running_var), _p(n_tracked),
+                                    _bn_partial(x, groups), N, C, H * W, 1 if relu else 0, 1 if training else 0, groups,
+                                    eps, momentum, _stream())
     if code:
         _lib.check(code, "sc_bn_act_forward")
     return y, stats
 
 
-def bn_act_backward(dy, x, y, gamma, beta, stats, training, relu, want_dx, want_dres):
+def bn_act_backward(dy, x, y, gamma, beta, stats, training, relu, want_dx, want_dres, groups=1):
     N, C, H, W = x.shape
     dx = torch.empty_like(x) if want_dx else None
     dres = torch.empty_like(x) if want_dres else None
     dgb = torch.empty(2, C, device=x.device, dtype=torch.float32)
     sp, gp = stats.data_ptr(), dgb.data_ptr()
-    code = _bn("sc_bn_act_backward")(dy.data_ptr(), x.data_ptr(), _p(y), gamma.data_ptr(), beta.data_ptr(), sp, sp + 4 * C,
-                                     _bn_partial(x), _p(dx), _p(dres), gp, gp + 4 * C, N, C, H * W, 1 if relu else 0,
-                                     1 if training else 0, _stream())
+    code = _bn("sc_bn_act_backward")(dy.data_ptr(), x.data_ptr(), _p(y), gamma.data_ptr(), beta.data_ptr(), sp,
+                                     sp + 4 * C * groups, _bn_partial(x, groups), _p(dx), _p(dres), gp, gp + 4 * C, N, C,
+                                     H * W, 1 if relu else 0, 1 if training else 0, groups, _stream())
     if code:
         _lib.check(code, "sc_bn_act_backward")
     return dx, dres, dgb[0], dgb[1]
 
 
-def bn_relu_pool_forward(x, gamma, beta, running_mean, running_var, n_tracked, training, momentum, eps):
+def bn_relu_pool_forward(x, gamma, beta, running_mean, running_var, n_tracked, training, momentum, eps, groups=1):
     N, C, H, W = x.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     y = torch.empty(N, C, Ho, Wo, device=x.device, dtype=torch.float32)
     idx = torch.empty(N, C, Ho, Wo, device=x.device, dtype=torch.int32)
-    stats = torch.empty(2, C, device=x.device, dtype=torch.float32)
+    stats = torch.empty(2, groups, C, device=x.device, dtype=torch.float32)
     sp = stats.data_ptr()
     code = _bn("sc_bn_relu_pool_forward")(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), idx.data_ptr(),
-                                          sp, sp + 4 * C, _p(running_mean), _p(running_var), _p(n_tracked),
-                                          _bn_partial(x), N, C, H, W, 1 if training else 0, eps, momentum, _stream())
+                                          sp, sp + 4 * C * groups, _p(running_mean), _p(running_var), _p(n_tracked),
+                                          _bn_partial(x, groups), N, C, H, W, 1 if training else 0, groups, eps, momentum,
+                                          _stream())
     if code:
         _lib.check(code, "sc_bn_relu_pool_forward")
     return y, idx, stats
 
 
-def bn_relu_pool_backward(dy, idx, x, gamma, beta, stats, training):
+def bn_relu_pool_backward(dy, idx, x, gamma, beta, stats, training, groups=1):
     N, C, H, W = x.shape
     dx = torch.empty_like(x)
     dgb = torch.empty(2, C, device=x.device, dtype=torch.float32)
     sp, gp = stats.data_ptr(), dgb.data_ptr()
     code = _bn("sc_bn_relu_pool_backward")(dy.data_ptr(), idx.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                                           sp, sp + 4 * C, _bn_partial(x), dx.data_ptr(), gp, gp + 4 * C, N, C, H, W,
-                                           1 if training else 0, _stream())
+                                           sp, sp + 4 * C * groups, _bn_partial(x, groups), dx.data_ptr(), gp, gp + 4 * C,
+                                           N, C, H, W, 1 if training else 0, groups, _stream())
     if code:
         _lib.check(code, "sc_bn_relu_pool_backward")
     return dx, dgb[0], dgb[1]

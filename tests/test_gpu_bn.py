@@ -133,3 +133,65 @@ def test_resnet18_fused_equals_stock_operators():
     for a, b, name in zip(res[1], res[0], ("logits", "d conv1.weight", "d layer4.1.bn2.weight", "running_var")):
         rel = float((a - b).norm() / b.norm().clamp_min(1e-12))
         assert rel < 5e-3, "%s: relative L2 error %.3e" % (name, rel)
+
+
+@pytest.mark.parametrize("shape,groups", [((6, 16, 14, 14), 3), ((8, 64, 28, 28), 2), ((96, 512, 1, 1), 3), ((4, 8, 5, 7), 4)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_grouped_bn_equals_consecutive_calls(shape, groups, with_res):
+    """groups = G: the result (outputs, gradients, running statistics, num_batches_tracked) of G consecutive
+    nn.BatchNorm2d calls on the G sub-batches -- what the reference does when it runs the same network on the input
+    view, the neighbour view and the mirrored image one after the other."""
+    from shapeclipper_amd.functional import bn_act
+    torch.manual_seed(3)
+    N, C, H, W = shape
+    x0 = torch.randn(shape, device="cuda") * torch.linspace(0.5, 2.0, N, device="cuda").view(N, 1, 1, 1) + 0.3
+    r0 = torch.randn(shape, device="cuda") if with_res else None
+    bn_a = nn.BatchNorm2d(C).cuda().train()
+    with torch.no_grad():
+        bn_a.weight.copy_(torch.rand(C) + 0.5)
+        bn_a.bias.copy_(torch.randn(C) * 0.3)
+        probe = copy.deepcopy(bn_a)
+        for _ in range(4):
+            z = torch.cat([probe(c) for c in x0.chunk(groups)], 0) + (r0 if with_res else 0)
+            near = z.abs() < 1e-3
+            if not bool(near.any()):
+                break
+            x0[near] += 0.25
+    bn_b = copy.deepcopy(bn_a)
+    cot = torch.randn(shape, device="cuda")
+    xa = x0.clone().requires_grad_(True)
+    ra = r0.clone().requires_grad_(True) if with_res else None
+    ya = torch.cat([bn_a(c) for c in xa.chunk(groups)], 0)
+    ya = torch.relu(ya + ra if with_res else ya)
+    (ya * cot).sum().backward()
+    xb = x0.clone().requires_grad_(True)
+    rb = r0.clone().requires_grad_(True) if with_res else None
+    yb = bn_act(bn_b, xb, residual=rb, relu=True, groups=groups)
+    (yb * cot).sum().backward()
+    _close(yb.detach(), ya.detach(), what="y")
+    _close(xb.grad, xa.grad, tol=5e-5, what="dx")
+    if with_res:
+        _close(rb.grad, ra.grad, what="dres")
+    _close(bn_b.weight.grad, bn_a.weight.grad, tol=1e-4, what="dgamma")
+    _close(bn_b.bias.grad, bn_a.bias.grad, tol=1e-4, what="dbeta")
+    _close(bn_b.running_mean, bn_a.running_mean, what="running_mean")
+    _close(bn_b.running_var, bn_a.running_var, what="running_var")
+    assert int(bn_b.num_batches_tracked) == int(bn_a.num_batches_tracked) == groups
+
+
+def test_resnet18_grouped_pass_equals_separate_passes():
+    from shapeclipper_amd.model import resnet
+    torch.manual_seed(4)
+    net = resnet.build("resnet18").cuda().train()
+    xs = [torch.randn(3, 3, 224, 224, device="cuda") * s for s in (1.0, 0.5, 2.0)]
+    a, b = copy.deepcopy(net), copy.deepcopy(net)
+    ya = torch.cat([a(x) for x in xs], 0)
+    yb = b(torch.cat(xs, 0), groups=3)
+    w = torch.randn_like(ya)
+    (ya * w).sum().backward()
+    (yb * w).sum().backward()
+    rel = lambda u, v: float((u - v).norm() / v.norm().clamp_min(1e-12))
+    assert rel(yb.detach(), ya.detach()) < 2e-3
+    assert rel(b.conv1.weight.grad, a.conv1.weight.grad) < 5e-3
+    assert rel(b.layer3[0].bn1.running_var, a.layer3[0].bn1.running_var) < 1e-4
+    assert int(b.bn1.num_batches_tracked) == int(a.bn1.num_batches_tracked) == 3

@@ -40,3 +40,45 @@ def test_two_training_iterations():
     moved = {n.split(".")[0] for n, p in g.named_parameters() if not torch.equal(p.detach(), before[n])}
     assert {"estimator", "sdf_network", "rgb_network", "renderer", "encoder", "latent_proj_shape", "latent_proj_rgb"} <= moved
     assert not torch.equal(g.renderer.density.beta.detach(), before["renderer.density.beta"])     # beta is trained by the HIP backward
+
+
+def test_batched_encoder_passes_equal_sequential_passes():
+    """hip.batched_encoders (one grouped encoder pass + one grouped estimator pass per step) gives the losses,
+    gradients and BatchNorm running statistics of the reference's five separate passes."""
+    import copy
+    import numpy as np
+    from shapeclipper_amd import synthetic
+    from shapeclipper_amd.model.graph import Graph
+    from shapeclipper_amd.utils import util
+    from shapeclipper_amd.utils.util import EasyDict as edict
+    from shapeclipper_amd.utils import options
+    o = options.set(options.parse_arguments(["--yaml=options/pix3d/config.yaml", "--name=pytest_batched", "--output_root=/tmp/sc_pytest",
+                                             "--batch_size=4", "--tb!", "--arch.enc_pretrained!"]), verbose=False)
+    o.device = 0
+    torch.manual_seed(0)
+    g0 = Graph(o).cuda().train()
+    batch = util.move_to_device(synthetic.make_batch(o, 4, seed=5, training=True), "cuda:0")
+    res = []
+    for batched in (False, True):
+        o.hip.batched_encoders = batched
+        g = copy.deepcopy(g0)
+        torch.manual_seed(11); np.random.seed(11)
+        o.H, o.W = o.image_size
+        var, loss = g(o, edict(batch), training=True, get_loss=True)
+        total = sum(float(o.loss_weight[k]) * loss[k].mean() for k in loss if o.loss_weight[k] is not None)
+        total.backward()
+        res.append((float(total), {k: float(v.mean()) for k, v in loss.items()},
+                    g.estimator.feature_extractor.conv1.weight.grad.clone(), g.encoder.layer2[0].conv1.weight.grad.clone(),
+                    g.sdf_network.lin3.weight.grad.clone(), g.encoder.bn1.running_var.clone(),
+                    g.estimator.feature_extractor.layer4[1].bn2.running_mean.clone(),
+                    int(g.estimator.feature_extractor.bn1.num_batches_tracked), int(g.encoder.bn1.num_batches_tracked)))
+    o.hip.batched_encoders = True
+    seq, bat = res
+    assert abs(bat[0] - seq[0]) < 2e-3 * abs(seq[0])
+    for k in seq[1]:
+        assert abs(bat[1][k] - seq[1][k]) < 2e-3 * abs(seq[1][k]) + 1e-6, k
+    rel = lambda u, v: float((u - v).norm() / v.norm().clamp_min(1e-12))
+    for i in (2, 3, 4):
+        assert rel(bat[i], seq[i]) < 2e-2, i
+    assert rel(bat[5], seq[5]) < 1e-4 and rel(bat[6], seq[6]) < 1e-3
+    assert bat[7] == seq[7] == 3 and bat[8] == seq[8] == 2
