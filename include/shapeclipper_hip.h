@@ -231,6 +231,30 @@ int sc_isosurface_count(const float* level, int n_images, int n_axis, float iso,
 int sc_isosurface_emit(const float* level, int n_images, int n_axis, float iso, const int* counts,
                        const long long* offsets, float* tris, void* stream);
 
+/* ---- camera algebra of a render -------------------------------------------------------------------
+ * sc_camera_rays_*: utils/camera.py:157-196 (get_center_and_ray on the rendered pixels only) + the normalisation of
+ * model/renderer.py:69-76.  pose [n_images][3][4] = [R|t] world->camera, intr [n_images][3][3], ray_idx
+ * [n_images][rays_per_image] int64 pixel indices (y*W + x) or NULL (= all pixels 0..rays_per_image-1).  Outputs per
+ * ray: cam_loc [.][3] (camera centre, repeated), ray_dirs [.][3] (unit), depth_fac [.] (= |dir| / |unnormalised ray|).
+ * Perspective model.  The backward returns d/d pose and d/d intr (g_* inputs may be NULL = zero).                */
+int sc_camera_rays_forward(const float* pose, const float* intr, const long long* ray_idx, int n_images,
+                           int rays_per_image, int image_width, float* cam_loc, float* ray_dirs, float* depth_fac,
+                           void* stream);
+int sc_camera_rays_backward(const float* pose, const float* intr, const long long* ray_idx, int n_images,
+                            int rays_per_image, int image_width, const float* g_cam_loc, const float* g_ray_dirs,
+                            const float* g_depth_fac, float* g_pose, float* g_intr, void* stream);
+
+/* sc_pose_from_trig_*: model/graph.py:272-293 (pred_pose) with utils/camera.py:105-155,198-211: (cos,sin) of azimuth,
+ * elevation, roll [n_images][2], scale_focal, scale_dist [n_images] -> pose [n_images][3][4] = [Rz Rx Ry P | (0,0,
+ * cam_dist*scale_dist)], intr [n_images][3][3] = [[f W,0,W/2],[0,f H,H/2],[0,0,1]], f = focal*scale_focal.        */
+int sc_pose_from_trig_forward(const float* azim, const float* elev, const float* theta, const float* scale_focal,
+                              const float* scale_dist, int n_images, float cam_dist, float focal, int image_width,
+                              int image_height, float* pose, float* intr, void* stream);
+int sc_pose_from_trig_backward(const float* azim, const float* elev, const float* theta, const float* scale_focal,
+                               const float* scale_dist, int n_images, float cam_dist, float focal, int image_width,
+                               int image_height, const float* g_pose, const float* g_intr, float* g_azim,
+                               float* g_elev, float* g_theta, float* g_scale_focal, float* g_scale_dist, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,7 @@ SYMBOLS = (
     "sc_ray_sample_forward", "sc_ray_sample_backward", "sc_render_forward", "sc_sdf_grid_forward", "sc_loss_fused_backward",
     "sc_bn_splits", "sc_bn_act_forward", "sc_bn_act_backward", "sc_bn_relu_pool_forward", "sc_bn_relu_pool_backward",
     "sc_isosurface_count", "sc_isosurface_emit",
+    "sc_camera_rays_forward", "sc_camera_rays_backward", "sc_pose_from_trig_forward", "sc_pose_from_trig_backward",
 )
 
 _lib: Optional[ctypes.CDLL] = None

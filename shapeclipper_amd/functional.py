@@ -202,3 +202,48 @@ def bn_relu_maxpool(bn, x, groups=1):
                                     bn.running_var if track else None,
                                     bn.num_batches_tracked if (track and training) else None,
                                     training, float(bn.momentum), float(bn.eps), groups)
+
+
+class CameraRaysFunction(torch.autograd.Function):
+    """pose [B,3,4], intr [B,3,3], ray_idx [B,R] | None -> cam_loc [B*R,3], ray_dirs [B*R,3] (unit), depth_fac [B*R]
+    (reference utils/camera.py:157-196 + model/renderer.py:69-76, perspective camera) in one launch each way."""
+
+    @staticmethod
+    def forward(ctx, pose, intr, ray_idx, n_rays, width):
+        pose, intr = pose.contiguous().float(), intr.contiguous().float()
+        if ray_idx is not None:
+            ray_idx = ray_idx.contiguous().long()
+        out = ops.camera_rays_forward(pose, intr, ray_idx, n_rays, width)
+        ctx.save_for_backward(pose, intr, ray_idx)
+        ctx.meta = (n_rays, width)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_loc, g_dirs, g_df):
+        pose, intr, ray_idx = ctx.saved_tensors
+        n_rays, width = ctx.meta
+        c = lambda t: t.contiguous() if t is not None else None
+        g_pose, g_intr = ops.camera_rays_backward(pose, intr, ray_idx, n_rays, width, c(g_loc), c(g_dirs), c(g_df))
+        return g_pose, g_intr, None, None, None
+
+
+class PoseFromTrigFunction(torch.autograd.Function):
+    """Estimator outputs -> (pose [B,3,4], intr [B,3,3]) (reference model/graph.py:272-293)."""
+
+    @staticmethod
+    def forward(ctx, azim, elev, theta, scale_focal, scale_dist, cam_dist, focal, width, height):
+        args = [t.contiguous().float() for t in (azim, elev, theta, scale_focal, scale_dist)]
+        ctx.save_for_backward(*args)
+        ctx.meta = (cam_dist, focal, width, height)
+        return ops.pose_from_trig_forward(*args, cam_dist, focal, width, height)
+
+    @staticmethod
+    def backward(ctx, g_pose, g_intr):
+        args = ctx.saved_tensors
+        B = args[0].shape[0]
+        if g_pose is None:
+            g_pose = torch.zeros(B, 3, 4, device=args[0].device)
+        if g_intr is None:
+            g_intr = torch.zeros(B, 3, 3, device=args[0].device)
+        ga, ge, gt, gsf, gsd = ops.pose_from_trig_backward(*args, *ctx.meta, g_pose.contiguous(), g_intr.contiguous())
+        return ga, ge, gt, gsf, gsd, None, None, None, None

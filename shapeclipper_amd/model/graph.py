@@ -298,11 +298,16 @@ class Graph(nn.Module):
         if estim is None and not pred_NN and "estim_input" in var:
             estim = var.estim_input
         trig_azim, trig_elev, trig_theta, scale_focal, scale_dist = estim if estim is not None else self.estimator(image)
-        pose_R = camera.pose(R=rotation_from_trig(trig_azim, trig_elev, trig_theta))
-        tz = scale_dist * opt.camera.dist
-        pose_T = camera.pose(t=torch.stack([torch.zeros_like(tz), torch.zeros_like(tz), tz], dim=-1))
-        pose = camera.pose.compose([pose_R, pose_T]).to(image.device)
-        intr = camera.get_intr(opt, scale_focal)
+        if trig_azim.is_cuda:      # one launch each way instead of ~50 [B]-sized torch operators (csrc/camera.hip)
+            from ..functional import PoseFromTrigFunction
+            pose, intr = PoseFromTrigFunction.apply(trig_azim, trig_elev, trig_theta, scale_focal, scale_dist,
+                                                    float(opt.camera.dist), float(opt.camera.focal), int(opt.W), int(opt.H))
+        else:
+            pose_R = camera.pose(R=rotation_from_trig(trig_azim, trig_elev, trig_theta))
+            tz = scale_dist * opt.camera.dist
+            pose_T = camera.pose(t=torch.stack([torch.zeros_like(tz), torch.zeros_like(tz), tz], dim=-1))
+            pose = camera.pose.compose([pose_R, pose_T]).to(image.device)
+            intr = camera.get_intr(opt, scale_focal)
         if not pred_NN:
             var.trig_azim, var.trig_elev, var.trig_theta = trig_azim, trig_elev, trig_theta
             var.scale_focal, var.scale_dist = scale_focal, scale_dist

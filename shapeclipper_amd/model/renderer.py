@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as torch_F
 
-from ..functional import RaySampleFunction, RgbCompositeFunction, SdfFunction
+from ..functional import CameraRaysFunction, RaySampleFunction, RgbCompositeFunction, SdfFunction
 from ..utils import camera
 from .implicit import LaplaceDensity
 
@@ -72,15 +72,21 @@ class Renderer(nn.Module):
                 visualize=False):
         S = self.N_samples
         sym = bool(self.sdf_network.force_symmetry)
-        cam_loc, ray_raw = camera.get_center_and_ray(opt, pose, intr=intr, device=pose.device, ray_idx=ray_idx)
-        ray_dirs = torch_F.normalize(ray_raw, dim=-1)
-        depth_fac = ray_dirs.norm(dim=-1, keepdim=True) / ray_raw.norm(dim=-1, keepdim=True)
-        B, R, _ = ray_dirs.shape
-        if opt.camera.model == "perspective":
-            cam_loc = cam_loc.expand(B, R, 3)
-        cam_loc = cam_loc.reshape(-1, 3)
-        ray_dirs = ray_dirs.reshape(-1, 3)
-        depth_fac = depth_fac.reshape(-1)
+        if opt.camera.model == "perspective" and pose.is_cuda:
+            # one launch: pixel centres -> K^-1 -> camera-to-world -> unit rays + depth factor (csrc/camera.hip)
+            B = pose.shape[0]
+            R = ray_idx.shape[1] if ray_idx is not None else opt.H * opt.W
+            cam_loc, ray_dirs, depth_fac = CameraRaysFunction.apply(pose, intr, ray_idx, R, int(opt.W))
+        else:
+            cam_loc, ray_raw = camera.get_center_and_ray(opt, pose, intr=intr, device=pose.device, ray_idx=ray_idx)
+            ray_dirs = torch_F.normalize(ray_raw, dim=-1)
+            depth_fac = ray_dirs.norm(dim=-1, keepdim=True) / ray_raw.norm(dim=-1, keepdim=True)
+            B, R, _ = ray_dirs.shape
+            if opt.camera.model == "perspective":
+                cam_loc = cam_loc.expand(B, R, 3)
+            cam_loc = cam_loc.reshape(-1, 3)
+            ray_dirs = ray_dirs.reshape(-1, 3)
+            depth_fac = depth_fac.reshape(-1)
 
         # reference CPU-generator draws, in its order (renderer.py:29,33): jitter then the eikonal sample index
         dev_rng = bool(opt.get("hip", {}).get("device_rng", False))   # True: draw on the GPU (no 4 MB H2D copy per render,

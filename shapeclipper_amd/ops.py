@@ -459,3 +459,52 @@ def isosurface_triangles(level: torch.Tensor, iso: float = 0.0):
         _lib.check(lib.sc_isosurface_emit(_lib.ptr(level), c_int(B), c_int(S), ctypes.c_float(iso), _lib.ptr(counts),
                                           _lib.ptr(offsets), _lib.ptr(tris), _lib.stream()), "sc_isosurface_emit")
     return tris, per_image
+
+
+# ---- camera algebra ------------------------------------------------------------------------------------------------
+def camera_rays_forward(pose, intr, ray_idx, n_rays, width):
+    lib = _lib.load()
+    B = pose.shape[0]
+    f32 = dict(device=pose.device, dtype=torch.float32)
+    cam_loc = torch.empty(B * n_rays, 3, **f32)
+    dirs = torch.empty(B * n_rays, 3, **f32)
+    depth_fac = torch.empty(B * n_rays, **f32)
+    _lib.check(lib.sc_camera_rays_forward(_lib.ptr(pose), _lib.ptr(intr), _lib.ptr(ray_idx), c_int(B), c_int(n_rays), c_int(width),
+                                          _lib.ptr(cam_loc), _lib.ptr(dirs), _lib.ptr(depth_fac), _lib.stream()),
+               "sc_camera_rays_forward")
+    return cam_loc, dirs, depth_fac
+
+
+def camera_rays_backward(pose, intr, ray_idx, n_rays, width, g_cam_loc, g_dirs, g_depth_fac):
+    lib = _lib.load()
+    B = pose.shape[0]
+    g_pose, g_intr = torch.empty_like(pose), torch.empty_like(intr)
+    _lib.check(lib.sc_camera_rays_backward(_lib.ptr(pose), _lib.ptr(intr), _lib.ptr(ray_idx), c_int(B), c_int(n_rays), c_int(width),
+                                           _lib.ptr(g_cam_loc), _lib.ptr(g_dirs), _lib.ptr(g_depth_fac), _lib.ptr(g_pose),
+                                           _lib.ptr(g_intr), _lib.stream()), "sc_camera_rays_backward")
+    return g_pose, g_intr
+
+
+def pose_from_trig_forward(azim, elev, theta, scale_focal, scale_dist, cam_dist, focal, width, height):
+    lib = _lib.load()
+    B = azim.shape[0]
+    pose = torch.empty(B, 3, 4, device=azim.device, dtype=torch.float32)
+    intr = torch.empty(B, 3, 3, device=azim.device, dtype=torch.float32)
+    _lib.check(lib.sc_pose_from_trig_forward(_lib.ptr(azim), _lib.ptr(elev), _lib.ptr(theta), _lib.ptr(scale_focal),
+                                             _lib.ptr(scale_dist), c_int(B), ctypes.c_float(cam_dist), ctypes.c_float(focal),
+                                             c_int(width), c_int(height), _lib.ptr(pose), _lib.ptr(intr), _lib.stream()),
+               "sc_pose_from_trig_forward")
+    return pose, intr
+
+
+def pose_from_trig_backward(azim, elev, theta, scale_focal, scale_dist, cam_dist, focal, width, height, g_pose, g_intr):
+    lib = _lib.load()
+    B = azim.shape[0]
+    g = torch.empty(8, B, device=azim.device, dtype=torch.float32)      # azim[B,2] | elev[B,2] | theta[B,2] | sf[B] | sd[B]
+    ga, ge, gt = g[0:2].view(B, 2), g[2:4].view(B, 2), g[4:6].view(B, 2)
+    _lib.check(lib.sc_pose_from_trig_backward(_lib.ptr(azim), _lib.ptr(elev), _lib.ptr(theta), _lib.ptr(scale_focal),
+                                              _lib.ptr(scale_dist), c_int(B), ctypes.c_float(cam_dist), ctypes.c_float(focal),
+                                              c_int(width), c_int(height), _lib.ptr(g_pose), _lib.ptr(g_intr), _lib.ptr(ga),
+                                              _lib.ptr(ge), _lib.ptr(gt), _lib.ptr(g[6]), _lib.ptr(g[7]), _lib.stream()),
+               "sc_pose_from_trig_backward")
+    return ga, ge, gt, g[6], g[7]
