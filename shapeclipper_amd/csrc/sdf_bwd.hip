@@ -92,15 +92,16 @@ __global__ __launch_bounds__(64 * SDFB_WAVES) void sdf_bwd_kernel(SdfBwdArgs a) 
             const int ptc = valid ? pt : a.n_points - 1;
             const float x0 = a.points[(size_t)ptc * 3 + 0], x1 = a.points[(size_t)ptc * 3 + 1], x2 = a.points[(size_t)ptc * 3 + 2];
             float e[PE_STEPS], d1[PE_STEPS], d2[PE_STEPS];
-            pe_slots<true, false>(x0, x1, x2, g, a.symmetric != 0, e, d1, d2);
+            pe_slots<true, true>(x0, x1, x2, g, a.symmetric != 0, e, d1, d2);
             float gam[3] = {0.f, 0.f, 0.f};
             if (valid) { gam[0] = a.g_grad[(size_t)pt * 3]; gam[1] = a.g_grad[(size_t)pt * 3 + 1]; gam[2] = a.g_grad[(size_t)pt * 3 + 2]; }
+            float gx[3] = {0.f, 0.f, 0.f};
             f32x4 acc[NT];
             float av[ACT_STEPS], pv[ACT_STEPS], gq[ACT_STEPS], gpv[ACT_STEPS];
             float eps[PE_STEPS];
 #pragma unroll
             for (int j = 0; j < PE_STEPS; ++j) eps[j] = gam[j >> 2] * d1[j];
-#define SC_R_STEP(L, WE, LD)                                                                \
+#define SC_R_STEP(L, WE, LD, HAS_PE)                                                        \
             acc_to_regs(acc, gq);                                                            \
             tbl_load(a.stash_a + (size_t)(L) * tbl, tile, p, g, av);                         \
             tbl_load(a.stash_p + (size_t)(L) * tbl, tile, p, g, pv);                         \
@@ -112,24 +113,26 @@ __global__ __launch_bounds__(64 * SDFB_WAVES) void sdf_bwd_kernel(SdfBwdArgs a) 
                     const float ds = softplus_d1(av[s], t, r);                               \
                     gpv[s] = gq[s] * ds;                                                     \
                     pn[s] = gq[s] * pv[s] * softplus_d2(t, r);                               \
+                    pv[s] = pv[s] * ds;                      /* q_l, for the second-order point term */ \
                 }                                                                            \
                 tbl_store(a.gp + (size_t)(L) * tbl, tile, p, g, gpv);                        \
                 tbl_store(a.ga + (size_t)(L) * tbl, tile, p, g, pn);                         \
-            }
+            }                                                                                \
+            if (HAS_PE && a.g_points) { SC_PE_DOT(WE, LD, pv, d2, gam[c]) }
             acc_zero(acc);
             mm_pe<SdfLds::LD0, NT, 0, PE_STEPS>(w0, eps, acc);                 // Gq0
-            SC_R_STEP(0, w0, SdfLds::LD0)
+            SC_R_STEP(0, w0, SdfLds::LD0, true)
             acc_zero(acc);
             mm_act<SdfLds::LD1, NT>(w1h, gpv, acc);
             mm_pe<SdfLds::LD1, NT, 0, PE_STEPS>(w1e, eps, acc);                // Gq1
-            SC_R_STEP(1, w1e, SdfLds::LD1)
+            SC_R_STEP(1, w1e, SdfLds::LD1, true)
             acc_zero(acc);
             mm_act<SdfLds::LD1, NT>(w2h, gpv, acc);
             mm_pe<SdfLds::LD1, NT, 0, PE_STEPS>(w2e, eps, acc);                // Gq2
-            SC_R_STEP(2, w2e, SdfLds::LD1)
+            SC_R_STEP(2, w2e, SdfLds::LD1, true)
             acc_zero(acc);
             mm_act<SdfLds::LD3, NT>(w3, gpv, acc);                             // Gq3
-            SC_R_STEP(3, w3, SdfLds::LD3)
+            SC_R_STEP(3, w3, SdfLds::LD3, false)
 #undef SC_R_STEP
             acc_zero(acc);
             mm_act<SdfLds::LD3, NT>(w4, gpv, acc);                             // Gq4
@@ -147,36 +150,7 @@ __global__ __launch_bounds__(64 * SDFB_WAVES) void sdf_bwd_kernel(SdfBwdArgs a) 
                 tbl_store(a.ga + 4 * tbl, tile, p, g, pend4);
                 tbl_store(a.r0, tile, p, g, u4);
             }
-        }
-        // ---- R2: second-order part of G point,  Gx_c = Gg_c * sum_l q_l . (W_le d2E/dx_c^2),  q_l = p_l * sp'(a_l) ----
-        // (its own loop: keeping q_l, d2E and the tangent accumulators live inside the R sweep pushed that body past
-        //  256 VGPRs and the spills cost ~2 GB of scratch traffic per launch)
-        if (a.g_points) {
-#pragma unroll 1
-            for (int tile = chunk; tile < min(chunk + CH, ntiles); ++tile) {
-                const int pt = tile * TP + p;
-                const bool valid = pt < a.n_points;
-                const int ptc = valid ? pt : a.n_points - 1;
-                const float x0 = a.points[(size_t)ptc * 3 + 0], x1 = a.points[(size_t)ptc * 3 + 1], x2 = a.points[(size_t)ptc * 3 + 2];
-                float e[PE_STEPS], d1[PE_STEPS], d2[PE_STEPS];
-                pe_slots<false, true>(x0, x1, x2, g, a.symmetric != 0, e, d1, d2);
-                float gam[3] = {0.f, 0.f, 0.f};
-                if (valid) { gam[0] = a.g_grad[(size_t)pt * 3]; gam[1] = a.g_grad[(size_t)pt * 3 + 1]; gam[2] = a.g_grad[(size_t)pt * 3 + 2]; }
-                float gx[3] = {0.f, 0.f, 0.f};
-                float av[ACT_STEPS], pv[ACT_STEPS], ql[ACT_STEPS];
-#define SC_R2(L, WE, LD)                                                                    \
-                tbl_load(a.stash_a + (size_t)(L) * tbl, tile, p, g, av);                     \
-                tbl_load(a.stash_p + (size_t)(L) * tbl, tile, p, g, pv);                     \
-                _Pragma("unroll") for (int s = 0; s < ACT_STEPS; ++s) {                       \
-                    float t, r;                                                              \
-                    softplus_parts(av[s], t, r);                                             \
-                    ql[s] = pv[s] * softplus_d1(av[s], t, r);                                \
-                }                                                                            \
-                SC_PE_DOT(WE, LD, ql, d2, gam[c])
-                SC_R2(0, w0, SdfLds::LD0)
-                SC_R2(1, w1e, SdfLds::LD1)
-                SC_R2(2, w2e, SdfLds::LD1)
-#undef SC_R2
+            if (a.g_points) {     // second-order part of G point: Gx_c = Gg_c * sum_l q_l . (W_le d2E/dx_c^2); the V sweep adds the rest
                 const float o0 = group_sum(gx[0]), o1 = group_sum(gx[1]), o2 = group_sum(gx[2]);
                 if (valid && g == 0) {
                     a.g_points[(size_t)pt * 3 + 0] = o0;
