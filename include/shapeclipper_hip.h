@@ -106,12 +106,16 @@ int sc_rgb_composite_backward(
  * Operand transform codes: 1 plain TBL64, 2 softplus(a), 3 p*softplus'(a), 4 w5row*softplus'(a),
  * 5 positional encoding of the point (48 columns), 6 g_grad-weighted PE Jacobian (48 columns).
  * Every one of the `nparts` workgroups writes its partial result at
- * partial[part*partial_stride + out_offset + row*out_ld + col]; sc_partial_reduce sums the parts.       */
+ * partial[part*partial_stride + out_offset + row*out_ld + col]; sc_partial_reduce sums the parts.
+ * rowsum (may be NULL): [n_images][64], zero-filled by the caller; receives, per image, the sum over its points of
+ * term 0's A operand (= the bias / per-image latent gradient of that layer) -- the operand is in registers anyway.
+ * Requires n_per_image % 16 == 0 (a 16-point tile never straddles two images).                          */
 int sc_wgrad(int nterms,
              const float* a0_0, const float* a1_0, int aop_0, const float* b0_0, int bop0_0, const float* b1_0, int bop1_0,
              const float* a0_1, const float* a1_1, int aop_1, const float* b0_1, int bop0_1, const float* b1_1, int bop1_1,
              const float* points, const float* g_grad, const float* w5row, int n_points, int symmetric,
-             int nb0, int nb1, float* partial, int nparts, int partial_stride, int out_offset, int out_ld, void* stream);
+             int nb0, int nb1, float* partial, int nparts, int partial_stride, int out_offset, int out_ld,
+             float* rowsum, int n_per_image, int n_images, void* stream);
 /* out[i] += sum_part partial[part*stride + i], i < n.  out must be zero-filled (16 atomic chunks per element). */
 int sc_partial_reduce(const float* partial, int nparts, int stride, int n, float* out, void* stream);
 

@@ -40,6 +40,8 @@ struct WgradArgs {
     int nb0, nb1;          // widths of the two B segments (48 or 64; nb1 may be 0)
     float* partial;        // [gridDim.x][partial_stride]
     int partial_stride, out_offset, out_ld;
+    float* rowsum;         // optional [n_images][64] (zero-filled): per-image sum over points of term 0's A operand
+    int n_per_image, n_images;   // (= the bias / latent gradient of the layer); needs n_per_image % 16 == 0
 };
 
 constexpr int WG_MAXNB = 112;
@@ -171,10 +173,14 @@ __device__ __forceinline__ void term_load(const WgradTerm& T, int tile, int i, i
 
 template <int A, int B0, int B1, int NT0, int NNT>
 __device__ __forceinline__ void term_compute(const TermRaw<A, B0, B1, NT0, NNT>& R, const PeLane& P, const float* w5row, int i,
-                                             bool valid, f32x4 (&acc)[NT][NNT]) {
+                                             bool valid, f32x4 (&acc)[NT][NNT], float* rowsum = nullptr) {
     float4 af[NT], bf[NNT];
 #pragma unroll
     for (int m = 0; m < NT; ++m) af[m] = wg_cook<A>(R.a0[m], R.a1[m], w5row, m, i, valid);
+    if (rowsum) {      // channel 16m + i of this lane, its 4 points of the tile
+#pragma unroll
+        for (int m = 0; m < NT; ++m) rowsum[m] += (af[m].x + af[m].y) + (af[m].z + af[m].w);
+    }
 #pragma unroll
     for (int n = 0; n < NNT; ++n) {
         if (n < NT0) {
@@ -219,28 +225,59 @@ __global__ __launch_bounds__(256, WPS) void wgrad_kernel(WgradArgs a) {
     // the current one, so every wave always has ~20 KB of HBM reads in flight
     TermRaw<A0, B00, B10, NT0, NNT> c0, n0;
     TermRaw<A1, B01, B11, NT0, NNT> c1, n1;
-    const int stride = gridDim.x * 4;
-    int tile = blockIdx.x * 4 + wave;
+    // every wave streams one CONTIGUOUS range of tiles (so that it stays inside one image most of the time and the
+    // per-image row sums below need one flush per image change, not one per tile)
+    const int nw = gridDim.x * 4, wid = blockIdx.x * 4 + wave;
+    const bool want_rs = a.rowsum != nullptr;
+    // with row sums: every WORKGROUP streams one contiguous range of tiles (its 4 waves interleaved), so a wave changes
+    // image rarely and flushes its row sums once per change; without: grid-stride (all waves sweep the tensor together)
+    const int per_wg = ((ntiles + gridDim.x - 1) / gridDim.x + 3) & ~3;
+    const int step = want_rs ? 4 : nw;
+    int tile = want_rs ? blockIdx.x * per_wg + wave : wid;
+    const int tile_end = want_rs ? min(ntiles, (int)(blockIdx.x + 1) * per_wg) : ntiles;
     bool nvalid = tile * TP + 4 * g + (i & 3) < a.n_points;   // validity of the point this lane LOADS
-    if (tile < ntiles) {
+    if (tile < tile_end) {
         term_load(a.t[0], tile, i, g, nvalid, n0);
         if constexpr (A1 != OP_NONE) term_load(a.t[1], tile, i, g, nvalid, n1);
     }
-    for (; tile < ntiles; tile += stride) {
+    float rsum[NT] = {0.f, 0.f, 0.f, 0.f};
+    const int tiles_per_image = want_rs ? a.n_per_image / TP : 1;
+    int cur_img = -1;
+    auto flush_rowsum = [&]() {          // wave-uniform: cur_img is the same in every lane
+        if (cur_img >= 0) {
+#pragma unroll
+            for (int m = 0; m < NT; ++m) {
+                float v = rsum[m];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (g == 0) atomicAdd(&a.rowsum[(size_t)cur_img * 64 + 16 * m + i], v);
+                rsum[m] = 0.f;
+            }
+        }
+    };
+    for (; tile < tile_end; tile += step) {
         c0 = n0;
         if constexpr (A1 != OP_NONE) c1 = n1;
         const bool valid = nvalid;
-        const int next = tile + stride;
-        if (next < ntiles) {
+        const int next = tile + step;
+        if (next < tile_end) {
             nvalid = next * TP + 4 * g + (i & 3) < a.n_points;
             term_load(a.t[0], next, i, g, nvalid, n0);
             if constexpr (A1 != OP_NONE) term_load(a.t[1], next, i, g, nvalid, n1);
         }
+        if (want_rs) {
+            const int img = min(tile / tiles_per_image, a.n_images - 1);
+            if (img != cur_img) {
+                flush_rowsum();
+                cur_img = img;
+            }
+        }
         PeLane P;
         if constexpr (need_pe) pe_lane_setup(P, a.points, a.g_grad, need_eps, tile, i, g, a.n_points, a.symmetric != 0);
-        term_compute(c0, P, a.w5row, i, valid, acc);
+        term_compute(c0, P, a.w5row, i, valid, acc, want_rs ? rsum : nullptr);
         if constexpr (A1 != OP_NONE) term_compute(c1, P, a.w5row, i, valid, acc);
     }
+    if (want_rs) flush_rowsum();
     // combine the four waves of the workgroup in LDS, then one partial image per workgroup
     __syncthreads();
     const int ld = 16 * nnt;
@@ -343,14 +380,17 @@ int sc_wgrad(int nterms,
              const float* a0_0, const float* a1_0, int aop_0, const float* b0_0, int bop0_0, const float* b1_0, int bop1_0,
              const float* a0_1, const float* a1_1, int aop_1, const float* b0_1, int bop0_1, const float* b1_1, int bop1_1,
              const float* points, const float* g_grad, const float* w5row, int n_points, int symmetric,
-             int nb0, int nb1, float* partial, int nparts, int partial_stride, int out_offset, int out_ld, void* stream_) {
+             int nb0, int nb1, float* partial, int nparts, int partial_stride, int out_offset, int out_ld,
+             float* rowsum, int n_per_image, int n_images, void* stream_) {
     if (n_points <= 0) return 0;
+    if (rowsum && (n_per_image <= 0 || n_per_image % sc::TP != 0 || n_images <= 0)) return (int)hipErrorInvalidValue;
     sc::WgradArgs a;
     a.t[0] = sc::WgradTerm{a0_0, a1_0, aop_0, b0_0, bop0_0, b1_0, bop1_0};
     a.t[1] = sc::WgradTerm{a0_1, a1_1, aop_1, b0_1, bop0_1, b1_1, bop1_1};
     a.nterms = nterms; a.points = points; a.g_grad = g_grad; a.w5row = w5row; a.n_points = n_points;
     a.symmetric = symmetric; a.nb0 = nb0; a.nb1 = nb1; a.partial = partial; a.partial_stride = partial_stride;
     a.out_offset = out_offset; a.out_ld = out_ld;
+    a.rowsum = rowsum; a.n_per_image = n_per_image; a.n_images = n_images;
     hipStream_t st = (hipStream_t)stream_;
     using namespace sc;
     const int key0 = aop_0 * 100 + bop0_0 * 10 + bop1_0;

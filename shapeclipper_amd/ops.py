@@ -83,15 +83,18 @@ OP_NONE, OP_PLAIN, OP_SP, OP_Q, OP_Q4, OP_PE, OP_EPS = range(7)
 WGRAD_PARTS = 512
 
 
-def _wgrad(lib, terms, points, g_grad, w5row, n_points, symmetric, nb0, nb1, partial, stride, out_offset, out_ld):
-    """terms: list of 1 or 2 tuples (a0, a1, aop, b0, bop0, b1, bop1)."""
+def _wgrad(lib, terms, points, g_grad, w5row, n_points, symmetric, nb0, nb1, partial, stride, out_offset, out_ld,
+           rowsum=None, n_per_image=0, n_images=0):
+    """terms: list of 1 or 2 tuples (a0, a1, aop, b0, bop0, b1, bop1).  rowsum [n_images,64] (zeroed): per-image sum
+    of term 0's A operand, produced on the way."""
     t = list(terms) + [(None, None, OP_NONE, None, OP_NONE, None, OP_NONE)] * (2 - len(terms))
     args = []
     for (a0, a1, aop, b0, bop0, b1, bop1) in t:
         args += [_lib.ptr(a0), _lib.ptr(a1), c_int(aop), _lib.ptr(b0), c_int(bop0), _lib.ptr(b1), c_int(bop1)]
     code = lib.sc_wgrad(c_int(len(terms)), *args, _lib.ptr(points), _lib.ptr(g_grad), _lib.ptr(w5row),
                         c_int(n_points), c_int(1 if symmetric else 0), c_int(nb0), c_int(nb1), _lib.ptr(partial),
-                        c_int(WGRAD_PARTS), c_int(stride), c_int(out_offset), c_int(out_ld), _lib.stream())
+                        c_int(WGRAD_PARTS), c_int(stride), c_int(out_offset), c_int(out_ld), _lib.ptr(rowsum),
+                        c_int(n_per_image), c_int(n_images), _lib.stream())
     _lib.check(code, "sc_wgrad")
 
 
@@ -145,18 +148,23 @@ def sdf_backward(points, w_pack, n_per_image, n_images, symmetric, stash_a, stas
     w5row = w_pack[SDF_OFF["W5"]:SDF_OFF["W5"] + 64]
     common = (points, g_grad, w5row, n, symmetric)
 
-    def launch(terms, nb0, nb1, off, ld):
-        _wgrad(lib, terms, *common, nb0, nb1, partial, stride, off, ld)
+    # per-image sums of Ga_l (the gradient of the per-image biases c_l) come out of the launch that streams Ga_l anyway
+    fold = n_per_image % 16 == 0
+    g_c5 = torch.zeros(5, n_images, 64, **f32) if fold else None
+
+    def launch(terms, nb0, nb1, off, ld, layer=None):
+        rs = g_c5[layer] if (fold and layer is not None) else None
+        _wgrad(lib, terms, *common, nb0, nb1, partial, stride, off, ld, rs, n_per_image, n_images)
 
     t = [(GA(0), None, OP_PLAIN, None, OP_PE, None, OP_NONE)]
     if gg:
         t.append((P(0), A(0), OP_Q, None, OP_EPS, None, OP_NONE))
-    launch(t, 48, 0, SDF_OFF["W0"], 48)
+    launch(t, 48, 0, SDF_OFF["W0"], 48, layer=0)
     for l, key in ((1, "W1"), (2, "W2")):      # [64][112] = [hidden 64 | PE 48]: two launches of <= 4 N tiles each
         t = [(GA(l), None, OP_PLAIN, A(l - 1), OP_SP, None, OP_NONE)]
         if gg:
             t.append((P(l), A(l), OP_Q, GP(l - 1), OP_PLAIN, None, OP_NONE))
-        launch(t, 64, 0, SDF_OFF[key], 112)
+        launch(t, 64, 0, SDF_OFF[key], 112, layer=l)
         t = [(GA(l), None, OP_PLAIN, None, OP_PE, None, OP_NONE)]
         if gg:
             t.append((P(l), A(l), OP_Q, None, OP_EPS, None, OP_NONE))
@@ -164,11 +172,11 @@ def sdf_backward(points, w_pack, n_per_image, n_images, symmetric, stash_a, stas
     t = [(GA(3), None, OP_PLAIN, A(2), OP_SP, None, OP_NONE)]
     if gg:
         t.append((P(3), A(3), OP_Q, GP(2), OP_PLAIN, None, OP_NONE))
-    launch(t, 64, 0, SDF_OFF["W3"], 64)
+    launch(t, 64, 0, SDF_OFF["W3"], 64, layer=3)
     t = [(GA(4), None, OP_PLAIN, A(3), OP_SP, None, OP_NONE)]
     if gg:
         t.append((None, A(4), OP_Q4, GP(3), OP_PLAIN, None, OP_NONE))
-    launch(t, 64, 0, SDF_OFF["W4"], 64)
+    launch(t, 64, 0, SDF_OFF["W4"], 64, layer=4)
     if g_feat is not None:
         launch([(g_feat, None, OP_PLAIN, A(4), OP_SP, None, OP_NONE)], 64, 0, SDF_OFF["W5"] + 64, 64)
 
@@ -185,7 +193,10 @@ def sdf_backward(points, w_pack, n_per_image, n_images, symmetric, stash_a, stas
     else:   # regions no launch wrote (the partial buffer is not zero-initialised)
         g_w[SDF_OFF["W5"] + 64:SDF_OFF["B5"]] = 0.0
         g_w[SDF_OFF["B5"] + 1:] = 0.0
-    g_c = tbl_sum_multi([GA(l) for l in range(5)], n, n_per_image, n_images).view(5, n_images, 64).permute(1, 0, 2).contiguous()
+    if fold:
+        g_c = g_c5.permute(1, 0, 2).contiguous()
+    else:
+        g_c = tbl_sum_multi([GA(l) for l in range(5)], n, n_per_image, n_images).view(5, n_images, 64).permute(1, 0, 2).contiguous()
     return g_points, g_w, g_c
 
 
@@ -223,10 +234,14 @@ def rgb_composite_backward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, d
     stride = RGB_PACK_FLOATS
     partial = torch.empty(WGRAD_PARTS * stride, **f32)
     common = (points, None, None, P, symmetric)
-    _wgrad(lib, [(GY(0), None, OP_PLAIN, None, OP_PE, None, OP_NONE)], *common, 48, 0, partial, stride, RGB_OFF["V0"], 112)
+    # per-image sums of Gy_l (gradient of the per-image biases d_l) are produced by the launch that streams Gy_l
+    npi = rays_per_image * 64
+    g_d3 = torch.zeros(3, n_images, 64, **f32)
+    rs = lambda l: (g_d3[l], npi, n_images)
+    _wgrad(lib, [(GY(0), None, OP_PLAIN, None, OP_PE, None, OP_NONE)], *common, 48, 0, partial, stride, RGB_OFF["V0"], 112, *rs(0))
     _wgrad(lib, [(GY(0), None, OP_PLAIN, feat, OP_PLAIN, None, OP_NONE)], *common, 64, 0, partial, stride, RGB_OFF["V0"] + 48, 112)
-    _wgrad(lib, [(GY(1), None, OP_PLAIN, RR(0), OP_PLAIN, None, OP_NONE)], *common, 64, 0, partial, stride, RGB_OFF["V1"], 64)
-    _wgrad(lib, [(GY(2), None, OP_PLAIN, RR(1), OP_PLAIN, None, OP_NONE)], *common, 64, 0, partial, stride, RGB_OFF["V2"], 64)
+    _wgrad(lib, [(GY(1), None, OP_PLAIN, RR(0), OP_PLAIN, None, OP_NONE)], *common, 64, 0, partial, stride, RGB_OFF["V1"], 64, *rs(1))
+    _wgrad(lib, [(GY(2), None, OP_PLAIN, RR(1), OP_PLAIN, None, OP_NONE)], *common, 64, 0, partial, stride, RGB_OFF["V2"], 64, *rs(2))
     g_v = torch.zeros(stride, **f32)
     code = lib.sc_partial_reduce(_lib.ptr(partial), c_int(WGRAD_PARTS), c_int(stride), c_int(stride), _lib.ptr(g_v),
                                  _lib.stream())
@@ -237,7 +252,7 @@ def rgb_composite_backward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, d
     g_v[RGB_OFF["B3"]:RGB_OFF["B3"] + 3] = gy3.view(chunks, P // chunks, 3).sum(dim=1).sum(dim=0)
     g_v[RGB_OFF["B3"] + 3:RGB_OFF["B3"] + 4].zero_()       # (indexing with a python scalar would synchronise)
     g["v_pack"] = g_v
-    g["dbias"] = tbl_sum_multi([GY(l) for l in range(3)], P, rays_per_image * 64, n_images).view(3, n_images, 64).permute(1, 0, 2).contiguous()
+    g["dbias"] = g_d3.permute(1, 0, 2).contiguous()
     return g
 
 
