@@ -81,30 +81,36 @@ __global__ __launch_bounds__(64 * SDFB_WAVES) void sdf_bwd_kernel(SdfBwdArgs a) 
     // sweep of the same chunk picks them up a few microseconds later (same wave, still in L2 / Infinity Cache, so the
     // round trip and the second read of a_l cost no HBM traffic).  Two loops instead of one fused body keep each body
     // under 256 VGPRs (2 waves per SIMD) -- a single fused body needed ~500 and spilled.
-    constexpr int CH = 2;   // tiles per wave between the R and the V sweep: the parked tensors stay in L2 / Infinity Cache
+    // One tile per iteration: R sweep, then V sweep of the same tile.  What the V sweep needs first (a_4, pend_4, u_4) and
+    // the running point gradient stay in registers across the junction; pend_0..3 are parked in Ga_0..3.
     const int wave_gid = blockIdx.x * SDFB_WAVES + wave, nwaves = gridDim.x * SDFB_WAVES;
-    for (int chunk = wave_gid * CH; chunk < ntiles; chunk += nwaves * CH) {
-    if (HAS_GG) {
 #pragma unroll 1
-        for (int tile = chunk; tile < min(chunk + CH, ntiles); ++tile) {
+    for (int tile = wave_gid; tile < ntiles; tile += nwaves) {
+    float gx[3] = {0.f, 0.f, 0.f};
+    float j_av[ACT_STEPS], j_pend[ACT_STEPS], j_u[ACT_STEPS];      // junction registers (HAS_GG only)
+    float d1[PE_STEPS];                                            // dE/dx of the tile, shared by both sweeps
+    if (HAS_GG) {
+        {
             const int pt = tile * TP + p;
             const bool valid = pt < a.n_points;
             const int ptc = valid ? pt : a.n_points - 1;
             const float x0 = a.points[(size_t)ptc * 3 + 0], x1 = a.points[(size_t)ptc * 3 + 1], x2 = a.points[(size_t)ptc * 3 + 2];
-            float e[PE_STEPS], d1[PE_STEPS], d2[PE_STEPS];
+            float e[PE_STEPS], d2[PE_STEPS];
             pe_slots<true, true>(x0, x1, x2, g, a.symmetric != 0, e, d1, d2);
             float gam[3] = {0.f, 0.f, 0.f};
             if (valid) { gam[0] = a.g_grad[(size_t)pt * 3]; gam[1] = a.g_grad[(size_t)pt * 3 + 1]; gam[2] = a.g_grad[(size_t)pt * 3 + 2]; }
-            float gx[3] = {0.f, 0.f, 0.f};
             f32x4 acc[NT];
             float av[ACT_STEPS], pv[ACT_STEPS], gq[ACT_STEPS], gpv[ACT_STEPS];
             float eps[PE_STEPS];
 #pragma unroll
             for (int j = 0; j < PE_STEPS; ++j) eps[j] = gam[j >> 2] * d1[j];
-#define SC_R_STEP(L, WE, LD, HAS_PE)                                                        \
-            acc_to_regs(acc, gq);                                                            \
+// the stash loads of layer L are issued BEFORE the layer's MFMAs (they do not depend on them) and consumed after
+#define SC_R_LOAD(L)                                                                        \
             tbl_load(a.stash_a + (size_t)(L) * tbl, tile, p, g, av);                         \
             tbl_load(a.stash_p + (size_t)(L) * tbl, tile, p, g, pv);                         \
+            __builtin_amdgcn_sched_barrier(0);
+#define SC_R_STEP(L, WE, LD, HAS_PE)                                                        \
+            acc_to_regs(acc, gq);                                                            \
             {                                                                                \
                 float pn[ACT_STEPS];                                                         \
                 _Pragma("unroll") for (int s = 0; s < ACT_STEPS; ++s) {                       \
@@ -120,58 +126,53 @@ __global__ __launch_bounds__(64 * SDFB_WAVES) void sdf_bwd_kernel(SdfBwdArgs a) 
             }                                                                                \
             if (HAS_PE && a.g_points) { SC_PE_DOT(WE, LD, pv, d2, gam[c]) }
             acc_zero(acc);
+            SC_R_LOAD(0)
             mm_pe<SdfLds::LD0, NT, 0, PE_STEPS>(w0, eps, acc);                 // Gq0
             SC_R_STEP(0, w0, SdfLds::LD0, true)
             acc_zero(acc);
+            SC_R_LOAD(1)
             mm_act<SdfLds::LD1, NT>(w1h, gpv, acc);
             mm_pe<SdfLds::LD1, NT, 0, PE_STEPS>(w1e, eps, acc);                // Gq1
             SC_R_STEP(1, w1e, SdfLds::LD1, true)
             acc_zero(acc);
+            SC_R_LOAD(2)
             mm_act<SdfLds::LD1, NT>(w2h, gpv, acc);
             mm_pe<SdfLds::LD1, NT, 0, PE_STEPS>(w2e, eps, acc);                // Gq2
             SC_R_STEP(2, w2e, SdfLds::LD1, true)
             acc_zero(acc);
+            SC_R_LOAD(3)
             mm_act<SdfLds::LD3, NT>(w3, gpv, acc);                             // Gq3
             SC_R_STEP(3, w3, SdfLds::LD3, false)
 #undef SC_R_STEP
+#undef SC_R_LOAD
             acc_zero(acc);
+            tbl_load(a.stash_a + 4 * tbl, tile, p, g, j_av);
+            __builtin_amdgcn_sched_barrier(0);
             mm_act<SdfLds::LD3, NT>(w4, gpv, acc);                             // Gq4
             acc_to_regs(acc, gq);
-            tbl_load(a.stash_a + 4 * tbl, tile, p, g, av);
-            {
-                float pend4[ACT_STEPS], u4[ACT_STEPS];
 #pragma unroll
-                for (int s = 0; s < ACT_STEPS; ++s) {
-                    float t, r;
-                    softplus_parts(av[s], t, r);
-                    pend4[s] = gq[s] * w5s[kp(s)] * softplus_d2(t, r);
-                    u4[s] = gq[s] * softplus_d1(av[s], t, r);
-                }
-                tbl_store(a.ga + 4 * tbl, tile, p, g, pend4);
-                tbl_store(a.r0, tile, p, g, u4);
+            for (int s = 0; s < ACT_STEPS; ++s) {
+                float t, r;
+                softplus_parts(j_av[s], t, r);
+                j_pend[s] = gq[s] * w5s[kp(s)] * softplus_d2(t, r);
+                j_u[s] = gq[s] * softplus_d1(j_av[s], t, r);
             }
-            if (a.g_points) {     // second-order part of G point: Gx_c = Gg_c * sum_l q_l . (W_le d2E/dx_c^2); the V sweep adds the rest
-                const float o0 = group_sum(gx[0]), o1 = group_sum(gx[1]), o2 = group_sum(gx[2]);
-                if (valid && g == 0) {
-                    a.g_points[(size_t)pt * 3 + 0] = o0;
-                    a.g_points[(size_t)pt * 3 + 1] = o1;
-                    a.g_points[(size_t)pt * 3 + 2] = o2;
-                }
-            }
+            // gx now holds the second-order part of G point (Gx_c = Gg_c * sum_l q_l . (W_le d2E/dx_c^2)); the V sweep adds the rest
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     // ================= V pass =================
-#pragma unroll 1
-    for (int tile = chunk; tile < min(chunk + CH, ntiles); ++tile) {
+    {
         const int pt = tile * TP + p;
         const bool valid = pt < a.n_points;
         const int ptc = valid ? pt : a.n_points - 1;
-        const float x0 = a.points[(size_t)ptc * 3 + 0], x1 = a.points[(size_t)ptc * 3 + 1], x2 = a.points[(size_t)ptc * 3 + 2];
-        float e[PE_STEPS], d1[PE_STEPS], d2[PE_STEPS];
-        pe_slots<true, false>(x0, x1, x2, g, a.symmetric != 0, e, d1, d2);
+        if (!HAS_GG) {
+            const float x0 = a.points[(size_t)ptc * 3 + 0], x1 = a.points[(size_t)ptc * 3 + 1], x2 = a.points[(size_t)ptc * 3 + 2];
+            float e[PE_STEPS], d2[PE_STEPS];
+            pe_slots<true, false>(x0, x1, x2, g, a.symmetric != 0, e, d1, d2);
+        }
         const float Gs = (valid && a.g_sdf) ? a.g_sdf[pt] : 0.f;
-        float gx[3] = {0.f, 0.f, 0.f};
         f32x4 acc[NT];
         float av[ACT_STEPS], pv[ACT_STEPS], gav[ACT_STEPS];
         acc_zero(acc);
@@ -180,29 +181,27 @@ __global__ __launch_bounds__(64 * SDFB_WAVES) void sdf_bwd_kernel(SdfBwdArgs a) 
             tbl_load(a.g_feat, tile, p, g, gf);
             mm_act_t<SdfLds::LD3, NT>(w5ft, gf, acc);
         }
-        tbl_load(a.stash_a + 4 * tbl, tile, p, g, av);
+        if (!HAS_GG) tbl_load(a.stash_a + 4 * tbl, tile, p, g, av);
         {
             float r0v[ACT_STEPS];
-            if (HAS_GG) {
-                tbl_load(a.ga + 4 * tbl, tile, p, g, pv);      // pend4
-                tbl_load(a.r0, tile, p, g, r0v);               // u4
-            }
 #pragma unroll
             for (int s = 0; s < ACT_STEPS; ++s) {
+                const float a4 = HAS_GG ? j_av[s] : av[s];
                 float t, r;
-                softplus_parts(av[s], t, r);
+                softplus_parts(a4, t, r);
                 const float gh = acc[s >> 2][s & 3] + w5s[kp(s)] * Gs;
-                r0v[s] = Gs * softplus_val(av[s], t) + (HAS_GG ? r0v[s] : 0.f);
-                gav[s] = gh * softplus_d1(av[s], t, r) + (HAS_GG ? pv[s] : 0.f);
+                r0v[s] = Gs * softplus_val(a4, t) + (HAS_GG ? j_u[s] : 0.f);
+                gav[s] = gh * softplus_d1(a4, t, r) + (HAS_GG ? j_pend[s] : 0.f);
             }
             tbl_store(a.r0, tile, p, g, r0v);
             tbl_store(a.ga + 4 * tbl, tile, p, g, gav);
         }
 #define SC_V_STEP(L, WT, LD)                                                                \
         acc_zero(acc);                                                                       \
-        mm_act_t<LD, NT>(WT, gav, acc);                                                      \
         tbl_load(a.stash_a + (size_t)(L) * tbl, tile, p, g, av);                             \
         if (HAS_GG) tbl_load(a.ga + (size_t)(L) * tbl, tile, p, g, pv);                      \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        mm_act_t<LD, NT>(WT, gav, acc);                                                      \
         _Pragma("unroll") for (int s = 0; s < ACT_STEPS; ++s) {                               \
             float t, r;                                                                      \
             softplus_parts(av[s], t, r);                                                     \
@@ -221,16 +220,13 @@ __global__ __launch_bounds__(64 * SDFB_WAVES) void sdf_bwd_kernel(SdfBwdArgs a) 
         if (a.g_points) {
             const float o0 = group_sum(gx[0]), o1 = group_sum(gx[1]), o2 = group_sum(gx[2]);
             if (valid && g == 0) {
-                const float b0 = HAS_GG ? a.g_points[(size_t)pt * 3 + 0] : 0.f;
-                const float b1 = HAS_GG ? a.g_points[(size_t)pt * 3 + 1] : 0.f;
-                const float b2 = HAS_GG ? a.g_points[(size_t)pt * 3 + 2] : 0.f;
-                a.g_points[(size_t)pt * 3 + 0] = o0 + b0;
-                a.g_points[(size_t)pt * 3 + 1] = o1 + b1;
-                a.g_points[(size_t)pt * 3 + 2] = o2 + b2;
+                a.g_points[(size_t)pt * 3 + 0] = o0;
+                a.g_points[(size_t)pt * 3 + 1] = o1;
+                a.g_points[(size_t)pt * 3 + 2] = o2;
             }
         }
     }
-    }   // chunk
+    }   // tile
 }
 
 }  // namespace sc
