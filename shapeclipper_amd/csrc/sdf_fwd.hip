@@ -147,10 +147,13 @@ __global__ __launch_bounds__(64 * SDF_WAVES) void sdf_fwd_kernel(SdfFwdArgs a) {
                     g2 = __builtin_fmaf(q[s], t2[s >> 2][s & 3], g2);                      \
                 }                                                                          \
             }
+// The parked pre-activation of layer L is requested before the MFMAs that precede its use (it does not depend on
+// them), so the reload latency hides behind the matrix pipe.
+#define SC_DSP_LOAD(L)                                                                      \
+            tbl_load(park + (size_t)(L) * park_stride, ptile, p, g, av);                   \
+            __builtin_amdgcn_sched_barrier(0);
 #define SC_DSP(L, EXPR)                                                                     \
             {                                                                              \
-                float av[ACT_STEPS];                                                       \
-                tbl_load(park + (size_t)(L) * park_stride, ptile, p, g, av);               \
                 _Pragma("unroll") for (int s = 0; s < ACT_STEPS; ++s) {                     \
                     float t, r;                                                            \
                     softplus_parts(av[s], t, r);                                           \
@@ -158,29 +161,36 @@ __global__ __launch_bounds__(64 * SDF_WAVES) void sdf_fwd_kernel(SdfFwdArgs a) {
                     q[s] = (EXPR) * ds;                                                    \
                 }                                                                          \
             }
+            float av[ACT_STEPS];
+            SC_DSP_LOAD(4)
             SC_DSP(4, w5s[kp(s)])
             acc_zero(acc);
+            SC_DSP_LOAD(3)
             mm_act_t<SdfLds::LD3, NT>(w4t, q, acc);                 // p3 = W4^T q4
             acc_to_regs(acc, pv);
             if (a.stash_p) tbl_store(a.stash_p + 3 * tbl, tile, p, g, pv);
             SC_DSP(3, pv[s])
             acc_zero(acc);
+            SC_DSP_LOAD(2)
             mm_act_t<SdfLds::LD3, NT>(w3t, q, acc);                 // p2 = W3^T q3
             acc_to_regs(acc, pv);
             if (a.stash_p) tbl_store(a.stash_p + 2 * tbl, tile, p, g, pv);
             SC_DSP(2, pv[s])
+            SC_DSP_LOAD(1)
             SC_PE_JAC(w2e, SdfLds::LD1)
             acc_zero(acc);
             mm_act_t<SdfLds::LD1, NT>(w2t, q, acc);                 // p1 = W2h^T q2
             acc_to_regs(acc, pv);
             if (a.stash_p) tbl_store(a.stash_p + 1 * tbl, tile, p, g, pv);
             SC_DSP(1, pv[s])
+            SC_DSP_LOAD(0)
             SC_PE_JAC(w1e, SdfLds::LD1)
             acc_zero(acc);
             mm_act_t<SdfLds::LD1, NT>(w1t, q, acc);                 // p0 = W1h^T q1
             acc_to_regs(acc, pv);
             if (a.stash_p) tbl_store(a.stash_p + 0 * tbl, tile, p, g, pv);
             SC_DSP(0, pv[s])
+#undef SC_DSP_LOAD
 #undef SC_DSP
             SC_PE_JAC(w0, SdfLds::LD0)
 #undef SC_PE_JAC
