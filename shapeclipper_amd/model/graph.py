@@ -169,18 +169,40 @@ class Graph(nn.Module):
         launches and every shared weight receives a single gradient."""
         B = len(var.idx)
         images = [var.rgb_input_map] + [nn_in.rgb_input_map for nn_in in views]
+        mirrored = [var.rgb_input_map.flip(dims=[3])] if opt.loss_weight.cam_sym is not None else []
+        est_in = torch.cat(images + mirrored, 0)
+        # The two networks are independent: the estimator pass runs on a second HIP stream next to the encoder pass
+        # (HBM-bound BatchNorm of one overlaps MFMA-bound convolutions of the other; autograd replays the backward of
+        # every operator on the stream of its forward, so the backward passes overlap the same way).
+        side = self._side_stream(est_in.device) if (est_in.is_cuda and opt.get("hip", {}).get("two_streams", True)) else None
+        if side is not None:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                est = self.estimator(est_in, groups=len(images) + len(mirrored))
         latent = self.encoder(torch.cat(images, 0), groups=len(images))
+        if side is not None:
+            main.wait_stream(side)
+            for t in est:
+                t.record_stream(main)
+            est_in.record_stream(side)
+        else:
+            est = self.estimator(est_in, groups=len(images) + len(mirrored))
         var.latent_raw = latent[:B]
         for v, nn_in in enumerate(views):
             nn_in.latent_raw = latent[(v + 1) * B:(v + 2) * B]
-        mirrored = [var.rgb_input_map.flip(dims=[3])] if opt.loss_weight.cam_sym is not None else []
-        est = self.estimator(torch.cat(images + mirrored, 0), groups=len(images) + len(mirrored))
         part = lambda k: tuple(t[k * B:(k + 1) * B] for t in est)
         var.estim_input = part(0)
         for v, nn_in in enumerate(views):
             nn_in.estim = part(v + 1)
         if mirrored:
             var.estim_flip = part(len(images))
+
+    def _side_stream(self, device):
+        streams = self.__dict__.setdefault("_streams", {})
+        if device not in streams:
+            streams[device] = torch.cuda.Stream(device=device)
+        return streams[device]
 
     def forward_NN(self, opt, var, training=True, idx_NN=None, views=None):
         B = len(var.idx)

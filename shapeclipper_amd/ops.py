@@ -371,11 +371,11 @@ def _bn(name):
 
 def _bn_partial(x, groups=1):
     """Workspace for the per-(channel, group) partial sums: at most 2*(2048 + C*G) floats."""
-    dev = x.device.index
+    key = (x.device.index, torch.cuda.current_stream().cuda_stream)      # one per stream: calls on a stream are ordered
     need = 2 * (2048 + x.shape[1] * groups)
-    ws = _bn_ws.get(dev)
+    ws = _bn_ws.get(key)
     if ws is None or ws.numel() < need:
-        ws = _bn_ws[dev] = torch.empty(max(need, 1 << 16), device=x.device, dtype=torch.float32)
+        ws = _bn_ws[key] = torch.empty(max(need, 1 << 16), device=x.device, dtype=torch.float32)
     return ws.data_ptr()
 
 
