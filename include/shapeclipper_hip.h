@@ -141,8 +141,10 @@ int sc_loss_fused_forward(const float* rgb, const float* rgb_t, const float* mas
 /* ---------------------------------------------------------------------------------------------
  * CLIP ViT image tower forward (replaces clip_encoder.encode_image, CLIP_anno.py:166; third-party
  * openai/CLIP, parity unpinned).  image [B][C][H][W] fp32 (already CLIP-normalised) -> out [B][proj_dim]
- * fp32 (NOT L2-normalised).  Requirements: head dim 64, D % 64 == 0, mlp % 64 == 0, (H/patch)*(W/patch)+1 <= 64.
- * w_bf16: bf16 matrices, row-major [out][in], in this order: patch [D][C*patch*patch]; per layer
+ * fp32 (NOT L2-normalised).  Requirements: head dim 64, D % 64 == 0, mlp % 64 == 0; any token count
+ * T = (H/patch)*(W/patch)+1 whose transposed V tile fits LDS (ViT-B/32: 50, ViT-L/14: 257).
+ * w_bf16: bf16 matrices, row-major [out][in], in this order: patch [D][Kp], Kp = C*patch*patch rounded up to a
+ *   multiple of 64 with zero columns; per layer
  *   qkv [3D][D] (q rows, k rows, v rows), out_proj [D][D], fc1 [mlp][D], fc2 [D][mlp]; then proj [proj_dim][D].
  * w_f32: fp32 vectors in this order: class_embedding [D], position_embedding [T][D], ln_pre gamma, beta;
  *   per layer ln_1 gamma, beta, qkv bias [3D], out_proj bias, ln_2 gamma, beta, fc1 bias [mlp], fc2 bias;

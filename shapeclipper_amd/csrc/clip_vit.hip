@@ -16,7 +16,7 @@
 //                   epilogues: fp32 store / fp32 residual add / quick_gelu->bf16 / bf16
 //   layernorm       fp32 row -> bf16 (GEMM input) or fp32, one wave per token
 //   embed           [cls; patch tokens] + positional embedding -> fp32 residual stream
-//   attention       one wave per (image, head): K,V in LDS, fp32 scores/softmax, <= 64 tokens
+//   attention       MFMA: one workgroup per (image, head), K/Q operands straight from global, V^T in LDS, any token count
 // Bound: the four GEMMs per layer -> bf16 MFMA (dense peak 2.5 PFLOP/s).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -35,13 +35,15 @@ __device__ __forceinline__ bf16_t f2bf(float f) {      // round-to-nearest-even
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
 // ---------------------------------------------------------------------------------------------------
+// out [B*np][Kpad]: columns >= C*P*P are zero (the GEMM wants K % 64 == 0; ViT-L/14 has 3*14*14 = 588 -> 640)
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, bf16_t* __restrict__ out,
-                                                       int B, int C, int H, int W, int P) {
+                                                       int B, int C, int H, int W, int P, int Kpad) {
     const int gw = W / P, gh = H / P, np = gw * gh, K = C * P * P;
-    const size_t total = (size_t)B * np * K;
+    const size_t total = (size_t)B * np * Kpad;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int k = (int)(idx % K);
-        const size_t row = idx / K;
+        const int k = (int)(idx % Kpad);
+        const size_t row = idx / Kpad;
+        if (k >= K) { out[idx] = 0; continue; }
         const int pidx = (int)(row % np), b = (int)(row / np);
         const int c = k / (P * P), ky = (k / P) % P, kx = k % P;
         const int py = pidx / gw, px = pidx % gw;
@@ -172,49 +174,113 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ pa
     }
 }
 
-// One wave per (image, head).  qkv: bf16 [B*T, 3*D] (q | k | v), head dim 64, T <= 64.  out bf16 [B*T, D].
-__global__ __launch_bounds__(64) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int T, int D,
-                                                       int heads, float scale) {
-    __shared__ float Ks[64 * 65];
-    __shared__ float Vs[64 * 64];
-    __shared__ float Ss[64 * 65];     // one score row per lane (dynamic indexing -> LDS, not scratch)
-    const int b = blockIdx.x / heads, h = blockIdx.x % heads, lane = threadIdx.x;
+// Multi-head self-attention on the matrix cores.  qkv: bf16 [B*T, 3*D] (q | k | v), head dim 64, any T.  out bf16 [B*T, D].
+// One workgroup (4 waves) per (image, head); a wave owns blocks of 32 queries and walks the keys 32 at a time.
+//   S^T[key][query] = K Q^T      A = K rows, B = Q rows, both read straight from global memory: the contraction index
+//                                (head dim) is contiguous in the qkv row, which is exactly the 32x32x16 operand layout
+//   softmax over keys            two passes over the key chunks (statistics, then probabilities): S is recomputed (4 MFMAs
+//                                per chunk) instead of rescaling the output accumulators
+//   O[query][d] += P V           A = P: the C/D registers of S^T ARE a legal A operand (lane = query, the 8 values of a
+//                                K-step are 8 keys); B = V with keys contiguous per lane -> V is staged once per
+//                                workgroup TRANSPOSED in LDS (Vt[d][key]), the K-step's key order follows the C/D layout
+// fp32 scores / statistics / accumulation, bf16 probabilities (openai/CLIP on GPU keeps them in fp16).
+__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int T, int D,
+                                                        int heads, float scale) {
+    extern __shared__ bf16_t Vt[];                   // [64][ldv], ldv = Tp + 4 (row stride = odd multiple of 2 words)
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
+    const int Tp = (T + 31) & ~31, ldv = Tp + 4;
     const size_t rs = (size_t)3 * D;
-    for (int e = lane; e < T * 64; e += 64) {
-        const int t = e >> 6, d = e & 63;
-        const bf16_t* base = qkv + ((size_t)b * T + t) * rs + h * 64 + d;
-        Ks[t * 65 + d] = bf2f(base[D]);
-        Vs[t * 64 + d] = bf2f(base[2 * D]);
+    const bf16_t* base = qkv + (size_t)b * T * rs + (size_t)hd * 64;
+    for (int e = threadIdx.x; e < Tp * 8; e += 256) {
+        const int key = e >> 3, dc = (e & 7) * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (key < T) v = *reinterpret_cast<const uint4*>(base + (size_t)key * rs + 2 * D + dc);
+        const bf16_t* pv = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Vt[(dc + j) * ldv + key] = pv[j];
     }
     __syncthreads();
-    if (lane >= T) return;
-    float q[64];
-    const bf16_t* qp = qkv + ((size_t)b * T + lane) * rs + h * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 31, h = lane >> 5;
+    const float NEG = -3.0e38f;
+    auto frag = [&](int row, int col_off) -> bf16x8 {       // 8 consecutive head-dim values of a qkv row (zero past T)
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < T) v = *reinterpret_cast<const uint4*>(base + (size_t)row * rs + col_off + 8 * h);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    for (int qb = wave; qb * 32 < T; qb += 4) {
+        const int q = qb * 32 + n;
+        bf16x8 qf[4];
 #pragma unroll
-    for (int d = 0; d < 64; ++d) q[d] = bf2f(qp[d]) * scale;
-    float* sc = Ss + lane * 65;
-    float mx = -3.0e38f;
-    for (int t = 0; t < T; ++t) {
-        float s = 0.f;
+        for (int s4 = 0; s4 < 4; ++s4) qf[s4] = frag(q, 16 * s4);
+        auto scores = [&](int kc, float (&v)[16]) {           // v[r] = scaled score of key kc + (r&3) + 8(r>>2) + 4h, query q
+            f32x16 S;
 #pragma unroll
-        for (int d = 0; d < 64; ++d) s = __builtin_fmaf(q[d], Ks[t * 65 + d], s);
-        sc[t] = s;
-        mx = fmaxf(mx, s);
+            for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(kc + n, D + 16 * s4), qf[s4], S, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kc + (r & 3) + 8 * (r >> 2) + 4 * h;
+                v[r] = key < T ? S[r] * scale : NEG;
+            }
+        };
+        // pass 1: running maximum and normaliser of this lane's query (the two halves of the wave hold 16 keys each)
+        float m = NEG, l = 0.f;
+        for (int kc = 0; kc < Tp; kc += 32) {
+            float v[16];
+            scores(kc, v);
+            float cm = NEG;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cm = fmaxf(cm, v[r]);
+            cm = fmaxf(cm, __shfl_xor(cm, 32));
+            const float nm = fmaxf(m, cm);
+            float cs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cs += v[r] > NEG ? __expf(v[r] - nm) : 0.f;
+            cs += __shfl_xor(cs, 32);
+            l = l * __expf(m - nm) + cs;
+            m = nm;
+        }
+        const float inv = 1.f / l;
+        // pass 2: probabilities and P V
+        f32x16 O[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[t][r] = 0.f;
+        for (int kc = 0; kc < Tp; kc += 32) {
+            float v[16];
+            scores(kc, v);
+            bf16x8 pf[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bf16_t tmp[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float x = v[8 * j + e];
+                    tmp[e] = f2bf(x > NEG ? __expf(x - m) * inv : 0.f);
+                }
+                pf[j] = __builtin_bit_cast(bf16x8, tmp);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    // B operand: keys kc + 16j + 4h + {0..3} and {8..11} of head-dim column 32t + n
+                    const bf16_t* vp = Vt + (32 * t + n) * ldv + kc + 16 * j + 4 * h;
+                    const uint2 lo = *reinterpret_cast<const uint2*>(vp), hi = *reinterpret_cast<const uint2*>(vp + 8);
+                    const uint4 pk = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[j], __builtin_bit_cast(bf16x8, pk), O[t], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qq = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (qq < T) out[((size_t)b * T + qq) * D + hd * 64 + 32 * t + n] = f2bf(O[t][r]);
+            }
     }
-    float den = 0.f;
-    for (int t = 0; t < T; ++t) { const float ev = __expf(sc[t] - mx); sc[t] = ev; den += ev; }
-    const float inv = 1.f / den;
-    float o[64];
-#pragma unroll
-    for (int d = 0; d < 64; ++d) o[d] = 0.f;
-    for (int t = 0; t < T; ++t) {
-        const float p = sc[t] * inv;
-#pragma unroll
-        for (int d = 0; d < 64; ++d) o[d] = __builtin_fmaf(p, Vs[t * 64 + d], o[d]);
-    }
-    bf16_t* op = out + ((size_t)b * T + lane) * D + h * 64;
-#pragma unroll
-    for (int d = 0; d < 64; ++d) op[d] = f2bf(o[d]);
 }
 
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n) {
@@ -258,9 +324,9 @@ int sc_clip_vit_forward(const float* image, int B, int C, int H, int W, int patc
                         void* workspace, long long workspace_bytes, void* stream_) {
     using namespace sc;
     hipStream_t st = (hipStream_t)stream_;
-    if (D % 64 || D / heads != 64 || mlp % 64 || (C * patch * patch) % 64) return (int)hipErrorInvalidValue;
-    const int np = (H / patch) * (W / patch), T = np + 1, M = B * T, Kp = C * patch * patch;
-    if (T > 64) return (int)hipErrorInvalidValue;
+    if (D % 64 || D / heads != 64 || mlp % 64) return (int)hipErrorInvalidValue;
+    const int np = (H / patch) * (W / patch), T = np + 1, M = B * T;
+    const int Kp = (C * patch * patch + 63) & ~63;      // patch-embedding K padded to the GEMM's K granularity (zeros)
     // workspace carve (all 256-byte aligned)
     char* ws = (char*)workspace;
     size_t off = 0;
@@ -283,7 +349,11 @@ int sc_clip_vit_forward(const float* image, int B, int C, int H, int W, int patc
     const float* lnpre_g = wf; wf += D;
     const float* lnpre_b = wf; wf += D;
 
-    hipLaunchKernelGGL(patchify_kernel, dim3(2048), dim3(256), 0, st, image, a_patch, B, C, H, W, patch);
+    hipLaunchKernelGGL(patchify_kernel, dim3(2048), dim3(256), 0, st, image, a_patch, B, C, H, W, patch, Kp);
+    const int att_lds = 64 * (((T + 31) & ~31) + 4) * (int)sizeof(bf16_t);
+    if (att_lds > 160 * 1024) return (int)hipErrorInvalidValue;
+    if (att_lds > 48 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, att_lds);
     int rc = launch_gemm(EPI_F32, a_patch, w_patch, nullptr, patch_out, B * np, D, Kp, st);
     if (rc) return rc;
     hipLaunchKernelGGL(embed_kernel, dim3(1024), dim3(256), 0, st, patch_out, cls, pos, x, B, T, D);
@@ -303,7 +373,7 @@ int sc_clip_vit_forward(const float* image, int B, int C, int H, int W, int patc
         const float* b_fc2 = wf; wf += D;
         hipLaunchKernelGGL(layernorm_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, x, D, ln1_g, ln1_b, (void*)xn, M, D, ln_eps);
         if ((rc = launch_gemm(EPI_BF16, xn, w_qkv, b_qkv, qkv, M, 3 * D, D, st))) return rc;
-        hipLaunchKernelGGL(attention_kernel, dim3(B * heads), dim3(64), 0, st, qkv, att, T, D, heads, 0.125f);
+        hipLaunchKernelGGL(attention_kernel, dim3(B * heads), dim3(256), att_lds, st, qkv, att, T, D, heads, 0.125f);
         if ((rc = launch_gemm(EPI_RESID, att, w_o, b_o, x, M, D, D, st))) return rc;
         hipLaunchKernelGGL(layernorm_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, x, D, ln2_g, ln2_b, (void*)xn, M, D, ln_eps);
         if ((rc = launch_gemm(EPI_GELU_BF16, xn, w_fc1, b_fc1, hbuf, M, mlp, D, st))) return rc;

@@ -16,7 +16,7 @@ import torch.nn as nn
 from .. import _lib
 
 VIT_B32 = dict(image_size=224, patch=32, width=768, layers=12, heads=12, mlp=3072, proj=512)
-VIT_L14 = dict(image_size=224, patch=14, width=1024, layers=24, heads=16, mlp=4096, proj=768)   # 257 tokens: not supported yet
+VIT_L14 = dict(image_size=224, patch=14, width=1024, layers=24, heads=16, mlp=4096, proj=768)   # the reference's model (CLIP_anno.py:16)
 
 
 class ClipVisionTower(nn.Module):
@@ -26,7 +26,7 @@ class ClipVisionTower(nn.Module):
         self.cfg = dict(image_size=image_size, patch=patch, width=width, layers=layers, heads=heads, mlp=mlp, proj=proj,
                         channels=channels)
         T = (image_size // patch) ** 2 + 1
-        assert width // heads == 64 and T <= 64, "kernels need head_dim 64 and <= 64 tokens (ViT-B/32 class)"
+        assert width // heads == 64 and width % 64 == 0 and mlp % 64 == 0, "kernels need head_dim 64"
         P = lambda *s: nn.Parameter(torch.randn(*s) * 0.02)
         vm = "vision_model."
         names = {vm + "embeddings.class_embedding": P(width),
@@ -68,7 +68,9 @@ class ClipVisionTower(nn.Module):
         c = self.cfg
         g = lambda n: self.params[n.replace(".", "/")].detach()
         vm = "vision_model."
-        mats = [g(vm + "embeddings.patch_embedding.weight").reshape(c["width"], -1)]
+        w_patch = g(vm + "embeddings.patch_embedding.weight").reshape(c["width"], -1)
+        pad = (-w_patch.shape[1]) % 64             # the GEMM wants K % 64 == 0 (ViT-L/14: 588 -> 640, zero columns)
+        mats = [torch.nn.functional.pad(w_patch, (0, pad))]
         vecs = [g(vm + "embeddings.class_embedding"), g(vm + "embeddings.position_embedding.weight").reshape(-1),
                 g(vm + "pre_layrnorm.weight"), g(vm + "pre_layrnorm.bias")]
         for l in range(c["layers"]):
@@ -88,7 +90,7 @@ class ClipVisionTower(nn.Module):
     def workspace_bytes(self, B):
         c = self.cfg
         np_ = (c["image_size"] // c["patch"]) ** 2
-        T, D, Kp = np_ + 1, c["width"], c["channels"] * c["patch"] ** 2
+        T, D, Kp = np_ + 1, c["width"], (c["channels"] * c["patch"] ** 2 + 63) // 64 * 64
         M = B * T
         sizes = [B * np_ * Kp * 2, B * np_ * D * 4, M * D * 4, M * D * 2, M * 3 * D * 2, M * D * 2, M * c["mlp"] * 2, B * D * 2]
         return sum((s + 255) // 256 * 256 for s in sizes)
