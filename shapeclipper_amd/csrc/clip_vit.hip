@@ -63,6 +63,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int bm = blockIdx.y * 128, bn = blockIdx.x * 128;
+    // split-K (gridDim.z > 1, residual epilogue only): slice z accumulates its K range into the fp32 output with atomics;
+    // used when the output has too few 128x128 tiles to fill 256 CUs (N = 768 at 1600 rows: 78 workgroups)
+    const int kslices = gridDim.z, kt0 = (K / 64) * blockIdx.z / kslices, kt1 = (K / 64) * (blockIdx.z + 1) / kslices;
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -81,9 +84,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
             rb[q] = gn < N ? *reinterpret_cast<const uint4*>(Wt + (size_t)gn * K + kt * 64 + kc * 8) : make_uint4(0, 0, 0, 0);
         }
     };
-    const int nk = K / 64;
-    gload(0);
-    for (int kt = 0; kt < nk; ++kt) {
+    const int nk = kt1;
+    gload(kt0);
+    for (int kt = kt0; kt < nk; ++kt) {
         __syncthreads();                      // previous tile fully consumed
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
         for (int j = 0; j < 2; ++j) {
             const int col = bn + 64 * wc + 32 * j + (lane & 31);
             if (col >= N) continue;
-            const float bv = bias ? bias[col] : 0.f;
+            const float bv = (bias && blockIdx.z == 0) ? bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = bm + 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -131,7 +134,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
                 const float v = acc[i][j][r] + bv;
                 const size_t o = (size_t)row * N + col;
                 if (EPI == EPI_F32) reinterpret_cast<float*>(out)[o] = v;
-                else if (EPI == EPI_RESID) reinterpret_cast<float*>(out)[o] += v;
+                else if (EPI == EPI_RESID) {
+                    if (kslices > 1) unsafeAtomicAdd(reinterpret_cast<float*>(out) + o, v);
+                    else reinterpret_cast<float*>(out)[o] += v;
+                }
                 else if (EPI == EPI_GELU_BF16) reinterpret_cast<bf16_t*>(out)[o] = f2bf(v / (1.f + __expf(-1.702f * v)));
                 else reinterpret_cast<bf16_t*>(out)[o] = f2bf(v);
             }
@@ -291,6 +297,11 @@ static int launch_gemm(int epi, const bf16_t* A, const bf16_t* Wt, const float* 
                        hipStream_t st) {
     if (K % 64) return (int)hipErrorInvalidValue;
     dim3 grid((N + 127) / 128, (M + 127) / 128);
+    if (epi == EPI_RESID) {        // fill the chip: split K while there are fewer than ~256 workgroups and >= 4 K tiles per slice
+        int z = 1;
+        while (grid.x * grid.y * z < 200 && K / 64 / (2 * z) >= 4 && z < 8) z *= 2;
+        grid.z = z;
+    }
     switch (epi) {
         case EPI_F32: hipLaunchKernelGGL(gemm_bf16_kernel<EPI_F32>, grid, dim3(256), 0, st, A, Wt, bias, out, M, N, K); break;
         case EPI_RESID: hipLaunchKernelGGL(gemm_bf16_kernel<EPI_RESID>, grid, dim3(256), 0, st, A, Wt, bias, out, M, N, K); break;
