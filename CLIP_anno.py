@@ -4,9 +4,9 @@ Offline CLIP nearest-neighbour annotation (reference CLIP_anno.py): embed every 
 the CLIP image tower, L2-normalise, cosine k-NN, write `<anno_root>/<cat>_<split>.csv` with the header
 Query,Top_1..Top_{k-1},Top_1_score..  sorted by query (same on-disk format; data/pix3d.py:95-108 reads it).
 
-MI355X build: the tower runs on the HIP kernels (shapeclipper_amd/model/clip_vit.py, ViT-B/32 class:
-<= 64 tokens, head dim 64); the O(N^2) similarity is ONE GEMM + top-k instead of a Python loop
-(reference :29-57).  Weights: pass --clip_ckpt (a transformers CLIPVisionModelWithProjection or
+MI355X build: the tower runs on the HIP kernels (shapeclipper_amd/model/clip_vit.py; --clip_model=ViT-B/32
+(default, BASELINE config[2]) or ViT-L/14 (the model the reference loads, CLIP_anno.py:16)); the O(N^2)
+similarity is ONE GEMM + top-k instead of a Python loop (reference :29-57).  Weights: pass --clip_ckpt (a transformers CLIPVisionModelWithProjection or
 openai/CLIP state dict); without it the tower is randomly initialised (no network here)."""
 import csv
 import importlib
@@ -18,21 +18,25 @@ import torch.nn.functional as torch_F
 
 import utils.options as options
 from utils.util import log
-from shapeclipper_amd.model.clip_vit import VIT_B32, ClipVisionTower
+from shapeclipper_amd.model.clip_vit import VIT_B32, VIT_L14, ClipVisionTower
 
 
 class NN_annotator:
     def __init__(self, opt):
-        self.tower = ClipVisionTower(**VIT_B32)
+        name = str(opt.get("clip_model", "ViT-B/32"))
+        if name not in ("ViT-B/32", "ViT-L/14"):
+            raise NotImplementedError("clip_model '%s' (available: ViT-B/32, ViT-L/14)" % name)
+        cfg = VIT_L14 if name == "ViT-L/14" else VIT_B32
+        self.tower = ClipVisionTower(**cfg)
         ckpt = opt.get("clip_ckpt", None)
         if ckpt:
             sd = torch.load(ckpt, map_location="cpu")
             if any(k.startswith("visual.") for k in sd):
-                self.tower = ClipVisionTower.from_openai_state_dict(sd, **VIT_B32)
+                self.tower = ClipVisionTower.from_openai_state_dict(sd, **cfg)
             else:
                 self.tower.load_state_dict(sd)
         self.tower = self.tower.to(opt.device)
-        self.clip_dim = VIT_B32["proj"]
+        self.clip_dim = cfg["proj"]
 
     @torch.no_grad()
     def calc_matches(self, opt, features, k_nearest=6):
