@@ -30,9 +30,10 @@ class FlatGradAllReduce:
     parameter is a pointer move, not an add kernel), then packed with one multi-tensor copy into the flat buffer,
     all-reduced with ONE collective, averaged, and handed back to the optimizer as views of the flat buffer."""
 
-    def __init__(self, module: nn.Module, world_size: int, broadcast_buffers: bool = True):
+    def __init__(self, module: nn.Module, world_size: int, broadcast_buffers: bool = True, always_communicate: bool = False):
         self.module = module
         self.world = world_size
+        self.comm = world_size > 1 or always_communicate      # always_communicate: run the collectives on 1 rank too (tests)
         self.params = [p for p in module.parameters() if p.requires_grad]
         # shared parameters (renderer.sdf_network is sdf_network) appear once in .parameters()
         total = sum(p.numel() for p in self.params)
@@ -43,7 +44,7 @@ class FlatGradAllReduce:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
         self.buffers = [b for b in module.buffers() if b.dtype.is_floating_point] if broadcast_buffers else []
-        if self.world > 1:
+        if self.comm:
             self.broadcast_parameters()
 
     @property
@@ -75,7 +76,7 @@ class FlatGradAllReduce:
 
     def broadcast_buffers(self, src=0):
         """BN running statistics follow rank 0, as DDP's broadcast_buffers=True does each forward."""
-        if self.world <= 1 or not self.buffers:
+        if not self.comm or not self.buffers:
             return
         flat = torch.cat([b.reshape(-1) for b in self.buffers])
         dist.broadcast(flat, src)
@@ -88,7 +89,7 @@ class FlatGradAllReduce:
     def all_reduce(self):
         """Call after backward(): mean of the gradients over all ranks, one collective."""
         self.pack()
-        if self.world > 1:
+        if self.comm:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.mul_(1.0 / self.world)
 
