@@ -16,8 +16,8 @@ _SCRATCH = {}
 
 
 def _sdf_scratch(dev):
-    """[256 workgroups x 8 waves][5][1024] floats (42 MB), one per device, reused by every call on a stream."""
-    key = (dev.type, dev.index)
+    """[256 workgroups x 8 waves][5][1024] floats (42 MB), one per (device, stream): calls on a stream are ordered."""
+    key = (dev.type, dev.index, torch.cuda.current_stream().cuda_stream if dev.type == "cuda" else 0)
     if key not in _SCRATCH:
         _SCRATCH[key] = torch.empty(256 * 8 * 5 * 1024, device=dev, dtype=torch.float32)
     return _SCRATCH[key]
