@@ -65,3 +65,17 @@ def test_gemm_bf16_transpose_detecting():
     torch.cuda.synchronize()
     ref = A.float() @ W.float().t() + bias
     assert (out - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
+
+
+def test_clip_tower_golden_fixture():
+    """G11 (tests/golden/make_golden_clip.py): committed weights / input / embedding of a shrunken tower."""
+    import os
+    from shapeclipper_amd.model.clip_vit import ClipVisionTower
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g11_clip_arch.npz"))
+    width, layers, heads, mlp, patch, image, proj = (int(v) for v in g["cfg"])
+    tower = ClipVisionTower(image_size=image, patch=patch, width=width, layers=layers, heads=heads, mlp=mlp, proj=proj)
+    tower.load_state_dict({k[2:]: torch.tensor(g[k]) for k in g.files if k.startswith("w.")})
+    got = tower.cuda().encode_image(torch.tensor(g["input"]).cuda()).cpu()
+    ref = torch.tensor(g["embedding"])
+    assert torch.nn.functional.cosine_similarity(got, ref, dim=-1).min().item() > 0.999
+    assert (got - ref).abs().max().item() < 0.03 * ref.abs().max().item()
