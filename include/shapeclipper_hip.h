@@ -173,15 +173,39 @@ int sc_ray_sample_backward(const float* ray_dirs, const float* z_vals, const flo
                            const float* g_z_extra, int n_rays, int rays_per_image, int n_images, float cam_dist,
                            float* g_cam_loc, float* g_ray_dirs, float* g_scale_dist, void* stream);
 
-/* One render without gradients in a single call (Renderer.forward, model/renderer.py:57-152):
+/* One render in a single call (Renderer.forward, model/renderer.py:57-152):
  * sc_ray_sample_forward -> sc_sdf_forward -> sc_rgb_composite_forward.  z_vals, points, sdf, grad, feat and
- * scratch are caller-provided work buffers (sizes as in the three entry points).                         */
+ * scratch are caller-provided work buffers (sizes as in the three entry points).  Inference: stash_a = stash_p =
+ * rgb_flat = NULL.  Training: pass stash_a (5 x TBL64), stash_p (4 x TBL64) and rgb_flat [P][3]; together with
+ * z_vals / points / sdf / grad / feat they are what sc_render_backward needs (scratch may then be NULL).    */
 int sc_render_forward(const float* cam_loc, const float* ray_dirs, const float* depth_fac, const float* scale_dist,
                       const float* u, const float* sdf_pack, const float* sdf_cbias, const float* rgb_pack,
                       const float* rgb_dbias, const float* beta_param, int n_rays, int rays_per_image, int n_images,
                       int symmetric, float cam_dist, float beta_min, float bgcolor, float normal_pow,
                       float* rgb, float* mask, float* mask_hard, float* depth, float* normal,
-                      float* z_vals, float* points, float* sdf, float* grad, float* feat, float* scratch, void* stream);
+                      float* z_vals, float* points, float* sdf, float* grad, float* feat, float* scratch,
+                      float* stash_a, float* stash_p, float* rgb_flat, void* stream);
+
+/* The whole reverse pass of one training render (what autograd does for model/renderer.py:57-185 and the MLPs of
+ * model/implicit.py:138-239, incl. the double backward through d sdf/dx): sc_rgb_composite_backward, the RGB
+ * weight-gradient GEMMs, sc_sdf_backward, the SDF weight-gradient GEMMs and sc_ray_sample_backward in one call.
+ * Inputs: the forward's operands and saved tensors (see sc_render_forward) and the upstream gradients of the per-ray
+ * outputs G_rgb [n_rays][3], G_mask, G_depth [n_rays], G_normal [n_rays][3] (NULL = zero), G_z_extra [n_rays][64]
+ * (extra gradient on z_vals, e.g. from the eikonal near-surface samples; may be NULL).
+ * Outputs (all fully written): g_sdf_pack [SC_SDF_PACK_FLOATS], g_cbias [5][n_images][64], g_rgb_pack
+ * [SC_RGB_PACK_FLOATS], g_dbias [3][n_images][64], g_beta [1], and per ray g_cam_loc [.][3], g_ray_dirs [.][3],
+ * g_scale_dist [.] (sum over the rays of an image = d/d scale_dist), g_depth_fac [.].
+ * workspace: sc_render_backward_workspace_bytes(n_rays) bytes of device memory (~17 TBL64 tensors).          */
+long long sc_render_backward_workspace_bytes(int n_rays);
+int sc_render_backward(
+    const float* ray_dirs, const float* depth_fac, const float* sdf_pack, const float* rgb_pack, const float* rgb_dbias,
+    const float* beta_param, const float* z_vals, const float* points, const float* sdf, const float* grad, const float* feat,
+    const float* stash_a, const float* stash_p, const float* rgb_flat, int n_rays, int rays_per_image, int n_images,
+    int symmetric, float cam_dist, float beta_min, float bgcolor, float normal_pow,
+    const float* G_rgb, const float* G_mask, const float* G_depth, const float* G_normal, const float* G_z_extra,
+    float* g_sdf_pack, float* g_cbias, float* g_rgb_pack, float* g_dbias, float* g_beta,
+    float* g_cam_loc, float* g_ray_dirs, float* g_scale_dist, float* g_depth_fac,
+    void* workspace, long long workspace_bytes, void* stream);
 
 /* compute_level_grid (utils/eval_3D.py:9-38): SDF on linspace(lo,hi,n_axis)^3 ('ij' order) for every image.
  * points_ws: [n_images*n_axis^3][3] floats of workspace; level: [n_images][n_axis][n_axis][n_axis].       */

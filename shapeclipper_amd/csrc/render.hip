@@ -127,15 +127,16 @@ int sc_render_forward(const float* cam_loc, const float* ray_dirs, const float* 
                       const float* rgb_dbias, const float* beta_param, int n_rays, int rays_per_image, int n_images,
                       int symmetric, float cam_dist, float beta_min, float bgcolor, float normal_pow,
                       float* rgb, float* mask, float* mask_hard, float* depth, float* normal,
-                      float* z_vals, float* points, float* sdf, float* grad, float* feat, float* scratch, void* stream) {
+                      float* z_vals, float* points, float* sdf, float* grad, float* feat, float* scratch,
+                      float* stash_a, float* stash_p, float* rgb_flat, void* stream) {
     int rc = sc_ray_sample_forward(cam_loc, ray_dirs, scale_dist, u, n_rays, rays_per_image, n_images, cam_dist, z_vals, points, stream);
     if (rc) return rc;
     rc = sc_sdf_forward(points, sdf_pack, sdf_cbias, n_rays * 64, rays_per_image * 64, n_images, symmetric, sdf, grad, feat,
-                        nullptr, nullptr, scratch, stream);
+                        stash_a, stash_p, scratch, stream);
     if (rc) return rc;
     return sc_rgb_composite_forward(points, z_vals, depth_fac, sdf, grad, feat, rgb_pack, rgb_dbias, beta_param, n_rays,
                                     rays_per_image, n_images, symmetric, beta_min, bgcolor, normal_pow, rgb, mask, mask_hard,
-                                    depth, normal, nullptr, nullptr, nullptr, stream);
+                                    depth, normal, nullptr, nullptr, rgb_flat, stream);
 }
 
 int sc_sdf_grid_forward(const float* sdf_pack, const float* sdf_cbias, float lo, float hi, int n_axis, int n_images,

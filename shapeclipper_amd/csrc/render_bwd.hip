@@ -1,0 +1,159 @@
+// render_bwd.hip -- the whole reverse pass of one training render behind ONE C entry point (SURVEY 8b:
+// sc_render_backward), the counterpart of sc_render_forward.
+//
+// What autograd does in the reference for Renderer.forward (model/renderer.py:57-185) and the two MLPs it calls
+// (model/implicit.py:138-239), including the double backward through d(sdf)/dx, is here the fixed sequence
+//   sc_rgb_composite_backward                    per-ray upstream gradients -> per-point gradients + RGB-net operands
+//   sc_wgrad x4, sc_partial_reduce, sc_tbl_sum   RGB weight / per-image bias gradients
+//   sc_sdf_backward                              first- and second-order input gradients + SDF-net operands
+//   sc_wgrad x8, sc_partial_reduce, sc_tbl_sum   SDF weight / per-image bias gradients
+//   sc_ray_sample_backward                       d/d camera centre, ray direction, scale_dist (per ray)
+// on caller-provided workspace.  The host-side Python of this build issues the same sequence step by step
+// (shapeclipper_amd/ops.py); this entry point is the same thing for a non-Python host.
+#include "mlp_tile.hpp"
+#include "shapeclipper_hip.h"
+
+namespace sc {
+
+enum { W_OP_NONE = 0, W_OP_PLAIN = 1, W_OP_SP = 2, W_OP_Q = 3, W_OP_Q4 = 4, W_OP_PE = 5, W_OP_EPS = 6 };
+constexpr int RB_PARTS = 512;
+
+__global__ __launch_bounds__(256) void rb_add_kernel(float* __restrict__ a, const float* __restrict__ b, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) a[i] += b[i];
+}
+
+// out[k] += sum_i x[i*stride + k], k < K <= 4 (out zero-filled); used for sum(g_sdf) (K = 1) and the column sums of gy3 (K = 3)
+__global__ __launch_bounds__(256) void rb_colsum_kernel(const float* __restrict__ x, size_t n, int stride, int K,
+                                                        float* __restrict__ out) {
+    __shared__ float red[4][4];
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        for (int k = 0; k < K; ++k) s[k] += x[i * stride + k];
+    for (int k = 0; k < K; ++k) {
+        float v = s[k];
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < K) atomicAdd(&out[threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+struct Carver {
+    char* base; size_t off;
+    float* f(size_t n_floats) { char* p = base + off; off += (n_floats * 4 + 255) & ~(size_t)255; return reinterpret_cast<float*>(p); }
+};
+
+static size_t rb_workspace_floats(int n_rays, int* T_out) {
+    const size_t P = (size_t)n_rays * 64, T = (size_t)((P + TP - 1) / TP) * 1024;
+    if (T_out) *T_out = (int)0;
+    size_t n = 0;
+    auto add = [&](size_t k) { n += (k + 63) & ~(size_t)63; };
+    add(P); add(3 * P); add(T); add(3 * P); add(3 * P);            // g_sdf, g_grad, g_feat, g_points (rgb), g_points (sdf)
+    add((size_t)n_rays * 64);                                       // g_z
+    add(3 * T); add(3 * T); add(3 * P);                            // gy, rr, gy3
+    add(5 * T); add(4 * T); add(T);                                // ga, gp, r0
+    add((size_t)RB_PARTS * SdfPack::TOTAL);                        // partial images (the larger of the two networks)
+    add(2 * 64);                                                   // tbl_sum outputs for [r0, g_feat]
+    return n;
+}
+
+static int wgrad1(const float* a0, const float* b0, int bop0, const float* points, int n, int symmetric, int nb0, float* partial,
+                  int stride, int off, int ld, float* rowsum, int npi, int nimg, void* st) {
+    return sc_wgrad(1, a0, nullptr, W_OP_PLAIN, b0, bop0, nullptr, W_OP_NONE, nullptr, nullptr, W_OP_NONE, nullptr, W_OP_NONE, nullptr,
+                    W_OP_NONE, points, nullptr, nullptr, n, symmetric, nb0, 0, partial, RB_PARTS, stride, off, ld, rowsum, npi, nimg, st);
+}
+
+}  // namespace sc
+
+extern "C" long long sc_render_backward_workspace_bytes(int n_rays) {
+    return (long long)(sc::rb_workspace_floats(n_rays, nullptr) * 4 + 64 * 256);
+}
+
+extern "C" int sc_render_backward(
+    const float* ray_dirs, const float* depth_fac, const float* sdf_pack, const float* rgb_pack, const float* rgb_dbias,
+    const float* beta_param, const float* z_vals, const float* points, const float* sdf, const float* grad, const float* feat,
+    const float* stash_a, const float* stash_p, const float* rgb_flat, int n_rays, int rays_per_image, int n_images,
+    int symmetric, float cam_dist, float beta_min, float bgcolor, float normal_pow,
+    const float* G_rgb, const float* G_mask, const float* G_depth, const float* G_normal, const float* G_z_extra,
+    float* g_sdf_pack, float* g_cbias, float* g_rgb_pack, float* g_dbias, float* g_beta,
+    float* g_cam_loc, float* g_ray_dirs, float* g_scale_dist, float* g_depth_fac,
+    void* workspace, long long workspace_bytes, void* stream_) {
+    using namespace sc;
+    if (n_rays <= 0) return 0;
+    if (workspace_bytes < sc_render_backward_workspace_bytes(n_rays)) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream_;
+    const int P = n_rays * 64, npi = rays_per_image * 64;
+    const size_t T = (size_t)((P + TP - 1) / TP) * 1024;
+    Carver ws{(char*)workspace, 0};
+    float* g_sdf = ws.f(P); float* g_grad = ws.f(3 * (size_t)P); float* g_feat = ws.f(T);
+    float* gpts_rgb = ws.f(3 * (size_t)P); float* gpts_sdf = ws.f(3 * (size_t)P); float* g_z = ws.f((size_t)n_rays * 64);
+    float* gy = ws.f(3 * T); float* rr = ws.f(3 * T); float* gy3 = ws.f(3 * (size_t)P);
+    float* ga = ws.f(5 * T); float* gp = ws.f(4 * T); float* r0 = ws.f(T);
+    float* partial = ws.f((size_t)RB_PARTS * SdfPack::TOTAL);
+    float* tot = ws.f(2 * 64);
+    int rc;
+#define SC_TRY(x) if ((rc = (x))) return rc
+    // ---------------- RGB network + compositing ----------------
+    hipMemsetAsync(g_beta, 0, 4, st);
+    SC_TRY(sc_rgb_composite_backward(points, z_vals, depth_fac, sdf, grad, feat, rgb_pack, rgb_dbias, beta_param, rgb_flat, n_rays,
+                                     rays_per_image, n_images, symmetric, beta_min, bgcolor, normal_pow, G_rgb, G_mask, G_depth,
+                                     G_normal, g_sdf, g_grad, g_feat, gpts_rgb, g_z, g_depth_fac, g_beta, gy, rr, gy3, stream_));
+    hipMemsetAsync(g_dbias, 0, (size_t)3 * n_images * 64 * 4, st);       // [3][n_images][64]
+    hipMemsetAsync(g_rgb_pack, 0, (size_t)RgbPack::TOTAL * 4, st);
+    const int rs = RgbPack::TOTAL;
+    SC_TRY(wgrad1(gy, nullptr, W_OP_PE, points, P, symmetric, 48, partial, rs, RgbPack::V0, 112, g_dbias, npi, n_images, stream_));
+    SC_TRY(wgrad1(gy, feat, W_OP_PLAIN, points, P, symmetric, 64, partial, rs, RgbPack::V0 + 48, 112, nullptr, 0, 0, stream_));
+    SC_TRY(wgrad1(gy + T, rr, W_OP_PLAIN, points, P, symmetric, 64, partial, rs, RgbPack::V1, 64, g_dbias + (size_t)n_images * 64, npi, n_images, stream_));
+    SC_TRY(wgrad1(gy + 2 * T, rr + T, W_OP_PLAIN, points, P, symmetric, 64, partial, rs, RgbPack::V2, 64, g_dbias + (size_t)2 * n_images * 64, npi, n_images, stream_));
+    // the 3-row output layer: V3 via the coefficient form of tbl_sum, its bias via column sums (both accumulate into zeros);
+    // the partial images only cover V0..V2 -- reduce exactly that prefix so V3/B3 are not overwritten with garbage
+    SC_TRY(sc_partial_reduce(partial, RB_PARTS, rs, RgbPack::V3, g_rgb_pack, stream_));
+    {
+        const float* xs[1] = {rr + 2 * T};
+        float* outs[1] = {g_rgb_pack + RgbPack::V3};
+        SC_TRY(sc_tbl_sum(xs, 1, gy3, P, P, 1, outs, stream_));
+    }
+    hipLaunchKernelGGL(rb_colsum_kernel, dim3(512), dim3(256), 0, st, gy3, (size_t)P, 3, 3, g_rgb_pack + RgbPack::B3);
+    // ---------------- SDF network (first and second order) ----------------
+    SC_TRY(sc_sdf_backward(points, sdf_pack, P, symmetric, stash_a, stash_p, g_sdf, g_grad, g_feat, gpts_sdf, ga, gp, r0, stream_));
+    hipMemsetAsync(g_cbias, 0, (size_t)5 * n_images * 64 * 4, st);       // [5][n_images][64]
+    hipMemsetAsync(g_sdf_pack, 0, (size_t)SdfPack::TOTAL * 4, st);
+    const int ss = SdfPack::TOTAL;
+    const float* w5row = sdf_pack + SdfPack::W5;
+    auto A = [&](int l) { return stash_a + (size_t)l * T; };
+    auto Pp = [&](int l) { return stash_p + (size_t)l * T; };
+    auto GA = [&](int l) { return ga + (size_t)l * T; };
+    auto GP = [&](int l) { return gp + (size_t)l * T; };
+    auto two = [&](const float* a0, const float* b0, int bop0, const float* a1p, const float* a1a, int aop1, const float* b1, int bop1,
+                   int nb0, int off, int ld, float* rowsum) {
+        return sc_wgrad(2, a0, nullptr, W_OP_PLAIN, b0, bop0, nullptr, W_OP_NONE, a1p, a1a, aop1, b1, bop1, nullptr, W_OP_NONE, points, g_grad,
+                        w5row, P, symmetric, nb0, 0, partial, RB_PARTS, ss, off, ld, rowsum, npi, n_images, stream_);
+    };
+    SC_TRY(two(GA(0), nullptr, W_OP_PE, Pp(0), A(0), W_OP_Q, nullptr, W_OP_EPS, 48, SdfPack::W0, 48, g_cbias));
+    for (int l = 1; l <= 2; ++l) {
+        const int off = l == 1 ? SdfPack::W1 : SdfPack::W2;
+        SC_TRY(two(GA(l), A(l - 1), W_OP_SP, Pp(l), A(l), W_OP_Q, GP(l - 1), W_OP_PLAIN, 64, off, 112, g_cbias + (size_t)l * n_images * 64));
+        SC_TRY(two(GA(l), nullptr, W_OP_PE, Pp(l), A(l), W_OP_Q, nullptr, W_OP_EPS, 48, off + 64, 112, nullptr));
+    }
+    SC_TRY(two(GA(3), A(2), W_OP_SP, Pp(3), A(3), W_OP_Q, GP(2), W_OP_PLAIN, 64, SdfPack::W3, 64, g_cbias + (size_t)3 * n_images * 64));
+    SC_TRY(two(GA(4), A(3), W_OP_SP, nullptr, A(4), W_OP_Q4, GP(3), W_OP_PLAIN, 64, SdfPack::W4, 64, g_cbias + (size_t)4 * n_images * 64));
+    SC_TRY(sc_wgrad(1, g_feat, nullptr, W_OP_PLAIN, A(4), W_OP_SP, nullptr, W_OP_NONE, nullptr, nullptr, W_OP_NONE, nullptr, W_OP_NONE, nullptr,
+                    W_OP_NONE, points, g_grad, w5row, P, symmetric, 64, 0, partial, RB_PARTS, ss, SdfPack::W5 + 64, 64, nullptr, 0, 0, stream_));
+    // every region of the image up to B5 is now covered by some launch except W5 row 0 (written below): reduce, then fix row 0
+    SC_TRY(sc_partial_reduce(partial, RB_PARTS, ss, SdfPack::B5, g_sdf_pack, stream_));
+    hipMemsetAsync(g_sdf_pack + SdfPack::W5, 0, 64 * 4, st);
+    hipMemsetAsync(tot, 0, 2 * 64 * 4, st);
+    {
+        const float* xs[2] = {r0, g_feat};
+        float* outs[2] = {g_sdf_pack + SdfPack::W5, g_sdf_pack + SdfPack::B5 + 1};     // W5 row 0 ; feature biases
+        SC_TRY(sc_tbl_sum(xs, 2, nullptr, P, P, 1, outs, stream_));
+    }
+    hipLaunchKernelGGL(rb_colsum_kernel, dim3(512), dim3(256), 0, st, g_sdf, (size_t)P, 1, 1, g_sdf_pack + SdfPack::B5);
+    // ---------------- points -> camera ----------------
+    hipLaunchKernelGGL(rb_add_kernel, dim3(2048), dim3(256), 0, st, gpts_sdf, gpts_rgb, (size_t)3 * P);
+    if (G_z_extra) hipLaunchKernelGGL(rb_add_kernel, dim3(1024), dim3(256), 0, st, g_z, G_z_extra, (size_t)n_rays * 64);
+    SC_TRY(sc_ray_sample_backward(ray_dirs, z_vals, gpts_sdf, g_z, n_rays, rays_per_image, n_images, cam_dist, g_cam_loc, g_ray_dirs,
+                                  g_scale_dist, stream_));
+#undef SC_TRY
+    return (int)hipGetLastError();
+}

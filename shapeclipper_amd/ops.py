@@ -340,7 +340,7 @@ def render_forward(cam_loc, ray_dirs, depth_fac, scale_dist, u, sdf_pack, sdf_cb
         c_int(scale_dist.shape[0]), c_int(1 if symmetric else 0), ctypes.c_float(cam_dist), ctypes.c_float(beta_min),
         ctypes.c_float(bgcolor), ctypes.c_float(normal_pow), _lib.ptr(out["rgb"]), _lib.ptr(out["mask"]), _lib.ptr(out["mask_hard"]),
         _lib.ptr(out["depth"]), _lib.ptr(out["normal"]), _lib.ptr(z), _lib.ptr(pts), _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(feat),
-        _lib.ptr(_sdf_scratch(dev)), _lib.stream())
+        _lib.ptr(_sdf_scratch(dev)), None, None, None, _lib.stream())
     _lib.check(code, "sc_render_forward")
     out.update(z_vals=z, points=pts)
     return out

@@ -8,7 +8,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "shapeclipper_hip.h")).read()
-    return sorted(set(re.findall(r"^int (sc_\w+)\(", text, flags=re.M)))
+    return sorted(set(re.findall(r"^(?:int|long long) (sc_\w+)\(", text, flags=re.M)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     cdll = ctypes.CDLL(_lib.LIB_PATH)          # loads without a GPU; no compute calls here
     for n in names:
         assert hasattr(cdll, n), n
-    assert sorted(_lib.SYMBOLS) == names, (sorted(_lib.SYMBOLS), names)
+    assert sorted(_lib.SYMBOLS + _lib.SYMBOLS_OTHER) == names, (sorted(_lib.SYMBOLS + _lib.SYMBOLS_OTHER), names)
 
 
 def test_product_fails_loudly_without_device_tensors():
