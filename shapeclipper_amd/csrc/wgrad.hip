@@ -173,11 +173,11 @@ __device__ __forceinline__ void term_load(const WgradTerm& T, int tile, int i, i
 
 template <int A, int B0, int B1, int NT0, int NNT>
 __device__ __forceinline__ void term_compute(const TermRaw<A, B0, B1, NT0, NNT>& R, const PeLane& P, const float* w5row, int i,
-                                             bool valid, f32x4 (&acc)[NT][NNT], float* rowsum = nullptr) {
+                                             bool valid, f32x4 (&acc)[NT][NNT], float (&rowsum)[NT], bool want_rowsum) {
     float4 af[NT], bf[NNT];
 #pragma unroll
     for (int m = 0; m < NT; ++m) af[m] = wg_cook<A>(R.a0[m], R.a1[m], w5row, m, i, valid);
-    if (rowsum) {      // channel 16m + i of this lane, its 4 points of the tile
+    if (want_rowsum) {      // channel 16m + i of this lane, its 4 points of the tile (array by reference: stays in registers)
 #pragma unroll
         for (int m = 0; m < NT; ++m) rowsum[m] += (af[m].x + af[m].y) + (af[m].z + af[m].w);
     }
@@ -274,8 +274,8 @@ __global__ __launch_bounds__(256, WPS) void wgrad_kernel(WgradArgs a) {
         }
         PeLane P;
         if constexpr (need_pe) pe_lane_setup(P, a.points, a.g_grad, need_eps, tile, i, g, a.n_points, a.symmetric != 0);
-        term_compute(c0, P, a.w5row, i, valid, acc, want_rs ? rsum : nullptr);
-        if constexpr (A1 != OP_NONE) term_compute(c1, P, a.w5row, i, valid, acc);
+        term_compute(c0, P, a.w5row, i, valid, acc, rsum, want_rs);
+        if constexpr (A1 != OP_NONE) term_compute(c1, P, a.w5row, i, valid, acc, rsum, false);
     }
     if (want_rs) flush_rowsum();
     // combine the four waves of the workgroup in LDS, then one partial image per workgroup
