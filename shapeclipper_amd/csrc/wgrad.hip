@@ -88,11 +88,13 @@ __device__ __forceinline__ void wg_raw(const float* x0, const float* x1, int til
     r0 = make_float4(0.f, 0.f, 0.f, 0.f);
     r1 = r0;
     const int grp = 4 * T + (i >> 2), pt = 4 * g + (i & 3);
-    if (valid) {
-        if constexpr (op == OP_PLAIN || op == OP_SP) r0 = wg_load4(x0, tile, grp, pt);
-        if constexpr (op == OP_Q) { r0 = wg_load4(x0, tile, grp, pt); r1 = wg_load4(x1, tile, grp, pt); }
-        if constexpr (op == OP_Q4) r1 = wg_load4(x1, tile, grp, pt);
-    }
+    // TBL64 tensors are allocated in whole 16-point tiles, so the load is always in bounds; points past n_points are
+    // zeroed after the transform (wg_cook).  Unconditional loads keep the loop body one basic block (a per-lane branch
+    // around each of the ~40 loads of a tile cost more than the loads).
+    (void)valid;
+    if constexpr (op == OP_PLAIN || op == OP_SP) r0 = wg_load4(x0, tile, grp, pt);
+    if constexpr (op == OP_Q) { r0 = wg_load4(x0, tile, grp, pt); r1 = wg_load4(x1, tile, grp, pt); }
+    if constexpr (op == OP_Q4) r1 = wg_load4(x1, tile, grp, pt);
 }
 // transform + quad transpose: x..w = K-steps 0..3 (points 4g..4g+3) of channel 16T + i
 template <int op>
