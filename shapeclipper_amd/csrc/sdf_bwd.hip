@@ -100,16 +100,17 @@ __global__ __launch_bounds__(64 * SDFB_WAVES) void sdf_bwd_kernel(SdfBwdArgs a) 
             float gam[3] = {0.f, 0.f, 0.f};
             if (valid) { gam[0] = a.g_grad[(size_t)pt * 3]; gam[1] = a.g_grad[(size_t)pt * 3 + 1]; gam[2] = a.g_grad[(size_t)pt * 3 + 2]; }
             f32x4 acc[NT];
-            float av[ACT_STEPS], pv[ACT_STEPS], gq[ACT_STEPS], gpv[ACT_STEPS];
+            float avA[ACT_STEPS], pvA[ACT_STEPS], avB[ACT_STEPS], pvB[ACT_STEPS], gq[ACT_STEPS], gpv[ACT_STEPS];
             float eps[PE_STEPS];
 #pragma unroll
             for (int j = 0; j < PE_STEPS; ++j) eps[j] = gam[j >> 2] * d1[j];
-// the stash loads of layer L are issued BEFORE the layer's MFMAs (they do not depend on them) and consumed after
-#define SC_R_LOAD(L)                                                                        \
+// the stash loads of layer L are issued one layer ahead (before the element-wise step of layer L-1 and the MFMAs of
+// layer L; two register buffers A/B) and consumed after the MFMAs of layer L
+#define SC_R_LOAD(L, av, pv)                                                                \
             tbl_load(a.stash_a + (size_t)(L) * tbl, tile, p, g, av);                         \
             tbl_load(a.stash_p + (size_t)(L) * tbl, tile, p, g, pv);                         \
             __builtin_amdgcn_sched_barrier(0);
-#define SC_R_STEP(L, WE, LD, HAS_PE)                                                        \
+#define SC_R_STEP(L, WE, LD, HAS_PE, av, pv)                                                \
             acc_to_regs(acc, gq);                                                            \
             {                                                                                \
                 float pn[ACT_STEPS];                                                         \
@@ -126,28 +127,28 @@ __global__ __launch_bounds__(64 * SDFB_WAVES) void sdf_bwd_kernel(SdfBwdArgs a) 
             }                                                                                \
             if (HAS_PE && a.g_points) { SC_PE_DOT(WE, LD, pv, d2, gam[c]) }
             acc_zero(acc);
-            SC_R_LOAD(0)
+            SC_R_LOAD(0, avA, pvA)
+            SC_R_LOAD(1, avB, pvB)
             mm_pe<SdfLds::LD0, NT, 0, PE_STEPS>(w0, eps, acc);                 // Gq0
-            SC_R_STEP(0, w0, SdfLds::LD0, true)
+            SC_R_STEP(0, w0, SdfLds::LD0, true, avA, pvA)
             acc_zero(acc);
-            SC_R_LOAD(1)
+            SC_R_LOAD(2, avA, pvA)
             mm_act<SdfLds::LD1, NT>(w1h, gpv, acc);
             mm_pe<SdfLds::LD1, NT, 0, PE_STEPS>(w1e, eps, acc);                // Gq1
-            SC_R_STEP(1, w1e, SdfLds::LD1, true)
+            SC_R_STEP(1, w1e, SdfLds::LD1, true, avB, pvB)
             acc_zero(acc);
-            SC_R_LOAD(2)
+            SC_R_LOAD(3, avB, pvB)
             mm_act<SdfLds::LD1, NT>(w2h, gpv, acc);
             mm_pe<SdfLds::LD1, NT, 0, PE_STEPS>(w2e, eps, acc);                // Gq2
-            SC_R_STEP(2, w2e, SdfLds::LD1, true)
-            acc_zero(acc);
-            SC_R_LOAD(3)
-            mm_act<SdfLds::LD3, NT>(w3, gpv, acc);                             // Gq3
-            SC_R_STEP(3, w3, SdfLds::LD3, false)
-#undef SC_R_STEP
-#undef SC_R_LOAD
+            SC_R_STEP(2, w2e, SdfLds::LD1, true, avA, pvA)
             acc_zero(acc);
             tbl_load(a.stash_a + 4 * tbl, tile, p, g, j_av);
             __builtin_amdgcn_sched_barrier(0);
+            mm_act<SdfLds::LD3, NT>(w3, gpv, acc);                             // Gq3
+            SC_R_STEP(3, w3, SdfLds::LD3, false, avB, pvB)
+#undef SC_R_STEP
+#undef SC_R_LOAD
+            acc_zero(acc);
             mm_act<SdfLds::LD3, NT>(w4, gpv, acc);                             // Gq4
             acc_to_regs(acc, gq);
 #pragma unroll
