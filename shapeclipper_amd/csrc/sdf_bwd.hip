@@ -175,7 +175,12 @@ __global__ __launch_bounds__(64 * SDFB_WAVES) void sdf_bwd_kernel(SdfBwdArgs a) 
         }
         const float Gs = (valid && a.g_sdf) ? a.g_sdf[pt] : 0.f;
         f32x4 acc[NT];
-        float av[ACT_STEPS], pv[ACT_STEPS], gav[ACT_STEPS];
+        float av[ACT_STEPS], pv[ACT_STEPS], avB[ACT_STEPS], pvB[ACT_STEPS], gav[ACT_STEPS];
+// a_L and the parked pend_L are requested one layer ahead of their use (two register buffers)
+#define SC_V_LOAD(L, av, pv)                                                                \
+        tbl_load(a.stash_a + (size_t)(L) * tbl, tile, p, g, av);                             \
+        if (HAS_GG) tbl_load(a.ga + (size_t)(L) * tbl, tile, p, g, pv);                      \
+        __builtin_amdgcn_sched_barrier(0);
         acc_zero(acc);
         if (a.g_feat) {
             float gf[ACT_STEPS];
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(64 * SDFB_WAVES) void sdf_bwd_kernel(SdfBwdArgs a) 
             float r0v[ACT_STEPS];
 #pragma unroll
             for (int s = 0; s < ACT_STEPS; ++s) {
-                const float a4 = HAS_GG ? j_av[s] : av[s];
+                const float a4 = HAS_GG ? j_av[s] : av[s];      /* (av is free again after this block) */
                 float t, r;
                 softplus_parts(a4, t, r);
                 const float gh = acc[s >> 2][s & 3] + w5s[kp(s)] * Gs;
@@ -197,11 +202,8 @@ __global__ __launch_bounds__(64 * SDFB_WAVES) void sdf_bwd_kernel(SdfBwdArgs a) 
             tbl_store(a.r0, tile, p, g, r0v);
             tbl_store(a.ga + 4 * tbl, tile, p, g, gav);
         }
-#define SC_V_STEP(L, WT, LD)                                                                \
+#define SC_V_STEP(L, WT, LD, av, pv)                                                        \
         acc_zero(acc);                                                                       \
-        tbl_load(a.stash_a + (size_t)(L) * tbl, tile, p, g, av);                             \
-        if (HAS_GG) tbl_load(a.ga + (size_t)(L) * tbl, tile, p, g, pv);                      \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
         mm_act_t<LD, NT>(WT, gav, acc);                                                      \
         _Pragma("unroll") for (int s = 0; s < ACT_STEPS; ++s) {                               \
             float t, r;                                                                      \
@@ -209,14 +211,19 @@ __global__ __launch_bounds__(64 * SDFB_WAVES) void sdf_bwd_kernel(SdfBwdArgs a) 
             gav[s] = acc[s >> 2][s & 3] * softplus_d1(av[s], t, r) + (HAS_GG ? pv[s] : 0.f); \
         }                                                                                    \
         tbl_store(a.ga + (size_t)(L) * tbl, tile, p, g, gav);
-        SC_V_STEP(3, w4t, SdfLds::LD3)
-        SC_V_STEP(2, w3t, SdfLds::LD3)
+        SC_V_LOAD(3, av, pv)
+        SC_V_LOAD(2, avB, pvB)
+        SC_V_STEP(3, w4t, SdfLds::LD3, av, pv)
+        SC_V_LOAD(1, av, pv)
+        SC_V_STEP(2, w3t, SdfLds::LD3, avB, pvB)
+        SC_V_LOAD(0, avB, pvB)
         SC_PE_DOT(w2e, SdfLds::LD1, gav, d1, 1.f)
-        SC_V_STEP(1, w2t, SdfLds::LD1)
+        SC_V_STEP(1, w2t, SdfLds::LD1, av, pv)
         SC_PE_DOT(w1e, SdfLds::LD1, gav, d1, 1.f)
-        SC_V_STEP(0, w1t, SdfLds::LD1)
+        SC_V_STEP(0, w1t, SdfLds::LD1, avB, pvB)
         SC_PE_DOT(w0, SdfLds::LD0, gav, d1, 1.f)
 #undef SC_V_STEP
+#undef SC_V_LOAD
 #undef SC_PE_DOT
         if (a.g_points) {
             const float o0 = group_sum(gx[0]), o1 = group_sum(gx[1]), o2 = group_sum(gx[2]);
