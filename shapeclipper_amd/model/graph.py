@@ -42,6 +42,7 @@ def rotation_from_trig(trig_azim, trig_elev, trig_theta):
 
 
 _PERM_CACHE = {}
+_SIDE_STREAMS = {}
 
 
 def _axis_permute(device):
@@ -112,6 +113,10 @@ class Graph(nn.Module):
         if use_NN:
             self.forward_NN(opt, var, views=views)
 
+        # the shared weight images are only valid inside this forward pass: drop them (they carry autograd history and
+        # must not end up in a deepcopy / pickle of the module)
+        self.sdf_network.begin_step(False)
+        self.rgb_network.begin_step(False)
         if get_loss:
             return var, self.compute_loss(opt, var, training)
         return var
@@ -198,11 +203,13 @@ class Graph(nn.Module):
         if mirrored:
             var.estim_flip = part(len(images))
 
-    def _side_stream(self, device):
-        streams = self.__dict__.setdefault("_streams", {})
-        if device not in streams:
-            streams[device] = torch.cuda.Stream(device=device)
-        return streams[device]
+    @staticmethod
+    def _side_stream(device):
+        """Second HIP stream of a device (process-wide: module attributes must stay deep-copyable / picklable)."""
+        key = str(device)
+        if key not in _SIDE_STREAMS:
+            _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+        return _SIDE_STREAMS[key]
 
     def forward_NN(self, opt, var, training=True, idx_NN=None, views=None):
         B = len(var.idx)

@@ -40,6 +40,10 @@ def test_two_training_iterations():
     moved = {n.split(".")[0] for n, p in g.named_parameters() if not torch.equal(p.detach(), before[n])}
     assert {"estimator", "sdf_network", "rgb_network", "renderer", "encoder", "latent_proj_shape", "latent_proj_rgb"} <= moved
     assert not torch.equal(g.renderer.density.beta.detach(), before["renderer.density.beta"])     # beta is trained by the HIP backward
+    import copy, pickle
+    clone = copy.deepcopy(runner.graph)            # no autograd history / stream objects left hanging on the modules
+    assert set(clone.state_dict().keys()) == set(runner.graph.state_dict().keys())
+    pickle.dumps(runner.graph.state_dict())
 
 
 def test_batched_encoder_passes_equal_sequential_passes():
