@@ -188,7 +188,7 @@ def main():
                                parallelism="dp%d" % world),
                    roofline=roofline, host_enqueue_ms_per_step=round(host_dt / a.steps * 1e3, 3),
                    hip_ms_per_step={k: round(v["total_ms"] / a.steps, 3) for k, v in sorted(per.items())})
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks must not wait ~25 s for rank 0)
             out["cpu_baseline"] = cpu_baseline(a.cpu_batch)
         print(json.dumps(out))
     if world > 1:
