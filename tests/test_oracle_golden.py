@@ -132,3 +132,27 @@ def test_g10_eval3d(golden):
     g2 = golden("g2_networks")
     lvl = R.level_grid(R.Cfg(), _W(g2, "pert.sdf."), t("z_sdf"), t("grid"))
     assert torch.allclose(lvl, t("level"), atol=1e-6)
+
+
+def test_config0_pretrain_plumbing_on_cpu():
+    """BASELINE config[0] (the reference's CPU-runnable case): sphere-SDF pre-training of the conditional SDF MLP
+    (reference model/pretrainer.py:160-176: MSE(sdf(x | z), |x| - radius) on uniform points) for a few Adam steps through
+    the CPU restatement.  The product itself has no CPU path (HIP entry points raise on host tensors); this is the
+    checker running the same plumbing: geometric init starts near a sphere and the loss goes down."""
+    import torch
+    from oracle import reference_ops as R
+    cfg = R.Cfg()
+    W = {k: v.clone().requires_grad_(True) for k, v in R.init_sdf_weights(cfg, 0).items()}
+    g = torch.Generator().manual_seed(0)
+    z = (torch.randn(1, 64, generator=g) * 0.1)
+    optim = torch.optim.Adam(list(W.values()), lr=1e-3)
+    losses = []
+    for _ in range(6):
+        pts = torch.rand(10000, 3, generator=g) * 2 - 1                      # pre.sample_range, 10 000 points, 1 image
+        sdf = R.sdf_conditional(cfg, W, 1, pts, z, compute_grad=False)[0]
+        loss = ((sdf - (pts.norm(dim=-1, keepdim=True) - 0.5)) ** 2).mean()
+        optim.zero_grad()
+        loss.backward()
+        optim.step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < 0.7 * losses[0], losses
