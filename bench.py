@@ -179,6 +179,17 @@ def main():
                         unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
                         launch_ms=round(mean_big, 4), points_per_launch=n_pts_main,
                         flops_per_point=FLOPS_PER_POINT[dom])
+        # second roofline: the weight-gradient GEMMs (largest hand-written time share, HBM-bound by design): the 12 launches
+        # of a main render read 37 TBL64 operand tensors of 256 B/point (counted from ops.sdf_backward /
+        # ops.rgb_composite_backward: W0 3, W1 5+3, W2 5+3, W3 5, W4 4, W5f 2; V0 1+2, V1 2, V2 2)
+        roofline_wgrad = None
+        if "sc_wgrad" in timing:
+            wd = sorted([s.elapsed_time(e) for s, e, _ in timing["sc_wgrad"]], reverse=True)[:24 * a.steps]
+            per_render_ms = sum(wd) / (2 * a.steps)
+            gbs = 37 * 256.0 * n_pts_main / (per_render_ms * 1e-3) / 1e9
+            roofline_wgrad = dict(kernel="sc_wgrad (12 launches of a main render)", bound="hbm", achieved=round(gbs, 1),
+                                  peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4),
+                                  ms_per_render=round(per_render_ms, 4), bytes_per_point=37 * 256)
         out = dict(metric="train-step images/sec (Pix3D cfg, bs32/GPU)", value=round(a.batch * world / (dt / a.steps), 2),
                    unit="images/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
@@ -186,7 +197,7 @@ def main():
                                         "(input + CLIP-NN view) + eikonal, ResNet-34 encoder + ResNet-18 estimator, Adam",
                                global_batch=a.batch * world, rays_per_image=opt.render.rand_sample, samples_per_ray=64,
                                parallelism="dp%d" % world),
-                   roofline=roofline, host_enqueue_ms_per_step=round(host_dt / a.steps * 1e3, 3),
+                   roofline=roofline, roofline_wgrad=roofline_wgrad, host_enqueue_ms_per_step=round(host_dt / a.steps * 1e3, 3),
                    hip_ms_per_step={k: round(v["total_ms"] / a.steps, 3) for k, v in sorted(per.items())})
         if not a.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks must not wait ~25 s for rank 0)
             out["cpu_baseline"] = cpu_baseline(a.cpu_batch)
