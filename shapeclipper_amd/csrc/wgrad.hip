@@ -136,8 +136,10 @@ __device__ __forceinline__ void pe_lane_setup(PeLane& P, const float* points, co
         if (symmetric) x[0] = fabsf(x[0]);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
+            // hardware sin/cos (|error| ~ 1e-6 for these |arguments| <= 64): the weight gradient is a sum over ~1e6
+            // points whose fp32 accumulation noise is larger; the accurate sincosf cost more than the MFMAs of this launch
             float sn, cs;
-            sincosf(x[c] * f, &sn, &cs);
+            __sincosf(x[c] * f, &sn, &cs);
             const float val = raw ? (first ? x[c] : 0.f) : (iscos ? cs : sn);
             const float der = raw ? (first ? 1.f : 0.f) : (iscos ? -f * sn : f * cs);
             P.pe[c][s] = valid ? val : 0.f;
