@@ -119,14 +119,14 @@ struct PeLane {
 };
 
 __device__ __forceinline__ void pe_lane_setup(PeLane& P, const float* points, const float* g_grad, bool want_eps,
-                                              int tile, int j, int g, int n_points, bool symmetric) {
+                                              int tile, int j, int g, int n_points, bool symmetric, bool full) {
     const int step = j >> 2, gq = j & 3;
     const bool raw = gq == 3, first = step == 0, iscos = step & 1;
     const float f = raw ? 0.f : (float)(1 << (2 * gq + (step >> 1)));
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int gp = tile * TP + 4 * g + s;
-        const bool valid = gp < n_points;
+        const bool valid = full || gp < n_points;
         float x[3] = {0.f, 0.f, 0.f}, gm[3] = {0.f, 0.f, 0.f};
         if (valid) {
             x[0] = points[(size_t)gp * 3]; x[1] = points[(size_t)gp * 3 + 1]; x[2] = points[(size_t)gp * 3 + 2];
@@ -209,7 +209,8 @@ __device__ __forceinline__ void term_compute(const TermRaw<A, B0, B1, NT0, NNT>&
 }
 
 // NT0: N tiles of B segment 0.  Term 0 = (A0; B00 | B10), optional term 1 = (A1; B01 | B11) (A1 == OP_NONE: absent).
-template <int NNT, int NT0, int WPS, int A0, int B00, int B10, int A1, int B01, int B11>
+// FULL: n_points is a multiple of 16 (always the case for renders: 64 samples per ray) -- no per-point validity masks.
+template <int NNT, int NT0, int WPS, int A0, int B00, int B10, int A1, int B01, int B11, bool FULL>
 __global__ __launch_bounds__(256, WPS) void wgrad_kernel(WgradArgs a) {
     __shared__ float red[64 * 16 * NNT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(256, WPS) void wgrad_kernel(WgradArgs a) {
     for (; tile < tile_end; tile += step) {
         c0 = n0;
         if constexpr (A1 != OP_NONE) c1 = n1;
-        const bool valid = nvalid;
+        const bool valid = FULL ? true : nvalid;
         const int next = tile + step;
         if (next < tile_end) {
             nvalid = next * TP + 4 * g + (i & 3) < a.n_points;
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256, WPS) void wgrad_kernel(WgradArgs a) {
             }
         }
         PeLane P;
-        if constexpr (need_pe) pe_lane_setup(P, a.points, a.g_grad, need_eps, tile, i, g, a.n_points, a.symmetric != 0);
+        if constexpr (need_pe) pe_lane_setup(P, a.points, a.g_grad, need_eps, tile, i, g, a.n_points, a.symmetric != 0, FULL);
         term_compute(c0, P, a.w5row, i, valid, acc, rsum, want_rs);
         if constexpr (A1 != OP_NONE) term_compute(c1, P, a.w5row, i, valid, acc, rsum, false);
     }
@@ -402,7 +403,10 @@ int sc_wgrad(int nterms,
 #define SC_WG(NNT, NT0, WPS, A0, B00, B10, A1, B01, B11)                                                         \
     if (nb0 == 16 * NT0 && nb0 + nb1 == 16 * NNT && key0 == A0 * 100 + B00 * 10 + B10 &&                         \
         key1 == (A1 == OP_NONE ? 0 : A1 * 100 + B01 * 10 + B11)) {                                               \
-        hipLaunchKernelGGL((wgrad_kernel<NNT, NT0, WPS, A0, B00, B10, A1, B01, B11>), dim3(nparts), dim3(256), 0, st, a); \
+        if (n_points % TP == 0)                                                                                  \
+            hipLaunchKernelGGL((wgrad_kernel<NNT, NT0, WPS, A0, B00, B10, A1, B01, B11, true>), dim3(nparts), dim3(256), 0, st, a); \
+        else                                                                                                     \
+            hipLaunchKernelGGL((wgrad_kernel<NNT, NT0, WPS, A0, B00, B10, A1, B01, B11, false>), dim3(nparts), dim3(256), 0, st, a); \
         return (int)hipGetLastError();                                                                           \
     }
     SC_WG(3, 3, 2, OP_PLAIN, OP_PE, OP_NONE, OP_Q, OP_EPS, OP_NONE)         // dW0e, dW1e, dW2e
