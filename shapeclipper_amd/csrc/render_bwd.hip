@@ -101,8 +101,10 @@ extern "C" int sc_render_backward(
     hipMemsetAsync(g_dbias, 0, (size_t)3 * n_images * 64 * 4, st);       // [3][n_images][64]
     hipMemsetAsync(g_rgb_pack, 0, (size_t)RgbPack::TOTAL * 4, st);
     const int rs = RgbPack::TOTAL;
-    SC_TRY(wgrad1(gy, nullptr, W_OP_PE, points, P, symmetric, 48, partial, rs, RgbPack::V0, 112, g_dbias, npi, n_images, stream_));
-    SC_TRY(wgrad1(gy, feat, W_OP_PLAIN, points, P, symmetric, 64, partial, rs, RgbPack::V0 + 48, 112, nullptr, 0, 0, stream_));
+    // V0 = [PE 48 | sdf feature 64] in one pass over Gy0
+    SC_TRY(sc_wgrad(1, gy, nullptr, W_OP_PLAIN, nullptr, W_OP_PE, feat, W_OP_PLAIN, nullptr, nullptr, W_OP_NONE, nullptr, W_OP_NONE, nullptr,
+                    W_OP_NONE, points, nullptr, nullptr, P, symmetric, 48, 64, partial, RB_PARTS, rs, RgbPack::V0, 112, g_dbias, npi, n_images,
+                    stream_));
     SC_TRY(wgrad1(gy + T, rr, W_OP_PLAIN, points, P, symmetric, 64, partial, rs, RgbPack::V1, 64, g_dbias + (size_t)n_images * 64, npi, n_images, stream_));
     SC_TRY(wgrad1(gy + 2 * T, rr + T, W_OP_PLAIN, points, P, symmetric, 64, partial, rs, RgbPack::V2, 64, g_dbias + (size_t)2 * n_images * 64, npi, n_images, stream_));
     // the 3-row output layer: V3 via the coefficient form of tbl_sum, its bias via column sums (both accumulate into zeros);

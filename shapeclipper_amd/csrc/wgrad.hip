@@ -415,6 +415,7 @@ int sc_wgrad(int nterms,
     SC_WG(4, 4, 2, OP_PLAIN, OP_SP, OP_NONE, OP_Q4, OP_PLAIN, OP_NONE)      // dW4
     SC_WG(4, 4, 2, OP_PLAIN, OP_SP, OP_NONE, OP_NONE, OP_NONE, OP_NONE)     // dW5 feature rows, no-Gg variants
     SC_WG(4, 4, 2, OP_PLAIN, OP_PLAIN, OP_NONE, OP_NONE, OP_NONE, OP_NONE)  // dV0f, dV1, dV2
+    SC_WG(7, 3, 2, OP_PLAIN, OP_PE, OP_PLAIN, OP_NONE, OP_NONE, OP_NONE)    // dV0 = [PE 48 | feature 64] in one pass over Gy0
 #undef SC_WG
     return (int)hipErrorInvalidValue;   // operand combination not instantiated
 }

@@ -238,8 +238,8 @@ def rgb_composite_backward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, d
     npi = rays_per_image * 64
     g_d3 = torch.zeros(3, n_images, 64, **f32)
     rs = lambda l: (g_d3[l], npi, n_images)
-    _wgrad(lib, [(GY(0), None, OP_PLAIN, None, OP_PE, None, OP_NONE)], *common, 48, 0, partial, stride, RGB_OFF["V0"], 112, *rs(0))
-    _wgrad(lib, [(GY(0), None, OP_PLAIN, feat, OP_PLAIN, None, OP_NONE)], *common, 64, 0, partial, stride, RGB_OFF["V0"] + 48, 112)
+    # V0 = [PE 48 | sdf feature 64]: one launch (Gy0 is streamed once, 7 N tiles)
+    _wgrad(lib, [(GY(0), None, OP_PLAIN, None, OP_PE, feat, OP_PLAIN)], *common, 48, 64, partial, stride, RGB_OFF["V0"], 112, *rs(0))
     _wgrad(lib, [(GY(1), None, OP_PLAIN, RR(0), OP_PLAIN, None, OP_NONE)], *common, 64, 0, partial, stride, RGB_OFF["V1"], 64, *rs(1))
     _wgrad(lib, [(GY(2), None, OP_PLAIN, RR(1), OP_PLAIN, None, OP_NONE)], *common, 64, 0, partial, stride, RGB_OFF["V2"], 64, *rs(2))
     g_v = torch.zeros(stride, **f32)
