@@ -144,3 +144,34 @@ def test_flat_reducer_path_on_rccl_single_rank():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("flag", ["--hip.two_streams!", "--hip.batched_encoders!", "--hip.fused_loss!", "--hip.fused_adam!", "--hip.device_rng"])
+def test_every_hip_option_has_a_working_alternate_path(flag):
+    """Each fast path of this build can be switched off (README): the step still runs and gives the same loss
+    (device_rng draws different jitter, so only finiteness is compared there)."""
+    from shapeclipper_amd import synthetic
+    from shapeclipper_amd.model.runner import Runner
+    from shapeclipper_amd.utils import options, util
+    from shapeclipper_amd.utils.util import EasyDict as edict
+    losses = []
+    for extra in ([], [flag]):
+        opt = options.set(options.parse_arguments(["--yaml=options/pix3d/config.yaml", "--name=pytest_opts", "--output_root=/tmp/sc_pytest",
+                                                   "--batch_size=2", "--tb!", "--arch.enc_pretrained!"] + extra), verbose=False)
+        opt.device, opt.world_size, opt.port = 0, 1, 0
+        opt.freq.scalar, opt.freq.ckpt_latest = 0, 10 ** 9
+        torch.manual_seed(0)
+        import numpy as np
+        np.random.seed(0)
+        runner = Runner(opt)
+        runner.build_networks(opt)
+        runner.setup_optimizer(opt)
+        runner.graph.train()
+        runner.it, runner.ep, runner.best_val = 1, 0, 0.0
+        runner.timer = edict(start=time.time(), it_mean=None)
+        batch = util.move_to_device(synthetic.make_batch(opt, 2, seed=0), "cuda:0")
+        opt.H, opt.W = opt.image_size
+        losses.append(float(runner.train_iteration(opt, edict(batch), None).all.detach()))
+    assert all(torch.isfinite(torch.tensor(losses)))
+    if flag != "--hip.device_rng":
+        assert abs(losses[1] - losses[0]) < 2e-3 * abs(losses[0]), losses
