@@ -3,7 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import torch
 import chamfer_3D
-for B, N in ((1, 100000), (8, 100000)):
+for B, N in ((1, 100000), (8, 100000), (32, 100000)):
     a = torch.rand(B, N, 3, device="cuda") - 0.5; b = torch.rand(B, N, 3, device="cuda") - 0.5
     d1 = torch.zeros(B, N, device="cuda"); d2 = torch.zeros(B, N, device="cuda")
     i1 = torch.zeros(B, N, dtype=torch.int32, device="cuda"); i2 = torch.zeros(B, N, dtype=torch.int32, device="cuda")

@@ -12,6 +12,7 @@ ap.add_argument("--B", type=int, default=32)
 ap.add_argument("--R", type=int, default=512)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--eval", action="store_true")
+ap.add_argument("--full", type=int, default=0, help="full-frame evaluation render of FULL x FULL pixels (BASELINE config[2]: 128)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 opt = options.set(options.parse_arguments(["--yaml=options/pix3d/config.yaml", "--name=perf", "--output_root=/tmp/sc_perf"]), verbose=False)
@@ -29,6 +30,12 @@ intr = camera.get_intr(opt, torch.ones(B)).to(dev)
 sd = torch.ones(B, device=dev, requires_grad=True)
 zs = torch.randn(B, 64, device=dev, requires_grad=True); zr = torch.randn(B, 64, device=dev, requires_grad=True)
 ray_idx = torch.stack([torch.randperm(224 * 224)[:R] for _ in range(B)]).to(dev)
+
+
+if a.full:
+    a.eval, ray_idx, R = True, None, a.full * a.full
+    opt.H = opt.W = a.full
+    intr = camera.get_intr(opt, torch.ones(B)).to(dev)
 
 
 def step():
