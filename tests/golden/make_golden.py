@@ -20,13 +20,24 @@ import yaml
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
 REF = "/root/reference"
+OUT = os.environ.get("GOLDEN_OUT", HERE)       # tests regenerate into a scratch directory
 sys.path.insert(0, ROOT)
 
 for name in ("termcolor", "vigra", "mcubes", "trimesh", "chamfer_3D"):
-    if name not in sys.modules:
-        sys.modules[name] = types.ModuleType(name)
+    sys.modules[name] = types.ModuleType(name)
 sys.modules["termcolor"].colored = lambda s, **k: s
-sys.path.insert(0, REF)
+
+# The repository root carries drop-in packages `model/` and `utils/` (regular packages with an
+# __init__.py); the reference's directories of the same name are namespace directories, so a plain
+# `import model.implicit` would resolve to the PRODUCT whatever the order of sys.path.  Bind the two
+# package names to the reference directories explicitly and verify every module's origin.
+for pkg in ("model", "utils"):
+    for k in [k for k in sys.modules if k == pkg or k.startswith(pkg + ".")]:
+        del sys.modules[k]
+    m = types.ModuleType(pkg)
+    m.__path__ = [os.path.join(REF, pkg)]
+    m.__package__ = pkg
+    sys.modules[pkg] = m
 
 import utils.camera as ref_camera            # noqa: E402  (reference)
 import utils.util as ref_util                # noqa: E402
@@ -34,6 +45,10 @@ import model.implicit as ref_implicit        # noqa: E402
 import model.renderer as ref_renderer        # noqa: E402
 import model.loss as ref_loss                # noqa: E402
 import utils.eval_3D as ref_eval3d           # noqa: E402
+
+for _m in (ref_camera, ref_util, ref_implicit, ref_renderer, ref_loss, ref_eval3d):
+    assert os.path.realpath(_m.__file__).startswith(REF + os.sep), \
+        "%s was imported from %s, not from the reference" % (_m.__name__, _m.__file__)
 
 from oracle import reference_ops as R        # noqa: E402
 from oracle import chamfer_ref               # noqa: E402
@@ -74,7 +89,7 @@ def save(name, **arrs):
         if isinstance(v, torch.Tensor):
             v = v.detach().numpy()
         out[k] = v
-    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print("wrote", name, sum(np.asarray(v).nbytes for v in out.values()) // 1024, "KiB")
 
 
@@ -342,7 +357,7 @@ def main():
     close(R.level_grid(cfg, Wsdf, z_sdf, grid), lvl, 0, "level grid")
     save("g10_eval3d", dist1=dA, dist2=dB, fscore=fs, pc=pc, pc_normalized=pcn, grid=grid, level=lvl, z_sdf=z_sdf)
 
-    print("all oracle-vs-reference checks passed; fixtures written to", HERE)
+    print("all oracle-vs-reference checks passed; fixtures written to", OUT)
 
 
 if __name__ == "__main__":

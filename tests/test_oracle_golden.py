@@ -1,12 +1,18 @@
 """The CPU oracle (oracle/reference_ops.py, oracle/chamfer_ref.c) against the golden vectors captured
 from the reference's own modules (tests/golden/make_golden.py).  CPU only."""
+import os
+import subprocess
+import sys
+
 import numpy as np
+import pytest
 import torch
 
 from oracle import chamfer_ref
 from oracle import reference_ops as R
 
 T = torch.tensor
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def _W(g, prefix):
@@ -156,3 +162,20 @@ def test_config0_pretrain_plumbing_on_cpu():
         optim.step()
         losses.append(float(loss))
     assert all(np.isfinite(losses)) and losses[-1] < 0.7 * losses[0], losses
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference only exists in the build container")
+def test_golden_recipe_reproduces_committed_fixtures(tmp_path):
+    """tests/golden/make_golden.py imports the reference's OWN modules (it asserts their origin), checks the oracle
+    against them and regenerates G1-G10: the arrays must equal the committed fixtures bit for bit."""
+    script = os.path.join(GOLDEN_DIR, "make_golden.py")
+    env = dict(os.environ, GOLDEN_OUT=str(tmp_path))
+    r = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    made = sorted(p.name for p in tmp_path.glob("*.npz"))
+    assert len(made) == 10, made
+    for name in made:
+        a, b = np.load(tmp_path / name), np.load(os.path.join(GOLDEN_DIR, name))
+        assert set(a.files) == set(b.files), name
+        for k in a.files:
+            assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k], equal_nan=True), (name, k)
