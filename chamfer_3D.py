@@ -14,6 +14,8 @@ C ABI (include/shapeclipper_hip.h); there is no CPU fallback.
 """
 import ctypes
 
+import torch
+
 from shapeclipper_amd import _lib
 
 
@@ -23,13 +25,34 @@ def _dims(xyz1, xyz2):
     return xyz1.shape[0], xyz1.shape[1], xyz2.shape[1]
 
 
+def _check(dev, **tensors):
+    """The C ABI takes raw pointers: a wrong dtype / shape / device would silently corrupt memory.  The reference
+    extension raises on a dtype mismatch (ATen accessor checks, chamfer3D.cu:144-149); so does this."""
+    for name, (t, dtype, shape) in tensors.items():
+        if t.dtype != dtype:
+            raise TypeError("chamfer_3D: %s must be %s, got %s" % (name, dtype, t.dtype))
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError("chamfer_3D: %s must have shape %s, got %s" % (name, tuple(shape), tuple(t.shape)))
+        if t.device != dev:
+            raise ValueError("chamfer_3D: %s is on %s, xyz1 is on %s" % (name, t.device, dev))
+        if not t.is_contiguous():
+            raise ValueError("chamfer_3D: %s must be contiguous" % name)
+
+
 def forward(xyz1, xyz2, dist1, dist2, idx1, idx2):
     lib = _lib.load()
     b, n, m = _dims(xyz1, xyz2)
+    f32, i32 = torch.float32, torch.int32
+    _check(xyz1.device, xyz1=(xyz1, f32, (b, n, 3)), xyz2=(xyz2, f32, (b, m, 3)), dist1=(dist1, f32, (b, n)),
+           dist2=(dist2, f32, (b, m)), idx1=(idx1, i32, (b, n)), idx2=(idx2, i32, (b, m)))
+    with torch.cuda.device(xyz1.device):
+        return _forward(lib, b, n, m, xyz1, xyz2, dist1, dist2, idx1, idx2)
+
+
+def _forward(lib, b, n, m, xyz1, xyz2, dist1, dist2, idx1, idx2):
     blocks = b * ((min(n, m) + 1023) // 1024)
     if 0 < blocks < 1024 and max(n, m) >= 4096:
         # too few workgroups to fill 256 CUs (evaluation: b = 1): split the target cloud over workgroup slices
-        import torch
         nsplit = max(1, min(32, 2048 // blocks))
         ws = torch.empty(b * (n + m), dtype=torch.int64, device=xyz1.device)
         code = lib.sc_chamfer3d_forward_split(_lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(dist1), _lib.ptr(dist2),
@@ -47,8 +70,13 @@ def forward(xyz1, xyz2, dist1, dist2, idx1, idx2):
 def backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2):
     lib = _lib.load()
     b, n, m = _dims(xyz1, xyz2)
-    code = lib.sc_chamfer3d_backward(_lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(gradxyz1), _lib.ptr(gradxyz2),
-                                     _lib.ptr(graddist1), _lib.ptr(graddist2), _lib.ptr(idx1), _lib.ptr(idx2),
-                                     ctypes.c_int(b), ctypes.c_int(n), ctypes.c_int(m), _lib.stream())
+    f32, i32 = torch.float32, torch.int32
+    _check(xyz1.device, xyz1=(xyz1, f32, (b, n, 3)), xyz2=(xyz2, f32, (b, m, 3)), gradxyz1=(gradxyz1, f32, (b, n, 3)),
+           gradxyz2=(gradxyz2, f32, (b, m, 3)), graddist1=(graddist1, f32, (b, n)), graddist2=(graddist2, f32, (b, m)),
+           idx1=(idx1, i32, (b, n)), idx2=(idx2, i32, (b, m)))
+    with torch.cuda.device(xyz1.device):
+        code = lib.sc_chamfer3d_backward(_lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(gradxyz1), _lib.ptr(gradxyz2),
+                                         _lib.ptr(graddist1), _lib.ptr(graddist2), _lib.ptr(idx1), _lib.ptr(idx2),
+                                         ctypes.c_int(b), ctypes.c_int(n), ctypes.c_int(m), _lib.stream())
     _lib.check(code, "sc_chamfer3d_backward")
     return 1

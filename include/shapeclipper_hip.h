@@ -131,12 +131,15 @@ int sc_tbl_sum(const float* const* xs, int n_tensors, const float* coef, int n_p
  * rgb, rgb_t, normal, normal_t [B][R][3]; mask, mask_t [B][R]; eik [B][E] or NULL.
  * normal mask = (mask_t > 0.5) & (mask > 0.5); keep_frac = 1 - reg.normal_tol (double: the cut is
  * int(n * keep_frac) as in loss.py:62).  out4 (zero-filled by the caller) receives
- * (render MSE, IoU + mask_mse*MSE, robust normal loss, eikonal MSE); g_* receive d loss_k / d prediction.
+ * (render MSE, IoU + mask_mse*MSE, robust normal loss, eikonal MSE); g_* receive d loss_k / d prediction;
+ * g_normal_t [B][R][3] (or NULL) receives d normal loss / d normal_t -- the target is
+ * camera.transform_normal(input normal, predicted pose) (graph.py:85,260), so autograd carries it into the estimator.
  * ang_ws: [B*R] floats of workspace.                                                               */
 int sc_loss_fused_forward(const float* rgb, const float* rgb_t, const float* mask, const float* mask_t,
                           const float* normal, const float* normal_t, const float* eik, int B, int R, int E,
                           float normal_l1, float mask_mse, double keep_frac, float* out4, float* g_rgb,
-                          float* g_mask, float* g_normal, float* g_eik, float* ang_ws, void* stream);
+                          float* g_mask, float* g_normal, float* g_eik, float* g_normal_t, float* ang_ws,
+                          void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * CLIP ViT image tower forward (replaces clip_encoder.encode_image, CLIP_anno.py:166; third-party
@@ -150,6 +153,7 @@ int sc_loss_fused_forward(const float* rgb, const float* rgb_t, const float* mas
  *   per layer ln_1 gamma, beta, qkv bias [3D], out_proj bias, ln_2 gamma, beta, fc1 bias [mlp], fc2 bias;
  *   then ln_post gamma, beta.
  * workspace: >= sc_clip_vit_workspace_bytes(...) bytes of device memory.                               */
+long long sc_clip_vit_workspace_bytes(int B, int C, int H, int W, int patch, int D, int mlp);
 int sc_clip_vit_forward(const float* image, int B, int C, int H, int W, int patch, int D, int mlp, int layers,
                         int heads, int proj_dim, const uint16_t* w_bf16, const float* w_f32, float ln_eps,
                         float* out, void* workspace, long long workspace_bytes, void* stream);
@@ -213,9 +217,10 @@ int sc_sdf_grid_forward(const float* sdf_pack, const float* sdf_cbias, float lo,
                         int symmetric, float* points_ws, float* level, void* stream);
 
 /* backward of sc_loss_fused_forward: scales the stored gradients in place by the upstream dL/dloss_k (G4[4],
- * device memory).  g_eik may be NULL.                                                                  */
+ * device memory).  g_eik and g_normal_t (n_normal elements, scaled by G4[2]) may be NULL.              */
 int sc_loss_fused_backward(const float* G4, float* g_rgb, long long n_rgb, float* g_mask, long long n_mask,
-                           float* g_normal, long long n_normal, float* g_eik, long long n_eik, void* stream);
+                           float* g_normal, long long n_normal, float* g_eik, long long n_eik, float* g_normal_t,
+                           void* stream);
 
 /* ---- encoder glue: BatchNorm2d fused with the residual add / ReLU / stem max-pool around it --------
  * Replaces, between the MIOpen convolutions of the reference's torchvision ResNet-18/34 (model/graph.py:52-54,

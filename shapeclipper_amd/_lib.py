@@ -26,7 +26,7 @@ SYMBOLS = (
     "sc_render_backward",
 )
 # entry points that do not return an int status
-SYMBOLS_OTHER = ("sc_render_backward_workspace_bytes",)
+SYMBOLS_OTHER = ("sc_render_backward_workspace_bytes", "sc_clip_vit_workspace_bytes")
 
 _lib: Optional[ctypes.CDLL] = None
 
@@ -61,6 +61,10 @@ class _LibProxy:
             fn = getattr(cdll, name)
             fn.restype = ctypes.c_int
             setattr(self, name, _Timed(name, fn))
+        for name in SYMBOLS_OTHER:          # size queries: long long result, host-only
+            fn = getattr(cdll, name)
+            fn.restype = ctypes.c_longlong
+            setattr(self, name, fn)
 
 
 class HipLibraryMissing(RuntimeError):

@@ -329,6 +329,17 @@ int sc_gemm_bf16(int epi, const uint16_t* A, const uint16_t* Wt, const float* bi
     return sc::launch_gemm(epi, A, Wt, bias, out, M, N, K, (hipStream_t)stream_);
 }
 
+// Bytes of device workspace sc_clip_vit_forward carves for this geometry (same carve order and 256-byte alignment).
+long long sc_clip_vit_workspace_bytes(int B, int C, int H, int W, int patch, int D, int mlp) {
+    const long long np = (long long)(H / patch) * (W / patch), T = np + 1, M = (long long)B * T;
+    const long long Kp = ((long long)C * patch * patch + 63) & ~63LL;
+    const long long sizes[8] = {B * np * Kp * 2, B * np * D * 4, M * D * 4, M * D * 2, M * 3 * D * 2, M * D * 2, M * mlp * 2,
+                                (long long)B * D * 2};
+    long long total = 0;
+    for (long long s : sizes) total += (s + 255) & ~255LL;
+    return total;
+}
+
 // Full image tower.  See include/shapeclipper_hip.h for the weight image layout.
 int sc_clip_vit_forward(const float* image, int B, int C, int H, int W, int patch, int D, int mlp, int layers, int heads,
                         int proj_dim, const uint16_t* w_bf16, const float* w_f32, float ln_eps, float* out,

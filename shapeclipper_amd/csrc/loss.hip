@@ -27,6 +27,7 @@ struct LossArgs {
     double keep_frac;                            // 1 - reg.normal_tol
     float* out;                                  // [4]: render, mask, normal, eikonal (pre-zeroed)
     float* g_rgb; float* g_mask; float* g_normal; float* g_eik;
+    float* g_normal_t;                           // d normal loss / d normal_t (the target is differentiable in the pose) or null
     float* ang_ws;                               // [B*R] workspace (angular error of masked rays)
 };
 
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(1024) void loss_fused_kernel(LossArgs a) {
             }
         }
         if (i < N) {
-            float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+            float g0 = 0.f, g1 = 0.f, g2 = 0.f, h0 = 0.f, h1 = 0.f, h2 = 0.f;
             if (keep) {
                 const float p0 = a.normal[i * 3], p1 = a.normal[i * 3 + 1], p2 = a.normal[i * 3 + 2];
                 const float t0 = a.normal_t[i * 3], t1 = a.normal_t[i * 3 + 1], t2 = a.normal_t[i * 3 + 2];
@@ -188,8 +189,14 @@ __global__ __launch_bounds__(1024) void loss_fused_kernel(LossArgs a) {
                 g0 = (a.normal_l1 * sgn(p0 - t0) - t0) * inv_keep;
                 g1 = (a.normal_l1 * sgn(p1 - t1) - t1) * inv_keep;
                 g2 = (a.normal_l1 * sgn(p2 - t2) - t2) * inv_keep;
+                // the target normal is transform_normal(input normal, predicted pose) (graph.py:85,260): it carries a
+                // gradient into the view estimator: d/dt [l1 |p - t| + 1 - p.t] = -l1 sgn(p - t) - p
+                h0 = (-a.normal_l1 * sgn(p0 - t0) - p0) * inv_keep;
+                h1 = (-a.normal_l1 * sgn(p1 - t1) - p1) * inv_keep;
+                h2 = (-a.normal_l1 * sgn(p2 - t2) - p2) * inv_keep;
             }
             a.g_normal[i * 3] = g0; a.g_normal[i * 3 + 1] = g1; a.g_normal[i * 3 + 2] = g2;
+            if (a.g_normal_t) { a.g_normal_t[i * 3] = h0; a.g_normal_t[i * 3 + 1] = h1; a.g_normal_t[i * 3 + 2] = h2; }
         }
     }
     s_loss = block_sum(s_loss, red);
@@ -201,10 +208,10 @@ __global__ __launch_bounds__(1024) void loss_fused_kernel(LossArgs a) {
 extern "C" int sc_loss_fused_forward(const float* rgb, const float* rgb_t, const float* mask, const float* mask_t,
                                      const float* normal, const float* normal_t, const float* eik, int B, int R, int E,
                                      float normal_l1, float mask_mse, double keep_frac, float* out4, float* g_rgb,
-                                     float* g_mask, float* g_normal, float* g_eik, float* ang_ws, void* stream_) {
+                                     float* g_mask, float* g_normal, float* g_eik, float* g_normal_t, float* ang_ws, void* stream_) {
     if (B <= 0 || R <= 0) return 0;
     sc::LossArgs a{rgb, rgb_t, mask, mask_t, normal, normal_t, eik, B, R, E, normal_l1, mask_mse, keep_frac,
-                   out4, g_rgb, g_mask, g_normal, g_eik, ang_ws};
+                   out4, g_rgb, g_mask, g_normal, g_eik, g_normal_t, ang_ws};
     hipLaunchKernelGGL(sc::loss_fused_kernel, dim3(B + 1), dim3(1024), 0, (hipStream_t)stream_, a);
     return (int)hipGetLastError();
 }

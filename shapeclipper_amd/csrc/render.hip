@@ -89,8 +89,9 @@ __global__ __launch_bounds__(256) void grid_points_kernel(float lo, float hi, in
 }
 
 __global__ __launch_bounds__(256) void scale4_kernel(const float* __restrict__ G, float* g_rgb, size_t n_rgb, float* g_mask, size_t n_mask,
-                                                     float* g_normal, size_t n_normal, float* g_eik, size_t n_eik) {
+                                                     float* g_normal, size_t n_normal, float* g_eik, size_t n_eik, float* g_normal_t) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (g_normal_t && i < n_normal) g_normal_t[i] *= G[2];
     if (i < n_rgb) g_rgb[i] *= G[0];
     if (i < n_mask) g_mask[i] *= G[1];
     if (i < n_normal) g_normal[i] *= G[2];
@@ -151,13 +152,13 @@ int sc_sdf_grid_forward(const float* sdf_pack, const float* sdf_cbias, float lo,
 }
 
 int sc_loss_fused_backward(const float* G4, float* g_rgb, long long n_rgb, float* g_mask, long long n_mask, float* g_normal,
-                           long long n_normal, float* g_eik, long long n_eik, void* stream_) {
+                           long long n_normal, float* g_eik, long long n_eik, float* g_normal_t, void* stream_) {
     long long n = n_rgb > n_normal ? n_rgb : n_normal;
     if (n_mask > n) n = n_mask;
     if (n_eik > n) n = n_eik;
     if (n <= 0) return 0;
     hipLaunchKernelGGL(sc::scale4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, G4, g_rgb,
-                       (size_t)n_rgb, g_mask, (size_t)n_mask, g_normal, (size_t)n_normal, g_eik, (size_t)n_eik);
+                       (size_t)n_rgb, g_mask, (size_t)n_mask, g_normal, (size_t)n_normal, g_eik, (size_t)n_eik, g_normal_t);
     return (int)hipGetLastError();
 }
 

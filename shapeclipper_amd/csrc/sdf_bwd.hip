@@ -251,12 +251,10 @@ extern "C" int sc_sdf_backward(const float* points, const float* w_pack, int n_p
     const size_t lds_bytes = sc::SdfLds::TOTAL * sizeof(float);
     hipStream_t stream = (hipStream_t)stream_;
     if (g_grad) {
-        static bool attr_g = false;
-        if (!attr_g) { (void)hipFuncSetAttribute((const void*)sc::sdf_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_g = true; }
+        (void)hipFuncSetAttribute((const void*)sc::sdf_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);   // per launch: the attribute is per device, no process-wide state
         hipLaunchKernelGGL(sc::sdf_bwd_kernel<true>, dim3(blocks), dim3(64 * sc::SDFB_WAVES), lds_bytes, stream, a);
     } else {
-        static bool attr_v = false;
-        if (!attr_v) { (void)hipFuncSetAttribute((const void*)sc::sdf_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); attr_v = true; }
+        (void)hipFuncSetAttribute((const void*)sc::sdf_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);   // per launch: the attribute is per device, no process-wide state
         hipLaunchKernelGGL(sc::sdf_bwd_kernel<false>, dim3(blocks), dim3(64 * sc::SDFB_WAVES), lds_bytes, stream, a);
     }
     return (int)hipGetLastError();

@@ -86,20 +86,25 @@ class FusedRenderLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rgb, rgb_t, mask, mask_t, normal, normal_t, eik, normal_l1, mask_mse, keep_frac):
-        out, grads = ops.loss_fused_forward(rgb, rgb_t, mask, mask_t, normal, normal_t, eik, normal_l1, mask_mse, keep_frac)
+        # The normal target is transform_normal(input normal, predicted pose): the reference's normal_loss
+        # back-propagates through it into the view estimator (model/loss.py:52-67, model/graph.py:85,260).
+        want_t = ctx.needs_input_grad[5]
+        out, grads = ops.loss_fused_forward(rgb, rgb_t, mask, mask_t, normal, normal_t, eik, normal_l1, mask_mse, keep_frac,
+                                            want_target_grad=want_t)
         ctx.shapes = (rgb.shape, mask.shape, normal.shape, eik.shape if eik is not None else None)
         ctx.save_for_backward(*[g for g in grads if g is not None])
-        ctx.has_eik = eik is not None
+        ctx.has_eik, ctx.has_t = eik is not None, want_t
         return out
 
     @staticmethod
     def backward(ctx, G):
-        saved = ctx.saved_tensors
+        saved = list(ctx.saved_tensors)
         g_rgb, g_mask, g_normal = saved[0], saved[1], saved[2]
         s_rgb, s_mask, s_normal, s_eik = ctx.shapes
         g_eik = (saved[3] * G[3]).view(s_eik) if ctx.has_eik else None
+        g_t = (saved[-1] * G[2]).view(s_normal) if ctx.has_t else None
         return ((g_rgb * G[0]).view(s_rgb), None, (g_mask * G[1]).view(s_mask), None, (g_normal * G[2]).view(s_normal),
-                None, g_eik, None, None, None)
+                g_t, g_eik, None, None, None)
 
 
 class RaySampleFunction(torch.autograd.Function):

@@ -89,11 +89,9 @@ class ClipVisionTower(nn.Module):
 
     def workspace_bytes(self, B):
         c = self.cfg
-        np_ = (c["image_size"] // c["patch"]) ** 2
-        T, D, Kp = np_ + 1, c["width"], (c["channels"] * c["patch"] ** 2 + 63) // 64 * 64
-        M = B * T
-        sizes = [B * np_ * Kp * 2, B * np_ * D * 4, M * D * 4, M * D * 2, M * 3 * D * 2, M * D * 2, M * c["mlp"] * 2, B * D * 2]
-        return sum((s + 255) // 256 * 256 for s in sizes)
+        return int(_lib.load().sc_clip_vit_workspace_bytes(ctypes.c_int(B), ctypes.c_int(c["channels"]), ctypes.c_int(c["image_size"]),
+                                                           ctypes.c_int(c["image_size"]), ctypes.c_int(c["patch"]),
+                                                           ctypes.c_int(c["width"]), ctypes.c_int(c["mlp"])))
 
     @torch.no_grad()
     def encode_image(self, image: torch.Tensor) -> torch.Tensor:

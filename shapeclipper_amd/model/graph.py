@@ -65,7 +65,8 @@ class Graph(nn.Module):
         self.sdf_network = SDFNetwork(opt)
         self.rgb_network = RGBNetwork(opt)
         self.renderer = Renderer(opt, self.sdf_network, self.rgb_network)
-        self.encoder = resnet.build(opt.arch.enc_network, pretrained=opt.arch.enc_pretrained)
+        self.encoder = resnet.build(opt.arch.enc_network, pretrained=opt.arch.enc_pretrained,
+                                    allow_random=bool(opt.get("load")) or bool(opt.get("resume")))
         self.encoder.fc = nn.Linear(self.encoder.fc.in_features, opt.arch.latent_dim_shape + opt.arch.latent_dim_rgb)
         self.latent_proj_shape = _latent_projector(opt.arch.latent_dim_shape, opt.arch.impl_sdf.proj_latent_dim)
         self.latent_proj_rgb = _latent_projector(opt.arch.latent_dim_rgb, opt.arch.impl_rgb.proj_latent_dim)
@@ -81,13 +82,17 @@ class Graph(nn.Module):
         use_NN = (opt.loss_weight.nearest_img is not None or opt.loss_weight.nearest_mask is not None) and training
         # The neighbour choice depends only on the input masks; it needs one device->host read (numpy RNG, as the
         # reference).  Done first, while the stream is empty, the host never has to wait for the main render.
+        for stale in ("_latent_batched", "_estim_input", "_estim_flip"):      # hand-over keys of a previous forward
+            var.pop(stale, None)
         idx_NN = self.select_neighbours(opt, var) if use_NN else None
         views = self.gather_neighbour_views(opt, var, idx_NN, sampled) if use_NN else []
         if use_NN and "latent" not in var and opt.get("hip", {}).get("batched_encoders", True):
             self.encode_all_views(opt, var, views)
 
-        if "latent_raw" not in var:
-            var.latent_raw = var.latent if "latent" in var else self.encoder(var.rgb_input_map)
+        # always (re)written, as in the reference (graph.py:73): a second forward of the same `var` after an optimiser
+        # step or a train()/eval() switch must not reuse features of the old weights
+        batched = var.pop("_latent_batched", None)
+        var.latent_raw = var.latent if "latent" in var else (batched if batched is not None else self.encoder(var.rgb_input_map))
         var.latent_shape = var.latent_raw[:, :opt.arch.latent_dim_shape]
         var.latent_rgb = var.latent_raw[:, opt.arch.latent_dim_shape:]
         var.proj_latent_sdf = self.latent_proj_shape(var.latent_shape)
@@ -193,15 +198,15 @@ class Graph(nn.Module):
             est_in.record_stream(side)
         else:
             est = self.estimator(est_in, groups=len(images) + len(mirrored))
-        var.latent_raw = latent[:B]
+        var._latent_batched = latent[:B]
         for v, nn_in in enumerate(views):
             nn_in.latent_raw = latent[(v + 1) * B:(v + 2) * B]
         part = lambda k: tuple(t[k * B:(k + 1) * B] for t in est)
-        var.estim_input = part(0)
+        var._estim_input = part(0)
         for v, nn_in in enumerate(views):
             nn_in.estim = part(v + 1)
         if mirrored:
-            var.estim_flip = part(len(images))
+            var._estim_flip = part(len(images))
 
     @staticmethod
     def _side_stream(device):
@@ -324,8 +329,8 @@ class Graph(nn.Module):
     # ------------------------------------------------------------------------------------------------
     def pred_pose(self, opt, var, pred_NN=False, given_input=None, estim=None):
         image = given_input if given_input is not None else var.rgb_input_map
-        if estim is None and not pred_NN and "estim_input" in var:
-            estim = var.estim_input
+        if estim is None and not pred_NN and "_estim_input" in var:
+            estim = var.pop("_estim_input")
         trig_azim, trig_elev, trig_theta, scale_focal, scale_dist = estim if estim is not None else self.estimator(image)
         if trig_azim.is_cuda:      # one launch each way instead of ~50 [B]-sized torch operators (csrc/camera.hip)
             from ..functional import PoseFromTrigFunction

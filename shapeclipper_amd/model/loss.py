@@ -95,7 +95,7 @@ class Loss(nn.Module):
 
     def cam_sym_loss(self, opt, var, estimator):
         # Graph.forward may already have run the mirrored images through the estimator (batched with the other views)
-        fa, fe, ft = var.estim_flip[:3] if "estim_flip" in var else estimator(var.rgb_input_map.flip(dims=[3]))[:3]
+        fa, fe, ft = var._estim_flip[:3] if "_estim_flip" in var else estimator(var.rgb_input_map.flip(dims=[3]))[:3]
         # mirrored image: azimuth and roll change sign (sin flips), elevation is unchanged
         def sq(trig, flipped, sign):
             return (trig[:, 0] - flipped[:, 0]) ** 2 + (sign * trig[:, 1] - flipped[:, 1]) ** 2

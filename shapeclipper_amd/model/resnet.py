@@ -87,16 +87,27 @@ class ResNet(nn.Module):
 _LAYERS = {"resnet18": [2, 2, 2, 2], "resnet34": [3, 4, 6, 3]}
 
 
-def build(name: str, pretrained: bool = False) -> ResNet:
+def build(name: str, pretrained: bool = False, allow_random: bool = False) -> ResNet:
+    """torchvision.models.<name>(pretrained=...) with this build's fused BatchNorm glue.
+
+    The reference hard-depends on the ImageNet weights (model/graph.py:52, model/view_estimator.py:40).  When they are
+    requested but cannot be loaded (no torchvision / no weight cache / no network) this raises, unless the caller says
+    the random initialisation is acceptable (`--arch.enc_pretrained!`, or a checkpoint given with --load / --resume
+    that overwrites the trunk anyway) -- and then it says so loudly instead of silently training from scratch."""
     if name not in _LAYERS:
         raise NotImplementedError("encoder '%s' (available: %s)" % (name, sorted(_LAYERS)))
     net = ResNet(_LAYERS[name])
     if pretrained:
-        # no network / weight cache in this environment: use torchvision's weights when it is importable,
-        # otherwise keep the random init (load a checkpoint with --load / --resume for real runs)
         try:
             import torchvision
-            net.load_state_dict(getattr(torchvision.models, name)(pretrained=True).state_dict())
-        except Exception:
-            pass
+            state = getattr(torchvision.models, name)(pretrained=True).state_dict()
+        except Exception as e:       # ImportError, URLError, missing cache ...
+            msg = "ImageNet weights for %s could not be loaded (%s: %s)" % (name, type(e).__name__, e)
+            if not allow_random:
+                raise RuntimeError(msg + "; pass --arch.enc_pretrained! to train the ResNet trunks from a random "
+                                         "initialisation, or --load/--resume a checkpoint") from e
+            from ..utils.util import log
+            log.warn("WARNING: " + msg + " -- %s starts from a RANDOM initialisation" % name)
+        else:
+            net.load_state_dict(state)
     return net

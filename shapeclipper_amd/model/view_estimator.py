@@ -30,13 +30,20 @@ class Bottleneck_Linear(nn.Module):
         return bn_act(self.bn2, self.linear2(out), residual=v, groups=groups)[..., 0, 0]
 
 
+def _random_trunk_ok(opt):
+    """Explicit opt-outs from the ImageNet initialisation: --arch.enc_pretrained!, or a checkpoint that overwrites it."""
+    return (not opt.arch.get("enc_pretrained", True)) or bool(opt.get("load")) or bool(opt.get("resume"))
+
+
 class Estimator(nn.Module):
 
     def __init__(self, opt):
         super().__init__()
         self.opt = opt
         self.dataset = opt.data.dataset
-        self.feature_extractor = resnet.build("resnet18", pretrained=True)
+        # always ImageNet-initialised in the reference (view_estimator.py:40); see resnet.build for what happens when
+        # the weights are unavailable
+        self.feature_extractor = resnet.build("resnet18", pretrained=True, allow_random=_random_trunk_ok(opt))
         n_features = self.feature_extractor.fc.in_features
         self.feature_extractor.fc = nn.Identity()
         self.extr_head = nn.Sequential(Bottleneck_Linear(n_features))

@@ -256,8 +256,8 @@ def rgb_composite_backward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, d
     return g
 
 
-def loss_fused_forward(rgb, rgb_t, mask, mask_t, normal, normal_t, eik, normal_l1, mask_mse, keep_frac):
-    """-> (out [4] = (render, mask, normal, eikonal) losses, (g_rgb, g_mask, g_normal, g_eik|None))."""
+def loss_fused_forward(rgb, rgb_t, mask, mask_t, normal, normal_t, eik, normal_l1, mask_mse, keep_frac, want_target_grad=False):
+    """-> (out [4] = (render, mask, normal, eikonal) losses, (g_rgb, g_mask, g_normal, g_eik|None, g_normal_t|None))."""
     lib = _lib.load()
     B, R = rgb.shape[0], rgb.shape[1]
     dev = rgb.device
@@ -272,14 +272,15 @@ def loss_fused_forward(rgb, rgb_t, mask, mask_t, normal, normal_t, eik, normal_l
     out = torch.zeros(4, **f32)
     g_rgb, g_mask, g_normal = torch.empty(B, R, 3, **f32), torch.empty(B, R, **f32), torch.empty(B, R, 3, **f32)
     g_eik = torch.empty(B, E, **f32) if eik is not None else None
+    g_normal_t = torch.empty(B, R, 3, **f32) if want_target_grad else None
     ws = torch.empty(B * R, **f32)
     code = lib.sc_loss_fused_forward(_lib.ptr(rgb), _lib.ptr(rgb_t), _lib.ptr(mask), _lib.ptr(mask_t), _lib.ptr(normal),
                                      _lib.ptr(normal_t), _lib.ptr(eik), c_int(B), c_int(R), c_int(E),
                                      ctypes.c_float(normal_l1), ctypes.c_float(mask_mse), ctypes.c_double(keep_frac),
                                      _lib.ptr(out), _lib.ptr(g_rgb), _lib.ptr(g_mask), _lib.ptr(g_normal),
-                                     _lib.ptr(g_eik), _lib.ptr(ws), _lib.stream())
+                                     _lib.ptr(g_eik), _lib.ptr(g_normal_t), _lib.ptr(ws), _lib.stream())
     _lib.check(code, "sc_loss_fused_forward")
-    return out, (g_rgb, g_mask, g_normal, g_eik)
+    return out, (g_rgb, g_mask, g_normal, g_eik, g_normal_t)
 
 
 def ray_sample_forward(cam_loc, ray_dirs, scale_dist, u, rays_per_image, cam_dist):

@@ -90,6 +90,7 @@ class Log:
     def process(self, pid): print(grey("Process ID: {}".format(pid), bold=True))
     def title(self, message): print(yellow(message, bold=True, underline=True))
     def info(self, message): print(magenta(message, bold=True))
+    def warn(self, message): print(red(message, bold=True), file=sys.stderr, flush=True)
 
     def options(self, opt, level=0):
         for key, value in sorted(opt.items()):

@@ -310,15 +310,16 @@ def main():
     # gradients of the three hot reductions (for the fused loss backward)
     pm_g = pm.clone().requires_grad_(True); pr_g = pred3.clone().requires_grad_(True)
     np_g = npred.clone().requires_grad_(True); ek_g = eik.clone().requires_grad_(True)
+    nt_g = ngt.clone().requires_grad_(True)     # the target normal is differentiable in the pose (graph.py:85,260)
     tot = (loss.MSE_loss(pr_g, tgt3) + 0.5 * loss.mask_loss(pm_g, tm)
-           + 0.01 * loss.normal_loss(np_g, ngt, nmask, tolerance=0.2) + 0.03 * loss.MSE_loss(ek_g, 1))
-    g_pr, g_pm, g_np, g_ek = torch.autograd.grad(tot, [pr_g, pm_g, np_g, ek_g])
+           + 0.01 * loss.normal_loss(np_g, nt_g, nmask, tolerance=0.2) + 0.03 * loss.MSE_loss(ek_g, 1))
+    g_pr, g_pm, g_np, g_ek, g_nt = torch.autograd.grad(tot, [pr_g, pm_g, np_g, ek_g, nt_g])
     # NN-view scores (graph.py:119-134)
     mNN = (torch.rand(Bq, Rq, 1, 5) > 0.5).float()
     probs = R.nn_view_scores(tm, mNN, 4)
     save("g7_losses", pred3=pred3, tgt3=tgt3, pm=pm, tm=tm, npred=npred, ngt=ngt, nmask=nmask, eik=eik,
          trig=trig, trig_e=trig_e, mask_NN=mNN, nn_probs=probs,
-         g_pred3=g_pr, g_pm=g_pm, g_npred=g_np, g_eik=g_ek,
+         g_pred3=g_pr, g_pm=g_pm, g_npred=g_np, g_eik=g_ek, g_ngt=g_nt,
          **{"val." + k: v.detach() for k, v in vals.items()})
 
     # ---------------- G9: chamfer ------------------------------------------------------

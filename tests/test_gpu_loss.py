@@ -13,13 +13,17 @@ def test_fused_losses_golden(golden):
     dev = torch.device("cuda:0")
     t = lambda k: torch.tensor(g[k], device=dev)
     rgb, pm, npred, eik = (t(k).requires_grad_(True) for k in ("pred3", "pm", "npred", "eik"))
-    out = FusedRenderLoss.apply(rgb, t("tgt3"), pm, t("tm"), npred, t("ngt"), eik, 5.0, 0.0, 1 - 0.2)
+    ngt = t("ngt").requires_grad_(True)      # transform_normal(input normal, predicted pose): differentiable target
+    out = FusedRenderLoss.apply(rgb, t("tgt3"), pm, t("tm"), npred, ngt, eik, 5.0, 0.0, 1 - 0.2)
     vals = out.detach().cpu().numpy()
     assert abs(vals[0] - g["val.mse"]) < 1e-6 and abs(vals[1] - g["val.mask"]) < 1e-6
     assert abs(vals[2] - g["val.normal"]) < 1e-5 and abs(vals[3] - g["val.mse_eik"]) < 1e-6
     (out[0] + 0.5 * out[1] + 0.01 * out[2] + 0.03 * out[3]).backward()
     torch.cuda.synchronize()
-    for got, key in ((rgb.grad, "g_pred3"), (pm.grad, "g_pm"), (npred.grad, "g_npred"), (eik.grad, "g_eik")):
+    for got, key in ((rgb.grad, "g_pred3"), (pm.grad, "g_pm"), (npred.grad, "g_npred"), (eik.grad, "g_eik"),
+                     (ngt.grad, "g_ngt")):
+        err = np.abs(got.cpu().numpy() - g[key]).max()
+        print("G7 %-8s max abs err %.3e (max |ref| %.3e)" % (key, err, np.abs(g[key]).max()))
         np.testing.assert_allclose(got.cpu().numpy(), g[key], atol=1e-6, rtol=1e-4)
 
 

@@ -75,9 +75,10 @@ def test_loss_backward_entry_point_scales_in_place():
     lib = _lib.load()
     dev = torch.device("cuda:0")
     G = torch.tensor([2.0, 3.0, 4.0, 5.0], device=dev)
-    a, b, c, e = (torch.ones(n, device=dev) for n in (30, 10, 30, 20))
+    a, b, c, e, t = (torch.ones(n, device=dev) for n in (30, 10, 30, 20, 30))
     rc = lib.sc_loss_fused_backward(_lib.ptr(G), _lib.ptr(a), ctypes.c_longlong(30), _lib.ptr(b), ctypes.c_longlong(10),
-                                    _lib.ptr(c), ctypes.c_longlong(30), _lib.ptr(e), ctypes.c_longlong(20), _lib.stream())
+                                    _lib.ptr(c), ctypes.c_longlong(30), _lib.ptr(e), ctypes.c_longlong(20), _lib.ptr(t), _lib.stream())
     assert rc == 0
     torch.cuda.synchronize()
     assert a.unique().item() == 2 and b.unique().item() == 3 and c.unique().item() == 4 and e.unique().item() == 5
+    assert t.unique().item() == 4

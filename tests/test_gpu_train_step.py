@@ -175,3 +175,41 @@ def test_every_hip_option_has_a_working_alternate_path(flag):
     assert all(torch.isfinite(torch.tensor(losses)))
     if flag != "--hip.device_rng":
         assert abs(losses[1] - losses[0]) < 2e-3 * abs(losses[0]), losses
+
+
+def test_fused_loss_carries_the_normal_target_gradient_into_the_estimator():
+    """The normal-loss target is transform_normal(input normal, predicted pose) (reference model/graph.py:85,260), so the
+    reference's normal_loss trains the view estimator through its TARGET as well.  The fused HIP loss must give the same
+    parameter gradients as the unfused torch restatement of model/loss.py for the normal terms alone."""
+    import copy
+    import numpy as np
+    from shapeclipper_amd import synthetic
+    from shapeclipper_amd.model.graph import Graph
+    from shapeclipper_amd.utils import options, util
+    from shapeclipper_amd.utils.util import EasyDict as edict
+    o = options.set(options.parse_arguments(["--yaml=options/pix3d/config.yaml", "--name=pytest_fusedloss", "--output_root=/tmp/sc_pytest",
+                                             "--batch_size=4", "--tb!", "--arch.enc_pretrained!"]), verbose=False)
+    o.device = 0
+    torch.manual_seed(0)
+    g0 = Graph(o).cuda().train()
+    batch = util.move_to_device(synthetic.make_batch(o, 4, seed=5, training=True), "cuda:0")
+    grads = []
+    for fused in (False, True):
+        o.hip.fused_loss = fused
+        g = copy.deepcopy(g0)
+        torch.manual_seed(11); np.random.seed(11)
+        o.H, o.W = o.image_size
+        var, loss = g(o, edict(batch), training=True, get_loss=True)
+        (loss.normal.mean() + loss.nearest_normal.mean()).backward()
+        grads.append({n: p.grad.clone() for n, p in g.named_parameters() if p.grad is not None})
+    o.hip.fused_loss = True
+    ref, got = grads
+    est = [n for n in ref if n.startswith("estimator.")]
+    assert est and all(n in got for n in est)
+    num = sum(float((got[n] - ref[n]).pow(2).sum()) for n in est)
+    den = sum(float(ref[n].pow(2).sum()) for n in est)
+    assert den > 0
+    print("estimator gradient of the normal losses, fused vs unfused: rel L2 err %.3e" % (num / den) ** 0.5)
+    assert (num / den) ** 0.5 < 2e-3
+    for n in ("sdf_network.lin3.weight", "renderer.density.beta"):
+        assert float((got[n] - ref[n]).norm() / ref[n].norm().clamp_min(1e-20)) < 2e-3, n
