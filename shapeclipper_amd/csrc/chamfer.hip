@@ -16,8 +16,10 @@
 //     and takes the first exact match.  "First sub-block whose min is strictly smaller" + "first
 //     index inside it" == the reference's "lowest index among equal minima" rule
 //     (chamfer3D.cu:36,46,126), bit for bit.
-//   * d = fmaf(dz,dz, fmaf(dy,dy, dx*dx)) with dx = target - query: nvcc's default contraction of
-//     chamfer3D.cu:32-35, written explicitly so host oracle and device agree exactly.
+//   * d = fmaf(dz,dz, fmaf(dx,dx, dy*dy)) with dx = target - query: the LLVM/NVPTX contraction order of
+//     chamfer3D.cu:35 `x2*x2+y2*y2+z2*z2` under nvcc's default -fmad=true (first product of an add fused, second
+//     rounded), written explicitly so host oracle and device agree exactly.  Which products nvcc really fuses
+//     cannot be verified without nvcc: the last bit of d is parity-unpinned (oracle/chamfer_ref.c header).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -31,7 +33,7 @@ constexpr float CH_FAR = 1.0e18f;  // padding coordinate: d ~ 3e36, finite, neve
 
 __device__ __forceinline__ float dist2(float tx, float ty, float tz, float qx, float qy, float qz) {
     const float dx = tx - qx, dy = ty - qy, dz = tz - qz;
-    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));
 }
 
 // One direction: for every query j of cloud `xyz` [b,n,3], min_k d(q_j, t_k) over `xyz2` [b,m,3].

@@ -358,6 +358,85 @@ def main():
     close(R.level_grid(cfg, Wsdf, z_sdf, grid), lvl, 0, "level grid")
     save("g10_eval3d", dist1=dA, dist2=dB, fscore=fs, pc=pc, pc_normalized=pcn, grid=grid, level=lvl, z_sdf=z_sdf)
 
+    # ---------------- G12: renders of a shape the rays actually HIT ---------------------
+    # (G5/G6 use the fully perturbed SDF weights, whose level set lies outside the ray interval: every ray misses,
+    # mask ~ 0.  Here the SDF weights are init + 0.3 (perturbed - init): ~60 % of the rays hit, most masks are
+    # strictly between 0 and 1, so compositing / normals / their gradients are pinned in the opaque regime too.)
+    g12 = torch.Generator().manual_seed(4321)
+    sdf_hit = ref_implicit.SDFNetwork(opt)
+    sdf_hit.load_state_dict({k: torch.tensor(init_sdf["sdf." + k]) + 0.3 * (Wsdf[k] - torch.tensor(init_sdf["sdf." + k]))
+                             for k in Wsdf})
+    Whit = weights_from(sdf_hit)
+    rend12 = ref_renderer.Renderer(opt, sdf_hit, rgb_net)
+    with torch.no_grad():
+        rend12.density.beta.fill_(0.05)
+    beta12 = rend12.density.beta.detach().clone()
+    opt16, cfg16 = ref_opt(16, 16), R.Cfg(H=16, W=16)
+    az = (torch.rand(2, generator=g12) * 2 - 1) * np.pi
+    el = (torch.rand(2, generator=g12) * 2 - 1) * np.pi / 6
+    trig12 = lambda t: torch.stack([torch.cos(t), torch.sin(t)], dim=1)
+    sd12 = 0.9 + 0.2 * torch.rand(2, generator=g12)
+    pose12 = ref_pose(trig12(az), trig12(el), trig12(torch.zeros(2)), sd12)
+    intr12 = ref_camera.get_intr(opt16, torch.ones(2))
+    zs12 = torch.randn(2, 64, generator=g12) * 0.3
+    zr12 = torch.randn(2, 64, generator=g12) * 0.3
+    torch.manual_seed(91)
+    state = torch.get_rng_state()
+    with torch.no_grad():
+        ev = rend12(opt16, pose12, intr12, sd12, zs12, zr12, ray_idx=None, training=False)
+    torch.set_rng_state(state)
+    t_rand, eik_idx, eik_pts = R.draw_render_randoms(2 * 256, 64, False)
+    o = R.render(cfg16, Whit, Wrgb, beta12, pose12, intr12, sd12, zs12, zr12, None, False, t_rand, eik_idx, eik_pts)
+    for k, v in zip(("rgb", "mask", "mask_hard", "depth", "normal"), ev[:5]):
+        close(o[k], v, 0, "G12 eval " + k)
+    hit_frac = float(ev[2].mean())
+    assert 0.3 < hit_frac < 0.9, hit_frac
+    R12 = 96
+    ray_idx12 = torch.stack([torch.randperm(256, generator=g12)[:R12] for _ in range(2)], 0)
+    lv = dict(pose=pose12.clone().requires_grad_(True), intr=intr12.clone().requires_grad_(True),
+              scale_dist=sd12.clone().requires_grad_(True), z_sdf=zs12.clone().requires_grad_(True),
+              z_rgb=zr12.clone().requires_grad_(True))
+    torch.manual_seed(92)
+    state = torch.get_rng_state()
+    tr = rend12(opt16, lv["pose"], lv["intr"], lv["scale_dist"], lv["z_sdf"], lv["z_rgb"], ray_idx=ray_idx12, training=True)
+    # the rendered normal of a ray that misses is rounding noise in the reference itself; the training loss reads it
+    # only where both masks are set (graph.py:230-236): the cotangent of the normal is masked the same way
+    cot12 = dict(rgb=torch.randn(2, R12, 3, generator=g12), mask=torch.randn(2, R12, 1, generator=g12),
+                 depth=torch.randn(2, R12, 1, generator=g12),
+                 normal=torch.randn(2, R12, 3, generator=g12) * tr[2].detach(),
+                 eik=torch.randn(2 * 2 * R12, generator=g12))
+    fun12 = lambda rgb, mask, depth, normal, eik: ((rgb * cot12["rgb"]).sum() + (mask * cot12["mask"]).sum()
+                                                   + (depth * cot12["depth"]).sum() + (normal * cot12["normal"]).sum()
+                                                   + (eik * cot12["eik"]).sum())
+    params12 = dict(rend12.named_parameters())
+    names12 = list(params12.keys()) + list(lv.keys())
+    tens12 = list(params12.values()) + list(lv.values())
+    gr = torch.autograd.grad(fun12(tr[0], tr[1], tr[3], tr[4], tr[5]), tens12, allow_unused=True)
+    ref12 = {n: (g_ if g_ is not None else torch.zeros_like(t_)) for n, g_, t_ in zip(names12, gr, tens12)}
+    torch.set_rng_state(state)
+    t_rand, eik_idx, eik_pts = R.draw_render_randoms(2 * R12, 64, True)
+    oWs = {k: v.clone().requires_grad_(True) for k, v in Whit.items()}
+    oWr = {k: v.clone().requires_grad_(True) for k, v in Wrgb.items()}
+    ob = beta12.clone().requires_grad_(True)
+    ol = {k: v.detach().clone().requires_grad_(True) for k, v in lv.items()}
+    o = R.render(cfg16, oWs, oWr, ob, ol["pose"], ol["intr"], ol["scale_dist"], ol["z_sdf"], ol["z_rgb"], ray_idx12, True,
+                 t_rand, eik_idx, eik_pts)
+    for k, v in zip(("rgb", "mask", "mask_hard", "depth", "normal", "grad_eikonal"), tr[:6]):
+        close(o[k], v, 0, "G12 train " + k)
+    ot = ([oWs[k[len("sdf_network."):]] for k in params12 if k.startswith("sdf_network.")]
+          + [oWr[k[len("rgb_network."):]] for k in params12 if k.startswith("rgb_network.")] + [ob] + list(ol.values()))
+    on = ([k for k in params12 if k.startswith("sdf_network.")] + [k for k in params12 if k.startswith("rgb_network.")]
+          + ["density.beta"] + list(ol.keys()))
+    og = torch.autograd.grad(fun12(o["rgb"], o["mask"], o["depth"], o["normal"], o["grad_eikonal"]), ot, allow_unused=True)
+    for n, g_ in zip(on, og):
+        close(g_ if g_ is not None else torch.zeros_like(ref12[n]), ref12[n], 1e-5, "G12 grad " + n)
+    save("g12_render_hits", beta=beta12, pose=pose12, intr=intr12, scale_dist=sd12, z_sdf=zs12, z_rgb=zr12,
+         ray_idx=ray_idx12, hit_frac=np.float32(hit_frac),
+         **{"w.sdf." + k: v for k, v in Whit.items()}, **{"w.rgb." + k: v for k, v in Wrgb.items()},
+         **{"eval." + k: v for k, v in zip(("rgb", "mask", "mask_hard", "depth", "normal"), ev[:5])},
+         **{"train." + k: v for k, v in zip(("rgb", "mask", "mask_hard", "depth", "normal", "grad_eikonal"), tr[:6])},
+         **{"cot." + k: v for k, v in cot12.items()}, **{"grad." + k: v for k, v in ref12.items()})
+
     print("all oracle-vs-reference checks passed; fixtures written to", OUT)
 
 

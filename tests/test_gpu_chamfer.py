@@ -1,6 +1,8 @@
 """Parity of the HIP Chamfer3D kernels (through the C ABI / chamfer_3D module) with the oracle.
 
-Bar: idx bit-exact (int32), dist bit-exact (same fma chain as oracle/chamfer_ref.c)."""
+Bar: idx and dist bit-exact against oracle/chamfer_ref.c, which uses the same fma chain as the kernel.  Which products
+nvcc fuses in chamfer3D.cu:35 cannot be verified here (oracle header): against exact arithmetic the bar is a few ulp
+and a true minimiser up to a near-tie (tests/test_gpu_parity_large.py)."""
 import numpy as np
 import pytest
 import torch
