@@ -167,15 +167,29 @@ def test_config0_pretrain_plumbing_on_cpu():
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference only exists in the build container")
 def test_golden_recipe_reproduces_committed_fixtures(tmp_path):
     """tests/golden/make_golden.py imports the reference's OWN modules (it asserts their origin), checks the oracle
-    against them and regenerates G1-G10: the arrays must equal the committed fixtures bit for bit."""
+    against them and regenerates G1-G10 and G12: the arrays must equal the committed fixtures bit for bit."""
     script = os.path.join(GOLDEN_DIR, "make_golden.py")
     env = dict(os.environ, GOLDEN_OUT=str(tmp_path))
     r = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     made = sorted(p.name for p in tmp_path.glob("*.npz"))
-    assert len(made) == 10, made
+    assert len(made) == 11, made
     for name in made:
         a, b = np.load(tmp_path / name), np.load(os.path.join(GOLDEN_DIR, name))
         assert set(a.files) == set(b.files), name
         for k in a.files:
             assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k], equal_nan=True), (name, k)
+
+
+def test_g12_render_with_hits(golden):
+    """The oracle's eval render on G12 (rays that hit the shape) equals the reference capture."""
+    g = golden("g12_render_hits")
+    cfg = R.Cfg(H=16, W=16)
+    Ws, Wr = _W(g, "w.sdf."), _W(g, "w.rgb.")
+    _, eik_idx, _ = R.draw_render_randoms(2 * 256, 64, False)
+    with torch.no_grad():
+        o = R.render(cfg, Ws, Wr, T(g["beta"]), T(g["pose"]), T(g["intr"]), T(g["scale_dist"]), T(g["z_sdf"]), T(g["z_rgb"]),
+                     None, False, None, eik_idx, None)
+    for k in ("rgb", "mask", "mask_hard", "depth", "normal"):
+        assert torch.allclose(o[k].detach(), T(g["eval." + k]), atol=1e-6), k
+    assert 0.3 < float(g["hit_frac"]) < 0.9 and float(o["mask_hard"].mean()) == float(g["hit_frac"])
