@@ -83,8 +83,8 @@ def test_full_size_properties():
     d1, d2, i1, i2 = run_hip(a, b)
     # reported distance equals the distance to the reported index (same fma chain, in fp32)
     diff = b[0][i1[0]] - a[0]
-    dd = np.float32(diff[:, 0]) * np.float32(diff[:, 0])
-    dd = np.float32(np.float64(diff[:, 1]) * np.float64(diff[:, 1]) + np.float64(dd))      # fma emulation
+    dd = np.float32(diff[:, 1]) * np.float32(diff[:, 1])                                   # fma(dz,dz,fma(dx,dx,dy*dy))
+    dd = np.float32(np.float64(diff[:, 0]) * np.float64(diff[:, 0]) + np.float64(dd))      # fma emulation
     dd = np.float32(np.float64(diff[:, 2]) * np.float64(diff[:, 2]) + np.float64(dd))
     assert np.array_equal(dd, d1[0])
     # no sampled target is closer than the reported minimum

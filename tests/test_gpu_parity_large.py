@@ -99,7 +99,7 @@ def test_training_render_b4_r512_vs_oracle_all_gradients(golden):
              normal_hit=float((normal.detach().cpu() - o["normal"].detach())[hm].abs().max()))
     print("B=4 R=512 train render, max abs err:", {k: "%.2e" % v for k, v in e.items()}, "hit fraction %.2f" % float(hm.float().mean()))
     assert 0.2 < float(hm.float().mean()) < 0.9
-    assert e["rgb"] < 5e-5 and e["mask"] < 5e-5 and e["depth"] < 2e-4 and e["eik"] < 2e-4 and e["normal_hit"] < 2e-3
+    assert e["rgb"] < 5e-5 and e["mask"] < 5e-5 and e["depth"] < 2e-4 and e["eik"] < 2e-4 and e["normal_hit"] < 2e-4
     guard = (o["mask"].detach() - 0.5).abs() > 1e-5
     assert torch.equal(mask_hard.cpu()[guard], o["mask_hard"].detach()[guard])
     cd = {k: v.to(dev) for k, v in cot.items()}
@@ -113,7 +113,7 @@ def test_training_render_b4_r512_vs_oracle_all_gradients(golden):
         gv = gg.cpu() if gg is not None else torch.zeros_like(rf)
         worst[n] = float((gv - rf).abs().max() / max(float(rf.abs().max()), 1e-4))
     print("B=4 R=512 gradient errors (max abs / max |ref|):", {k: "%.1e" % v for k, v in worst.items()})
-    bad = {k: v for k, v in worst.items() if v > 1e-3}
+    bad = {k: v for k, v in worst.items() if v > 2e-4}       # measured: <= 3.2e-5
     assert not bad, bad
 
 
@@ -171,7 +171,7 @@ def test_full_frame_eval_render_128_one_image_vs_oracle(golden):
     print("128x128 eval render (1,048,576 points), max abs err:", {k: "%.2e" % v for k, v in e.items()},
           "hit fraction %.2f" % float(hm.float().mean()))
     assert 0.1 < float(hm.float().mean()) < 0.9
-    assert e["rgb"] < 5e-5 and e["mask"] < 5e-5 and e["depth"] < 2e-4 and e["normal_hit"] < 2e-3
+    assert e["rgb"] < 5e-5 and e["mask"] < 5e-5 and e["depth"] < 2e-4 and e["normal_hit"] < 2e-4
     guard = (ref["mask"] - 0.5).abs() > 1e-5
     assert torch.equal(mask_hard.cpu()[guard], ref["mask_hard"][guard])
 

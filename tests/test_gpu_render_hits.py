@@ -2,7 +2,7 @@
 ray misses (mask ~ 0); here ~46 % of the rays are opaque and half of the masks lie strictly between 0 and 1, so the
 compositing, the rendered normals and all 28 gradient tensors are pinned in the regime training runs in.
 
-Bars (fp32): outputs 5e-5 abs (normals 2e-3 where the ray hits); gradients relative to each tensor's max entry, bar
+Bars (fp32): outputs 5e-5 abs (depth 2e-4, normals 2e-4 where the ray hits); gradients relative to each tensor's max entry, bar
 printed per tensor."""
 import numpy as np
 import pytest
@@ -10,7 +10,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-GRAD_BAR = 1e-3
+GRAD_BAR = 2e-4      # measured on MI355X: <= 4e-5 for every tensor
 
 
 def _opt(H, W):
@@ -48,7 +48,7 @@ def test_eval_render_with_hits(golden):
     e = dict(rgb=err(rgb, "rgb"), mask=err(mask, "mask"), depth=err(depth, "depth"),
              normal_hit=float(np.abs(normal.cpu().numpy() - g["eval.normal"])[hit].max()))
     print("G12 eval max abs err:", {k: "%.2e" % v for k, v in e.items()}, "hit fraction %.2f" % hit.mean())
-    assert e["rgb"] < 5e-5 and e["mask"] < 5e-5 and e["depth"] < 2e-4 and e["normal_hit"] < 2e-3
+    assert e["rgb"] < 5e-5 and e["mask"] < 5e-5 and e["depth"] < 2e-4 and e["normal_hit"] < 2e-4
     guard = np.abs(g["eval.mask"] - 0.5) > 1e-5
     assert np.array_equal(mask_hard.cpu().numpy()[guard], g["eval.mask_hard"][guard])        # integer ray-hit mask: exact
 
@@ -68,7 +68,7 @@ def test_training_render_with_hits_all_gradients(golden):
     e = dict(rgb=err(rgb, "rgb"), mask=err(mask, "mask"), depth=err(depth, "depth"), eik=err(eik, "grad_eikonal"),
              normal_hit=float(np.abs(normal.detach().cpu().numpy() - g["train.normal"])[hit].max()))
     print("G12 train max abs err:", {k: "%.2e" % v for k, v in e.items()})
-    assert e["rgb"] < 5e-5 and e["mask"] < 5e-5 and e["depth"] < 2e-4 and e["eik"] < 2e-4 and e["normal_hit"] < 2e-3
+    assert e["rgb"] < 5e-5 and e["mask"] < 5e-5 and e["depth"] < 2e-4 and e["eik"] < 2e-4 and e["normal_hit"] < 2e-4
     guard = np.abs(g["train.mask"] - 0.5) > 1e-5
     assert np.array_equal(mask_hard.cpu().numpy()[guard], g["train.mask_hard"][guard])
     L = ((rgb * t("cot.rgb")).sum() + (mask * t("cot.mask")).sum() + (depth * t("cot.depth")).sum()

@@ -3,7 +3,8 @@ Renderer.forward(training=True) + autograd (model/renderer.py:57-185), B=2, R=32
 8x8 image, 64 samples, eikonal branch included.  The CPU generator is seeded like the capture, so
 the product draws the identical stratified jitter / eikonal samples.
 
-Bars (fp32): outputs 5e-5 abs (normals 2e-3); gradients 2e-3 relative to each tensor's max entry."""
+Bars (fp32): outputs 5e-5 abs (normals 2e-3: every ray of G6 misses the shape, its normals are rounding noise --
+G12 / tests/test_gpu_render_hits.py pins the hit regime at 2e-4); gradients 5e-4 relative to each tensor's max entry."""
 import numpy as np
 import pytest
 import torch
@@ -61,7 +62,8 @@ def test_render_train_outputs_and_all_gradients(golden):
         got = gr.cpu().numpy() if gr is not None else np.zeros_like(ref)
         scale = max(np.abs(ref).max(), 1e-4)
         worst[n] = np.abs(got - ref).max() / scale
-    bad = {k: v for k, v in worst.items() if v > 2e-3}
+    print("G6 gradient errors (max abs / max |ref|):", {k: "%.1e" % v for k, v in worst.items()})
+    bad = {k: v for k, v in worst.items() if v > 5e-4}
     assert not bad, bad
 
 

@@ -139,7 +139,8 @@ def test_flat_reducer_path_on_rccl_single_rank():
             if n.startswith("estimator."):
                 est_bad += int(((a - b).abs() > 2e-5).sum())
                 est_total += a.numel()
-        assert est_bad / est_total < 0.05, est_bad / est_total
+        # (the estimator also receives the normal-target gradient through the pose: more atomically accumulated terms)
+        assert est_bad / est_total < 0.15, est_bad / est_total
         assert torch.allclose(results[0]["renderer.density.beta"], results[1]["renderer.density.beta"], atol=1e-6)
     finally:
         if created:
