@@ -40,30 +40,46 @@ class NN_annotator:
 
     @torch.no_grad()
     def calc_matches(self, opt, features, k_nearest=6):
-        """features [N,D] L2-normalised -> (indices [N,k], values [N,k]); row i starts with i itself."""
-        sim = features @ features.t()
-        if opt.thres is None:
-            values, indices = sim.topk(k_nearest, dim=1, largest=True)
-            return indices, values
-        # thresholded random neighbours (reference :43-53); falls back to top-k when too few pass
-        N = features.shape[0]
-        values, indices = sim.topk(k_nearest, dim=1, largest=True)
-        for i in range(N):
-            ok = ((sim[i] >= opt.thres) & (sim[i] < 1.)).nonzero().squeeze(1)
-            if len(ok) >= k_nearest - 1:
-                pick = ok[torch.randperm(len(ok), device=ok.device)[:k_nearest - 1]]
-                idx = torch.cat([torch.tensor([i], device=ok.device), pick])
-                indices[i], values[i] = idx, sim[i][idx]
-        return indices, values
+        """features [N,D] L2-normalised -> (indices [N,k], values [N,k]); row i starts with i itself
+        (reference CLIP_anno.py:29-57).
 
-    def save_anno(self, opt, labels, index_topk, value_topk, split, k_nearest=6):
-        cat = opt.data[opt.data.dataset].cat.replace(", ", "_") if opt.data.dataset in opt.data else "all"
+        Default (opt.thres is None): ONE similarity GEMM + top-k instead of the reference's per-query Python loop.
+        Thresholded branch (:43-53, off in options/clip/pix3d.yaml): k-1 random neighbours among cos >= thres; it keeps
+        the reference's per-query operator sequence -- (query * features).sum(1), the `< 1.` test that is meant to drop
+        the query itself (a query whose self-similarity rounds to 0.99999994 stays a candidate, as in the reference) and
+        one CPU-generator randperm per qualifying query, in query order -- so a seeded run picks the same neighbours."""
+        if opt.thres is None:
+            values, indices = (features @ features.t()).topk(k_nearest, dim=1, largest=True)
+            return indices, values
+        indices, values = [], []
+        for i in range(features.shape[0]):
+            cos_sim = (features[i].unsqueeze(0) * features).sum(dim=1)
+            index = ((cos_sim >= opt.thres) & (cos_sim < 1.)).nonzero()
+            n_valid = len(index)
+            if n_valid < k_nearest - 1:
+                top_k_val, top_k_ind = cos_sim.topk(k_nearest, largest=True)
+                indices.append(top_k_ind)
+                values.append(top_k_val)
+            else:
+                sampled = index[torch.randperm(n_valid)[:k_nearest - 1].to(index.device)].squeeze(1)
+                chosen = torch.cat([torch.tensor([i], device=features.device), sampled], dim=0)
+                indices.append(chosen)
+                values.append(cos_sim[chosen])
+        return torch.stack(indices, dim=0), torch.stack(values, dim=0)
+
+    def label2path(self, root, label):
+        return os.path.join(root, label), None
+
+    def save_anno(self, opt, label2path, labels, index_topk, value_topk, k_nearest=6, category_set="all"):
+        """`<anno_root>/<category>_<split>.csv`, header Query,Top_1..,Top_1_score.., rows sorted by query
+        (reference CLIP_anno.py:98-127; read back by data/pix3d.py:95-108).  self.split names the split."""
+        category = opt.data[opt.data.dataset].cat.replace(", ", "_") if category_set == "custom" else category_set
         os.makedirs(opt.anno_root, exist_ok=True)
-        path = os.path.join(opt.anno_root, "{}_{}.csv".format(cat, split))
+        path = os.path.join(opt.anno_root, "{}_{}.csv".format(category, self.split))
         rows = []
         for i, label in enumerate(labels):
-            rows.append([label] + [labels[j] for j in index_topk[i][1:].tolist()]
-                        + ["{:.4f}".format(v) for v in value_topk[i][1:].tolist()])
+            rows.append([label2path("", label)[0]] + [label2path("", labels[int(j)])[0] for j in index_topk[i][1:]]
+                        + ["{:.4f}".format(v) for v in value_topk[i][1:]])
         header = ["Query"] + ["Top_{}".format(i) for i in range(1, k_nearest)] + ["Top_{}_score".format(i) for i in range(1, k_nearest)]
         with open(path, "w") as f:
             w = csv.writer(f)
@@ -96,7 +112,9 @@ def main():
     for split, (images, labels) in splits.items():
         feats = ann.embed_split(opt, images)
         idx, val = ann.calc_matches(opt, feats, k_nearest=opt.k_nearest)
-        print("wrote", ann.save_anno(opt, labels, idx.cpu(), val.cpu(), split, k_nearest=opt.k_nearest))
+        ann.split = split
+        custom = "custom" if opt.data.dataset in opt.data else "all"
+        print("wrote", ann.save_anno(opt, ann.label2path, labels, idx.cpu(), val.cpu(), k_nearest=opt.k_nearest, category_set=custom))
 
 
 if __name__ == "__main__":

@@ -17,13 +17,19 @@ def _disc_masks(n, H, W, gen):
     return (d2[None] <= (rad ** 2)[:, None, None]).float().unsqueeze(1)        # [n,1,H,W]
 
 
-def _views(n, H, W, R, gen):
+def _views(n, H, W, R, gen, opt=None, importance=False):
     rgb = torch.rand(n, 3, H, W, generator=gen)
     mask = _disc_masks(n, H, W, gen)
     normal = torch.nn.functional.normalize(torch.randn(n, 3, H, W, generator=gen), dim=1) * mask
     out = dict(rgb_input_map=rgb, mask_input_map=mask, normal_input_map=normal)
     if R:
-        ray_idx = torch.stack([torch.randperm(H * W, generator=gen)[:R] for _ in range(n)], 0)
+        if importance:
+            # the reference's training loader draws the rays around the silhouette (data/pix3d.py:230-240 ->
+            # utils/util.py:237-248; numpy global RNG): same call, same arguments
+            from .utils.util import compute_sampling_prob
+            ray_idx = torch.stack([compute_sampling_prob(opt, mask[i, 0], opt.render.ray_uniform_fac) for i in range(n)], 0).long()
+        else:
+            ray_idx = torch.stack([torch.randperm(H * W, generator=gen)[:R] for _ in range(n)], 0)
         take = lambda m: m.flatten(2).permute(0, 2, 1).gather(1, ray_idx[..., None].expand(-1, -1, m.shape[1]))
         out.update(ray_idx=ray_idx, rgb_input=take(rgb), mask_input=take(mask), normal_input=take(normal))
     else:
@@ -32,13 +38,16 @@ def _views(n, H, W, R, gen):
     return out
 
 
-def make_batch(opt, batch_size, seed=0, training=True, n_gt_points=2048):
-    """One batch with the reference's keys; neighbour stacks carry a trailing K dimension."""
+def make_batch(opt, batch_size, seed=0, training=True, n_gt_points=2048, importance=False):
+    """One batch with the reference's keys; neighbour stacks carry a trailing K dimension.
+    importance=True: ray_idx from the reference's silhouette importance sampler instead of a uniform permutation
+    (needs opt.H == image height, consumes numpy's global RNG like the reference's loader)."""
     gen = torch.Generator().manual_seed(seed)
     H, W = opt.image_size
     R = opt.render.rand_sample if training else 0
     K = opt.data.k_nearest
-    v = _views(batch_size, H, W, R, gen)
+    views = lambda: _views(batch_size, H, W, R, gen, opt, importance)
+    v = views()
     batch = edict(idx=torch.arange(batch_size), category_label=torch.zeros(batch_size, dtype=torch.long), **v)
     azim = (torch.rand(batch_size, generator=gen) * 2 - 1) * np.pi
     elev = (torch.rand(batch_size, generator=gen) * 2 - 1) * np.pi / 6
@@ -54,7 +63,7 @@ def make_batch(opt, batch_size, seed=0, training=True, n_gt_points=2048):
     pts = torch.rand(batch_size, n_gt_points, 3, generator=gen) - 0.5
     batch.dpc = edict(points=pts, normals=torch.nn.functional.normalize(torch.randn(batch_size, n_gt_points, 3, generator=gen), dim=-1))
     if training:
-        stacks = [_views(batch_size, H, W, R, gen) for _ in range(K)]
+        stacks = [views() for _ in range(K)]
         for key in ("rgb_input", "mask_input", "normal_input", "rgb_input_map", "mask_input_map", "normal_input_map", "ray_idx"):
             batch[key + "_NN"] = torch.stack([s[key] for s in stacks], dim=-1)
         batch.pose_gt_NN = pose[..., None].expand(-1, -1, -1, K).contiguous()
