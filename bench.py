@@ -38,6 +38,7 @@ FLOPS_PER_POINT = {
     "sc_rgb_composite_forward": RGB_VALUE,
     "sc_rgb_composite_backward": RGB_VALUE + RGB_VALUE,     # recompute + input-gradient sweep
 }
+WGRAD_FLOPS_PER_POINT = 1064 * 2048 // 16     # weight-gradient GEMMs of one render: 1064 MFMAs per 16-point tile
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2 dense peak
 PEAK_HBM_GBS = 8000.0
 
@@ -49,23 +50,36 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=0, help="images of the CPU baseline step (0: --batch if host memory allows)")
+    ap.add_argument("--sustained", type=int, default=200, help="extra steps timed after the K-step region (0: off)")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the other SURVEY 8(d) workloads (tools/workloads.py)")
+    ap.add_argument("--workloads-only", action="store_true", help="only those workloads (the rocprofv3 command of profiles/)")
     return ap.parse_args()
 
 
 def cpu_baseline(batch, rays=512):
-    """Oracle hot path on the host cores: two training renders (fwd + bwd incl. eikonal) per step."""
+    """Oracle hot path on the host cores, SURVEY 8(d): one training step's two render calls (fwd + bwd incl. eikonal) on a
+    batch of the bench's size -- 1 warm-up + >= 1 timed step.  The oracle keeps ~0.6 GB of autograd state per image and
+    render, so each render is back-propagated before the next one starts and the batch is halved until it fits the
+    host's free memory (stated in `sample`)."""
     from oracle import reference_ops as R
     # Bounded: many small ops + a double backward scale badly past a few dozen threads (256 threads on the GPU
     # box's host made this 200x slower than 8 threads in the build container), so cap the pool and the wall time.
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
+    try:
+        import psutil
+        free_gb = psutil.virtual_memory().available / 2 ** 30
+    except Exception:
+        free_gb = 16.0
+    B = batch
+    while B > 1 and 1.5 * B > 0.5 * free_gb:          # ~0.6 GB per image measured, x2.5 head room, use half of what is free
+        B //= 2
     cfg = R.Cfg()
     torch.manual_seed(0)
     Ws = {k: v.requires_grad_(True) for k, v in R.init_sdf_weights(cfg).items()}
     Wr = {k: v.requires_grad_(True) for k, v in R.init_rgb_weights(cfg).items()}
     beta = torch.tensor(0.1, requires_grad=True)
-    B = batch
     az = (torch.rand(B) * 2 - 1) * 3.14159
     trig = lambda t: torch.stack([torch.cos(t), torch.sin(t)], 1)
     sd = (0.8 + 0.4 * torch.rand(B)).requires_grad_(True)
@@ -74,23 +88,30 @@ def cpu_baseline(batch, rays=512):
     ray_idx = torch.stack([torch.randperm(cfg.H * cfg.W)[:rays] for _ in range(B)])
 
     def step():
-        total = 0
-        pose = R.pose_from_trig(cfg, trig(az), trig(torch.zeros(B)), trig(torch.zeros(B)), sd)
         for _ in range(2):
+            pose = R.pose_from_trig(cfg, trig(az), trig(torch.zeros(B)), trig(torch.zeros(B)), sd)
             t_rand, eik_idx, eik_pts = R.draw_render_randoms(B * rays, 64, True)
             o = R.render(cfg, Ws, Wr, beta, pose, intr, sd, zs, zr, ray_idx, True, t_rand, eik_idx, eik_pts)
-            total = total + o["rgb"].sum() + o["mask"].sum() + o["normal"].sum() + ((o["grad_eikonal"] - 1) ** 2).mean()
-        total.backward()
+            (o["rgb"].sum() + o["mask"].sum() + o["normal"].sum() + ((o["grad_eikonal"] - 1) ** 2).mean()).backward()
     t0 = time.time()
     step()                                   # warm-up (allocator, thread pool)
     warm = time.time() - t0
     t0, n = time.time(), 0
-    while n < 1 or (time.time() - t0 + warm < 20 and n < 10):
+    while n < 1 or (time.time() - t0 + warm < 30 and n < 5):
         step(); n += 1
     dt = (time.time() - t0) / n
-    return dict(value=round(B / dt, 3), unit="images/s", cores=cores, kind="port",
-                sample="oracle hot path only: 2 training renders fwd+bwd (512 rays x 64 samples, eikonal incl.), "
-                       "B=%d, %d timed steps, no encoders/optimizer" % (B, n))
+    return dict(value=round(B / dt, 3), unit="images/s", cores=cores, host_cpu_count=os.cpu_count(), kind="port",
+                s_per_step=round(dt, 2),
+                sample="oracle hot path only: the 2 training renders of a step, fwd+bwd (512 rays x 64 samples, eikonal incl.), "
+                       "B=%d (host memory free %.0f GB), 1 warm-up + %d timed steps, no encoders/optimizer" % (B, free_gb, n))
+
+
+def _workloads():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sc_bench_workloads", os.path.join(ROOT, "tools", "workloads.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
 def build_runner(batch_per_gpu, rank=0, local=0, world=1):
@@ -129,6 +150,9 @@ def main():
 
     from shapeclipper_amd import _lib
     from shapeclipper_amd.utils.util import EasyDict as edict
+    if a.workloads_only:
+        print(json.dumps(dict(workloads=_workloads().run_all(with_cpu=not a.no_cpu_baseline))))
+        return
     runner, opt, batch = build_runner(a.batch, rank, local, world)
 
     def step():
@@ -155,6 +179,39 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
     assert torch.isfinite(loss.all.detach()).item(), "non-finite loss in the timed region"
+    # the K-step region above is a burst (clocks have not settled): time a longer run as well
+    sustained = None
+    if a.sustained > 0:
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t1 = time.time()
+        for _ in range(a.sustained):
+            step()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        sdt = time.time() - t1
+        if world > 1:
+            t = torch.tensor([sdt], device="cuda")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            sdt = t.item()
+        sustained = dict(steps=a.sustained, ms_per_step=round(sdt / a.sustained * 1e3, 3),
+                         value=round(a.batch * world / (sdt / a.sustained), 2))
+    allreduce = None
+    if world > 1 and runner.reducer is not None:      # the step's only exchange: one flat all-reduce
+        flat = runner.reducer.flat
+        for _ in range(2):
+            torch.distributed.all_reduce(flat)
+        torch.cuda.synchronize()
+        t1 = time.time()
+        for _ in range(10):
+            torch.distributed.all_reduce(flat)
+        torch.cuda.synchronize()
+        ar = (time.time() - t1) / 10
+        nbytes = flat.numel() * 4
+        allreduce = dict(ms=round(ar * 1e3, 3), payload_bytes=nbytes,
+                         bus_GBps=round(2 * (world - 1) / world * nbytes / ar / 1e9, 1), peak_per_link_GBps=153.0)
 
     if rank == 0:
         ms = dt / a.steps * 1e3
@@ -170,15 +227,23 @@ def main():
         mean_big = sum(big) / len(big)
         achieved = FLOPS_PER_POINT[dom] * n_pts_main / (mean_big * 1e-3) / 1e12
         traffic = None
-        try:   # HBM-side bytes per launch measured with rocprofv3 --pmc on this workload (profiles/, see its _comment)
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-                traffic = json.load(f)["kernels"][dom]["traffic_bytes"] if a.batch == 32 else None
-        except Exception:
-            pass
-        roofline = dict(kernel=dom, bound="mfma", achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS,
+        for prof in ("r02_traffic.json", "r01_traffic.json"):
+            try:   # HBM-side bytes per launch measured with rocprofv3 --pmc on this workload (profiles/, see its _comment)
+                with open(os.path.join(ROOT, "profiles", prof)) as f:
+                    traffic = json.load(f)["kernels"][dom]["traffic_bytes"] if a.batch == 32 else None
+                break
+            except Exception:
+                pass
+        # Which roof: the kernel's algorithmic bytes are ~0 (a fused backward would need none of its hand-off tensors), so
+        # its roof is the fp32 matrix pipe; but when the bytes it actually moves run at >= 75 % of the achievable HBM rate
+        # (6.3 TB/s measured float4 copy, MI355X_MICROARCH.md) the HBM traffic it creates is what sets its time: say so.
+        hbm_rate = traffic / (mean_big * 1e-3) / 1e9 if traffic else None
+        bound = "hbm" if (hbm_rate and hbm_rate >= 0.75 * 6300.0) else "mfma"
+        roofline = dict(kernel=dom, bound=bound, achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS,
                         unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
                         launch_ms=round(mean_big, 4), points_per_launch=n_pts_main,
-                        flops_per_point=FLOPS_PER_POINT[dom])
+                        flops_per_point=FLOPS_PER_POINT[dom],
+                        hbm_GBps_of_measured_traffic=round(hbm_rate, 1) if hbm_rate else None)
         # second roofline: the weight-gradient GEMMs (largest hand-written time share, HBM-bound by design): the 12 launches
         # of a main render read 37 TBL64 operand tensors of 256 B/point (counted from ops.sdf_backward /
         # ops.rgb_composite_backward: W0 3, W1 5+3, W2 5+3, W3 5, W4 4, W5f 2; V0 1+2, V1 2, V2 2)
@@ -187,9 +252,13 @@ def main():
             wd = sorted([s.elapsed_time(e) for s, e, _ in timing["sc_wgrad"]], reverse=True)[:24 * a.steps]
             per_render_ms = sum(wd) / (2 * a.steps)
             gbs = 37 * 256.0 * n_pts_main / (per_render_ms * 1e-3) / 1e9
-            roofline_wgrad = dict(kernel="sc_wgrad (12 launches of a main render)", bound="hbm", achieved=round(gbs, 1),
-                                  peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4),
-                                  ms_per_render=round(per_render_ms, 4), bytes_per_point=37 * 256)
+            # scored on its FLOPs (1064 v_mfma_f32_16x16x4 per 16 points = 136,192 FLOP/point): the operand bytes it
+            # streams exist only because the backward kernels materialise them, they are not algorithmic bytes
+            wg_tf = WGRAD_FLOPS_PER_POINT * n_pts_main / (per_render_ms * 1e-3) / 1e12
+            roofline_wgrad = dict(kernel="sc_wgrad (12 launches of a main render)", bound="mfma", achieved=round(wg_tf, 2),
+                                  peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(wg_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                                  ms_per_render=round(per_render_ms, 4), flops_per_point=WGRAD_FLOPS_PER_POINT,
+                                  operand_stream_GBps=round(gbs, 1), operand_bytes_per_point=37 * 256)
         out = dict(metric="train-step images/sec (Pix3D cfg, bs32/GPU)", value=round(a.batch * world / (dt / a.steps), 2),
                    unit="images/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
@@ -198,9 +267,14 @@ def main():
                                global_batch=a.batch * world, rays_per_image=opt.render.rand_sample, samples_per_ray=64,
                                parallelism="dp%d" % world),
                    roofline=roofline, roofline_wgrad=roofline_wgrad, host_enqueue_ms_per_step=round(host_dt / a.steps * 1e3, 3),
-                   hip_ms_per_step={k: round(v["total_ms"] / a.steps, 3) for k, v in sorted(per.items())})
-        if not a.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks must not wait ~25 s for rank 0)
-            out["cpu_baseline"] = cpu_baseline(a.cpu_batch)
+                   hip_ms_per_step={k: round(v["total_ms"] / a.steps, 3) for k, v in sorted(per.items())},
+                   sustained=sustained)
+        if allreduce is not None:
+            out["allreduce"] = allreduce
+        if not a.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks must not wait for rank 0)
+            out["cpu_baseline"] = cpu_baseline(a.cpu_batch or a.batch)
+        if not a.no_workloads and world == 1:
+            out["workloads"] = _workloads().run_all(with_cpu=not a.no_cpu_baseline)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -1,0 +1,231 @@
+"""The SURVEY 8(d) workloads besides the train step, each timed with events on the launch stream and with a bounded
+CPU leg beside it (bench.py prints them in its `workloads` object; `python bench.py --workloads-only` runs only these,
+which is the command the rocprofv3 summaries under profiles/ are taken from).
+
+  chamfer_b1 / chamfer_b32   Chamfer3D forward, N = M = 100,000, both directions   utils/eval_3D.py:155-165, chamfer3D.cu:142-143
+  clip_vit_b32               CLIP ViT-B/32 image tower, batch 32                   CLIP_anno.py:166-167
+  render_eval_128            full-frame evaluation render 128x128, batch 32        model/renderer.py:57-152
+  level_grid_100             SDF level grid, vox_res = 100, one image              utils/eval_3D.py:21-38
+
+Algorithmic work per unit is SURVEY 8(d)'s: 8 FLOP per ordered pair (Chamfer), 8.725 GFLOP per image (ViT-B/32),
+12,763,136 FLOP per ray (evaluation render), 80,640 FLOP per grid point.  `frac` = achieved / peak of the unit that
+bounds the kernel (fp32 VALU / bf16 MFMA / fp32 MFMA, MI355X_MICROARCH.md).  CPU legs ("cpu"): the oracle
+(oracle/reference_ops.py), a chunked torch.cdist brute force, and transformers' CLIP vision model, on a bounded sample
+of the same workload with min(os.cpu_count(), 32) threads -- reported baselines, not targets.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32 = 157.3       # TFLOP/s, fp32 vector = fp32 MFMA dense peak
+PEAK_BF16 = 2500.0      # TFLOP/s, bf16 MFMA dense peak
+CHAMFER_FLOP_PER_PAIR = 8
+VIT_B32_GFLOP = 8.725
+RENDER_EVAL_FLOP_PER_RAY = 64 * 199424
+GRID_FLOP_PER_POINT = 80640
+
+
+def _gpu_ms(fn, iters, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(iters):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); fn(); e.record()
+        evs.append((s, e))
+    torch.cuda.synchronize()
+    d = sorted(s.elapsed_time(e) for s, e in evs)
+    return sum(d) / len(d), d[0]
+
+
+def _cpu_time(fn, budget_s=6.0, max_n=5):
+    fn()                                     # warm-up (thread pool, allocator)
+    t0, n = time.time(), 0
+    while n < 1 or (time.time() - t0 < budget_s and n < max_n):
+        fn(); n += 1
+    return (time.time() - t0) / n, n
+
+
+def cpu_threads():
+    return min(os.cpu_count() or 1, 32)
+
+
+def chamfer(B, N=100000, with_cpu=True):
+    import chamfer_3D
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(B)
+    a = (torch.rand(B, N, 3, generator=g) - 0.5).to(dev); b = (torch.rand(B, N, 3, generator=g) - 0.5).to(dev)
+    d1 = torch.zeros(B, N, device=dev); d2 = torch.zeros(B, N, device=dev)
+    i1 = torch.zeros(B, N, dtype=torch.int32, device=dev); i2 = torch.zeros(B, N, dtype=torch.int32, device=dev)
+    ms, best = _gpu_ms(lambda: chamfer_3D.forward(a, b, d1, d2, i1, i2), iters=5 if B > 1 else 20)
+    pairs = 2.0 * B * N * N
+    tf = CHAMFER_FLOP_PER_PAIR * pairs / (ms * 1e-3) / 1e12
+    out = dict(workload="Chamfer3D forward B=%d, N=M=%d, both directions" % (B, N), ms=round(ms, 3), ms_best=round(best, 3),
+               algorithmic_flop=CHAMFER_FLOP_PER_PAIR * pairs, algorithmic_bytes=B * 2 * N * (12 + 8),
+               achieved=round(tf, 2), peak=PEAK_FP32, unit="TFLOP/s", bound="fp32 VALU", frac=round(tf / PEAK_FP32, 4),
+               tpairs_per_s=round(pairs / (ms * 1e-3) / 1e12, 3))
+    if with_cpu:
+        n = 20000
+        x, y = a[0, :n].cpu(), b[0, :n].cpu()
+        torch.set_num_threads(cpu_threads())
+
+        def brute():
+            for q, t in ((x, y), (y, x)):
+                for s in range(0, n, 5000):
+                    D = torch.cdist(q[s:s + 5000], t)
+                    D.min(dim=1)
+        dt, k = _cpu_time(brute)
+        out["cpu"] = dict(value=round(2.0 * n * n / dt / 1e9, 3), unit="Gpairs/s", cores=cpu_threads(), kind="port",
+                          sample="chunked torch.cdist + min/argmin, N=M=%d, both directions, %d timed runs" % (n, k),
+                          gpu_value=round(pairs / (ms * 1e-3) / 1e9, 1))
+    return out
+
+
+def clip_vit(B=32, with_cpu=True):
+    from shapeclipper_amd.model.clip_vit import VIT_B32, ClipVisionTower
+    torch.manual_seed(0)
+    tower = ClipVisionTower(**VIT_B32).cuda()
+    x = torch.randn(B, 3, 224, 224, device="cuda")
+    ms, best = _gpu_ms(lambda: tower.encode_image(x), iters=20, warm=3)
+    tf = B * VIT_B32_GFLOP * 1e9 / (ms * 1e-3) / 1e12
+    out = dict(workload="CLIP ViT-B/32 image tower forward, B=%d, 224x224" % B, ms=round(ms, 3), ms_best=round(best, 3),
+               algorithmic_flop=B * VIT_B32_GFLOP * 1e9, achieved=round(tf, 1), peak=PEAK_BF16, unit="TFLOP/s", bound="bf16 MFMA",
+               frac=round(tf / PEAK_BF16, 4), images_per_s=round(B / (ms * 1e-3), 1))
+    if with_cpu:
+        try:
+            from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+            torch.set_num_threads(cpu_threads())
+            cfg = CLIPVisionConfig(hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
+                                   patch_size=32, image_size=224, projection_dim=512, hidden_act="quick_gelu")
+            m = CLIPVisionModelWithProjection(cfg).eval()
+            xc = x[:8].cpu()
+            with torch.no_grad():
+                dt, k = _cpu_time(lambda: m(pixel_values=xc))
+            out["cpu"] = dict(value=round(8 / dt, 2), unit="images/s", cores=cpu_threads(), kind="port",
+                              sample="transformers CLIPVisionModelWithProjection (ViT-B/32 geometry, fp32), batch 8, %d timed runs" % k,
+                              gpu_value=out["images_per_s"])
+        except Exception as e:      # transformers missing on the box: say so instead of failing the bench
+            out["cpu"] = dict(value=None, error="%s: %s" % (type(e).__name__, e))
+    return out
+
+
+def _renderer(opt):
+    from shapeclipper_amd.model.implicit import RGBNetwork, SDFNetwork
+    from shapeclipper_amd.model.renderer import Renderer
+    torch.manual_seed(0)
+    sdf, rgb = SDFNetwork(opt), RGBNetwork(opt)
+    return Renderer(opt, sdf, rgb).cuda(), sdf, rgb
+
+
+def _options(extra=()):
+    from shapeclipper_amd.utils import options
+    return options.set(options.parse_arguments(["--yaml=%s/options/pix3d/config.yaml" % ROOT, "--name=bench_workloads",
+                                                "--output_root=/tmp/sc_bench_w"] + list(extra)), verbose=False)
+
+
+def _cameras(opt, B):
+    """Random turn-table cameras through the PRODUCT's camera algebra (the oracle only ever appears in the CPU legs)."""
+    from shapeclipper_amd.model.graph import rotation_from_trig
+    from shapeclipper_amd.utils import camera
+    g = torch.Generator().manual_seed(1)
+    az = (torch.rand(B, generator=g) * 2 - 1) * np.pi
+    el = (torch.rand(B, generator=g) - 0.5) * np.pi / 3
+    trig = lambda t: torch.stack([torch.cos(t), torch.sin(t)], 1)
+    sd = 0.8 + 0.4 * torch.rand(B, generator=g)
+    Rm = rotation_from_trig(trig(az), trig(el), trig(torch.zeros(B)))
+    tz = sd * opt.camera.dist
+    pose = camera.pose.compose([camera.pose(R=Rm), camera.pose(t=torch.stack([torch.zeros(B), torch.zeros(B), tz], -1))])
+    return pose, camera.get_intr(opt, torch.ones(B)), sd, torch.randn(B, 64, generator=g), torch.randn(B, 64, generator=g)
+
+
+def render_eval_128(B=32, with_cpu=True):
+    opt = _options()
+    opt.H = opt.W = 128
+    r, sdf_net, rgb_net = _renderer(opt)
+    pose, intr, sd, zs, zr = _cameras(opt, B)
+    dev = torch.device("cuda")
+    args = [t.to(dev) for t in (pose, intr, sd, zs, zr)]
+
+    def run():
+        with torch.no_grad():
+            return r(opt, *args, ray_idx=None, training=False)
+    ms, best = _gpu_ms(run, iters=5)
+    rays = B * 128 * 128
+    tf = RENDER_EVAL_FLOP_PER_RAY * rays / (ms * 1e-3) / 1e12
+    out = dict(workload="full-frame evaluation render 128x128, B=%d (%d rays x 64 samples)" % (B, rays), ms=round(ms, 3),
+               ms_best=round(best, 3), algorithmic_flop=RENDER_EVAL_FLOP_PER_RAY * rays, algorithmic_bytes=rays * 44,
+               achieved=round(tf, 2), peak=PEAK_FP32, unit="TFLOP/s", bound="fp32 MFMA", frac=round(tf / PEAK_FP32, 4),
+               mrays_per_s=round(rays / (ms * 1e-3) / 1e6, 2))
+    if with_cpu:
+        from oracle import reference_ops as R
+        cfg = R.Cfg(H=128, W=128)
+        torch.set_num_threads(cpu_threads())
+        Ws = {k: v.detach().cpu() for k, v in sdf_net.state_dict().items()}
+        Wr = {k: v.detach().cpu() for k, v in rgb_net.state_dict().items()}
+        beta = r.density.beta.detach().cpu().reshape(())
+        idx = torch.arange(4096).view(1, -1)
+        _, eik_idx, _ = R.draw_render_randoms(4096, 64, False)
+
+        def oracle():
+            with torch.no_grad():
+                R.render(cfg, Ws, Wr, beta, pose[:1], intr[:1], sd[:1], zs[:1], zr[:1], idx, False, None, eik_idx, None)
+        dt, k = _cpu_time(oracle)
+        out["cpu"] = dict(value=round(4096 / dt / 1e6, 4), unit="Mrays/s", cores=cpu_threads(), kind="port",
+                          sample="oracle evaluation render of 4096 rays (a quarter frame of one image), %d timed runs" % k,
+                          gpu_value=out["mrays_per_s"])
+    return out
+
+
+def level_grid_100(with_cpu=True):
+    from shapeclipper_amd.utils import eval_3D
+    from shapeclipper_amd.utils.util import EasyDict as edict
+    opt = _options(["--eval.vox_res=100"])
+    opt.device = "cuda:0"
+    r, sdf_net, _ = _renderer(opt)
+    z = torch.randn(1, 64, generator=torch.Generator().manual_seed(2)).cuda()
+    grid = eval_3D.get_dense_3D_grid(opt, edict(idx=torch.arange(1)))
+    ms, best = _gpu_ms(lambda: eval_3D.compute_level_grid(opt, sdf_net, z, grid), iters=20)
+    n = 101 ** 3
+    tf = GRID_FLOP_PER_POINT * n / (ms * 1e-3) / 1e12
+    out = dict(workload="SDF level grid, vox_res=100, one image (%d points)" % n, ms=round(ms, 3), ms_best=round(best, 3),
+               algorithmic_flop=GRID_FLOP_PER_POINT * n, algorithmic_bytes=4 * n, achieved=round(tf, 2), peak=PEAK_FP32, unit="TFLOP/s",
+               bound="fp32 MFMA", frac=round(tf / PEAK_FP32, 4), mpoints_per_s=round(n / (ms * 1e-3) / 1e6, 1))
+    if with_cpu:
+        from oracle import reference_ops as R
+        torch.set_num_threads(cpu_threads())
+        Ws = {k: v.detach().cpu() for k, v in sdf_net.state_dict().items()}
+        k_pts = 10 * 101 * 101
+        flat = grid[0, :10].reshape(-1, 3).cpu()
+        lat = z.cpu().repeat(k_pts, 1)
+
+        def oracle():
+            with torch.no_grad():
+                R.sdf_mlp(R.Cfg(), Ws, flat, lat)
+        dt, k = _cpu_time(oracle)
+        out["cpu"] = dict(value=round(k_pts / dt / 1e6, 3), unit="Mpoints/s", cores=cpu_threads(), kind="port",
+                          sample="oracle SDF MLP on 10 of the 101 x-slabs (%d points), %d timed runs" % (k_pts, k),
+                          gpu_value=out["mpoints_per_s"])
+    return out
+
+
+def run_all(with_cpu=True):
+    out = {}
+    for name, fn in (("chamfer_b1", lambda: chamfer(1, with_cpu=with_cpu)), ("chamfer_b32", lambda: chamfer(32, with_cpu=False)),
+                     ("clip_vit_b32", lambda: clip_vit(32, with_cpu=with_cpu)), ("render_eval_128", lambda: render_eval_128(32, with_cpu=with_cpu)),
+                     ("level_grid_100", lambda: level_grid_100(with_cpu=with_cpu))):
+        out[name] = fn()
+        torch.cuda.empty_cache()
+    return out
+
+
+if __name__ == "__main__":
+    import json
+    print(json.dumps(run_all("--no-cpu" not in sys.argv)))
