@@ -57,6 +57,24 @@ def _latent_projector(dim_in, dim_out):
     return nn.Sequential(Bottleneck_Linear(dim_in), Bottleneck_Linear(dim_in), nn.Linear(dim_in, dim_out))
 
 
+def choice_from_uniform(probs, u):
+    """np.random.choice(K, size=(1,), replace=False, p=probs[i] / np.sum(probs[i])) for every row i, given the uniform
+    u[i] that call would draw (numpy mtrand.pyx legacy `choice`: cdf = cumsum(float64(p)); cdf /= cdf[-1];
+    searchsorted(u, side='right')).  Same operation order as numpy (float32 sequential sum and division, float64
+    sequential cumsum), so the picks are identical.  probs [B,K] float32, u [B] float64 -> (idx [B] int64, any-NaN flag)."""
+    K = probs.shape[1]
+    s = probs[:, 0]
+    for k in range(1, K):
+        s = s + probs[:, k]
+    p = (probs / s[:, None]).double()
+    cols = [p[:, 0]]
+    for k in range(1, K):
+        cols.append(cols[-1] + p[:, k])
+    cdf = torch.stack(cols, dim=1)
+    cdf = cdf / cdf[:, -1:]
+    return (cdf <= u[:, None].to(cdf.dtype)).sum(dim=1), torch.isnan(cdf).any()
+
+
 class Graph(nn.Module):
 
     def __init__(self, opt):
@@ -130,18 +148,33 @@ class Graph(nn.Module):
     @torch.no_grad()
     def select_neighbours(self, opt, var):
         """IoU-weighted choice of n_views of the K CLIP neighbours per image (graph.py:119-142).
-        One device->host copy of the [B,K] probabilities (the reference syncs once per image)."""
+
+        The reference reads the probabilities back to the host once per image and calls np.random.choice.  For
+        n_views == 1 (the shipped config) that call consumes exactly one uniform of numpy's global stream per image and
+        does a searchsorted on the normalised cdf: here the B uniforms are drawn on the host in image order (same
+        stream position afterwards), uploaded asynchronously, and the cdf search runs on the device in numpy's own
+        operation order (`choice_from_uniform`, bit-identical picks, tests/test_host_logic.py) -- NO device->host copy,
+        the host never waits for the stream.  n_views > 1 draws a data-dependent number of uniforms: host path."""
         B, K = len(var.idx), opt.data.k_nearest
         inp = var.mask_input.view(B, -1, 1)
         nn_masks = var.mask_input_NN.reshape(B, -1, K)
         inter = (nn_masks * inp).sum(dim=1)
         union = (nn_masks + inp - nn_masks * inp + 1.e-8).sum(dim=1)
-        probs = torch_F.normalize((1 - inter / union) ** opt.reg.sample_temp, dim=-1, p=1).cpu().numpy()
+        probs = torch_F.normalize((1 - inter / union) ** opt.reg.sample_temp, dim=-1, p=1)
+        dev = var.rgb_input_map.device
+        if opt.reg.n_views == 1 and opt.get("hip", {}).get("device_choice", True):
+            u = torch.from_numpy(np.random.random_sample(B))
+            if probs.is_cuda:
+                u = u.pin_memory().to(probs.device, non_blocking=True)
+            idx, nan = choice_from_uniform(probs, u)
+            var._bad_choice = nan                  # np.random.choice raises on NaN probabilities: joins the finite check
+            return idx.view(B, 1).to(dev)
+        probs = probs.cpu().numpy()
         picks = []
         for i in range(B):
             p = probs[i] / np.sum(probs[i])
             picks.append(np.random.choice(K, size=(opt.reg.n_views,), replace=False, p=p))
-        return torch.tensor(np.stack(picks, axis=0)).long().to(var.rgb_input_map.device)
+        return torch.tensor(np.stack(picks, axis=0)).long().to(dev)
 
     def gather_neighbour_views(self, opt, var, idx_NN, sampled):
         """The n_views chosen neighbours of every image as batch dictionaries (reference graph.py:144-193)."""

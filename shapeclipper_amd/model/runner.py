@@ -153,6 +153,7 @@ class Runner:
             opt.H, opt.W = opt.image_size
             var = util.move_to_device(var, opt.device)
             loss = self.train_iteration(opt, var, progress)
+        self.check_finite()                   # the last iteration's deferred NaN/Inf check
         if _rank0(opt) and loss is not None:
             log.loss_train(opt, self.ep + 1, opt.optim.lr, loss, self.timer)
         if (self.ep + 1) % opt.freq.eval == 0 and _rank0(opt):
@@ -177,16 +178,17 @@ class Runner:
             self.reducer.broadcast_buffers()
         else:
             optim.zero_grad()
+        self.check_finite()                   # the PREVIOUS step's flag (copied to pinned memory asynchronously): long there
         var, loss = self.graph.forward(opt, var, training=True, get_loss=True)
         loss = self.summarize_loss(opt, var, loss, non_act_loss_key=frozen_keys, defer_check=True)
         loss.all.backward()
         if self.reducer is not None:
             self.reducer.all_reduce()
-        self.check_finite(loss)               # the flag was copied to the host asynchronously: no stream drain
         optim.step()
 
         if _rank0(opt):
             if (self.it + 1) % opt.freq.ckpt_latest == 0:
+                self.check_finite()           # never checkpoint a step whose losses were not verified
                 self.save_checkpoint(opt, ep=self.ep, it=self.it + 1, best_val=self.best_val, latest=True)
             if opt.freq.scalar and self.it % opt.freq.scalar == 0 and self.tb is not None:
                 self.log_scalars(opt, var, loss, step=self.it, split="train")
@@ -213,6 +215,8 @@ class Runner:
             flag = ~torch.isfinite(value)
             bad = flag if bad is None else (bad | flag)
             total = total + (0.0 if key in non_act_loss_key else float(opt.loss_weight[key])) * value
+        if "_bad_choice" in var and bad is not None:          # NaN neighbour probabilities (np.random.choice would have raised)
+            bad = bad | var.pop("_bad_choice").to(bad.device)
         self._pending_check = None
         if bad is not None and opt.get("check_finite", True):
             if defer_check and bad.is_cuda:
@@ -220,7 +224,7 @@ class Runner:
                 host.copy_(bad, non_blocking=True)
                 done = torch.cuda.Event()
                 done.record()
-                self._pending_check = (host, done)
+                self._pending_check = (host, done, {k: v.detach() for k, v in loss.items()})
             elif bool(bad):
                 self._raise_not_finite(loss)
         loss.update(all=total)
@@ -235,13 +239,16 @@ class Runner:
             assert not torch.isinf(v), "loss {} is Inf".format(key)
             assert not torch.isnan(v), "loss {} is NaN".format(key)
 
-    def check_finite(self, loss):
+    def check_finite(self, loss=None):
+        """Raise the reference's NaN/Inf assertions (runner.py:296-302) for the step whose flag is pending.  The training
+        loop calls this at the start of the NEXT iteration (and before a checkpoint / at the end of an epoch), when the
+        flag has long arrived in pinned memory: the host never waits for the stream inside a step."""
         pending, self._pending_check = getattr(self, "_pending_check", None), None
         if pending is not None:
-            host, done = pending
+            host, done, pending_loss = pending
             done.synchronize()
             if bool(host):
-                self._raise_not_finite(loss)
+                self._raise_not_finite(loss if loss is not None else pending_loss)
 
     # ---- evaluation -----------------------------------------------------------------------------------
     @torch.no_grad()

@@ -253,3 +253,27 @@ def test_importance_ray_sampler_and_its_consumer():
     dist = np.maximum(ndimage.distance_transform_edt(m > 0.5) + ndimage.distance_transform_edt(m <= 0.5) - 0.5, 0)
     near = dist.reshape(-1)[b.ray_idx[0].numpy()].mean()
     assert near < 0.75 * dist.mean(), (near, dist.mean())      # 1/(d+3) weighting: mean distance of the drawn rays 16 px vs 27 px uniform
+
+
+def test_device_side_neighbour_choice_equals_numpy_choice():
+    """Graph.select_neighbours without a device->host copy: given the uniforms np.random.choice would draw, the cdf
+    search in numpy's operation order picks the same neighbour, and numpy's global stream ends at the same position."""
+    from shapeclipper_amd.model.graph import choice_from_uniform
+    B, K = 32, 5
+    for seed in range(200):
+        rng = np.random.RandomState(seed)
+        iou = rng.rand(B, K).astype(np.float32)
+        if seed % 7 == 0:
+            iou[3] = iou[3, 0]                                             # equal probabilities
+        probs = torch.nn.functional.normalize((1 - torch.tensor(iou)) ** 4, dim=-1, p=1)
+        pn = probs.numpy()
+        np.random.seed(seed)
+        ref = np.stack([np.random.choice(K, size=(1,), replace=False, p=pn[i] / np.sum(pn[i])) for i in range(B)])[:, 0]
+        next_ref = np.random.random_sample()
+        np.random.seed(seed)
+        u = np.random.random_sample(B)
+        next_got = np.random.random_sample()
+        idx, nan = choice_from_uniform(probs, torch.from_numpy(u))
+        assert np.array_equal(idx.numpy(), ref) and next_got == next_ref and not bool(nan)
+    _, nan = choice_from_uniform(torch.zeros(2, 5), torch.rand(2).double())       # all neighbours identical to the input: 0/0
+    assert bool(nan)
