@@ -216,6 +216,21 @@ int sc_render_backward(
 int sc_sdf_grid_forward(const float* sdf_pack, const float* sdf_cbias, float lo, float hi, int n_axis, int n_images,
                         int symmetric, float* points_ws, float* level, void* stream);
 
+/* Workgroup-cooperative reverse pass of the SDF MLP (csrc/sdf_bwdw.hip): what sc_sdf_backward + the eight sc_wgrad launches
+ * + sc_tbl_sum of the SDF network do, in ONE launch and without the Ga/Gp/r0 hand-off tensors (chain waves and
+ * weight-gradient waves of a workgroup exchange operands through LDS).  Requires g_grad and stash_p (the d sdf/dx output
+ * is differentiated: every training render) and n_per_image % 16 == 0.
+ *   park     workspace, sc_sdf_backward_fused_parts(n_points) * 4 * 4 * 1024 floats (per-wave scratch, stays in L2)
+ *   partial  [sc_sdf_backward_fused_parts(n_points)][SdfPack floats]: one partial image of d/d(w_pack) per workgroup,
+ *            fully written; sum them with sc_partial_reduce(partial, parts, SdfPack floats, SdfPack floats, g_w_pack)
+ *   g_cbias  [n_images][5][64], zero-filled by the caller: d/d(per-image biases)
+ *   g_points [n_points][3] or NULL.                                                                              */
+int sc_sdf_backward_fused_parts(int n_points);
+int sc_sdf_backward_fused(const float* points, const float* w_pack, int n_points, int n_per_image, int n_images,
+                          int symmetric, const float* stash_a, const float* stash_p, const float* g_sdf,
+                          const float* g_grad, const float* g_feat, float* g_points, float* park, float* partial,
+                          float* g_cbias, void* stream);
+
 /* backward of sc_loss_fused_forward: scales the stored gradients in place by the upstream dL/dloss_k (G4[4],
  * device memory).  g_eik and g_normal_t (n_normal elements, scaled by G4[2]) may be NULL.              */
 int sc_loss_fused_backward(const float* G4, float* g_rgb, long long n_rgb, float* g_mask, long long n_mask,

@@ -1,0 +1,509 @@
+// sdf_bwdw.hip -- workgroup-cooperative reverse pass of the conditional SDF MLP: input gradients (first and
+// second order) AND all weight / bias gradients in ONE launch, with no hand-off tensors in HBM.
+//
+// Replaces, for a render whose d(sdf)/dx output is differentiated (every training render: the reference reaches this
+// through loss.backward() over the create_graph=True graph of model/renderer.py:101-107 / model/implicit.py:180-186),
+// the pair  sdf_bwd.hip (chain) + 8 launches of wgrad.hip (addmm-backward GEMMs) + tbl_sum: that pair moved 8.2 + 9.5 KB
+// per sample point through HBM (Ga_l, Gp_l, r0 written by one kernel and read back by the other, a_l / p_l read three
+// times) for ~0 algorithmic bytes.  Here a 512-thread workgroup splits into two roles:
+//
+//   waves 0-3  "chain"  one 16-point tile each: the R sweep (reverse of the adjoint chain) and the V sweep (reverse of
+//                       the value chain) of sdf_bwd.hip, in registers, weights read from the LDS image;
+//   waves 4-7  "wgrad"  wave w owns rows 16w..16w+15 of EVERY weight-gradient matrix (116 accumulator registers) and
+//                       adds  A(point)[row] * B(point)[col]  over the points of all four chain tiles with fp32 MFMAs.
+//
+// After each layer of a sweep the chain waves drop the operand pair of that layer (A = q_l | Ga_l | Gf, B = Gp_{l-1} |
+// h_{l-1}; 64 channels x 16 points each) into a 4 KiB LDS slot in the layout the MFMA wants with K = point
+// ([point/4][channel ^ point/4][point%4]: conflict-free ds_write_b32 on one side, conflict-free ds_read_b128 that
+// yields the four K-steps of a channel on the other -- this IS the transpose wgrad.hip did with quad shuffles), two
+// workgroup barriers bracket the write, and the wgrad waves consume the pair while the chain waves run the next layer.
+// One chain wave and one wgrad wave share every SIMD: the matrix pipe alternates between the dependent MFMA chain of
+// one and the independent outer-product MFMAs of the other (1008 + 864 per 16 points).  The positional-encoding
+// operands (e, eps = Gg * dE/dx) are recomputed by the wgrad waves from the points (hardware sin/cos, as wgrad.hip).
+// Per-image bias gradients (= latent gradients) are row sums of the A operands; W5 row 0 / b5 sums go through LDS.
+// Every workgroup writes one partial image of the packed gradient; sc_partial_reduce sums them in a fixed order.
+//
+// HBM traffic: a_0..4, p_0..3, Gf read once per point (2.6 KB), g_points written (12 B); the parked second-order terms
+// (pend_0..3, 1 KiB per layer and wave) live in a per-wave scratch that never leaves L2.
+// LDS: weight image 118 KiB + 4 x 2 x 4 KiB exchange slots + point stash = 153 KiB of the 160 KiB.
+// Bound: fp32 MFMA (1872 v_mfma_f32_16x16x4 per 16 points; 157.3 TFLOP/s dense peak).
+#include "mlp_tile.hpp"
+
+namespace sc {
+
+struct SdfBwdwArgs {
+    const float* points;   // [n_points][3]
+    const float* w;        // SdfPack image
+    int n_points, n_per_image, n_images, symmetric;
+    const float* stash_a;  // 5 x TBL64
+    const float* stash_p;  // 4 x TBL64
+    const float* g_sdf;    // [n_points] or null
+    const float* g_grad;   // [n_points][3]
+    const float* g_feat;   // TBL64 or null
+    float* g_points;       // [n_points][3] or null
+    float* park;           // [gridDim.x * 4][4][1024] floats of per-wave scratch (L2-resident)
+    float* partial;        // [gridDim.x][SdfPack::TOTAL]: one partial gradient image per workgroup (fully written)
+    float* g_cbias;        // [n_images][5][64], zero-filled by the caller (atomicAdd)
+};
+
+constexpr int BW_CHAIN = 4;                          // chain waves (= wgrad waves) per workgroup
+constexpr int BW_WLDS = (SdfLds::TOTAL + 3) & ~3;    // weight image, floats
+constexpr int BW_XCH = BW_WLDS;                      // exchange slots: [chain wave][A|B][1024]
+constexpr int BW_PTS = BW_XCH + BW_CHAIN * 2 * 1024; // point stash: [chain wave][16 points][8] = x0 x1 x2 gam0 gam1 gam2 valid -
+constexpr int BW_RED = BW_PTS + BW_CHAIN * 16 * 8;   // [0..63] sum r0 (dW5 row 0), [64] sum Gs (db5[0])
+constexpr int BW_LDS_FLOATS = BW_RED + 68;
+static_assert(BW_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+
+// LDS-only barrier: does NOT drain the global loads in flight (the stash prefetches must survive it)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// sum over the 16 lanes of a DPP row (= the 16 points of lane group g); every lane ends up with the total
+__device__ __forceinline__ float row_sum16(float v) {
+    v += dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);     // row_half_mirror
+    v += dpp_mov<0x140>(v);     // row_mirror
+    return v;
+}
+
+// ---- chain side: drop a 64-channel operand (C/D register layout, v[4T+r] = channel 16T+4g+r of point p) into a slot ----
+// slot layout: float4 chunk index = (p>>2)*64 + (channel ^ (p>>2)), element p&3
+__device__ __forceinline__ void xch_write(float* slot, const int (&wr)[4], const float (&v)[ACT_STEPS], float mask) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slot[wr[r] + 64 * t] = v[4 * t + r] * mask;
+}
+__device__ __forceinline__ void xch_zero(float* slot, int lane) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) reinterpret_cast<float4*>(slot)[lane + 64 * k] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// ---- wgrad side ---------------------------------------------------------------------------------------------------
+// fragment of channel tile m: x..w = K-steps 0..3 = points 4kg..4kg+3 of channel 16m + i
+__device__ __forceinline__ float4 xch_frag(const float* slot, int rd, int m) {
+    return *reinterpret_cast<const float4*>(slot + rd + 64 * m);
+}
+__device__ __forceinline__ float f4(const float4& v, int s) { return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)); }
+
+// positional-encoding operand of this lane (PE column 16c + i <-> step = i>>2, owner group = i&3) at the 4 points of
+// its K slot, from the point stash: MODE 1 = E, MODE 2 = eps = Gg_c * dE/dx_c (cf. pe_lane_setup in wgrad.hip)
+template <int MODE>
+__device__ __forceinline__ void pe_frags(const float* pts, int i, int kg, bool symmetric, float4 (&out)[3]) {
+    const int step = i >> 2, gq = i & 3;
+    const bool raw = gq == 3, first = step == 0, iscos = step & 1;
+    const float f = raw ? 0.f : (float)(1 << (2 * gq + (step >> 1)));
+    float o[3][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const float4 xa = *reinterpret_cast<const float4*>(pts + (4 * kg + s) * 8);        // x0 x1 x2 gam0
+        const float4 xb = *reinterpret_cast<const float4*>(pts + (4 * kg + s) * 8 + 4);    // gam1 gam2 valid -
+        float x[3] = {xa.x, xa.y, xa.z};
+        const float gm[3] = {xa.w, xb.x, xb.y};
+        const float valid = xb.z;
+        const float sg0 = symmetric ? (x[0] > 0.f ? 1.f : (x[0] < 0.f ? -1.f : 0.f)) : 1.f;
+        if (symmetric) x[0] = fabsf(x[0]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float sn, cs;
+            __sincosf(x[c] * f, &sn, &cs);
+            if (MODE == 1) o[c][s] = valid * (raw ? (first ? x[c] : 0.f) : (iscos ? cs : sn));
+            else o[c][s] = gm[c] * (raw ? (first ? 1.f : 0.f) : (iscos ? -f * sn : f * cs)) * (c == 0 ? sg0 : 1.f);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[c] = make_float4(o[c][0], o[c][1], o[c][2], o[c][3]);
+}
+
+// acc[n] += A (this wave's 16 rows) x B[n]^T over the 16 points of one chain tile
+template <int N>
+__device__ __forceinline__ void outer16(const float4& af, const float4 (&bf)[N], f32x4 (&acc)[N]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int n = 0; n < N; ++n) acc[n] = mfma16(f4(af, s), f4(bf[n], s), acc[n]);
+}
+
+__global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    stage_sdf_weights(lds, a.w, tid, 512);
+    for (int e = tid; e < BW_LDS_FLOATS - BW_XCH; e += 512) lds[BW_XCH + e] = 0.f;      // slots, point stash, sums
+    __syncthreads();
+
+    const int ntiles = (a.n_points + TP - 1) / TP;
+    const size_t tbl = (size_t)ntiles * 1024;
+    // every workgroup owns one contiguous range of tiles (a wave changes image rarely: one flush of the bias sums per change)
+    const int per_wg = ((ntiles + (int)gridDim.x - 1) / (int)gridDim.x + BW_CHAIN - 1) & ~(BW_CHAIN - 1);
+    const int t_begin = blockIdx.x * per_wg, t_end = min(ntiles, t_begin + per_wg);
+    const int tiles_per_image = a.n_per_image / TP;
+    const bool symmetric = a.symmetric != 0;
+
+    if (wave < BW_CHAIN) {
+        // =====================================================================================================
+        // chain role
+        // =====================================================================================================
+        const int cw = wave, p = lane & 15, g = lane >> 4;
+        float* slotA = lds + BW_XCH + (cw * 2 + 0) * 1024;
+        float* slotB = lds + BW_XCH + (cw * 2 + 1) * 1024;
+        float* ptsw = lds + BW_PTS + cw * 16 * 8;
+        float* red = lds + BW_RED;
+        int wr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wr[r] = (((p >> 2) * 64 + 4 * g + (r ^ (p >> 2))) << 2) + (p & 3);
+        float* park = a.park + (size_t)(blockIdx.x * BW_CHAIN + cw) * 4 * 1024;
+
+        const float* w0 = lds + SdfLds::W0 + p * SdfLds::LD0 + g;
+        const float* w1h = lds + SdfLds::W1 + p * SdfLds::LD1 + 4 * g;
+        const float* w1e = lds + SdfLds::W1 + p * SdfLds::LD1 + 64 + g;
+        const float* w2h = lds + SdfLds::W2 + p * SdfLds::LD1 + 4 * g;
+        const float* w2e = lds + SdfLds::W2 + p * SdfLds::LD1 + 64 + g;
+        const float* w3 = lds + SdfLds::W3 + p * SdfLds::LD3 + 4 * g;
+        const float* w4 = lds + SdfLds::W4 + p * SdfLds::LD3 + 4 * g;
+        const float* w5s = lds + SdfLds::W5 + 4 * g;
+        const float* w5ft = lds + SdfLds::W5 + (1 + 4 * g) * SdfLds::LD3 + p;
+        const float* w4t = lds + SdfLds::W4 + 4 * g * SdfLds::LD3 + p;
+        const float* w3t = lds + SdfLds::W3 + 4 * g * SdfLds::LD3 + p;
+        const float* w2t = lds + SdfLds::W2 + 4 * g * SdfLds::LD1 + p;
+        const float* w1t = lds + SdfLds::W1 + 4 * g * SdfLds::LD1 + p;
+
+// gx_c += scale_c * sum_s V[s] * (W_le * DV[4c..4c+3])[s]
+#define BW_PE_DOT(WE, LD, V, DV, SCALE)                                                     \
+        _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                      \
+            f32x4 tacc[NT];                                                                  \
+            acc_zero(tacc);                                                                  \
+            if (c == 0) mm_pe<LD, NT, 0, 4>(WE, DV + 0, tacc);                               \
+            if (c == 1) mm_pe<LD, NT, 4, 4>(WE, DV + 4, tacc);                               \
+            if (c == 2) mm_pe<LD, NT, 8, 4>(WE, DV + 8, tacc);                               \
+            float dsum = 0.f;                                                                \
+            _Pragma("unroll") for (int s = 0; s < ACT_STEPS; ++s)                             \
+                dsum = __builtin_fmaf(V[s], tacc[s >> 2][s & 3], dsum);                      \
+            gx[c] = __builtin_fmaf(SCALE, dsum, gx[c]);                                      \
+        }
+// the write phase of one step: B1 (the wgrad waves have finished reading the previous pair), write, B2 (visible)
+#define BW_EXCHANGE(WRITES)                                                                 \
+        lds_barrier();                                                                       \
+        { WRITES }                                                                           \
+        lds_barrier();
+
+#pragma unroll 1
+        for (int base = t_begin; base < t_end; base += BW_CHAIN) {
+            const int tile = base + cw;
+            if (tile >= t_end) {            // tail: nothing to do but keep the barrier count (11 steps) and feed zeros
+                for (int k = 0; k < 11; ++k) {
+                    lds_barrier();
+                    if (k == 0) {
+                        xch_zero(slotA, lane); xch_zero(slotB, lane);
+                        if (lane < 32) reinterpret_cast<float4*>(ptsw)[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                    lds_barrier();
+                }
+                continue;
+            }
+            const int pt = tile * TP + p;
+            const bool valid = pt < a.n_points;
+            const float vmask = valid ? 1.f : 0.f;
+            const int ptc = valid ? pt : a.n_points - 1;
+            const float x0 = a.points[(size_t)ptc * 3 + 0], x1 = a.points[(size_t)ptc * 3 + 1], x2 = a.points[(size_t)ptc * 3 + 2];
+            float gam[3] = {0.f, 0.f, 0.f};
+            if (valid) { gam[0] = a.g_grad[(size_t)pt * 3]; gam[1] = a.g_grad[(size_t)pt * 3 + 1]; gam[2] = a.g_grad[(size_t)pt * 3 + 2]; }
+            float gx[3] = {0.f, 0.f, 0.f};
+            float d1[PE_STEPS];
+            float j_av[ACT_STEPS], j_pend[ACT_STEPS], j_u[ACT_STEPS];      // R -> V junction registers
+            // ================= R sweep =================
+            {
+                float e[PE_STEPS], d2[PE_STEPS], eps[PE_STEPS];
+                pe_slots<true, true>(x0, x1, x2, g, symmetric, e, d1, d2);
+#pragma unroll
+                for (int j = 0; j < PE_STEPS; ++j) eps[j] = gam[j >> 2] * d1[j];
+                f32x4 acc[NT];
+                float avA[ACT_STEPS], pvA[ACT_STEPS], avB[ACT_STEPS], pvB[ACT_STEPS], gpA[ACT_STEPS], gpB[ACT_STEPS];
+#define BW_R_LOAD(L, av, pv)                                                                \
+                tbl_load(a.stash_a + (size_t)(L) * tbl, tile, p, g, av);                     \
+                tbl_load(a.stash_p + (size_t)(L) * tbl, tile, p, g, pv);                     \
+                __builtin_amdgcn_sched_barrier(0);
+// element-wise part of R layer L: acc = Gq_L -> gpn = Gp_L, pend_L parked, pv <- q_L
+#define BW_R_ELEM(L, av, pv, gpn)                                                           \
+                {                                                                            \
+                    float pn[ACT_STEPS];                                                     \
+                    _Pragma("unroll") for (int s = 0; s < ACT_STEPS; ++s) {                   \
+                        float t, r;                                                          \
+                        softplus_parts(av[s], t, r);                                         \
+                        const float ds = softplus_d1(av[s], t, r);                           \
+                        const float gq = acc[s >> 2][s & 3];                                 \
+                        gpn[s] = gq * ds;                                                    \
+                        pn[s] = gq * pv[s] * softplus_d2(t, r);                              \
+                        pv[s] = pv[s] * ds;                                                  \
+                    }                                                                        \
+                    tbl_store(park + (size_t)(L) * 1024, 0, p, g, pn);                       \
+                }
+                acc_zero(acc);
+                BW_R_LOAD(0, avA, pvA)
+                BW_R_LOAD(1, avB, pvB)
+                mm_pe<SdfLds::LD0, NT, 0, PE_STEPS>(w0, eps, acc);                 // Gq0
+                BW_R_ELEM(0, avA, pvA, gpA)
+                BW_EXCHANGE(                                                        // step 0: A = q0 (pairs with eps)
+                    xch_write(slotA, wr, pvA, vmask);
+                    if (g == 0) {
+                        *reinterpret_cast<float4*>(ptsw + p * 8) = make_float4(x0, x1, x2, gam[0]);
+                        *reinterpret_cast<float4*>(ptsw + p * 8 + 4) = make_float4(gam[1], gam[2], vmask, 0.f);
+                    })
+                if (a.g_points) { BW_PE_DOT(w0, SdfLds::LD0, pvA, d2, gam[c]) }
+                acc_zero(acc);
+                BW_R_LOAD(2, avA, pvA)
+                mm_act<SdfLds::LD1, NT>(w1h, gpA, acc);
+                mm_pe<SdfLds::LD1, NT, 0, PE_STEPS>(w1e, eps, acc);                // Gq1
+                BW_R_ELEM(1, avB, pvB, gpB)
+                BW_EXCHANGE(xch_write(slotA, wr, pvB, vmask); xch_write(slotB, wr, gpA, vmask);)      // step 1: (q1, Gp0)
+                if (a.g_points) { BW_PE_DOT(w1e, SdfLds::LD1, pvB, d2, gam[c]) }
+                acc_zero(acc);
+                BW_R_LOAD(3, avB, pvB)
+                mm_act<SdfLds::LD1, NT>(w2h, gpB, acc);
+                mm_pe<SdfLds::LD1, NT, 0, PE_STEPS>(w2e, eps, acc);                // Gq2
+                BW_R_ELEM(2, avA, pvA, gpA)
+                BW_EXCHANGE(xch_write(slotA, wr, pvA, vmask); xch_write(slotB, wr, gpB, vmask);)      // step 2: (q2, Gp1)
+                if (a.g_points) { BW_PE_DOT(w2e, SdfLds::LD1, pvA, d2, gam[c]) }
+                acc_zero(acc);
+                tbl_load(a.stash_a + 4 * tbl, tile, p, g, j_av);
+                __builtin_amdgcn_sched_barrier(0);
+                mm_act<SdfLds::LD3, NT>(w3, gpA, acc);                             // Gq3
+                BW_R_ELEM(3, avB, pvB, gpB)
+                BW_EXCHANGE(xch_write(slotA, wr, pvB, vmask); xch_write(slotB, wr, gpA, vmask);)      // step 3: (q3, Gp2)
+                acc_zero(acc);
+                mm_act<SdfLds::LD3, NT>(w4, gpB, acc);                             // Gq4
+                {
+                    float q4[ACT_STEPS];
+#pragma unroll
+                    for (int s = 0; s < ACT_STEPS; ++s) {
+                        float t, r;
+                        softplus_parts(j_av[s], t, r);
+                        const float ds = softplus_d1(j_av[s], t, r), gq = acc[s >> 2][s & 3], w5 = w5s[kp(s)];
+                        j_pend[s] = gq * w5 * softplus_d2(t, r);
+                        j_u[s] = gq * ds;
+                        q4[s] = w5 * ds;
+                    }
+                    BW_EXCHANGE(xch_write(slotA, wr, q4, vmask); xch_write(slotB, wr, gpB, vmask);)   // step 4: (q4, Gp3)
+                }
+#undef BW_R_ELEM
+#undef BW_R_LOAD
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ================= V sweep =================
+            {
+                const float Gs = (valid && a.g_sdf) ? a.g_sdf[pt] : 0.f;
+                f32x4 acc[NT];
+                float av[ACT_STEPS], pv[ACT_STEPS], avB[ACT_STEPS], pvB[ACT_STEPS], gaA[ACT_STEPS], gaB[ACT_STEPS], hv[ACT_STEPS];
+#define BW_V_LOAD(L, av, pv)                                                                \
+                tbl_load(a.stash_a + (size_t)(L) * tbl, tile, p, g, av);                     \
+                tbl_load(park + (size_t)(L) * 1024, 0, p, g, pv);                            \
+                __builtin_amdgcn_sched_barrier(0);
+// V layer L: acc = W_{L+1}^T Ga_{L+1} -> gan = Ga_L = acc * sp'(a_L) + pend_L,  hv = h_L = sp(a_L)
+#define BW_V_ELEM(av, pv, gan)                                                              \
+                _Pragma("unroll") for (int s = 0; s < ACT_STEPS; ++s) {                       \
+                    float t, r;                                                              \
+                    softplus_parts(av[s], t, r);                                             \
+                    gan[s] = acc[s >> 2][s & 3] * softplus_d1(av[s], t, r) + pv[s];          \
+                    hv[s] = softplus_val(av[s], t);                                          \
+                }
+                acc_zero(acc);
+                float gf[ACT_STEPS];
+                if (a.g_feat) {
+                    tbl_load(a.g_feat, tile, p, g, gf);
+                    mm_act_t<SdfLds::LD3, NT>(w5ft, gf, acc);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < ACT_STEPS; ++s) gf[s] = 0.f;
+                }
+                BW_V_LOAD(3, av, pv)
+                BW_V_LOAD(2, avB, pvB)
+                {
+                    float r0v[ACT_STEPS];
+#pragma unroll
+                    for (int s = 0; s < ACT_STEPS; ++s) {
+                        float t, r;
+                        softplus_parts(j_av[s], t, r);
+                        const float gh = acc[s >> 2][s & 3] + w5s[kp(s)] * Gs;
+                        hv[s] = softplus_val(j_av[s], t);
+                        r0v[s] = (Gs * hv[s] + j_u[s]) * vmask;
+                        gaA[s] = gh * softplus_d1(j_av[s], t, r) + j_pend[s];
+                    }
+                    // dW5 row 0 = sum over points of r0, db5[0] = sum Gs: row reduction + one LDS atomic per channel
+#pragma unroll
+                    for (int s = 0; s < ACT_STEPS; ++s) {
+                        const float tot = row_sum16(r0v[s]);
+                        if (p == 0) atomicAdd(&red[16 * (s >> 2) + 4 * g + (s & 3)], tot);
+                    }
+                    const float gs_tot = row_sum16(Gs);
+                    if (lane == 0) atomicAdd(&red[64], gs_tot);
+                }
+                BW_EXCHANGE(xch_write(slotA, wr, gf, vmask); xch_write(slotB, wr, hv, vmask);)        // step 5: (Gf, h4)
+                acc_zero(acc);
+                mm_act_t<SdfLds::LD3, NT>(w4t, gaA, acc);
+                BW_V_ELEM(av, pv, gaB)                                                              // Ga3, h3
+                BW_EXCHANGE(xch_write(slotA, wr, gaA, vmask); xch_write(slotB, wr, hv, vmask);)       // step 6: (Ga4, h3)
+                BW_V_LOAD(1, av, pv)
+                acc_zero(acc);
+                mm_act_t<SdfLds::LD3, NT>(w3t, gaB, acc);
+                BW_V_ELEM(avB, pvB, gaA)                                                            // Ga2, h2
+                BW_EXCHANGE(xch_write(slotA, wr, gaB, vmask); xch_write(slotB, wr, hv, vmask);)       // step 7: (Ga3, h2)
+                BW_V_LOAD(0, avB, pvB)
+                BW_PE_DOT(w2e, SdfLds::LD1, gaA, d1, 1.f)
+                acc_zero(acc);
+                mm_act_t<SdfLds::LD1, NT>(w2t, gaA, acc);
+                BW_V_ELEM(av, pv, gaB)                                                              // Ga1, h1
+                BW_EXCHANGE(xch_write(slotA, wr, gaA, vmask); xch_write(slotB, wr, hv, vmask);)       // step 8: (Ga2, h1)
+                BW_PE_DOT(w1e, SdfLds::LD1, gaB, d1, 1.f)
+                acc_zero(acc);
+                mm_act_t<SdfLds::LD1, NT>(w1t, gaB, acc);
+                BW_V_ELEM(avB, pvB, gaA)                                                            // Ga0, h0
+                BW_EXCHANGE(xch_write(slotA, wr, gaB, vmask); xch_write(slotB, wr, hv, vmask);)       // step 9: (Ga1, h0)
+                BW_PE_DOT(w0, SdfLds::LD0, gaA, d1, 1.f)
+                BW_EXCHANGE(xch_write(slotA, wr, gaA, vmask);)                                      // step 10: Ga0 (pairs with e)
+#undef BW_V_ELEM
+#undef BW_V_LOAD
+                if (a.g_points) {
+                    const float o0 = group_sum(gx[0]), o1 = group_sum(gx[1]), o2 = group_sum(gx[2]);
+                    if (valid && g == 0) {
+                        a.g_points[(size_t)pt * 3 + 0] = o0;
+                        a.g_points[(size_t)pt * 3 + 1] = o1;
+                        a.g_points[(size_t)pt * 3 + 2] = o2;
+                    }
+                }
+            }
+        }
+#undef BW_PE_DOT
+#undef BW_EXCHANGE
+        __syncthreads();        // all sums are in LDS
+        float* out = a.partial + (size_t)blockIdx.x * SdfPack::TOTAL;
+        if (tid < 64) out[SdfPack::W5 + tid] = lds[BW_RED + tid];
+        if (tid == 64) out[SdfPack::B5] = lds[BW_RED + 64];
+    } else {
+        // =====================================================================================================
+        // wgrad role: wave w owns rows 16w..16w+15 of every matrix
+        // =====================================================================================================
+        const int w = wave - BW_CHAIN, i = lane & 15, kg = lane >> 4;
+        const int rd = (kg * 64 + (i ^ kg)) << 2;            // this lane's float4 chunk of channel tile 0 (+ 64 floats per tile)
+        f32x4 d0e[3], d1h[4], d1e[3], d2h[4], d2e[3], d3[4], d4[4], d5[4];
+        acc_zero(d0e); acc_zero(d1h); acc_zero(d1e); acc_zero(d2h); acc_zero(d2e); acc_zero(d3); acc_zero(d4); acc_zero(d5);
+        float rs[5] = {0.f, 0.f, 0.f, 0.f, 0.f};            // per-image bias-gradient partials (this lane's 4 points of every tile)
+        float rsf = 0.f;                                     // sum over all points of Gf (db5 feature rows)
+        int cur_img = -1;                                    // >= 0: rs[] belongs to this image; -2: mixed iteration (direct atomics)
+        auto flush = [&]() {
+            if (cur_img >= 0) {
+#pragma unroll
+                for (int l = 0; l < 5; ++l) {
+                    float v = rs[l];
+                    v += __shfl_xor(v, 16);
+                    v += __shfl_xor(v, 32);
+                    if (kg == 0) atomicAdd(&a.g_cbias[((size_t)cur_img * 5 + l) * 64 + 16 * w + i], v);
+                    rs[l] = 0.f;
+                }
+            }
+        };
+#define BW_STEP_BEGIN lds_barrier(); lds_barrier();
+// one step over the four chain tiles.  HP: 64-wide B operand in slot B; PEM: 0 none, 1 E, 2 eps; RS: bias layer (-1 none, 5 = Gf)
+#define BW_CONSUME(ACCH, ACCE, HP, PEM, RS)                                                 \
+        _Pragma("unroll") for (int c = 0; c < BW_CHAIN; ++c) {                               \
+            const float* sA = lds + BW_XCH + (c * 2 + 0) * 1024;                             \
+            const float* sB = lds + BW_XCH + (c * 2 + 1) * 1024;                             \
+            const float4 af = xch_frag(sA, rd, w);                                           \
+            if (HP) {                                                                        \
+                float4 bf[4];                                                                \
+                _Pragma("unroll") for (int n = 0; n < 4; ++n) bf[n] = xch_frag(sB, rd, n);   \
+                outer16<4>(af, bf, ACCH);                                                    \
+            }                                                                                \
+            if (PEM) {                                                                       \
+                float4 pf[3];                                                                \
+                pe_frags<PEM ? PEM : 1>(lds + BW_PTS + c * 16 * 8, i, kg, symmetric, pf);    \
+                outer16<3>(af, pf, ACCE);                                                    \
+            }                                                                                \
+            if (RS >= 0) {                                                                   \
+                const float v = (af.x + af.y) + (af.z + af.w);                               \
+                if (RS == 5) rsf += v;                                                       \
+                else if (cur_img >= 0) rs[(RS >= 0 && RS < 5) ? RS : 0] += v;                             \
+                else {                                                                       \
+                    float t = v;                                                             \
+                    t += __shfl_xor(t, 16);                                                  \
+                    t += __shfl_xor(t, 32);                                                  \
+                    const int img = min((base + c) / tiles_per_image, a.n_images - 1);       \
+                    if (kg == 0 && base + c < t_end)                                         \
+                        atomicAdd(&a.g_cbias[((size_t)img * 5 + ((RS >= 0 && RS < 5) ? RS : 0)) * 64 + 16 * w + i], t); \
+                }                                                                            \
+            }                                                                                \
+        }
+#pragma unroll 1
+        for (int base = t_begin; base < t_end; base += BW_CHAIN) {
+            const int img0 = min(base / tiles_per_image, a.n_images - 1);
+            const int img3 = min(min(base + BW_CHAIN - 1, t_end - 1) / tiles_per_image, a.n_images - 1);
+            if (img0 != cur_img || img3 != img0) {
+                flush();
+                cur_img = img0 == img3 ? img0 : -2;
+            }
+            BW_STEP_BEGIN BW_CONSUME(d3, d0e, false, 2, -1)        // 0: q0 x eps
+            BW_STEP_BEGIN BW_CONSUME(d1h, d1e, true, 2, -1)         // 1: q1 x (Gp0 | eps)
+            BW_STEP_BEGIN BW_CONSUME(d2h, d2e, true, 2, -1)         // 2: q2 x (Gp1 | eps)
+            BW_STEP_BEGIN BW_CONSUME(d3, d0e, true, 0, -1)          // 3: q3 x Gp2
+            BW_STEP_BEGIN BW_CONSUME(d4, d0e, true, 0, -1)          // 4: q4 x Gp3
+            BW_STEP_BEGIN BW_CONSUME(d5, d0e, true, 0, 5)           // 5: Gf x h4
+            BW_STEP_BEGIN BW_CONSUME(d4, d0e, true, 0, 4)           // 6: Ga4 x h3
+            BW_STEP_BEGIN BW_CONSUME(d3, d0e, true, 0, 3)           // 7: Ga3 x h2
+            BW_STEP_BEGIN BW_CONSUME(d2h, d2e, true, 1, 2)          // 8: Ga2 x (h1 | E)
+            BW_STEP_BEGIN BW_CONSUME(d1h, d1e, true, 1, 1)          // 9: Ga1 x (h0 | E)
+            BW_STEP_BEGIN BW_CONSUME(d3, d0e, false, 1, 0)          // 10: Ga0 x E
+        }
+#undef BW_CONSUME
+#undef BW_STEP_BEGIN
+        flush();
+        __syncthreads();
+        // ---- this workgroup's partial image: rows 16w + 4kg + r, columns 16n + i of every matrix ----
+        float* out = a.partial + (size_t)blockIdx.x * SdfPack::TOTAL;
+        auto put = [&](const f32x4* acc, int ntile, int off, int ld, int col0) {
+            for (int n = 0; n < ntile; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[off + (16 * w + 4 * kg + r) * ld + col0 + 16 * n + i] = acc[n][r];
+        };
+        put(d0e, 3, SdfPack::W0, 48, 0);
+        put(d1h, 4, SdfPack::W1, 112, 0);
+        put(d1e, 3, SdfPack::W1, 112, 64);
+        put(d2h, 4, SdfPack::W2, 112, 0);
+        put(d2e, 3, SdfPack::W2, 112, 64);
+        put(d3, 4, SdfPack::W3, 64, 0);
+        put(d4, 4, SdfPack::W4, 64, 0);
+        put(d5, 4, SdfPack::W5 + 64, 64, 0);
+        float v = rsf;
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (kg == 0) out[SdfPack::B5 + 1 + 16 * w + i] = v;
+    }
+}
+
+}  // namespace sc
+
+extern "C" {
+
+// Number of workgroups (= partial images, = 4-wave park slots / 4) sc_sdf_backward_fused launches for n_points.
+int sc_sdf_backward_fused_parts(int n_points) {
+    const int ntiles = (n_points + sc::TP - 1) / sc::TP;
+    int blocks = (ntiles + sc::BW_CHAIN - 1) / sc::BW_CHAIN;
+    return blocks > 256 ? 256 : (blocks < 1 ? 1 : blocks);
+}
+
+int sc_sdf_backward_fused(const float* points, const float* w_pack, int n_points, int n_per_image, int n_images, int symmetric,
+                          const float* stash_a, const float* stash_p, const float* g_sdf, const float* g_grad,
+                          const float* g_feat, float* g_points, float* park, float* partial, float* g_cbias, void* stream_) {
+    if (n_points <= 0) return 0;
+    if (!g_grad || !stash_p || n_per_image <= 0 || n_per_image % sc::TP != 0 || n_images <= 0) return (int)hipErrorInvalidValue;
+    sc::SdfBwdwArgs a{points, w_pack, n_points, n_per_image, n_images, symmetric, stash_a, stash_p, g_sdf, g_grad, g_feat,
+                      g_points, park, partial, g_cbias};
+    const int blocks = sc_sdf_backward_fused_parts(n_points);
+    const size_t lds_bytes = (size_t)sc::BW_LDS_FLOATS * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)sc::sdf_bwdw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL(sc::sdf_bwdw_kernel, dim3(blocks), dim3(512), lds_bytes, (hipStream_t)stream_, a);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -14,13 +14,14 @@ class SdfFunction(torch.autograd.Function):
     hand-written sdf_bwd.hip / wgrad.hip path)."""
 
     @staticmethod
-    def forward(ctx, points, w_pack, cbias, n_per_image, symmetric, want_grad, want_feat):
+    def forward(ctx, points, w_pack, cbias, n_per_image, symmetric, want_grad, want_feat, fused_backward=True):
         points = points.contiguous()
         need = any(ctx.needs_input_grad[:3])
         res = ops.sdf_forward(points, w_pack, cbias, n_per_image, symmetric=symmetric, want_grad=want_grad,
                               want_feat=want_feat, stash=need)
         sdf, grad, feat = res[0], res[1], res[2]
         ctx.meta = (n_per_image, cbias.shape[0], symmetric, want_grad, want_feat)
+        ctx.fused_backward = fused_backward
         if need:
             ctx.save_for_backward(points, w_pack, res[3], res[4] if want_grad else None)
         empty = points.new_empty(0)
@@ -38,8 +39,9 @@ class SdfFunction(torch.autograd.Function):
         g_grad = g_grad.contiguous() if (want_grad and g_grad is not None) else None
         g_feat = g_feat.contiguous() if (want_feat and g_feat is not None) else None
         gp, gw, gc = ops.sdf_backward(points, w_pack, n_per_image, n_images, symmetric, stash_a, stash_p,
-                                      g_sdf, g_grad, g_feat, want_points_grad=ctx.needs_input_grad[0])
-        return gp, gw, gc, None, None, None, None
+                                      g_sdf, g_grad, g_feat, want_points_grad=ctx.needs_input_grad[0],
+                                      fused=ctx.fused_backward)
+        return gp, gw, gc, None, None, None, None, None
 
 
 class RgbCompositeFunction(torch.autograd.Function):

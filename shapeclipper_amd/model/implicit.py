@@ -147,7 +147,7 @@ class SDFNetwork(nn.Module):
             proj_latent = proj_latent.detach()
         w_pack, cbias = self.packed(proj_latent)
         sdf, grad, feat = SdfFunction.apply(points_flat, w_pack, cbias, n // batch_size, bool(self.force_symmetry),
-                                            bool(compute_grad), True)
+                                            bool(compute_grad), True, bool(opt.get("hip", {}).get("fused_backward", True)))
         return sdf[:, None], packing.tbl_to_rows(feat, n), (grad if compute_grad else None)
 
 

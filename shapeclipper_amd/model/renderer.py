@@ -103,7 +103,8 @@ class Renderer(nn.Module):
 
         # fused SDF value + feature + d(sdf)/dx, then RGB MLP + density + compositing
         w_pack, cbias = self.sdf_network.packed(proj_latent_sdf)
-        sdf, grad, feat = SdfFunction.apply(points_flat, w_pack, cbias, R * S, sym, True, True)
+        fused_bwd = bool(opt.get("hip", {}).get("fused_backward", True))
+        sdf, grad, feat = SdfFunction.apply(points_flat, w_pack, cbias, R * S, sym, True, True, fused_bwd)
         v_pack, dbias = self.rgb_network.packed(proj_latent_rgb)
         outs = RgbCompositeFunction.apply(points_flat, z_vals, depth_fac.contiguous(), sdf, grad, feat,
                                           v_pack, dbias, self.density.beta, R, sym, float(self.density.beta_min),

@@ -118,10 +118,48 @@ def tbl_sum(x, n_points, n_per_image, n_images, coef=None):
     return tbl_sum_multi([x], n_points, n_per_image, n_images, coef)[0]
 
 
+def _park_scratch(dev, n_floats):
+    """Per-(device, stream) scratch of the fused backward (parked second-order terms; L2-resident)."""
+    key = ("park", dev.type, dev.index, torch.cuda.current_stream().cuda_stream if dev.type == "cuda" else 0)
+    if key not in _SCRATCH or _SCRATCH[key].numel() < n_floats:
+        _SCRATCH[key] = torch.empty(n_floats, device=dev, dtype=torch.float32)
+    return _SCRATCH[key]
+
+
+def sdf_backward_fused(points, w_pack, n_per_image, n_images, symmetric, stash_a, stash_p, g_sdf, g_grad, g_feat,
+                       want_points_grad=True):
+    """csrc/sdf_bwdw.hip: input gradients and every weight / bias gradient of the SDF network in one launch."""
+    from .packing import SDF_PACK_FLOATS
+    lib = _lib.load()
+    n = points.shape[0]
+    dev = points.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    parts = int(lib.sc_sdf_backward_fused_parts(c_int(n)))
+    park = _park_scratch(dev, 256 * 4 * 4 * 1024)
+    partial = torch.empty(parts * SDF_PACK_FLOATS, **f32)
+    g_c = torch.zeros(n_images, 5, 64, **f32)
+    g_points = torch.empty(n, 3, **f32) if want_points_grad else None
+    code = lib.sc_sdf_backward_fused(_lib.ptr(points), _lib.ptr(w_pack), c_int(n), c_int(n_per_image), c_int(n_images),
+                                     c_int(1 if symmetric else 0), _lib.ptr(stash_a), _lib.ptr(stash_p), _lib.ptr(g_sdf),
+                                     _lib.ptr(g_grad), _lib.ptr(g_feat), _lib.ptr(g_points), _lib.ptr(park),
+                                     _lib.ptr(partial), _lib.ptr(g_c), _lib.stream())
+    _lib.check(code, "sc_sdf_backward_fused")
+    g_w = torch.zeros(SDF_PACK_FLOATS, **f32)
+    code = lib.sc_partial_reduce(_lib.ptr(partial), c_int(parts), c_int(SDF_PACK_FLOATS), c_int(SDF_PACK_FLOATS),
+                                 _lib.ptr(g_w), _lib.stream())
+    _lib.check(code, "sc_partial_reduce")
+    return g_points, g_w, g_c
+
+
 def sdf_backward(points, w_pack, n_per_image, n_images, symmetric, stash_a, stash_p, g_sdf, g_grad, g_feat,
-                 want_points_grad=True):
-    """Reverse pass of sdf_forward (incl. second-order terms) -> (g_points | None, g_w_pack, g_cbias)."""
+                 want_points_grad=True, fused=True):
+    """Reverse pass of sdf_forward (incl. second-order terms) -> (g_points | None, g_w_pack, g_cbias).
+    fused (hip.fused_backward): one workgroup-cooperative launch (csrc/sdf_bwdw.hip) when the d sdf/dx output is
+    differentiated; otherwise sdf_bwd.hip + 8 wgrad.hip launches + tbl_sum through hand-off tensors in HBM."""
     from .packing import SDF_OFF, SDF_PACK_FLOATS
+    if fused and g_grad is not None and stash_p is not None and n_per_image % 16 == 0:
+        return sdf_backward_fused(points, w_pack, n_per_image, n_images, symmetric, stash_a, stash_p, g_sdf, g_grad,
+                                  g_feat, want_points_grad)
     lib = _lib.load()
     n = points.shape[0]
     dev = points.device

@@ -49,7 +49,7 @@ def _oracle(cfg, W, z, pts, c1, c2, c3, B, use_grad, use_feat, detach_latent=Fal
     return out
 
 
-def _hip(W, z, pts, c1, c2, c3, N, use_grad, use_feat):
+def _hip(W, z, pts, c1, c2, c3, N, use_grad, use_feat, fused=True):
     from shapeclipper_amd import packing
     from shapeclipper_amd.functional import SdfFunction
     dev = torch.device("cuda:0")
@@ -57,7 +57,7 @@ def _hip(W, z, pts, c1, c2, c3, N, use_grad, use_feat):
     zd = z.to(dev).requires_grad_(True)
     pd = pts.to(dev).requires_grad_(True)
     pack, cb = packing.pack_sdf(Wd, zd)
-    sdf, grad, feat = SdfFunction.apply(pd, pack, cb, N, True, use_grad, use_feat)
+    sdf, grad, feat = SdfFunction.apply(pd, pack, cb, N, True, use_grad, use_feat, fused)
     L = (sdf * c1.to(dev)).sum()
     if use_grad:
         L = L + (grad * c2.to(dev)).sum()
@@ -82,3 +82,23 @@ def test_sdf_backward_vs_oracle(B, N, use_grad, use_feat):
         scale = max(ref[k].abs().max().item(), 1e-3)
         err = (got[k] - ref[k]).abs().max().item()
         assert err <= 1e-3 * scale, (k, err, scale)
+
+
+@pytest.mark.parametrize("B,N,use_feat", [(1, 16, True), (1, 48, True), (2, 96, True), (2, 512, False), (3, 1040, True),
+                                          (2, 16384, True)])
+def test_fused_backward_vs_oracle_and_vs_the_unfused_kernels(B, N, use_feat):
+    """csrc/sdf_bwdw.hip (chain waves + weight-gradient waves exchanging operands through LDS; taken when d sdf/dx is
+    differentiated and n_per_image % 16 == 0): fewer tiles than chain waves, tails, several sweeps of the persistent
+    loop, image boundaries inside a workgroup's range.  Same bar as the unfused path, and the two paths agree."""
+    cfg, W, z, pts, c1, c2, c3 = _setup(B, N, 7 * B + N)
+    ref = _oracle(cfg, W, z, pts, c1, c2, c3, B, True, use_feat)
+    got = _hip(W, z, pts, c1, c2, c3, N, True, use_feat, fused=True)
+    old = _hip(W, z, pts, c1, c2, c3, N, True, use_feat, fused=False)
+    worst = {}
+    for k in ref:
+        scale = max(ref[k].abs().max().item(), 1e-3)
+        worst[k] = ((got[k] - ref[k]).abs().max().item() / scale, (got[k] - old[k]).abs().max().item() / scale)
+    print("fused SDF backward B=%d N=%d: max err vs oracle / vs unfused (relative to max |ref|):" % (B, N),
+          {k: "%.1e / %.1e" % v for k, v in worst.items()})
+    bad = {k: v for k, v in worst.items() if v[0] > 1e-3 or v[1] > 1e-3}
+    assert not bad, bad

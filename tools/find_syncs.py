@@ -20,6 +20,9 @@ def main():
         if "synchroniz" in str(message):
             st = [f for f in traceback.extract_stack() if "/repo/" in f.filename and "find_syncs" not in f.filename]
             key = " <- ".join("%s:%d" % (os.path.basename(f.filename), f.lineno) for f in reversed(st[-3:]))
+            if not key:
+                key = str(message)[:80] + " @ " + " <- ".join("%s:%d" % (os.path.basename(f.filename), f.lineno)
+                                                               for f in reversed(traceback.extract_stack()[-8:-1]))
             seen[key] = seen.get(key, 0) + 1
     warnings.showwarning = hook
     warnings.simplefilter("always")
