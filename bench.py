@@ -35,6 +35,8 @@ RGB_VALUE = 2 * 19072
 FLOPS_PER_POINT = {
     "sc_sdf_forward": SDF_VALUE + SDF_GRAD,
     "sc_sdf_backward": 2 * (SDF_VALUE + SDF_GRAD) // 2,     # input-gradient half of the double backward
+    # fused backward: input-gradient half + the weight-gradient GEMMs of the SDF network (864 MFMAs per 16 points)
+    "sc_sdf_backward_fused": 2 * (SDF_VALUE + SDF_GRAD) // 2 + 864 * 2048 // 16,
     "sc_rgb_composite_forward": RGB_VALUE,
     "sc_rgb_composite_backward": RGB_VALUE + RGB_VALUE,     # recompute + input-gradient sweep
 }
@@ -54,6 +56,7 @@ def parse():
     ap.add_argument("--sustained", type=int, default=200, help="extra steps timed after the K-step region (0: off)")
     ap.add_argument("--no-workloads", action="store_true", help="skip the other SURVEY 8(d) workloads (tools/workloads.py)")
     ap.add_argument("--workloads-only", action="store_true", help="only those workloads (the rocprofv3 command of profiles/)")
+    ap.add_argument("--opt", action="append", default=[], help="extra option override(s), e.g. --opt=--hip.fused_backward!")
     return ap.parse_args()
 
 
@@ -114,7 +117,7 @@ def _workloads():
     return mod
 
 
-def build_runner(batch_per_gpu, rank=0, local=0, world=1):
+def build_runner(batch_per_gpu, rank=0, local=0, world=1, extra=()):
     """Runner + options + HBM-resident synthetic batch for the Pix3D training configuration."""
     from shapeclipper_amd import synthetic
     from shapeclipper_amd.model.runner import Runner
@@ -123,7 +126,7 @@ def build_runner(batch_per_gpu, rank=0, local=0, world=1):
 
     opt = options.set(options.parse_arguments([
         "--yaml=%s/options/pix3d/config.yaml" % ROOT, "--name=bench", "--output_root=/tmp/sc_bench_%d" % rank,
-        "--batch_size=%d" % (batch_per_gpu * world), "--tb!", "--arch.enc_pretrained!"]), verbose=False)
+        "--batch_size=%d" % (batch_per_gpu * world), "--tb!", "--arch.enc_pretrained!"] + list(extra)), verbose=False)
     opt.device, opt.world_size, opt.port = local, world, 0
     opt.freq.scalar, opt.freq.ckpt_latest = 0, 10 ** 9
     torch.manual_seed(rank)
@@ -153,7 +156,7 @@ def main():
     if a.workloads_only:
         print(json.dumps(dict(workloads=_workloads().run_all(with_cpu=not a.no_cpu_baseline))))
         return
-    runner, opt, batch = build_runner(a.batch, rank, local, world)
+    runner, opt, batch = build_runner(a.batch, rank, local, world, a.opt)
 
     def step():
         opt.H, opt.W = opt.image_size

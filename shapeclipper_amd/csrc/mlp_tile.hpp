@@ -106,7 +106,13 @@ __device__ __forceinline__ void softplus_parts(float a, float& t, float& r) {
     t = __expf(-fabsf(100.f * a));
     r = __builtin_amdgcn_rcpf(1.f + t);
 }
-__device__ __forceinline__ float softplus_val(float a, float t) { return fmaxf(a, 0.f) + 0.01f * __logf(1.f + t); }
+// log(1+t)/100 with the hardware log2 (v_log_f32, ~1 ulp on [1,2]: absolute error < 1e-9 after the 0.0069 scale); the
+// library logf spends ~12 more VALU instructions per element on denormal / accuracy handling this argument range never
+// needs -- and on gfx950 VALU instructions do NOT overlap with MFMAs of the same SIMD (tools/micro/mfma_valu_overlap.hip:
+// time = MFMA time + VALU time), so every VALU instruction of the chain kernels is on the critical path.
+__device__ __forceinline__ float softplus_val(float a, float t) {
+    return __builtin_fmaf(0.0069314718056f, __builtin_amdgcn_logf(1.f + t), fmaxf(a, 0.f));
+}
 __device__ __forceinline__ float softplus_d1(float a, float t, float r) { return (a >= 0.f ? 1.f : t) * r; }
 __device__ __forceinline__ float softplus_d2(float t, float r) { return 100.f * t * r * r; }
 
@@ -114,7 +120,9 @@ __device__ __forceinline__ float softplus_d2(float t, float r) { return 100.f * 
 // e[4c+j]: value, d1[4c+j]: d/dx_c, d2[4c+j]: d2/dx_c^2 of the slot this lane (group g) owns.
 // Symmetry (implicit.py:139-145): coordinate 0 enters as |x0|; chain-rule factor sign(x0) with
 // sign(0)=0 exactly as torch.abs' backward; the second derivative carries sign^2.
-template <bool D1, bool D2>
+// FAST: hardware sin/cos (|error| ~ 1e-6 for these |arguments| <= 64) -- used by the backward kernels, whose outputs are
+// gradients accumulated over many points; the forward value path keeps the accurate sincosf.
+template <bool D1, bool D2, bool FAST = false>
 __device__ __forceinline__ void pe_slots(float x0, float x1, float x2, int g, bool symmetric,
                                          float (&e)[PE_STEPS], float (&d1)[PE_STEPS], float (&d2)[PE_STEPS]) {
     const float fbase = g == 0 ? 1.f : (g == 1 ? 4.f : 16.f);
@@ -129,7 +137,8 @@ __device__ __forceinline__ void pe_slots(float x0, float x1, float x2, int g, bo
         for (int m = 0; m < 2; ++m) {
             const float f = fbase * (float)(1 << m);
             float sn, cs;
-            sincosf(xs[c] * f, &sn, &cs);
+            if (FAST) __sincosf(xs[c] * f, &sn, &cs);
+            else sincosf(xs[c] * f, &sn, &cs);
             e[4 * c + 2 * m] = raw ? (m == 0 ? xs[c] : 0.f) : sn;
             e[4 * c + 2 * m + 1] = raw ? 0.f : cs;
             if (D1) {

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void rgb_composite_bwd_kernel(RgbBwdArgs a) {
             const float gc0 = __shfl(Gc0, src), gc1 = __shfl(Gc1, src), gc2 = __shfl(Gc2, src);
             const float x0 = a.points[pt * 3 + 0], x1 = a.points[pt * 3 + 1], x2 = a.points[pt * 3 + 2];
             float e[PE_STEPS], d1[PE_STEPS], d2[PE_STEPS];
-            pe_slots<true, false>(x0, x1, x2, g, a.symmetric != 0, e, d1, d2);
+            pe_slots<true, false, true>(x0, x1, x2, g, a.symmetric != 0, e, d1, d2);
             float f[ACT_STEPS];
             tbl_load(a.feat, tile, p, g, f);
             float r[3][ACT_STEPS];

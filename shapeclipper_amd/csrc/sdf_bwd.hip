@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64 * SDFB_WAVES) void sdf_bwd_kernel(SdfBwdArgs a) 
             const int ptc = valid ? pt : a.n_points - 1;
             const float x0 = a.points[(size_t)ptc * 3 + 0], x1 = a.points[(size_t)ptc * 3 + 1], x2 = a.points[(size_t)ptc * 3 + 2];
             float e[PE_STEPS], d2[PE_STEPS];
-            pe_slots<true, true>(x0, x1, x2, g, a.symmetric != 0, e, d1, d2);
+            pe_slots<true, true, true>(x0, x1, x2, g, a.symmetric != 0, e, d1, d2);
             float gam[3] = {0.f, 0.f, 0.f};
             if (valid) { gam[0] = a.g_grad[(size_t)pt * 3]; gam[1] = a.g_grad[(size_t)pt * 3 + 1]; gam[2] = a.g_grad[(size_t)pt * 3 + 2]; }
             f32x4 acc[NT];
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64 * SDFB_WAVES) void sdf_bwd_kernel(SdfBwdArgs a) 
         if (!HAS_GG) {
             const float x0 = a.points[(size_t)ptc * 3 + 0], x1 = a.points[(size_t)ptc * 3 + 1], x2 = a.points[(size_t)ptc * 3 + 2];
             float e[PE_STEPS], d2[PE_STEPS];
-            pe_slots<true, false>(x0, x1, x2, g, a.symmetric != 0, e, d1, d2);
+            pe_slots<true, false, true>(x0, x1, x2, g, a.symmetric != 0, e, d1, d2);
         }
         const float Gs = (valid && a.g_sdf) ? a.g_sdf[pt] : 0.f;
         f32x4 acc[NT];

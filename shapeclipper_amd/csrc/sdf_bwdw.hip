@@ -27,6 +27,8 @@
 // (pend_0..3, 1 KiB per layer and wave) live in a per-wave scratch that never leaves L2.
 // LDS: weight image 118 KiB + 4 x 2 x 4 KiB exchange slots + point stash = 153 KiB of the 160 KiB.
 // Bound: fp32 MFMA (1872 v_mfma_f32_16x16x4 per 16 points; 157.3 TFLOP/s dense peak).
+#include <stdlib.h>
+
 #include "mlp_tile.hpp"
 
 namespace sc {
@@ -44,6 +46,7 @@ struct SdfBwdwArgs {
     float* park;           // [gridDim.x * 4][4][1024] floats of per-wave scratch (L2-resident)
     float* partial;        // [gridDim.x][SdfPack::TOTAL]: one partial gradient image per workgroup (fully written)
     float* g_cbias;        // [n_images][5][64], zero-filled by the caller (atomicAdd)
+    int dbg;               // tuning experiments only (SC_BWDW_DBG): 1 = wgrad waves skip their MFMAs, 2 = skip the PE operands
 };
 
 constexpr int BW_CHAIN = 4;                          // chain waves (= wgrad waves) per workgroup
@@ -91,28 +94,35 @@ __device__ __forceinline__ float4 xch_frag(const float* slot, int rd, int m) {
 __device__ __forceinline__ float f4(const float4& v, int s) { return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)); }
 
 // positional-encoding operand of this lane (PE column 16c + i <-> step = i>>2, owner group = i&3) at the 4 points of
-// its K slot, from the point stash: MODE 1 = E, MODE 2 = eps = Gg_c * dE/dx_c (cf. pe_lane_setup in wgrad.hip)
+// its K slot, from the point stash: MODE 1 = E, MODE 2 = eps = Gg_c * dE/dx_c.  A lane's column is sin OR cos of one
+// frequency, and d/dx sin = f cos, d/dx cos = -f sin are again a sine with a quarter-turn phase: every entry is
+//   amp * sin(2 pi (x * f/2pi + phase))   ->  one v_fma + one v_sin_f32 (argument in revolutions) + one v_mul;
+// the raw-coordinate lanes (group 3) select x / 1 / 0 instead.  (VALU instructions are not hidden behind MFMAs on this
+// chip, see mlp_tile.hpp: this operand is re-evaluated for 6 of the 11 steps, so it is kept to ~50 instructions.)
 template <int MODE>
 __device__ __forceinline__ void pe_frags(const float* pts, int i, int kg, bool symmetric, float4 (&out)[3]) {
     const int step = i >> 2, gq = i & 3;
     const bool raw = gq == 3, first = step == 0, iscos = step & 1;
     const float f = raw ? 0.f : (float)(1 << (2 * gq + (step >> 1)));
+    const float frev = f * 0.15915494309189535f;                         // f / 2 pi
+    // E: sin -> phase 0, cos -> 0.25;  dE/dx: f cos -> 0.25, -f sin -> 0.5
+    const float phase = MODE == 1 ? (iscos ? 0.25f : 0.f) : (iscos ? 0.5f : 0.25f);
+    const float amp = MODE == 1 ? 1.f : f;
     float o[3][4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const float4 xa = *reinterpret_cast<const float4*>(pts + (4 * kg + s) * 8);        // x0 x1 x2 gam0
         const float4 xb = *reinterpret_cast<const float4*>(pts + (4 * kg + s) * 8 + 4);    // gam1 gam2 valid -
         float x[3] = {xa.x, xa.y, xa.z};
-        const float gm[3] = {xa.w, xb.x, xb.y};
-        const float valid = xb.z;
         const float sg0 = symmetric ? (x[0] > 0.f ? 1.f : (x[0] < 0.f ? -1.f : 0.f)) : 1.f;
         if (symmetric) x[0] = fabsf(x[0]);
+        // per-point factor: validity (E) or the upstream gradient of d sdf/dx_c times the |x0| chain-rule sign (eps)
+        const float k[3] = {MODE == 1 ? xb.z : xa.w * sg0, MODE == 1 ? xb.z : xb.x, MODE == 1 ? xb.z : xb.y};
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float sn, cs;
-            __sincosf(x[c] * f, &sn, &cs);
-            if (MODE == 1) o[c][s] = valid * (raw ? (first ? x[c] : 0.f) : (iscos ? cs : sn));
-            else o[c][s] = gm[c] * (raw ? (first ? 1.f : 0.f) : (iscos ? -f * sn : f * cs)) * (c == 0 ? sg0 : 1.f);
+            const float trig = amp * __builtin_amdgcn_sinf(__builtin_fmaf(x[c], frev, phase));
+            const float rawv = first ? (MODE == 1 ? x[c] : 1.f) : 0.f;
+            o[c][s] = k[c] * (raw ? rawv : trig);
         }
     }
 #pragma unroll
@@ -217,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
             // ================= R sweep =================
             {
                 float e[PE_STEPS], d2[PE_STEPS], eps[PE_STEPS];
-                pe_slots<true, true>(x0, x1, x2, g, symmetric, e, d1, d2);
+                pe_slots<true, true, true>(x0, x1, x2, g, symmetric, e, d1, d2);
 #pragma unroll
                 for (int j = 0; j < PE_STEPS; ++j) eps[j] = gam[j >> 2] * d1[j];
                 f32x4 acc[NT];
@@ -411,12 +421,13 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
             const float* sA = lds + BW_XCH + (c * 2 + 0) * 1024;                             \
             const float* sB = lds + BW_XCH + (c * 2 + 1) * 1024;                             \
             const float4 af = xch_frag(sA, rd, w);                                           \
+            if (a.dbg & 1) continue;                                                         \
             if (HP) {                                                                        \
                 float4 bf[4];                                                                \
                 _Pragma("unroll") for (int n = 0; n < 4; ++n) bf[n] = xch_frag(sB, rd, n);   \
                 outer16<4>(af, bf, ACCH);                                                    \
             }                                                                                \
-            if (PEM) {                                                                       \
+            if (PEM && !(a.dbg & 2)) {                                                       \
                 float4 pf[3];                                                                \
                 pe_frags<PEM ? PEM : 1>(lds + BW_PTS + c * 16 * 8, i, kg, symmetric, pf);    \
                 outer16<3>(af, pf, ACCE);                                                    \
@@ -481,6 +492,7 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
     }
 }
 
+
 }  // namespace sc
 
 extern "C" {
@@ -498,7 +510,8 @@ int sc_sdf_backward_fused(const float* points, const float* w_pack, int n_points
     if (n_points <= 0) return 0;
     if (!g_grad || !stash_p || n_per_image <= 0 || n_per_image % sc::TP != 0 || n_images <= 0) return (int)hipErrorInvalidValue;
     sc::SdfBwdwArgs a{points, w_pack, n_points, n_per_image, n_images, symmetric, stash_a, stash_p, g_sdf, g_grad, g_feat,
-                      g_points, park, partial, g_cbias};
+                      g_points, park, partial, g_cbias, 0};
+    if (const char* e = getenv("SC_BWDW_DBG")) a.dbg = atoi(e);
     const int blocks = sc_sdf_backward_fused_parts(n_points);
     const size_t lds_bytes = (size_t)sc::BW_LDS_FLOATS * sizeof(float);
     (void)hipFuncSetAttribute((const void*)sc::sdf_bwdw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
