@@ -5,8 +5,8 @@
 // (model/implicit.py:138-239), including the double backward through d(sdf)/dx, is here the fixed sequence
 //   sc_rgb_composite_backward                    per-ray upstream gradients -> per-point gradients + RGB-net operands
 //   sc_wgrad x4, sc_partial_reduce, sc_tbl_sum   RGB weight / per-image bias gradients
-//   sc_sdf_backward                              first- and second-order input gradients + SDF-net operands
-//   sc_wgrad x8, sc_partial_reduce, sc_tbl_sum   SDF weight / per-image bias gradients
+//   sc_sdf_backward_fused, sc_partial_reduce     first- and second-order input gradients + SDF weight / per-image bias
+//                                                gradients in one workgroup-cooperative launch (csrc/sdf_bwdw.hip)
 //   sc_ray_sample_backward                       d/d camera centre, ray direction, scale_dist (per ray)
 // on caller-provided workspace.  The host-side Python of this build issues the same sequence step by step
 // (shapeclipper_amd/ops.py); this entry point is the same thing for a non-Python host.
@@ -38,6 +38,14 @@ __global__ __launch_bounds__(256) void rb_colsum_kernel(const float* __restrict_
     if (threadIdx.x < K) atomicAdd(&out[threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
+// [n_images][5][64] -> [5][n_images][64]
+__global__ __launch_bounds__(256) void rb_transpose_cbias_kernel(const float* __restrict__ src, float* __restrict__ dst, int n_images) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= 5 * n_images * 64) return;
+    const int ch = idx & 63, l = (idx >> 6) % 5, img = idx / 320;
+    dst[((size_t)l * n_images + img) * 64 + ch] = src[idx];
+}
+
 struct Carver {
     char* base; size_t off;
     float* f(size_t n_floats) { char* p = base + off; off += (n_floats * 4 + 255) & ~(size_t)255; return reinterpret_cast<float*>(p); }
@@ -51,7 +59,9 @@ static size_t rb_workspace_floats(int n_rays, int* T_out) {
     add(P); add(3 * P); add(T); add(3 * P); add(3 * P);            // g_sdf, g_grad, g_feat, g_points (rgb), g_points (sdf)
     add((size_t)n_rays * 64);                                       // g_z
     add(3 * T); add(3 * T); add(3 * P);                            // gy, rr, gy3
-    add(5 * T); add(4 * T); add(T);                                // ga, gp, r0
+    add(5 * T > (size_t)256 * 4 * 4 * 1024 ? 5 * T : (size_t)256 * 4 * 4 * 1024);   // park scratch of the fused SDF backward (was Ga)
+    add(4 * T > (size_t)5 * 4096 * 64 ? 4 * T : (size_t)5 * 4096 * 64);             // per-image bias-gradient staging (was Gp)
+    add(T);                                                                          // (unused, kept for layout stability)
     add((size_t)RB_PARTS * SdfPack::TOTAL);                        // partial images (the larger of the two networks)
     add(2 * 64);                                                   // tbl_sum outputs for [r0, g_feat]
     return n;
@@ -88,9 +98,14 @@ extern "C" int sc_render_backward(
     float* g_sdf = ws.f(P); float* g_grad = ws.f(3 * (size_t)P); float* g_feat = ws.f(T);
     float* gpts_rgb = ws.f(3 * (size_t)P); float* gpts_sdf = ws.f(3 * (size_t)P); float* g_z = ws.f((size_t)n_rays * 64);
     float* gy = ws.f(3 * T); float* rr = ws.f(3 * T); float* gy3 = ws.f(3 * (size_t)P);
-    float* ga = ws.f(5 * T); float* gp = ws.f(4 * T); float* r0 = ws.f(T);
+    float* ga = ws.f(5 * T > (size_t)256 * 4 * 4 * 1024 ? 5 * T : (size_t)256 * 4 * 4 * 1024);
+    float* gp = ws.f(4 * T > (size_t)5 * 4096 * 64 ? 4 * T : (size_t)5 * 4096 * 64);
+    float* r0 = ws.f(T);
+    (void)r0;
+    if (n_images > 4096) return (int)hipErrorInvalidValue;
     float* partial = ws.f((size_t)RB_PARTS * SdfPack::TOTAL);
     float* tot = ws.f(2 * 64);
+    (void)tot;
     int rc;
 #define SC_TRY(x) if ((rc = (x))) return rc
     // ---------------- RGB network + compositing ----------------
@@ -116,41 +131,19 @@ extern "C" int sc_render_backward(
         SC_TRY(sc_tbl_sum(xs, 1, gy3, P, P, 1, outs, stream_));
     }
     hipLaunchKernelGGL(rb_colsum_kernel, dim3(512), dim3(256), 0, st, gy3, (size_t)P, 3, 3, g_rgb_pack + RgbPack::B3);
-    // ---------------- SDF network (first and second order) ----------------
-    SC_TRY(sc_sdf_backward(points, sdf_pack, P, symmetric, stash_a, stash_p, g_sdf, g_grad, g_feat, gpts_sdf, ga, gp, r0, stream_));
-    hipMemsetAsync(g_cbias, 0, (size_t)5 * n_images * 64 * 4, st);       // [5][n_images][64]
+    // ---------------- SDF network (first and second order): one workgroup-cooperative launch ----------------
+    // (csrc/sdf_bwdw.hip: input gradients + all weight / bias gradients, no Ga/Gp/r0 hand-off tensors; g_cbias comes out as
+    //  [n_images][5][64] and is transposed into this entry point's [5][n_images][64] below)
+    if (npi % TP != 0) return (int)hipErrorInvalidValue;
+    const int parts = sc_sdf_backward_fused_parts(P);
+    float* park = ga;                                   // 256 x 4 x 4 KiB x ... : carved from the (now unused) Ga region
+    float* g_c_img = gp;                                // [n_images][5][64] staging
+    hipMemsetAsync(g_c_img, 0, (size_t)5 * n_images * 64 * 4, st);
+    SC_TRY(sc_sdf_backward_fused(points, sdf_pack, P, npi, n_images, symmetric, stash_a, stash_p, g_sdf, g_grad, g_feat, gpts_sdf,
+                                 park, partial, g_c_img, stream_));
     hipMemsetAsync(g_sdf_pack, 0, (size_t)SdfPack::TOTAL * 4, st);
-    const int ss = SdfPack::TOTAL;
-    const float* w5row = sdf_pack + SdfPack::W5;
-    auto A = [&](int l) { return stash_a + (size_t)l * T; };
-    auto Pp = [&](int l) { return stash_p + (size_t)l * T; };
-    auto GA = [&](int l) { return ga + (size_t)l * T; };
-    auto GP = [&](int l) { return gp + (size_t)l * T; };
-    auto two = [&](const float* a0, const float* b0, int bop0, const float* a1p, const float* a1a, int aop1, const float* b1, int bop1,
-                   int nb0, int off, int ld, float* rowsum) {
-        return sc_wgrad(2, a0, nullptr, W_OP_PLAIN, b0, bop0, nullptr, W_OP_NONE, a1p, a1a, aop1, b1, bop1, nullptr, W_OP_NONE, points, g_grad,
-                        w5row, P, symmetric, nb0, 0, partial, RB_PARTS, ss, off, ld, rowsum, npi, n_images, stream_);
-    };
-    SC_TRY(two(GA(0), nullptr, W_OP_PE, Pp(0), A(0), W_OP_Q, nullptr, W_OP_EPS, 48, SdfPack::W0, 48, g_cbias));
-    for (int l = 1; l <= 2; ++l) {
-        const int off = l == 1 ? SdfPack::W1 : SdfPack::W2;
-        SC_TRY(two(GA(l), A(l - 1), W_OP_SP, Pp(l), A(l), W_OP_Q, GP(l - 1), W_OP_PLAIN, 64, off, 112, g_cbias + (size_t)l * n_images * 64));
-        SC_TRY(two(GA(l), nullptr, W_OP_PE, Pp(l), A(l), W_OP_Q, nullptr, W_OP_EPS, 48, off + 64, 112, nullptr));
-    }
-    SC_TRY(two(GA(3), A(2), W_OP_SP, Pp(3), A(3), W_OP_Q, GP(2), W_OP_PLAIN, 64, SdfPack::W3, 64, g_cbias + (size_t)3 * n_images * 64));
-    SC_TRY(two(GA(4), A(3), W_OP_SP, nullptr, A(4), W_OP_Q4, GP(3), W_OP_PLAIN, 64, SdfPack::W4, 64, g_cbias + (size_t)4 * n_images * 64));
-    SC_TRY(sc_wgrad(1, g_feat, nullptr, W_OP_PLAIN, A(4), W_OP_SP, nullptr, W_OP_NONE, nullptr, nullptr, W_OP_NONE, nullptr, W_OP_NONE, nullptr,
-                    W_OP_NONE, points, g_grad, w5row, P, symmetric, 64, 0, partial, RB_PARTS, ss, SdfPack::W5 + 64, 64, nullptr, 0, 0, stream_));
-    // every region of the image up to B5 is now covered by some launch except W5 row 0 (written below): reduce, then fix row 0
-    SC_TRY(sc_partial_reduce(partial, RB_PARTS, ss, SdfPack::B5, g_sdf_pack, stream_));
-    hipMemsetAsync(g_sdf_pack + SdfPack::W5, 0, 64 * 4, st);
-    hipMemsetAsync(tot, 0, 2 * 64 * 4, st);
-    {
-        const float* xs[2] = {r0, g_feat};
-        float* outs[2] = {g_sdf_pack + SdfPack::W5, g_sdf_pack + SdfPack::B5 + 1};     // W5 row 0 ; feature biases
-        SC_TRY(sc_tbl_sum(xs, 2, nullptr, P, P, 1, outs, stream_));
-    }
-    hipLaunchKernelGGL(rb_colsum_kernel, dim3(512), dim3(256), 0, st, g_sdf, (size_t)P, 1, 1, g_sdf_pack + SdfPack::B5);
+    SC_TRY(sc_partial_reduce(partial, parts, SdfPack::TOTAL, SdfPack::TOTAL, g_sdf_pack, stream_));
+    hipLaunchKernelGGL(rb_transpose_cbias_kernel, dim3((5 * n_images * 64 + 255) / 256), dim3(256), 0, st, g_c_img, g_cbias, n_images);
     // ---------------- points -> camera ----------------
     hipLaunchKernelGGL(rb_add_kernel, dim3(2048), dim3(256), 0, st, gpts_sdf, gpts_rgb, (size_t)3 * P);
     if (G_z_extra) hipLaunchKernelGGL(rb_add_kernel, dim3(1024), dim3(256), 0, st, g_z, G_z_extra, (size_t)n_rays * 64);

@@ -147,7 +147,8 @@ def test_flat_reducer_path_on_rccl_single_rank():
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("flag", ["--hip.two_streams!", "--hip.batched_encoders!", "--hip.fused_loss!", "--hip.fused_adam!", "--hip.device_rng"])
+@pytest.mark.parametrize("flag", ["--hip.two_streams!", "--hip.batched_encoders!", "--hip.fused_loss!", "--hip.fused_adam!", "--hip.device_rng",
+                                  "--hip.fused_backward!", "--hip.device_choice!"])
 def test_every_hip_option_has_a_working_alternate_path(flag):
     """Each fast path of this build can be switched off (README): the step still runs and gives the same loss
     (device_rng draws different jitter, so only finiteness is compared there)."""

@@ -25,10 +25,27 @@ __device__ __forceinline__ void mm_act128(const float* wl, const float (&in)[ACT
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// MODE 2: like MODE 0 plus a sched_group_barrier pipeline {1 MFMA, 1 DS read, NV VALU} x 64 over the region
+// [element-wise part of layer l | MFMAs of layer l+1]
+template <int LD, int NV>
+__device__ __forceinline__ void mm_act_il(const float* wl, const float (&in)[ACT_STEPS], f32x4 (&acc)[NT]) {
+#pragma unroll
+    for (int s = 0; s < ACT_STEPS; ++s)
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) acc[mt] = mfma16(wl[mt * 16 * LD + kp(s)], in[s], acc[mt]);
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int MODE, bool SP>
 __global__ void chain_loop(float* out, int iters) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int LD = MODE == 0 ? 65 : 68;
+    constexpr int LD = MODE == 1 ? 68 : 65;
     for (int e = threadIdx.x; e < 64 * LD * 2; e += blockDim.x) lds[e] = 0.001f * (e % 97);
     __syncthreads();
     const int lane = threadIdx.x & 63, p = lane & 15, g = lane >> 4;
@@ -43,7 +60,9 @@ __global__ void chain_loop(float* out, int iters) {
             f32x4 acc[NT];
             acc_zero(acc);
             if (MODE == 0) mm_act<LD, NT>((l & 1) ? wB : wA, h, acc);
-            else mm_act128<LD>((l & 1) ? wB : wA, h, acc);
+            else if (MODE == 1) mm_act128<LD>((l & 1) ? wB : wA, h, acc);
+            else if (MODE == 2) mm_act_il<LD, 7>((l & 1) ? wB : wA, h, acc);
+            else mm_act_il<LD, 5>((l & 1) ? wB : wA, h, acc);
 #pragma unroll
             for (int s = 0; s < ACT_STEPS; ++s) {
                 if (SP) { float t, r; softplus_parts(acc[s >> 2][s & 3], t, r); h[s] = softplus_val(acc[s >> 2][s & 3], t) * softplus_d1(acc[s >> 2][s & 3], t, r); }
@@ -72,12 +91,12 @@ void run(int waves_per_simd) {
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     const double flops = (double)cus * (threads / 64) * iters * 4 * 64 * 2048.0;
-    printf("weights %s softplus=%d waves/SIMD=%d: %.1f TFLOP/s (%.0f cycles per 64-MFMA layer per wave)\n", MODE == 0 ? "ds_read_b32 " : "ds_read_b128",
+    printf("weights %s softplus=%d waves/SIMD=%d: %.1f TFLOP/s (%.0f cycles per 64-MFMA layer per wave)\n", MODE == 0 ? "ds_read_b32 " : (MODE == 1 ? "ds_read_b128" : (MODE == 2 ? "b32 interleave7" : "b32 interleave5")),
            (int)SP, waves_per_simd, flops / (ms * 1e-3) / 1e12, ms * 1e-3 * 2.4e9 / (iters * 4.0));
     hipFree(out);
 }
 
 int main() {
-    for (int w = 1; w <= 2; ++w) { run<0, false>(w); run<1, false>(w); run<0, true>(w); run<1, true>(w); }
+    for (int w = 1; w <= 2; ++w) { run<0, false>(w); run<1, false>(w); run<0, true>(w); run<1, true>(w); run<2, true>(w); run<3, true>(w); }
     return 0;
 }
