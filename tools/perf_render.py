@@ -12,10 +12,11 @@ ap.add_argument("--B", type=int, default=32)
 ap.add_argument("--R", type=int, default=512)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--eval", action="store_true")
+ap.add_argument("--yaml", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "options/pix3d/config.yaml"))
 ap.add_argument("--full", type=int, default=0, help="full-frame evaluation render of FULL x FULL pixels (BASELINE config[2]: 128)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
-opt = options.set(options.parse_arguments(["--yaml=options/pix3d/config.yaml", "--name=perf", "--output_root=/tmp/sc_perf"]), verbose=False)
+opt = options.set(options.parse_arguments(["--yaml=" + a.yaml, "--name=perf", "--output_root=/tmp/sc_perf"]), verbose=False)
 torch.manual_seed(0)
 sdf, rgb = SDFNetwork(opt), RGBNetwork(opt)
 r = Renderer(opt, sdf, rgb).to(dev)
