@@ -11,9 +11,12 @@
 //
 // Kernels:
 //   patchify        image fp32 NCHW -> bf16 [B*np, 3*P*P]  (im2col of non-overlapping patches)
-//   gemm_bf16<EPI>  C[M,N] = A[M,K] * W[N,K]^T + bias, 128x128x64 tiles, 4 waves x (2x2) 32x32x16 MFMA,
-//                   XOR-swizzled LDS (conflict-free ds_read_b128), register-prefetched next K tile;
-//                   epilogues: fp32 store / fp32 residual add / quick_gelu->bf16 / bf16
+//   gemm_bf16<EPI>  C[M,N] = A[M,K] * W[N,K]^T + bias, 128x128x64 tiles, 4 waves x (2x2) 32x32x16 MFMA, operand tiles by
+//                   LDS-DMA (global_load_lds_dwordx4) into two XOR-swizzled LDS stages, one raw barrier per K-step;
+//                   epilogues: fp32 store / fp32 residual add / quick_gelu->bf16 / bf16.
+//                   Measured round 2 (ViT-B/32, batch 256): 385 TFLOP/s whole tower, 480 TFLOP/s in the 12800-row GEMMs
+//                   (19 % of the bf16 peak); the register-staged loop of round 1 with the same epilogue: 392 / 500.  At
+//                   K = 768 a tile has 12 K-steps: prologue, epilogue and tile quantisation weigh as much as the K loop.
 //   layernorm       fp32 row -> bf16 (GEMM input) or fp32, one wave per token
 //   embed           [cls; patch tokens] + positional embedding -> fp32 residual stream
 //   attention       MFMA: one workgroup per (image, head), K/Q operands straight from global, V^T in LDS, any token count
@@ -54,12 +57,36 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------------
 enum { EPI_F32 = 0, EPI_RESID = 1, EPI_GELU_BF16 = 2, EPI_BF16 = 3 };
 
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
-                                                        const float* __restrict__ bias, void* __restrict__ out,
-                                                        int M, int N, int K) {
-    __shared__ uint4 As[128 * 8];
-    __shared__ uint4 Bs[128 * 8];
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// One LDS-DMA wave instruction: every lane fetches 16 bytes from its own global address; the wave's 1 KiB lands at LDS byte
+// address `lds_dst` (wave-uniform) + 16 x lane.  Inline asm on purpose: hipcc drains ANY outstanding LDS-DMA (vmcnt(0)) before
+// the next ds_read it cannot prove disjoint, which serialises a double-buffered loop; issued from asm the DMA is invisible to
+// its bookkeeping and completion is counted by hand (the s_waitcnt vmcnt(0) of SC_GEMM_SYNC).  M0 holds the LDS base.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(lptr_t)p; }
+
+// C[M,N] = A[M,K] W[N,K]^T (+ bias, epilogue).  128x128x64 tiles, 4 waves x (2x2) v_mfma_f32_32x32x16_bf16.
+// Operand tiles go global -> LDS with the gfx950 LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass),
+// double-buffered: the tile of K-step k+1 is in flight while the MFMAs of step k run, ONE raw s_barrier per K-step, the only
+// vmcnt wait is the one for the tile about to be read.  The DMA writes lane-linear (base + 16 B x lane), so the XOR swizzle that
+// makes the fragment ds_read_b128 conflict-free is applied to the SOURCE address: LDS chunk c = row*8 + slot holds the 8 bf16 of
+// logical K-chunk slot ^ (row & 7) of that row (the read side applies the same involution).  Rows past M / N are clamped to the
+// last valid row (their products are never stored).  The two buffers are separate __shared__ objects so that the compiler can
+// prove the DMA of one does not alias the fragment reads of the other (otherwise it drains the DMA before the first ds_read).
+// NSTAGE LDS stages of 32 KiB: NSTAGE - 1 tiles are in flight while one is consumed.  2 stages leave room for two workgroups
+// per CU (large grids: the other workgroup hides the rest of the latency); 4 stages (128 KiB, one workgroup per CU) are for
+// grids that give a CU a single workgroup anyway (batch 32: 78-312 tiles on 256 CUs), where the K loop would otherwise run at
+// one HBM/L2 round trip per K-step.
+template <int EPI, int NSTAGE>
+__global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void gemm_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
+                                                                             const float* __restrict__ bias, void* __restrict__ out,
+                                                                             int M, int N, int K) {
+    extern __shared__ uint4 Sbuf[];      // [NSTAGE][A 128 rows x 8 chunks | B 128 rows x 8 chunks]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int bm = blockIdx.y * 128, bn = blockIdx.x * 128;
@@ -74,28 +101,28 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    uint4 ra[4], rb[4];
-    auto gload = [&](int kt) {
+    // per-thread DMA sources: chunk c = q*256 + tid of each operand tile
+    const bf16_t* pa[4];
+    const bf16_t* pb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c = q * 256 + tid, row = c >> 3, kc = (c & 7) ^ (row & 7);
+        pa[q] = A + (size_t)min(bm + row, M - 1) * K + kc * 8;
+        pb[q] = Wt + (size_t)min(bn + row, N - 1) * K + kc * 8;
+    }
+    const unsigned wave_off = (unsigned)__builtin_amdgcn_readfirstlane(wave * 64 * 16);
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(Sbuf)) + wave_off;
+    auto issue = [&](int kt, int stage) {
+        const unsigned base = lds0 + (unsigned)stage * 2048u * 16u;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int c = tid + 256 * q, row = c >> 3, kc = c & 7;
-            const int gm = bm + row, gn = bn + row;
-            ra[q] = gm < M ? *reinterpret_cast<const uint4*>(A + (size_t)gm * K + kt * 64 + kc * 8) : make_uint4(0, 0, 0, 0);
-            rb[q] = gn < N ? *reinterpret_cast<const uint4*>(Wt + (size_t)gn * K + kt * 64 + kc * 8) : make_uint4(0, 0, 0, 0);
+            glds16(pa[q] + (size_t)kt * 64, base + q * 256 * 16);
+            glds16(pb[q] + (size_t)kt * 64, base + (1024 + q * 256) * 16);
         }
     };
-    const int nk = kt1;
-    gload(kt0);
-    for (int kt = kt0; kt < nk; ++kt) {
-        __syncthreads();                      // previous tile fully consumed
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c = tid + 256 * q, row = c >> 3, kc = c & 7;
-            As[row * 8 + (kc ^ (row & 7))] = ra[q];
-            Bs[row * 8 + (kc ^ (row & 7))] = rb[q];
-        }
-        __syncthreads();
-        if (kt + 1 < nk) gload(kt + 1);       // in flight while the MFMAs below run
+    auto compute = [&](int stage) {
+        const uint4* As = Sbuf + stage * 2048;
+        const uint4* Bs = As + 1024;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             bf16x8 af[2], bf[2];
@@ -103,14 +130,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = 64 * wr + 32 * i + (lane & 31);
-                const uint4 v = As[row * 8 + (kc ^ (row & 7))];
-                af[i] = __builtin_bit_cast(bf16x8, v);
+                af[i] = __builtin_bit_cast(bf16x8, As[row * 8 + (kc ^ (row & 7))]);
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int row = 64 * wc + 32 * j + (lane & 31);
-                const uint4 v = Bs[row * 8 + (kc ^ (row & 7))];
-                bf[j] = __builtin_bit_cast(bf16x8, v);
+                bf[j] = __builtin_bit_cast(bf16x8, Bs[row * 8 + (kc ^ (row & 7))]);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -118,8 +143,55 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
+    };
+    // Tile kt is complete for every wave once each wave has waited for its own DMA and all have met at the barrier; the same
+    // barrier says that everybody has finished reading the stage the next DMA overwrites (the one consumed last iteration).
+    // DMA completes in issue order, 8 instructions per tile and thread: "at most 8 x (tiles issued after kt) outstanding".
+#define SC_GEMM_SYNC(NOUT) asm volatile("s_waitcnt vmcnt(" #NOUT ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#pragma unroll
+    for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
+        if (kt0 + s0 < kt1) issue(kt0 + s0, s0);
+    int stage = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int after = min(NSTAGE - 2, kt1 - 1 - kt);          // tiles issued after kt that may still be in flight
+        if (after >= 2) SC_GEMM_SYNC(16);
+        else if (after == 1) SC_GEMM_SYNC(8);
+        else SC_GEMM_SYNC(0);
+        if (kt + NSTAGE - 1 < kt1) issue(kt + NSTAGE - 1, stage == 0 ? NSTAGE - 1 : stage - 1);
+        compute(stage);
+        stage = stage + 1 == NSTAGE ? 0 : stage + 1;
     }
+#undef SC_GEMM_SYNC
     // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (EPI == EPI_RESID && kslices == 1) {
+        // residual add: fetch all 64 residual values of this lane FIRST (independent loads in flight together), then add and
+        // store -- `x[o] += v` element by element makes every load wait for the previous store (64 dependent round trips)
+        float res[2][2][16];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = bn + 64 * wc + 32 * j + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = bm + 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    res[i][j][r] = (col < N && row < M) ? __builtin_nontemporal_load(reinterpret_cast<const float*>(out) + (size_t)row * N + col) : 0.f;
+                }
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = bn + 64 * wc + 32 * j + (lane & 31);
+                const float bv = (bias && col < N) ? bias[col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = bm + 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (col < N && row < M) reinterpret_cast<float*>(out)[(size_t)row * N + col] = res[i][j][r] + acc[i][j][r] + bv;
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -134,10 +206,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const bf16_t* __restrict
                 const float v = acc[i][j][r] + bv;
                 const size_t o = (size_t)row * N + col;
                 if (EPI == EPI_F32) reinterpret_cast<float*>(out)[o] = v;
-                else if (EPI == EPI_RESID) {
-                    if (kslices > 1) unsafeAtomicAdd(reinterpret_cast<float*>(out) + o, v);
-                    else reinterpret_cast<float*>(out)[o] += v;
-                }
+                else if (EPI == EPI_RESID) unsafeAtomicAdd(reinterpret_cast<float*>(out) + o, v);
                 else if (EPI == EPI_GELU_BF16) reinterpret_cast<bf16_t*>(out)[o] = f2bf(v / (1.f + __expf(-1.702f * v)));
                 else reinterpret_cast<bf16_t*>(out)[o] = f2bf(v);
             }
@@ -302,12 +371,24 @@ static int launch_gemm(int epi, const bf16_t* A, const bf16_t* Wt, const float* 
         while (grid.x * grid.y * z < 200 && K / 64 / (2 * z) >= 4 && z < 8) z *= 2;
         grid.z = z;
     }
-    switch (epi) {
-        case EPI_F32: hipLaunchKernelGGL(gemm_bf16_kernel<EPI_F32>, grid, dim3(256), 0, st, A, Wt, bias, out, M, N, K); break;
-        case EPI_RESID: hipLaunchKernelGGL(gemm_bf16_kernel<EPI_RESID>, grid, dim3(256), 0, st, A, Wt, bias, out, M, N, K); break;
-        case EPI_GELU_BF16: hipLaunchKernelGGL(gemm_bf16_kernel<EPI_GELU_BF16>, grid, dim3(256), 0, st, A, Wt, bias, out, M, N, K); break;
-        default: hipLaunchKernelGGL(gemm_bf16_kernel<EPI_BF16>, grid, dim3(256), 0, st, A, Wt, bias, out, M, N, K); break;
+    // few tiles (a CU gets one workgroup anyway): 4 LDS stages hide the operand latency inside the workgroup
+    const bool deep = false;   // measured (MI355X, ViT-B/32 batch 32): 4 stages at one workgroup per CU are not faster (21.7 vs 21.2 us for
+                               // qkv, 43 vs 29 us for fc1) -- those launches are bound by their fixed prologue / epilogue, not by operand latency
+#define SC_LAUNCH(E)                                                                                                   \
+    if (deep) {                                                                                                        \
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<E, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768); \
+        hipLaunchKernelGGL((gemm_bf16_kernel<E, 4>), grid, dim3(256), 4 * 32768, st, A, Wt, bias, out, M, N, K);       \
+    } else {                                                                                                           \
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<E, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768); \
+        hipLaunchKernelGGL((gemm_bf16_kernel<E, 2>), grid, dim3(256), 2 * 32768, st, A, Wt, bias, out, M, N, K);       \
     }
+    switch (epi) {
+        case EPI_F32: SC_LAUNCH(EPI_F32) break;
+        case EPI_RESID: SC_LAUNCH(EPI_RESID) break;
+        case EPI_GELU_BF16: SC_LAUNCH(EPI_GELU_BF16) break;
+        default: SC_LAUNCH(EPI_BF16) break;
+    }
+#undef SC_LAUNCH
     return (int)hipGetLastError();
 }
 
