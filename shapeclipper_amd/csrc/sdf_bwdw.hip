@@ -181,19 +181,6 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
         const float* w2t = lds + SdfLds::W2 + 4 * g * SdfLds::LD1 + p;
         const float* w1t = lds + SdfLds::W1 + 4 * g * SdfLds::LD1 + p;
 
-// gx_c += scale_c * sum_s V[s] * (W_le * DV[4c..4c+3])[s]
-#define BW_PE_DOT(WE, LD, V, DV, SCALE)                                                     \
-        _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                      \
-            f32x4 tacc[NT];                                                                  \
-            acc_zero(tacc);                                                                  \
-            if (c == 0) mm_pe<LD, NT, 0, 4>(WE, DV + 0, tacc);                               \
-            if (c == 1) mm_pe<LD, NT, 4, 4>(WE, DV + 4, tacc);                               \
-            if (c == 2) mm_pe<LD, NT, 8, 4>(WE, DV + 8, tacc);                               \
-            float dsum = 0.f;                                                                \
-            _Pragma("unroll") for (int s = 0; s < ACT_STEPS; ++s)                             \
-                dsum = __builtin_fmaf(V[s], tacc[s >> 2][s & 3], dsum);                      \
-            gx[c] = __builtin_fmaf(SCALE, dsum, gx[c]);                                      \
-        }
 // the write phase of one step: B1 (the wgrad waves have finished reading the previous pair), write, B2 (visible)
 #define BW_EXCHANGE(WRITES)                                                                 \
         lds_barrier();                                                                       \
@@ -221,13 +208,12 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
             const float x0 = a.points[(size_t)ptc * 3 + 0], x1 = a.points[(size_t)ptc * 3 + 1], x2 = a.points[(size_t)ptc * 3 + 2];
             float gam[3] = {0.f, 0.f, 0.f};
             if (valid) { gam[0] = a.g_grad[(size_t)pt * 3]; gam[1] = a.g_grad[(size_t)pt * 3 + 1]; gam[2] = a.g_grad[(size_t)pt * 3 + 2]; }
-            float gx[3] = {0.f, 0.f, 0.f};
             float d1[PE_STEPS];
             float j_av[ACT_STEPS], j_pend[ACT_STEPS], j_u[ACT_STEPS];      // R -> V junction registers
             // ================= R sweep =================
             {
                 float e[PE_STEPS], d2[PE_STEPS], eps[PE_STEPS];
-                pe_slots<true, true, true>(x0, x1, x2, g, symmetric, e, d1, d2);
+                pe_slots<true, false, true>(x0, x1, x2, g, symmetric, e, d1, d2);
 #pragma unroll
                 for (int j = 0; j < PE_STEPS; ++j) eps[j] = gam[j >> 2] * d1[j];
                 f32x4 acc[NT];
@@ -262,21 +248,18 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
                         *reinterpret_cast<float4*>(ptsw + p * 8) = make_float4(x0, x1, x2, gam[0]);
                         *reinterpret_cast<float4*>(ptsw + p * 8 + 4) = make_float4(gam[1], gam[2], vmask, 0.f);
                     })
-                if (a.g_points) { BW_PE_DOT(w0, SdfLds::LD0, pvA, d2, gam[c]) }
                 acc_zero(acc);
                 BW_R_LOAD(2, avA, pvA)
                 mm_act<SdfLds::LD1, NT>(w1h, gpA, acc);
                 mm_pe<SdfLds::LD1, NT, 0, PE_STEPS>(w1e, eps, acc);                // Gq1
                 BW_R_ELEM(1, avB, pvB, gpB)
                 BW_EXCHANGE(xch_write(slotA, wr, pvB, vmask); xch_write(slotB, wr, gpA, vmask);)      // step 1: (q1, Gp0)
-                if (a.g_points) { BW_PE_DOT(w1e, SdfLds::LD1, pvB, d2, gam[c]) }
                 acc_zero(acc);
                 BW_R_LOAD(3, avB, pvB)
                 mm_act<SdfLds::LD1, NT>(w2h, gpB, acc);
                 mm_pe<SdfLds::LD1, NT, 0, PE_STEPS>(w2e, eps, acc);                // Gq2
                 BW_R_ELEM(2, avA, pvA, gpA)
                 BW_EXCHANGE(xch_write(slotA, wr, pvA, vmask); xch_write(slotB, wr, gpB, vmask);)      // step 2: (q2, Gp1)
-                if (a.g_points) { BW_PE_DOT(w2e, SdfLds::LD1, pvA, d2, gam[c]) }
                 acc_zero(acc);
                 tbl_load(a.stash_a + 4 * tbl, tile, p, g, j_av);
                 __builtin_amdgcn_sched_barrier(0);
@@ -361,31 +344,19 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
                 BW_V_ELEM(avB, pvB, gaA)                                                            // Ga2, h2
                 BW_EXCHANGE(xch_write(slotA, wr, gaB, vmask); xch_write(slotB, wr, hv, vmask);)       // step 7: (Ga3, h2)
                 BW_V_LOAD(0, avB, pvB)
-                BW_PE_DOT(w2e, SdfLds::LD1, gaA, d1, 1.f)
                 acc_zero(acc);
                 mm_act_t<SdfLds::LD1, NT>(w2t, gaA, acc);
                 BW_V_ELEM(av, pv, gaB)                                                              // Ga1, h1
                 BW_EXCHANGE(xch_write(slotA, wr, gaA, vmask); xch_write(slotB, wr, hv, vmask);)       // step 8: (Ga2, h1)
-                BW_PE_DOT(w1e, SdfLds::LD1, gaB, d1, 1.f)
                 acc_zero(acc);
                 mm_act_t<SdfLds::LD1, NT>(w1t, gaB, acc);
                 BW_V_ELEM(avB, pvB, gaA)                                                            // Ga0, h0
                 BW_EXCHANGE(xch_write(slotA, wr, gaB, vmask); xch_write(slotB, wr, hv, vmask);)       // step 9: (Ga1, h0)
-                BW_PE_DOT(w0, SdfLds::LD0, gaA, d1, 1.f)
                 BW_EXCHANGE(xch_write(slotA, wr, gaA, vmask);)                                      // step 10: Ga0 (pairs with e)
 #undef BW_V_ELEM
 #undef BW_V_LOAD
-                if (a.g_points) {
-                    const float o0 = group_sum(gx[0]), o1 = group_sum(gx[1]), o2 = group_sum(gx[2]);
-                    if (valid && g == 0) {
-                        a.g_points[(size_t)pt * 3 + 0] = o0;
-                        a.g_points[(size_t)pt * 3 + 1] = o1;
-                        a.g_points[(size_t)pt * 3 + 2] = o2;
-                    }
-                }
             }
         }
-#undef BW_PE_DOT
 #undef BW_EXCHANGE
         __syncthreads();        // all sums are in LDS
         float* out = a.partial + (size_t)blockIdx.x * SdfPack::TOTAL;
@@ -397,6 +368,43 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
         // =====================================================================================================
         const int w = wave - BW_CHAIN, i = lane & 15, kg = lane >> 4;
         const int rd = (kg * 64 + (i ^ kg)) << 2;            // this lane's float4 chunk of channel tile 0 (+ 64 floats per tile)
+        // Besides the outer products, wave w evaluates the point-gradient terms of chain tile w that only need the A operand
+        // of a step and the PE derivatives of the point:  gx_c += Gg_c * q_l . (W_le d2E/dx_c^2)  (steps 0-2) and
+        // gx_c += Ga_l . (W_le dE/dx_c)  (steps 8-10) -- 288 of the 1008 chain MFMAs move from the latency-bound chain wave to
+        // this one.  In this view the lane is point p = i of the tile, channel group g = kg (the chain waves' layout).
+        const float* w0 = lds + SdfLds::W0 + i * SdfLds::LD0 + kg;
+        const float* w1e = lds + SdfLds::W1 + i * SdfLds::LD1 + 64 + kg;
+        const float* w2e = lds + SdfLds::W2 + i * SdfLds::LD1 + 64 + kg;
+        const float* slotAw = lds + BW_XCH + (w * 2 + 0) * 1024;
+        const float* ptsw = lds + BW_PTS + w * 16 * 8;
+        int wr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wr[r] = (((i >> 2) * 64 + 4 * kg + (r ^ (i >> 2))) << 2) + (i & 3);
+        float gx[3] = {0.f, 0.f, 0.f}, gam[3] = {0.f, 0.f, 0.f};
+        float pd1[PE_STEPS], pd2[PE_STEPS];
+        float pvalid = 0.f;
+// gx_c += scale_c * sum_s V[s] * (W_le * DV[4c..4c+3])[s]
+#define BW_PE_DOT(WE, LD, V, DV, SCALE)                                                     \
+        _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                      \
+            f32x4 tacc[NT];                                                                  \
+            acc_zero(tacc);                                                                  \
+            if (c == 0) mm_pe<LD, NT, 0, 4>(WE, DV + 0, tacc);                               \
+            if (c == 1) mm_pe<LD, NT, 4, 4>(WE, DV + 4, tacc);                               \
+            if (c == 2) mm_pe<LD, NT, 8, 4>(WE, DV + 8, tacc);                               \
+            float dsum = 0.f;                                                                \
+            _Pragma("unroll") for (int s = 0; s < ACT_STEPS; ++s)                             \
+                dsum = __builtin_fmaf(V[s], tacc[s >> 2][s & 3], dsum);                      \
+            gx[c] = __builtin_fmaf(SCALE, dsum, gx[c]);                                      \
+        }
+// the A operand of chain tile w back in the chain layout (v[4T+r] = channel 16T+4g+r of point p), then the PE dot products
+#define BW_POINT_TERMS(WE, LD, DV, SCALE)                                                   \
+        if (a.g_points) {                                                                    \
+            float vv[ACT_STEPS];                                                             \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                    \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) vv[4 * t + r] = slotAw[wr[r] + 64 * t]; \
+            BW_PE_DOT(WE, LD, vv, DV, SCALE)                                                 \
+        }
+
         f32x4 d0e[3], d1h[4], d1e[3], d2h[4], d2e[3], d3[4], d4[4], d5[4];
         acc_zero(d0e); acc_zero(d1h); acc_zero(d1e); acc_zero(d2h); acc_zero(d2e); acc_zero(d3); acc_zero(d4); acc_zero(d5);
         float rs[5] = {0.f, 0.f, 0.f, 0.f, 0.f};            // per-image bias-gradient partials (this lane's 4 points of every tile)
@@ -454,19 +462,45 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
                 flush();
                 cur_img = img0 == img3 ? img0 : -2;
             }
-            BW_STEP_BEGIN BW_CONSUME(d3, d0e, false, 2, -1)        // 0: q0 x eps
+            BW_STEP_BEGIN
+            if (a.g_points) {                                       // PE derivatives of this wave's tile (point stash written in step 0)
+                const float4 xa = *reinterpret_cast<const float4*>(ptsw + i * 8);
+                const float4 xb = *reinterpret_cast<const float4*>(ptsw + i * 8 + 4);
+                float pe[PE_STEPS];
+                pe_slots<true, true, true>(xa.x, xa.y, xa.z, kg, symmetric, pe, pd1, pd2);
+                gam[0] = xa.w; gam[1] = xb.x; gam[2] = xb.y; pvalid = xb.z;
+                gx[0] = gx[1] = gx[2] = 0.f;
+            }
+            BW_CONSUME(d3, d0e, false, 2, -1)                      // 0: q0 x eps
+            BW_POINT_TERMS(w0, SdfLds::LD0, pd2, gam[c])
             BW_STEP_BEGIN BW_CONSUME(d1h, d1e, true, 2, -1)         // 1: q1 x (Gp0 | eps)
+            BW_POINT_TERMS(w1e, SdfLds::LD1, pd2, gam[c])
             BW_STEP_BEGIN BW_CONSUME(d2h, d2e, true, 2, -1)         // 2: q2 x (Gp1 | eps)
+            BW_POINT_TERMS(w2e, SdfLds::LD1, pd2, gam[c])
             BW_STEP_BEGIN BW_CONSUME(d3, d0e, true, 0, -1)          // 3: q3 x Gp2
             BW_STEP_BEGIN BW_CONSUME(d4, d0e, true, 0, -1)          // 4: q4 x Gp3
             BW_STEP_BEGIN BW_CONSUME(d5, d0e, true, 0, 5)           // 5: Gf x h4
             BW_STEP_BEGIN BW_CONSUME(d4, d0e, true, 0, 4)           // 6: Ga4 x h3
             BW_STEP_BEGIN BW_CONSUME(d3, d0e, true, 0, 3)           // 7: Ga3 x h2
             BW_STEP_BEGIN BW_CONSUME(d2h, d2e, true, 1, 2)          // 8: Ga2 x (h1 | E)
+            BW_POINT_TERMS(w2e, SdfLds::LD1, pd1, 1.f)
             BW_STEP_BEGIN BW_CONSUME(d1h, d1e, true, 1, 1)          // 9: Ga1 x (h0 | E)
+            BW_POINT_TERMS(w1e, SdfLds::LD1, pd1, 1.f)
             BW_STEP_BEGIN BW_CONSUME(d3, d0e, false, 1, 0)          // 10: Ga0 x E
+            BW_POINT_TERMS(w0, SdfLds::LD0, pd1, 1.f)
+            if (a.g_points) {
+                const float o0 = group_sum(gx[0]), o1 = group_sum(gx[1]), o2 = group_sum(gx[2]);
+                const size_t pt = (size_t)(base + w) * TP + i;
+                if (base + w < t_end && pvalid != 0.f && kg == 0) {
+                    a.g_points[pt * 3 + 0] = o0;
+                    a.g_points[pt * 3 + 1] = o1;
+                    a.g_points[pt * 3 + 2] = o2;
+                }
+            }
         }
 #undef BW_CONSUME
+#undef BW_POINT_TERMS
+#undef BW_PE_DOT
 #undef BW_STEP_BEGIN
         flush();
         __syncthreads();
