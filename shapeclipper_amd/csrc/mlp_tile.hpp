@@ -53,12 +53,24 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 
 // ---- products ------------------------------------------------------------------------------------
 // acc[mt] += W[row0 + 16*mt + i][col0 + kp(s) + 4*g] * in[s]       wl = W + (row0+i)*LD + col0 + 4*g
+// Row strides are multiples of 4 floats: the weights of the four K-steps 4T..4T+3 of a lane (columns 16T+4g .. +3 of its row)
+// are one aligned ds_read_b128 -- a quarter of the LDS instructions (and of their address adds) of the per-MFMA ds_read_b32.
 template <int LD, int MT>
 __device__ __forceinline__ void mm_act(const float* wl, const float (&in)[ACT_STEPS], f32x4 (&acc)[MT]) {
+    static_assert(LD % 4 == 0, "row stride must keep the float4 weight reads aligned");
 #pragma unroll
-    for (int s = 0; s < ACT_STEPS; ++s)
+    for (int T = 0; T < NT; ++T) {
+        float4 w[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(wl[mt * 16 * LD + kp(s)], in[s], acc[mt]);
+        for (int mt = 0; mt < MT; ++mt) w[mt] = *reinterpret_cast<const float4*>(wl + mt * 16 * LD + 16 * T);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float wv = r == 0 ? w[mt].x : (r == 1 ? w[mt].y : (r == 2 ? w[mt].z : w[mt].w));
+                acc[mt] = mfma16(wv, in[4 * T + r], acc[mt]);
+            }
+    }
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -102,8 +114,13 @@ __device__ __forceinline__ void acc_zero(f32x4 (&acc)[MT]) {
 // softplus(beta=100) and derivatives (model/implicit.py:136; torch threshold=20 is reproduced to
 // well below fp32 resolution: beyond it log1p(t) < 2.1e-9*0.01).  t = exp(-|100a|), r = 1/(1+t):
 //   sp = max(a,0) + log(1+t)/100,  sp' = (a>=0 ? 1 : t) * r,  sp'' = 100 * t * r^2
+// (one multiply by -100 log2(e) with the |.| source modifier + v_exp_f32; max(a, 0) as ONE v_med3_f32: fmaxf() costs a second
+//  v_max for sNaN quieting -- every vector instruction of these kernels is on the critical path, see below.  NOT inline asm:
+//  the hazard recogniser does not see an asm statement reading an MFMA result and omits the wait states -- measured: wrong
+//  colours at 1e-2.)
+__device__ __forceinline__ float relu_f(float a) { return __builtin_amdgcn_fmed3f(a, 0.f, __builtin_inff()); }
 __device__ __forceinline__ void softplus_parts(float a, float& t, float& r) {
-    t = __expf(-fabsf(100.f * a));
+    t = __builtin_amdgcn_exp2f(-144.26950408889634f * fabsf(a));
     r = __builtin_amdgcn_rcpf(1.f + t);
 }
 // log(1+t)/100 with the hardware log2 (v_log_f32, ~1 ulp on [1,2]: absolute error < 1e-9 after the 0.0069 scale); the
@@ -111,7 +128,7 @@ __device__ __forceinline__ void softplus_parts(float a, float& t, float& r) {
 // needs -- and on gfx950 VALU instructions do NOT overlap with MFMAs of the same SIMD (tools/micro/mfma_valu_overlap.hip:
 // time = MFMA time + VALU time), so every VALU instruction of the chain kernels is on the critical path.
 __device__ __forceinline__ float softplus_val(float a, float t) {
-    return __builtin_fmaf(0.0069314718056f, __builtin_amdgcn_logf(1.f + t), fmaxf(a, 0.f));
+    return __builtin_fmaf(0.0069314718056f, __builtin_amdgcn_logf(1.f + t), relu_f(a));
 }
 __device__ __forceinline__ float softplus_d1(float a, float t, float r) { return (a >= 0.f ? 1.f : t) * r; }
 __device__ __forceinline__ float softplus_d2(float t, float r) { return 100.f * t * r * r; }
@@ -195,9 +212,10 @@ struct SdfPack {
     static constexpr int B5 = W5 + 65 * 64;           // [65]
     static constexpr int TOTAL = B5 + 65;             // floats
 };
-// LDS image: same matrices with odd row strides (bank-conflict-free row- and column-wise reads).
+// LDS image: same matrices with row strides = 4 mod 64 floats (16 rows of a ds_read_b128 fall on 16 distinct bank quads;
+// column-wise ds_read_b32 is conflict-free for any stride).
 struct SdfLds {
-    static constexpr int LD0 = 49, LD1 = 113, LD3 = 65;
+    static constexpr int LD0 = 52, LD1 = 116, LD3 = 68;
     static constexpr int W0 = 0;
     static constexpr int W1 = W0 + 64 * LD0;
     static constexpr int W2 = W1 + 64 * LD1;
@@ -217,7 +235,7 @@ struct RgbPack {
     static constexpr int TOTAL = B3 + 4;
 };
 struct RgbLds {
-    static constexpr int LD0 = 113, LD1 = 65;
+    static constexpr int LD0 = 116, LD1 = 68;
     static constexpr int V0 = 0;
     static constexpr int V1 = V0 + 64 * LD0;
     static constexpr int V2 = V1 + 64 * LD1;

@@ -23,7 +23,7 @@ struct RgbLanePtrs {
 
 __device__ __forceinline__ void relu_from_acc(const f32x4 (&acc)[NT], float (&r)[ACT_STEPS]) {
 #pragma unroll
-    for (int s = 0; s < ACT_STEPS; ++s) r[s] = fmaxf(acc[s >> 2][s & 3], 0.f);
+    for (int s = 0; s < ACT_STEPS; ++s) r[s] = relu_f(acc[s >> 2][s & 3]);
 }
 
 // RGBNetwork.forward (model/implicit.py:220-239) for one 16-point tile.
