@@ -28,6 +28,7 @@ def _hf(width, layers, heads, mlp, patch, image, proj, seed):
 @pytest.mark.parametrize("width,layers,heads,mlp,patch,image,proj,B", [
     (128, 2, 2, 256, 32, 64, 64, 3),             # 5 tokens
     (768, 12, 12, 3072, 32, 224, 512, 4),        # ViT-B/32: 50 tokens
+    (768, 12, 12, 3072, 32, 224, 512, 32),       # ViT-B/32 at the BASELINE config[2] batch (1600 token rows: split-K proj / fc2)
     (128, 2, 2, 256, 14, 112, 64, 2),            # 65 tokens (> one key chunk... and 2 query blocks + 1), patch K = 588 (padded)
     (192, 2, 3, 384, 8, 112, 96, 2),             # 197 tokens: 7 key chunks, query blocks wrap over the 4 waves
     (1024, 2, 16, 4096, 14, 224, 768, 2),        # ViT-L/14 geometry (257 tokens), 2 layers

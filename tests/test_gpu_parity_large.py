@@ -230,3 +230,57 @@ def test_chamfer_20000_both_entry_points(split):
     print("Chamfer 20000x20000 (split=%s): dist vs float64 brute force %.2f ulp, chosen index within %.2f ulp of the minimum"
           % (split, worst_ulp, worst_gap))
     assert worst_ulp <= 4.0 and worst_gap <= 8.0     # dx = t - q is itself rounded: a few ulp against exact arithmetic
+
+
+def test_config2_chamfer_b32_100k_equals_single_item_runs():
+    """BASELINE config[2]: Chamfer at B=32, N=M=100,000 (the batched kernel, 32 x 98 workgroups per direction).  Every
+    item must equal the B=1 call on the same clouds bit for bit (that call takes the target-split / atomicMin variant, which
+    is itself compared with the oracle at 20,000^2 above), and swapping the clouds swaps the outputs."""
+    import chamfer_3D
+    dev = torch.device("cuda:0")
+    B, N = 32, 100000
+    g = torch.Generator().manual_seed(9)
+    a = (torch.rand(B, N, 3, generator=g) - 0.5).to(dev)
+    b = (torch.rand(B, N, 3, generator=g) - 0.5).to(dev)
+
+    def run(x, y):
+        n = x.shape[0]
+        d1 = torch.zeros(n, N, device=dev); d2 = torch.zeros(n, N, device=dev)
+        i1 = torch.zeros(n, N, dtype=torch.int32, device=dev); i2 = torch.zeros(n, N, dtype=torch.int32, device=dev)
+        assert chamfer_3D.forward(x, y, d1, d2, i1, i2) == 1
+        return d1, d2, i1, i2
+    full = run(a, b)
+    for item in (0, 17, 31):
+        one = run(a[item:item + 1].contiguous(), b[item:item + 1].contiguous())
+        for x, y in zip(full, one):
+            assert torch.equal(x[item], y[0]), item
+    swapped = run(b, a)
+    assert torch.equal(swapped[0], full[1]) and torch.equal(swapped[3], full[2])
+    assert int(full[2].min()) >= 0 and int(full[2].max()) < N
+    print("Chamfer B=32 N=M=100000: items 0/17/31 bit-identical to their B=1 runs; mean sqrt distance %.5f" % float(full[0].sqrt().mean()))
+
+
+def test_config2_render_128_b32_rows_equal_single_image_renders(golden):
+    """BASELINE config[2]: full-frame 128x128 evaluation render at B=32 (524,288 rays, 33.5 M sample points in one call).
+    Images are independent: rows of the batched render equal the single-image renders (compared with the oracle above)."""
+    from oracle import reference_ops as R
+    dev = torch.device("cuda:0")
+    B, beta = 32, 0.05
+    opt, cfg = _opt(128, 128), R.Cfg(H=128, W=128)
+    Ws, Wr = _weights(golden)
+    pose, intr, sd, zs, zr = _cameras(cfg, B, seed=21)
+    r = _renderer(Ws, Wr, opt, dev, beta)
+    to = lambda t: t.to(dev)
+    with torch.no_grad():
+        full = r(opt, to(pose), to(intr), to(sd), to(zs), to(zr), ray_idx=None, training=False)
+        assert full[0].shape == (B, 128 * 128, 3) and full[5] is None
+        worst = 0.0
+        for item in (0, 13, 31):
+            s = slice(item, item + 1)
+            one = r(opt, to(pose[s]), to(intr[s]), to(sd[s]), to(zs[s]), to(zr[s]), ray_idx=None, training=False)
+            for k in (0, 1, 3):
+                worst = max(worst, float((full[k][item] - one[k][0]).abs().max()))
+            assert torch.equal(full[2][item], one[2][0]) or float((full[1][item] - 0.5).abs().min()) < 1e-5
+    hit = float(full[2].mean())
+    print("128x128 render B=32: rows vs single-image renders max abs diff %.2e, hit fraction %.2f" % (worst, hit))
+    assert worst < 2e-6 and 0.1 < hit < 0.9
