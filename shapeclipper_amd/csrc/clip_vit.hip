@@ -89,7 +89,15 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void gemm_bf16_kernel(con
     extern __shared__ uint4 Sbuf[];      // [NSTAGE][A 128 rows x 8 chunks | B 128 rows x 8 chunks]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int bm = blockIdx.y * 128, bn = blockIdx.x * 128;
+    // XCD-aware tile order.  Workgroup b runs on XCD b % 8 and every XCD has its own 4 MiB L2: with the plain (n, m) grid each
+    // XCD touched every row tile of A, so the operand tiles were re-fetched from the Infinity Cache at ~30 GB/s per CU -- 64
+    // FLOP per staged byte x 30 GB/s = the 480 TFLOP/s this kernel was stuck at whatever its inner loop looked like.  Here XCD k
+    // owns a CONTIGUOUS range of the row-major tile list (all N tiles of a few M tiles): its A slice (1/8 of A) and W stay in L2.
+    const int ntn = gridDim.x, tiles = gridDim.x * gridDim.y;
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, idx = lin >> 3;
+    const int tq = tiles >> 3, trem = tiles & 7;
+    const int tile = (xcd < trem ? xcd * (tq + 1) : trem * (tq + 1) + (xcd - trem) * tq) + idx;
+    const int bm = (tile / ntn) * 128, bn = (tile % ntn) * 128;
     // split-K (gridDim.z > 1, residual epilogue only): slice z accumulates its K range into the fp32 output with atomics;
     // used when the output has too few 128x128 tiles to fill 256 CUs (N = 768 at 1600 rows: 78 workgroups)
     const int kslices = gridDim.z, kt0 = (K / 64) * blockIdx.z / kslices, kt1 = (K / 64) * (blockIdx.z + 1) / kslices;
@@ -106,7 +114,7 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void gemm_bf16_kernel(con
     const bf16_t* pb[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int c = q * 256 + tid, row = c >> 3, kc = (c & 7) ^ (row & 7);
+        const int c = q * 256 + tid, row = c >> 3, kc = (c & 7) ^ ((row >> 1) & 7);
         pa[q] = A + (size_t)min(bm + row, M - 1) * K + kc * 8;
         pb[q] = Wt + (size_t)min(bn + row, N - 1) * K + kc * 8;
     }
@@ -120,28 +128,33 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void gemm_bf16_kernel(con
             glds16(pb[q] + (size_t)kt * 64, base + (1024 + q * 256) * 16);
         }
     };
+    // fragment reads: lanes 0-31 = 32 consecutive rows, lanes 32-63 the next 16-byte K chunk.  ds_read_b128 is serviced in the
+    // lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32): with 128-byte rows the bank quad of a chunk is
+    // 8 (row & 1) + slot, so the slot permutation must differ for the 8 rows of equal parity inside each group --
+    // slot = chunk ^ ((row >> 1) & 7) does (round 1's chunk ^ (row & 7) left every read 2-way conflicted: PMC
+    // SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE).  The fragments of K sub-step kk+1 are requested before the MFMAs of kk.
     auto compute = [&](int stage) {
         const uint4* As = Sbuf + stage * 2048;
         const uint4* Bs = As + 1024;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 af[2], bf[2];
+        const int ra = 64 * wr + (lane & 31), rb = 64 * wc + (lane & 31);
+        const int sa = (ra >> 1) & 7, sb = (rb >> 1) & 7;          // rows +32 keep (row >> 1) & 7
+        bf16x8 af[2][2], bf[2][2];
+        auto frags = [&](int kk, bf16x8 (&a2)[2], bf16x8 (&b2)[2]) {
             const int kc = 2 * kk + (lane >> 5);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = 64 * wr + 32 * i + (lane & 31);
-                af[i] = __builtin_bit_cast(bf16x8, As[row * 8 + (kc ^ (row & 7))]);
-            }
+            for (int i = 0; i < 2; ++i) a2[i] = __builtin_bit_cast(bf16x8, As[(ra + 32 * i) * 8 + (kc ^ sa)]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int row = 64 * wc + 32 * j + (lane & 31);
-                bf[j] = __builtin_bit_cast(bf16x8, Bs[row * 8 + (kc ^ (row & 7))]);
-            }
+            for (int j = 0; j < 2; ++j) b2[j] = __builtin_bit_cast(bf16x8, Bs[(rb + 32 * j) * 8 + (kc ^ sb)]);
+        };
+        frags(0, af[0], bf[0]);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (kk + 1 < 4) frags(kk + 1, af[(kk + 1) & 1], bf[(kk + 1) & 1]);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
         }
     };
     // Tile kt is complete for every wave once each wave has waited for its own DMA and all have met at the barrier; the same
@@ -162,10 +175,62 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void gemm_bf16_kernel(con
         stage = stage + 1 == NSTAGE ? 0 : stage + 1;
     }
 #undef SC_GEMM_SYNC
-    // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // Fast path (full-width tile, row pitch a multiple of 16 bytes, no split-K): the tile goes through the (now free) LDS stages
+    // and leaves as 16-byte row-contiguous stores -- 8 (bf16) / 16 (fp32) store instructions per lane instead of 64 two- or
+    // four-byte ones.  A K-sweep showed the element-wise epilogue costing as much as 12 K-steps (46 us of the 92 us of the
+    // 12800 x 2304 x 768 qkv GEMM were spent at K = 64); the residual add reads its rows the same way.
+    constexpr bool OUT_BF16 = EPI == EPI_GELU_BF16 || EPI == EPI_BF16;
+    if (kslices == 1 && bn + 128 <= N && (N % 8) == 0) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");       // every wave is done with the stages
+        float* Cf = reinterpret_cast<float*>(Sbuf);
+        bf16_t* Ch = reinterpret_cast<bf16_t*>(Sbuf);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int cl = 64 * wc + 32 * j + (lane & 31);
+                const float bv = bias ? bias[bn + cl] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const float v = acc[i][j][r] + bv;
+                    if (EPI == EPI_GELU_BF16) Ch[rl * 128 + cl] = f2bf(v / (1.f + __expf(-1.702f * v)));
+                    else if (EPI == EPI_BF16) Ch[rl * 128 + cl] = f2bf(v);
+                    else Cf[rl * 128 + cl] = v;
+                }
+            }
+        __syncthreads();
+        if (OUT_BF16) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int chunk = q * 256 + tid, rl = chunk >> 4, c8 = (chunk & 15) * 8;
+                if (bm + rl < M)
+                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(out) + (size_t)(bm + rl) * N + bn + c8) =
+                        *reinterpret_cast<const uint4*>(Ch + rl * 128 + c8);
+            }
+        } else {
+            float4 res[16];
+            if (EPI == EPI_RESID) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int chunk = q * 256 + tid, rl = chunk >> 5, c4 = (chunk & 31) * 4;
+                    res[q] = bm + rl < M ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(out) + (size_t)(bm + rl) * N + bn + c4)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int chunk = q * 256 + tid, rl = chunk >> 5, c4 = (chunk & 31) * 4;
+                float4 v = *reinterpret_cast<const float4*>(Cf + rl * 128 + c4);
+                if (EPI == EPI_RESID) { v.x += res[q].x; v.y += res[q].y; v.z += res[q].z; v.w += res[q].w; }
+                if (bm + rl < M) *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)(bm + rl) * N + bn + c4) = v;
+            }
+        }
+        return;
+    }
+    // general path: partial tiles, odd row pitch, split-K (atomic accumulation)
     if (EPI == EPI_RESID && kslices == 1) {
-        // residual add: fetch all 64 residual values of this lane FIRST (independent loads in flight together), then add and
-        // store -- `x[o] += v` element by element makes every load wait for the previous store (64 dependent round trips)
         float res[2][2][16];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -175,7 +240,7 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void gemm_bf16_kernel(con
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = bm + 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    res[i][j][r] = (col < N && row < M) ? __builtin_nontemporal_load(reinterpret_cast<const float*>(out) + (size_t)row * N + col) : 0.f;
+                    res[i][j][r] = (col < N && row < M) ? reinterpret_cast<const float*>(out)[(size_t)row * N + col] : 0.f;
                 }
             }
 #pragma unroll
