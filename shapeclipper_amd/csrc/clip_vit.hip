@@ -78,42 +78,42 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(
 // logical K-chunk slot ^ (row & 7) of that row (the read side applies the same involution).  Rows past M / N are clamped to the
 // last valid row (their products are never stored).  The two buffers are separate __shared__ objects so that the compiler can
 // prove the DMA of one does not alias the fragment reads of the other (otherwise it drains the DMA before the first ds_read).
-// NSTAGE LDS stages of 32 KiB: NSTAGE - 1 tiles are in flight while one is consumed.  2 stages leave room for two workgroups
-// per CU (large grids: the other workgroup hides the rest of the latency); 4 stages (128 KiB, one workgroup per CU) are for
-// grids that give a CU a single workgroup anyway (batch 32: 78-312 tiles on 256 CUs), where the K loop would otherwise run at
-// one HBM/L2 round trip per K-step.
-template <int EPI, int NSTAGE>
-__global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void gemm_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
-                                                                             const float* __restrict__ bias, void* __restrict__ out,
-                                                                             int M, int N, int K) {
-    extern __shared__ uint4 Sbuf[];      // [NSTAGE][A 128 rows x 8 chunks | B 128 rows x 8 chunks]
+// BT x BT output tiles (BT = 128: four waves x (2x2) MFMA tiles; BT = 64: four waves x one MFMA tile, for launches whose 128-wide
+// grid would leave most CUs without a workgroup -- batch 32: 78 tiles for N = 768 -- instead of round 1's split-K with fp32
+// atomics, which also made the summation order run-dependent).  Two LDS stages: the tile of K-step k+1 is in flight while k is
+// consumed; large grids put two (BT = 128) or more workgroups on a CU and they hide the rest of the latency.
+template <int EPI, int BT>
+__global__ __launch_bounds__(256, BT == 128 ? 2 : 4) void gemm_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
+                                                                           const float* __restrict__ bias, void* __restrict__ out,
+                                                                           int M, int N, int K) {
+    constexpr int MI = BT / 64;                // MFMA tiles per wave and dimension
+    constexpr int CH = BT * 8;                 // 16-byte chunks per operand tile (BT rows x 64 K)
+    constexpr int QN = CH / 256;               // DMA instructions per thread and operand
+    extern __shared__ uint4 Sbuf[];            // [2 stages][A: BT rows x 8 chunks | B: BT rows x 8 chunks]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     // XCD-aware tile order.  Workgroup b runs on XCD b % 8 and every XCD has its own 4 MiB L2: with the plain (n, m) grid each
-    // XCD touched every row tile of A, so the operand tiles were re-fetched from the Infinity Cache at ~30 GB/s per CU -- 64
-    // FLOP per staged byte x 30 GB/s = the 480 TFLOP/s this kernel was stuck at whatever its inner loop looked like.  Here XCD k
-    // owns a CONTIGUOUS range of the row-major tile list (all N tiles of a few M tiles): its A slice (1/8 of A) and W stay in L2.
+    // XCD touched every row tile of A, so the operand tiles were re-fetched from the Infinity Cache.  Here XCD k owns a
+    // CONTIGUOUS range of the row-major tile list (all N tiles of a few M tiles): its A slice (1/8 of A) and W stay in L2.
     const int ntn = gridDim.x, tiles = gridDim.x * gridDim.y;
     const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, idx = lin >> 3;
     const int tq = tiles >> 3, trem = tiles & 7;
     const int tile = (xcd < trem ? xcd * (tq + 1) : trem * (tq + 1) + (xcd - trem) * tq) + idx;
-    const int bm = (tile / ntn) * 128, bn = (tile % ntn) * 128;
-    // split-K (gridDim.z > 1, residual epilogue only): slice z accumulates its K range into the fp32 output with atomics;
-    // used when the output has too few 128x128 tiles to fill 256 CUs (N = 768 at 1600 rows: 78 workgroups)
-    const int kslices = gridDim.z, kt0 = (K / 64) * blockIdx.z / kslices, kt1 = (K / 64) * (blockIdx.z + 1) / kslices;
-    f32x16 acc[2][2];
+    const int bm = (tile / ntn) * BT, bn = (tile % ntn) * BT;
+    const int kt1 = K / 64;
+    f32x16 acc[MI][MI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < MI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // per-thread DMA sources: chunk c = q*256 + tid of each operand tile
-    const bf16_t* pa[4];
-    const bf16_t* pb[4];
+    const bf16_t* pa[QN];
+    const bf16_t* pb[QN];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < QN; ++q) {
         const int c = q * 256 + tid, row = c >> 3, kc = (c & 7) ^ ((row >> 1) & 7);
         pa[q] = A + (size_t)min(bm + row, M - 1) * K + kc * 8;
         pb[q] = Wt + (size_t)min(bn + row, N - 1) * K + kc * 8;
@@ -121,11 +121,11 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void gemm_bf16_kernel(con
     const unsigned wave_off = (unsigned)__builtin_amdgcn_readfirstlane(wave * 64 * 16);
     const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(Sbuf)) + wave_off;
     auto issue = [&](int kt, int stage) {
-        const unsigned base = lds0 + (unsigned)stage * 2048u * 16u;
+        const unsigned base = lds0 + (unsigned)stage * (2u * CH) * 16u;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < QN; ++q) {
             glds16(pa[q] + (size_t)kt * 64, base + q * 256 * 16);
-            glds16(pb[q] + (size_t)kt * 64, base + (1024 + q * 256) * 16);
+            glds16(pb[q] + (size_t)kt * 64, base + (CH + q * 256) * 16);
         }
     };
     // fragment reads: lanes 0-31 = 32 consecutive rows, lanes 32-63 the next 16-byte K chunk.  ds_read_b128 is serviced in the
@@ -134,144 +134,126 @@ __global__ __launch_bounds__(256, NSTAGE == 2 ? 2 : 1) void gemm_bf16_kernel(con
     // slot = chunk ^ ((row >> 1) & 7) does (round 1's chunk ^ (row & 7) left every read 2-way conflicted: PMC
     // SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE).  The fragments of K sub-step kk+1 are requested before the MFMAs of kk.
     auto compute = [&](int stage) {
-        const uint4* As = Sbuf + stage * 2048;
-        const uint4* Bs = As + 1024;
-        const int ra = 64 * wr + (lane & 31), rb = 64 * wc + (lane & 31);
+        const uint4* As = Sbuf + stage * (2 * CH);
+        const uint4* Bs = As + CH;
+        const int ra = (BT / 2) * wr + (lane & 31), rb = (BT / 2) * wc + (lane & 31);
         const int sa = (ra >> 1) & 7, sb = (rb >> 1) & 7;          // rows +32 keep (row >> 1) & 7
-        bf16x8 af[2][2], bf[2][2];
-        auto frags = [&](int kk, bf16x8 (&a2)[2], bf16x8 (&b2)[2]) {
+        bf16x8 af[2][MI], bf[2][MI];
+        auto frags = [&](int kk, bf16x8 (&a2)[MI], bf16x8 (&b2)[MI]) {
             const int kc = 2 * kk + (lane >> 5);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a2[i] = __builtin_bit_cast(bf16x8, As[(ra + 32 * i) * 8 + (kc ^ sa)]);
+            for (int i = 0; i < MI; ++i) a2[i] = __builtin_bit_cast(bf16x8, As[(ra + 32 * i) * 8 + (kc ^ sa)]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b2[j] = __builtin_bit_cast(bf16x8, Bs[(rb + 32 * j) * 8 + (kc ^ sb)]);
+            for (int j = 0; j < MI; ++j) b2[j] = __builtin_bit_cast(bf16x8, Bs[(rb + 32 * j) * 8 + (kc ^ sb)]);
         };
         frags(0, af[0], bf[0]);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             if (kk + 1 < 4) frags(kk + 1, af[(kk + 1) & 1], bf[(kk + 1) & 1]);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < MI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
         }
     };
-    // Tile kt is complete for every wave once each wave has waited for its own DMA and all have met at the barrier; the same
-    // barrier says that everybody has finished reading the stage the next DMA overwrites (the one consumed last iteration).
-    // DMA completes in issue order, 8 instructions per tile and thread: "at most 8 x (tiles issued after kt) outstanding".
-#define SC_GEMM_SYNC(NOUT) asm volatile("s_waitcnt vmcnt(" #NOUT ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#pragma unroll
-    for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
-        if (kt0 + s0 < kt1) issue(kt0 + s0, s0);
-    int stage = 0;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int after = min(NSTAGE - 2, kt1 - 1 - kt);          // tiles issued after kt that may still be in flight
-        if (after >= 2) SC_GEMM_SYNC(16);
-        else if (after == 1) SC_GEMM_SYNC(8);
-        else SC_GEMM_SYNC(0);
-        if (kt + NSTAGE - 1 < kt1) issue(kt + NSTAGE - 1, stage == 0 ? NSTAGE - 1 : stage - 1);
-        compute(stage);
-        stage = stage + 1 == NSTAGE ? 0 : stage + 1;
+    // Tile kt is complete for every wave once each wave has waited for its own DMA (issued from asm: counted by hand) and all
+    // have met at the barrier; the same barrier says that everybody has finished reading the stage the next DMA overwrites.
+#define SC_GEMM_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    if (kt1 > 0) issue(0, 0);
+    for (int kt = 0; kt < kt1; ++kt) {
+        SC_GEMM_SYNC();
+        if (kt + 1 < kt1) issue(kt + 1, (kt + 1) & 1);
+        compute(kt & 1);
     }
-#undef SC_GEMM_SYNC
     // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    // Fast path (full-width tile, row pitch a multiple of 16 bytes, no split-K): the tile goes through the (now free) LDS stages
-    // and leaves as 16-byte row-contiguous stores -- 8 (bf16) / 16 (fp32) store instructions per lane instead of 64 two- or
+    // Fast path (full-width tile, row pitch a multiple of 16 bytes): the tile goes through the (now free) LDS stages and leaves
+    // as 16-byte row-contiguous stores -- BT/16 (bf16) / BT/8 (fp32) store instructions per lane instead of 16 MI^2 two- or
     // four-byte ones.  A K-sweep showed the element-wise epilogue costing as much as 12 K-steps (46 us of the 92 us of the
-    // 12800 x 2304 x 768 qkv GEMM were spent at K = 64); the residual add reads its rows the same way.
+    // 12800 x 2304 x 768 qkv GEMM were spent at K = 64); the residual add reads its rows the same way, all of them before the
+    // first store (`x[o] += v` element by element made every load wait for the previous store).
     constexpr bool OUT_BF16 = EPI == EPI_GELU_BF16 || EPI == EPI_BF16;
-    if (kslices == 1 && bn + 128 <= N && (N % 8) == 0) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");       // every wave is done with the stages
+    if (bn + BT <= N && (N % 8) == 0) {
+        SC_GEMM_SYNC();                                         // every wave is done with the stages
         float* Cf = reinterpret_cast<float*>(Sbuf);
         bf16_t* Ch = reinterpret_cast<bf16_t*>(Sbuf);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int cl = 64 * wc + 32 * j + (lane & 31);
+            for (int j = 0; j < MI; ++j) {
+                const int cl = (BT / 2) * wc + 32 * j + (lane & 31);
                 const float bv = bias ? bias[bn + cl] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int rl = 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int rl = (BT / 2) * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     const float v = acc[i][j][r] + bv;
-                    if (EPI == EPI_GELU_BF16) Ch[rl * 128 + cl] = f2bf(v / (1.f + __expf(-1.702f * v)));
-                    else if (EPI == EPI_BF16) Ch[rl * 128 + cl] = f2bf(v);
-                    else Cf[rl * 128 + cl] = v;
+                    if (EPI == EPI_GELU_BF16) Ch[rl * BT + cl] = f2bf(v / (1.f + __expf(-1.702f * v)));
+                    else if (EPI == EPI_BF16) Ch[rl * BT + cl] = f2bf(v);
+                    else Cf[rl * BT + cl] = v;
                 }
             }
         __syncthreads();
         if (OUT_BF16) {
+            constexpr int CPR = BT / 8;                          // 16-byte chunks per tile row
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int chunk = q * 256 + tid, rl = chunk >> 4, c8 = (chunk & 15) * 8;
+            for (int q = 0; q < BT * CPR / 256; ++q) {
+                const int chunk = q * 256 + tid, rl = chunk / CPR, c8 = (chunk % CPR) * 8;
                 if (bm + rl < M)
                     *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(out) + (size_t)(bm + rl) * N + bn + c8) =
-                        *reinterpret_cast<const uint4*>(Ch + rl * 128 + c8);
+                        *reinterpret_cast<const uint4*>(Ch + rl * BT + c8);
             }
         } else {
-            float4 res[16];
+            constexpr int CPR = BT / 4, NQ = BT * CPR / 256;
+            float4 res[NQ];
             if (EPI == EPI_RESID) {
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int chunk = q * 256 + tid, rl = chunk >> 5, c4 = (chunk & 31) * 4;
+                for (int q = 0; q < NQ; ++q) {
+                    const int chunk = q * 256 + tid, rl = chunk / CPR, c4 = (chunk % CPR) * 4;
                     res[q] = bm + rl < M ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(out) + (size_t)(bm + rl) * N + bn + c4)
                                          : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int chunk = q * 256 + tid, rl = chunk >> 5, c4 = (chunk & 31) * 4;
-                float4 v = *reinterpret_cast<const float4*>(Cf + rl * 128 + c4);
+            for (int q = 0; q < NQ; ++q) {
+                const int chunk = q * 256 + tid, rl = chunk / CPR, c4 = (chunk % CPR) * 4;
+                float4 v = *reinterpret_cast<const float4*>(Cf + rl * BT + c4);
                 if (EPI == EPI_RESID) { v.x += res[q].x; v.y += res[q].y; v.z += res[q].z; v.w += res[q].w; }
                 if (bm + rl < M) *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)(bm + rl) * N + bn + c4) = v;
             }
         }
         return;
     }
-    // general path: partial tiles, odd row pitch, split-K (atomic accumulation)
-    if (EPI == EPI_RESID && kslices == 1) {
-        float res[2][2][16];
+#undef SC_GEMM_SYNC
+    // general path: partial tiles in N or a row pitch that is not a multiple of 16 bytes
+    float res[MI][MI][16];
+    if (EPI == EPI_RESID) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = bn + 64 * wc + 32 * j + (lane & 31);
+            for (int j = 0; j < MI; ++j) {
+                const int col = bn + (BT / 2) * wc + 32 * j + (lane & 31);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = bm + 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int row = bm + (BT / 2) * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     res[i][j][r] = (col < N && row < M) ? reinterpret_cast<const float*>(out)[(size_t)row * N + col] : 0.f;
                 }
             }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = bn + 64 * wc + 32 * j + (lane & 31);
-                const float bv = (bias && col < N) ? bias[col] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = bm + 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (col < N && row < M) reinterpret_cast<float*>(out)[(size_t)row * N + col] = res[i][j][r] + acc[i][j][r] + bv;
-                }
-            }
-        return;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = bn + 64 * wc + 32 * j + (lane & 31);
+        for (int j = 0; j < MI; ++j) {
+            const int col = bn + (BT / 2) * wc + 32 * j + (lane & 31);
             if (col >= N) continue;
-            const float bv = (bias && blockIdx.z == 0) ? bias[col] : 0.f;
+            const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = bm + 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int row = bm + (BT / 2) * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row >= M) continue;
                 const float v = acc[i][j][r] + bv;
                 const size_t o = (size_t)row * N + col;
                 if (EPI == EPI_F32) reinterpret_cast<float*>(out)[o] = v;
-                else if (EPI == EPI_RESID) unsafeAtomicAdd(reinterpret_cast<float*>(out) + o, v);
+                else if (EPI == EPI_RESID) reinterpret_cast<float*>(out)[o] = res[i][j][r] + v;
                 else if (EPI == EPI_GELU_BF16) reinterpret_cast<bf16_t*>(out)[o] = f2bf(v / (1.f + __expf(-1.702f * v)));
                 else reinterpret_cast<bf16_t*>(out)[o] = f2bf(v);
             }
@@ -430,22 +412,17 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
 static int launch_gemm(int epi, const bf16_t* A, const bf16_t* Wt, const float* bias, void* out, int M, int N, int K,
                        hipStream_t st) {
     if (K % 64) return (int)hipErrorInvalidValue;
-    dim3 grid((N + 127) / 128, (M + 127) / 128);
-    if (epi == EPI_RESID) {        // fill the chip: split K while there are fewer than ~256 workgroups and >= 4 K tiles per slice
-        int z = 1;
-        while (grid.x * grid.y * z < 200 && K / 64 / (2 * z) >= 4 && z < 8) z *= 2;
-        grid.z = z;
-    }
-    // few tiles (a CU gets one workgroup anyway): 4 LDS stages hide the operand latency inside the workgroup
-    const bool deep = false;   // measured (MI355X, ViT-B/32 batch 32): 4 stages at one workgroup per CU are not faster (21.7 vs 21.2 us for
-                               // qkv, 43 vs 29 us for fc1) -- those launches are bound by their fixed prologue / epilogue, not by operand latency
-#define SC_LAUNCH(E)                                                                                                   \
-    if (deep) {                                                                                                        \
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<E, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768); \
-        hipLaunchKernelGGL((gemm_bf16_kernel<E, 4>), grid, dim3(256), 4 * 32768, st, A, Wt, bias, out, M, N, K);       \
-    } else {                                                                                                           \
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<E, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768); \
-        hipLaunchKernelGGL((gemm_bf16_kernel<E, 2>), grid, dim3(256), 2 * 32768, st, A, Wt, bias, out, M, N, K);       \
+    // 128-wide tiles when they give every CU work (>= 1.5 workgroups per CU), 64-wide ones otherwise
+    const long long t128 = (long long)((N + 127) / 128) * ((M + 127) / 128);
+    const bool small = t128 < 384;
+#define SC_LAUNCH(E)                                                                                                          \
+    if (small) {                                                                                                              \
+        hipLaunchKernelGGL((gemm_bf16_kernel<E, 64>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 2 * 2 * 64 * 8 * 16, st, \
+                           A, Wt, bias, out, M, N, K);                                                                        \
+    } else {                                                                                                                  \
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<E, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);  \
+        hipLaunchKernelGGL((gemm_bf16_kernel<E, 128>), dim3((N + 127) / 128, (M + 127) / 128), dim3(256), 65536, st,          \
+                           A, Wt, bias, out, M, N, K);                                                                        \
     }
     switch (epi) {
         case EPI_F32: SC_LAUNCH(EPI_F32) break;
