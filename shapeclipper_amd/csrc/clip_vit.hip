@@ -270,6 +270,41 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const int row = blockIdx.x * 4 + wave;
     if (row >= rows) return;
     const float* xr = x + (size_t)row * stride;
+    if ((D & 255) == 0 && D <= 1024 && (stride & 3) == 0) {
+        // the row lives in registers: D/256 float4 per lane, one pass (two-pass variance: mean first, then centred squares)
+        float4 v[4];
+        const int nv = D >> 8;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < nv) { v[k] = reinterpret_cast<const float4*>(xr)[k * 64 + lane]; s += (v[k].x + v[k].y) + (v[k].z + v[k].w); }
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s / D;
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < nv) {
+                v[k].x -= mean; v[k].y -= mean; v[k].z -= mean; v[k].w -= mean;
+                ss += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
+            }
+        for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+        const float inv = rsqrtf(ss / D + eps);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < nv) {
+                const int d = (k * 64 + lane) * 4;
+                const float4 gg = *reinterpret_cast<const float4*>(g + d), bb = *reinterpret_cast<const float4*>(b + d);
+                const float o0 = v[k].x * inv * gg.x + bb.x, o1 = v[k].y * inv * gg.y + bb.y;
+                const float o2 = v[k].z * inv * gg.z + bb.z, o3 = v[k].w * inv * gg.w + bb.w;
+                if (OUT_BF16) {
+                    const uint2 pk = make_uint2((uint32_t)f2bf(o0) | ((uint32_t)f2bf(o1) << 16), (uint32_t)f2bf(o2) | ((uint32_t)f2bf(o3) << 16));
+                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (size_t)row * D + d) = pk;
+                } else {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)row * D + d) = make_float4(o0, o1, o2, o3);
+                }
+            }
+        return;
+    }
     float s = 0.f, ss = 0.f;
     for (int d = lane; d < D; d += 64) { const float v = xr[d]; s += v; ss += v * v; }
     for (int o = 32; o >= 1; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
