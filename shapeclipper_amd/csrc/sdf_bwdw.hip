@@ -27,8 +27,6 @@
 // (pend_0..3, 1 KiB per layer and wave) live in a per-wave scratch that never leaves L2.
 // LDS: weight image 118 KiB + 4 x 2 x 4 KiB exchange slots + point stash = 153 KiB of the 160 KiB.
 // Bound: fp32 MFMA (1872 v_mfma_f32_16x16x4 per 16 points; 157.3 TFLOP/s dense peak).
-#include <stdlib.h>
-
 #include "mlp_tile.hpp"
 
 namespace sc {
@@ -46,7 +44,6 @@ struct SdfBwdwArgs {
     float* park;           // [gridDim.x * 4][4][1024] floats of per-wave scratch (L2-resident)
     float* partial;        // [gridDim.x][SdfPack::TOTAL]: one partial gradient image per workgroup (fully written)
     float* g_cbias;        // [n_images][5][64], zero-filled by the caller (atomicAdd)
-    int dbg;               // tuning experiments only (SC_BWDW_DBG): 1 = wgrad waves skip their MFMAs, 2 = skip the PE operands
 };
 
 constexpr int BW_CHAIN = 4;                          // chain waves (= wgrad waves) per workgroup
@@ -429,13 +426,12 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
             const float* sA = lds + BW_XCH + (c * 2 + 0) * 1024;                             \
             const float* sB = lds + BW_XCH + (c * 2 + 1) * 1024;                             \
             const float4 af = xch_frag(sA, rd, w);                                           \
-            if (a.dbg & 1) continue;                                                         \
             if (HP) {                                                                        \
                 float4 bf[4];                                                                \
                 _Pragma("unroll") for (int n = 0; n < 4; ++n) bf[n] = xch_frag(sB, rd, n);   \
                 outer16<4>(af, bf, ACCH);                                                    \
             }                                                                                \
-            if (PEM && !(a.dbg & 2)) {                                                       \
+            if (PEM) {                                                                       \
                 float4 pf[3];                                                                \
                 pe_frags<PEM ? PEM : 1>(lds + BW_PTS + c * 16 * 8, i, kg, symmetric, pf);    \
                 outer16<3>(af, pf, ACCE);                                                    \
@@ -544,8 +540,7 @@ int sc_sdf_backward_fused(const float* points, const float* w_pack, int n_points
     if (n_points <= 0) return 0;
     if (!g_grad || !stash_p || n_per_image <= 0 || n_per_image % sc::TP != 0 || n_images <= 0) return (int)hipErrorInvalidValue;
     sc::SdfBwdwArgs a{points, w_pack, n_points, n_per_image, n_images, symmetric, stash_a, stash_p, g_sdf, g_grad, g_feat,
-                      g_points, park, partial, g_cbias, 0};
-    if (const char* e = getenv("SC_BWDW_DBG")) a.dbg = atoi(e);
+                      g_points, park, partial, g_cbias};
     const int blocks = sc_sdf_backward_fused_parts(n_points);
     const size_t lds_bytes = (size_t)sc::BW_LDS_FLOATS * sizeof(float);
     (void)hipFuncSetAttribute((const void*)sc::sdf_bwdw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

@@ -27,5 +27,5 @@ for _ in range(10):
 torch.cuda.synchronize()
 ms = sorted(s.elapsed_time(e) for s, e in evs)
 flop = (161280 + 864 * 2048 // 16) * n
-print("%s dbg=%s: %.3f ms (best %.3f) per SDF backward of %d points -> %.1f TFLOP/s algorithmic (input-gradient + weight-gradient)"
-      % (mode, os.environ.get("SC_BWDW_DBG", "0"), sum(ms) / len(ms), ms[0], n, flop / (sum(ms) / len(ms) * 1e-3) / 1e12))
+print("%s%s: %.3f ms (best %.3f) per SDF backward of %d points -> %.1f TFLOP/s algorithmic (input-gradient + weight-gradient)"
+      % (mode, "", sum(ms) / len(ms), ms[0], n, flop / (sum(ms) / len(ms) * 1e-3) / 1e12))
