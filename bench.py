@@ -40,7 +40,6 @@ FLOPS_PER_POINT = {
     "sc_rgb_composite_forward": RGB_VALUE,
     "sc_rgb_composite_backward": RGB_VALUE + RGB_VALUE,     # recompute + input-gradient sweep
 }
-WGRAD_FLOPS_PER_POINT = 1064 * 2048 // 16     # weight-gradient GEMMs of one render: 1064 MFMAs per 16-point tile
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2 dense peak
 PEAK_HBM_GBS = 8000.0
 
@@ -247,21 +246,22 @@ def main():
                         launch_ms=round(mean_big, 4), points_per_launch=n_pts_main,
                         flops_per_point=FLOPS_PER_POINT[dom],
                         hbm_GBps_of_measured_traffic=round(hbm_rate, 1) if hbm_rate else None)
-        # second roofline: the weight-gradient GEMMs (largest hand-written time share, HBM-bound by design): the 12 launches
-        # of a main render read 37 TBL64 operand tensors of 256 B/point (counted from ops.sdf_backward /
-        # ops.rgb_composite_backward: W0 3, W1 5+3, W2 5+3, W3 5, W4 4, W5f 2; V0 1+2, V1 2, V2 2)
+        # second roofline: the separate weight-gradient GEMM launches (wgrad.hip).  With the fused SDF backward (default) only the
+        # RGB network's remain: 3 launches per main render (V0 = [PE | feature] 112 + V1 64 + V2 64 = 240 MFMAs per 16 points);
+        # with --hip.fused_backward! the SDF network's 9 are there as well (1064 MFMAs in all).  Scored on FLOPs: the operand
+        # bytes they stream exist only because the backward kernels materialise them.
         roofline_wgrad = None
         if "sc_wgrad" in timing:
-            wd = sorted([s.elapsed_time(e) for s, e, _ in timing["sc_wgrad"]], reverse=True)[:24 * a.steps]
+            fused = "sc_sdf_backward_fused" in timing
+            per_render, mfmas = (3, 240) if fused else (12, 1064)
+            wd = sorted([s.elapsed_time(e) for s, e, _ in timing["sc_wgrad"]], reverse=True)[:2 * per_render * a.steps]
             per_render_ms = sum(wd) / (2 * a.steps)
-            gbs = 37 * 256.0 * n_pts_main / (per_render_ms * 1e-3) / 1e9
-            # scored on its FLOPs (1064 v_mfma_f32_16x16x4 per 16 points = 136,192 FLOP/point): the operand bytes it
-            # streams exist only because the backward kernels materialise them, they are not algorithmic bytes
-            wg_tf = WGRAD_FLOPS_PER_POINT * n_pts_main / (per_render_ms * 1e-3) / 1e12
-            roofline_wgrad = dict(kernel="sc_wgrad (12 launches of a main render)", bound="mfma", achieved=round(wg_tf, 2),
-                                  peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(wg_tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                                  ms_per_render=round(per_render_ms, 4), flops_per_point=WGRAD_FLOPS_PER_POINT,
-                                  operand_stream_GBps=round(gbs, 1), operand_bytes_per_point=37 * 256)
+            flops_pt = mfmas * 2048 // 16
+            wg_tf = flops_pt * n_pts_main / (per_render_ms * 1e-3) / 1e12
+            roofline_wgrad = dict(kernel="sc_wgrad (%d launches of a main render: %s)" % (per_render, "RGB network" if fused else "SDF + RGB networks"),
+                                  bound="mfma", achieved=round(wg_tf, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                                  frac=round(wg_tf / PEAK_FP32_MFMA_TFLOPS, 4), ms_per_render=round(per_render_ms, 4),
+                                  flops_per_point=flops_pt)
         out = dict(metric="train-step images/sec (Pix3D cfg, bs32/GPU)", value=round(a.batch * world / (dt / a.steps), 2),
                    unit="images/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
