@@ -1,0 +1,50 @@
+"""bench.py prints ONE JSON line with the driver's contract fields plus `roofline`, `sustained` and (with the CPU legs switched
+off here for speed) no `cpu_baseline`; `--workloads-only` prints the other SURVEY 8(d) workloads."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _last_json(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert lines, out[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_line_contract():
+    env = dict(os.environ, MIOPEN_LOG_LEVEL="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "2", "--sustained", "2",
+                        "--no-cpu-baseline", "--no-workloads"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "sustained", "hip_ms_per_step", "host_enqueue_ms_per_step"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "images/s" and d["dtype"] == "f32"
+    assert d["vs_baseline"] is None and d["scaling"] == "weak" and d["higher_is_better"] is True and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 2 / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]
+    rf = d["roofline"]
+    assert rf["kernel"] == "sc_sdf_backward_fused" and rf["bound"] in ("mfma", "hbm") and rf["unit"] == "TFLOP/s"
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["peak"] == 157.3
+    assert d["sustained"]["steps"] == 2 and d["sustained"]["ms_per_step"] > 0
+    assert "sc_sdf_forward" in d["hip_ms_per_step"] and "sc_rgb_composite_backward" in d["hip_ms_per_step"]
+
+
+def test_workloads_line():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sc_workloads_test", os.path.join(ROOT, "tools", "workloads.py"))
+    w = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(w)
+    out = w.level_grid_100(with_cpu=False)
+    for k in ("workload", "ms", "algorithmic_flop", "algorithmic_bytes", "achieved", "peak", "unit", "bound", "frac"):
+        assert k in out, k
+    assert out["algorithmic_flop"] == 80640 * 101 ** 3 and 0 < out["frac"] < 1.0
+    c = w.chamfer(1, N=20000, with_cpu=False)
+    assert c["algorithmic_flop"] == 16.0 * 20000 * 20000 and 0 < c["frac"] < 1.0
