@@ -260,6 +260,159 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 4) void gemm_bf16_kernel(const
         }
 }
 
+// Persistent form of the 128x128 kernel for large grids: 2 workgroups per CU stay resident and walk the tile list of their XCD.
+// What it buys over one workgroup per tile: the first K-step of the NEXT tile is requested during the last K-step of the current
+// one, so its DMA round trip (~1.3 us under load) and the pointer set-up run under the epilogue instead of in front of an idle
+// matrix pipe, and no workgroup is re-launched per tile.  The epilogue stages the tile through the LDS stage that was consumed
+// last (the other one is receiving the next tile): 32 KiB = the whole bf16 tile, or the fp32 tile in two 64-row halves.
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_persist_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
+                                                                   const float* __restrict__ bias, void* __restrict__ out,
+                                                                   int M, int N, int K, int ntn, int tiles) {
+    constexpr int BT = 128, CH = 1024, QN = 4;
+    extern __shared__ uint4 Sbuf[];            // [2 stages][A 1024 chunks | B 1024 chunks]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    // XCD k owns a contiguous range of the row-major tile list; its workgroups take the tiles of that range round-robin
+    const int xcd = blockIdx.x & 7, wloc = blockIdx.x >> 3, wpx = gridDim.x >> 3;       // gridDim.x is a multiple of 8
+    const int tq = tiles >> 3, trem = tiles & 7;
+    const int t_lo = xcd < trem ? xcd * (tq + 1) : trem * (tq + 1) + (xcd - trem) * tq;
+    const int t_hi = t_lo + tq + (xcd < trem ? 1 : 0);
+    const int kt1 = K / 64;
+    const unsigned wave_off = (unsigned)__builtin_amdgcn_readfirstlane(wave * 64 * 16);
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(Sbuf)) + wave_off;
+    const int ra = 64 * wr + (lane & 31), rb = 64 * wc + (lane & 31);
+    const int sa = (ra >> 1) & 7, sb = (rb >> 1) & 7;
+
+    const bf16_t* pa[QN];
+    const bf16_t* pb[QN];
+    auto pointers = [&](int tile) {
+        const int bm = (tile / ntn) * BT, bn = (tile % ntn) * BT;
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+            const int c = q * 256 + tid, row = c >> 3, kc = (c & 7) ^ ((row >> 1) & 7);
+            pa[q] = A + (size_t)min(bm + row, M - 1) * K + kc * 8;
+            pb[q] = Wt + (size_t)min(bn + row, N - 1) * K + kc * 8;
+        }
+    };
+    auto issue = [&](int kt, int stage) {
+        const unsigned base = lds0 + (unsigned)stage * (2u * CH) * 16u;
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+            glds16(pa[q] + (size_t)kt * 64, base + q * 256 * 16);
+            glds16(pb[q] + (size_t)kt * 64, base + (CH + q * 256) * 16);
+        }
+    };
+#define SC_GEMM_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define SC_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    int g = 0;                                  // running K-step count: stage = g & 1
+    int tile = t_lo + wloc;
+    if (tile < t_hi && kt1 > 0) { pointers(tile); issue(0, 0); }
+    for (; tile < t_hi; tile += wpx) {
+        const int bm = (tile / ntn) * BT, bn = (tile % ntn) * BT;
+        const int next = tile + wpx;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int kt = 0; kt < kt1; ++kt, ++g) {
+            SC_GEMM_SYNC();                     // stage g & 1 has landed for everybody; stage (g + 1) & 1 is free
+            if (kt + 1 < kt1) issue(kt + 1, (g + 1) & 1);
+            else if (next < t_hi) { pointers(next); issue(0, (g + 1) & 1); }       // first K-step of the NEXT tile
+            const uint4* As = Sbuf + (g & 1) * (2 * CH);
+            const uint4* Bs = As + CH;
+            bf16x8 af[2][2], bf[2][2];
+            auto frags = [&](int kk, bf16x8 (&a2)[2], bf16x8 (&b2)[2]) {
+                const int kc = 2 * kk + (lane >> 5);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a2[i] = __builtin_bit_cast(bf16x8, As[(ra + 32 * i) * 8 + (kc ^ sa)]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b2[j] = __builtin_bit_cast(bf16x8, Bs[(rb + 32 * j) * 8 + (kc ^ sb)]);
+            };
+            frags(0, af[0], bf[0]);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                if (kk + 1 < 4) frags(kk + 1, af[(kk + 1) & 1], bf[(kk + 1) & 1]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+            }
+        }
+        // ---- epilogue through the stage consumed last, (g - 1) & 1; the other one may be receiving the next tile ----
+        constexpr bool OUT_BF16 = EPI == EPI_GELU_BF16 || EPI == EPI_BF16;
+        uint4* Cs = Sbuf + ((g - 1) & 1) * (2 * CH);
+        if (OUT_BF16) {
+            bf16_t* Ch = reinterpret_cast<bf16_t*>(Cs);
+            SC_LDS_SYNC();                      // every wave is done reading that stage
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int cl = 64 * wc + 32 * j + (lane & 31);
+                    const float bv = bias ? bias[min(bn + cl, N - 1)] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        const float v = acc[i][j][r] + bv;
+                        Ch[rl * BT + cl] = EPI == EPI_GELU_BF16 ? f2bf(v / (1.f + __expf(-1.702f * v))) : f2bf(v);
+                    }
+                }
+            SC_LDS_SYNC();
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int chunk = q * 256 + tid, rl = chunk >> 4, c8 = (chunk & 15) * 8;
+                if (bm + rl < M && bn + c8 < N)
+                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(out) + (size_t)(bm + rl) * N + bn + c8) =
+                        *reinterpret_cast<const uint4*>(Ch + rl * BT + c8);
+            }
+        } else {
+            float* Cf = reinterpret_cast<float*>(Cs);                       // [64 rows][128] per half
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                SC_LDS_SYNC();                  // stage free (half 0) / previous half stored (half 1)
+                if (wr == half) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int cl = 64 * wc + 32 * j + (lane & 31);
+                            const float bv = bias ? bias[min(bn + cl, N - 1)] : 0.f;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int rl = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                                Cf[rl * BT + cl] = acc[i][j][r] + bv;
+                            }
+                        }
+                }
+                SC_LDS_SYNC();
+                float4 res[8];
+                if (EPI == EPI_RESID) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int chunk = q * 256 + tid, rl = chunk >> 5, c4 = (chunk & 31) * 4, row = bm + 64 * half + rl;
+                        res[q] = (row < M && bn + c4 < N) ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(out) + (size_t)row * N + bn + c4)
+                                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int chunk = q * 256 + tid, rl = chunk >> 5, c4 = (chunk & 31) * 4, row = bm + 64 * half + rl;
+                    float4 v = *reinterpret_cast<const float4*>(Cf + rl * BT + c4);
+                    if (EPI == EPI_RESID) { v.x += res[q].x; v.y += res[q].y; v.z += res[q].z; v.w += res[q].w; }
+                    if (row < M && bn + c4 < N) *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)row * N + bn + c4) = v;
+                }
+            }
+        }
+    }
+#undef SC_LDS_SYNC
+#undef SC_GEMM_SYNC
+}
+
 // ---------------------------------------------------------------------------------------------------
 // LayerNorm over D (multiple of 64, <= 1024 here) per row; x rows are `stride` floats apart.
 template <bool OUT_BF16>
@@ -454,6 +607,10 @@ static int launch_gemm(int epi, const bf16_t* A, const bf16_t* Wt, const float* 
     if (small) {                                                                                                              \
         hipLaunchKernelGGL((gemm_bf16_kernel<E, 64>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 2 * 2 * 64 * 8 * 16, st, \
                            A, Wt, bias, out, M, N, K);                                                                        \
+    } else if ((N % 8) == 0) {          /* persistent: 2 resident workgroups per CU walk the tile list */                     \
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_persist_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); \
+        hipLaunchKernelGGL((gemm_bf16_persist_kernel<E>), dim3(512), dim3(256), 65536, st, A, Wt, bias, out, M, N, K,         \
+                           (N + 127) / 128, (int)t128);                                                                       \
     } else {                                                                                                                  \
         (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<E, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);  \
         hipLaunchKernelGGL((gemm_bf16_kernel<E, 128>), dim3((N + 127) / 128, (M + 127) / 128), dim3(256), 65536, st,          \
