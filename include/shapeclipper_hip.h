@@ -305,6 +305,30 @@ int sc_pose_from_trig_backward(const float* azim, const float* elev, const float
                                int image_height, const float* g_pose, const float* g_intr, float* g_azim,
                                float* g_elev, float* g_theta, float* g_scale_focal, float* g_scale_dist, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * 3x3 / stride 1 / pad 1 convolution of the ResNet-18/34 trunks (torchvision BasicBlock conv1/conv2 behind
+ * model/graph.py:50-54 and model/view_estimator.py:40-42), NCHW fp32, on the fp32 matrix pipe (csrc/conv3x3.hip).
+ * hw = side of the square feature map: 56, 28, 14 or 7 (anything else returns -1: the caller keeps MIOpen for it).
+ *   sc_conv3x3_pack_floats  size of the kernel-ready weight image (floats), -1 for an unsupported shape
+ *   sc_conv3x3_pack         w [cout][cin][3][3] -> w_pack.  transpose_flip = 1 writes the filter of the backward-data pass,
+ *                           w'[ci][co][ky][kx] = w[co][ci][2-ky][2-kx], for w stored [cin][cout][3][3] in THIS call's naming
+ *                           (cin = channels of dL/dy, cout = channels of dL/dx)
+ *   sc_conv3x3_forward      out [batch][cout][hw][hw] = conv(x [batch][cin][hw][hw], w), fully overwritten.
+ *                           dL/dx = sc_conv3x3_forward(dL/dy, pack(w, transpose_flip = 1)).
+ *                           workspace: sc_conv3x3_workspace_floats(hw) floats of device scratch (partial tiles of the
+ *                           workgroups that share the last round's tiles; summed in a fixed order by a second launch).
+ *   sc_conv3x3_pack_multi   the same images for MANY filters in one launch (a network's filters change once per optimizer
+ *                           step): table = n rows of 6 int64 on the device, {address of w, first float of the image inside dst,
+ *                           cin, cout, sc_conv3x3_tile_channels(hw), transpose_flip}, rows sorted by first float; total = floats
+ *                           of all images.  Image e is then  dst + row[1]  and has sc_conv3x3_pack_floats(cin, cout, hw) floats.  */
+long long sc_conv3x3_pack_floats(int cin, int cout, int hw);
+long long sc_conv3x3_workspace_floats(int hw);
+int sc_conv3x3_tile_channels(int hw);
+int sc_conv3x3_pack_multi(const long long* table, int n, float* dst, long long total, void* stream);
+int sc_conv3x3_pack(const float* w, float* w_pack, int cin, int cout, int hw, int transpose_flip, void* stream);
+int sc_conv3x3_forward(const float* x, const float* w_pack, float* out, float* workspace, int batch, int cin, int cout, int hw,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,448 @@
+// 3x3 / stride 1 / pad 1 convolutions of the ResNet-18/34 trunks (model/graph.py:50-54 encoder,
+// model/view_estimator.py:40-42 estimator; torchvision BasicBlock conv1/conv2), fp32 in / fp32 accumulate, NCHW.
+//
+// Direct convolution on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32), no im2col, no Winograd:
+//     out[co][p] = sum_{ci, tap} Wt[co][ci, tap] * x[ci][p + shift(tap)]          p = flat pixel (image, y, x)
+// as the GEMM  D[co][p] = A[co][k] B[k][p], k = (tap, ci) -- computed "transposed" so that the 32 lanes of a C/D column group are 32
+// CONSECUTIVE PIXELS: the stores are 128-byte contiguous runs of the NCHW output and the B operand is a plain shifted read of the
+// input.  One workgroup (8 waves, two per SIMD) per CU; a tile is CT output channels x PT consecutive flat pixels, every wave owns
+// WM x WN 32x32 accumulators of it.  Per K-step (8 input channels x 9 taps):
+//   * the input is staged ONCE as a zero-padded patch in "padded flat" coordinates  q = b (W+2)^2 + (y+1)(W+2) + (x+1): in that space
+//     tap (ky, kx) is the constant offset ky (W+2) + kx, so the nine B operands of a pixel are nine reads of the same patch with
+//     different IMMEDIATE offsets (each input element is fetched once per tile and used 9 CT times from LDS); lanes find their
+//     pixel through one per-lane patch offset computed once per tile;
+//   * the patch is channel-interleaved, [half][position][4 channels], and the weight image is [tap][half][channel out][4 channels in]:
+//     ONE ds_read_b128 per operand tile feeds FOUR MFMAs (the MFMA's two k of a lane half are k = (tap, 4 half + s), s = 0..3 over the
+//     four MFMAs).  This is what the kernel is built around: on this chip a vector or LDS instruction costs ~4.5 issue cycles that the
+//     matrix pipe cannot hide, so the loop carries WM + WN reads per 4 WM WN MFMAs and nothing else;
+//   * the weight image arrives by LDS-DMA as a verbatim copy of what sc_conv3x3_pack wrote (for the backward-data pass that is the
+//     transposed + flipped filter: the same kernel computes dL/dx from dL/dy).
+// Two LDS stages, one raw barrier per K-step.
+//
+// Load balance ("stream-K"): the feature maps hold 49 * 2^n pixels, so no tile size divides the work evenly over 256 CUs.  The tiles
+// that fill whole rounds of the grid are computed one per workgroup; the K-steps of the remaining tiles are cut into gridDim.x equal
+// contiguous spans, every workgroup writes the (at most two) partial tiles of its span to a workspace and conv3x3_fixup_kernel adds
+// the partials of a tile in K order -- a fixed summation order, results do not depend on timing.
+//
+// Roofline: 2 * 9 * Cin FLOP per output element on the 157.3 TFLOP/s fp32 matrix pipe; HBM traffic is one read of x and one write of
+// out (<= 0.1 byte per FLOP), i.e. compute bound by two orders of magnitude.
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+
+#include "shapeclipper_hip.h"
+
+namespace sc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lptr_cv_t;
+
+__device__ __forceinline__ void conv_glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int W_, int CT_, int PT_, int WGM_, int WGN_>
+struct ConvCfg {
+    static constexpr int W = W_, CT = CT_, PT = PT_, WGM = WGM_, WGN = WGN_, CB = 8;
+    static constexpr int Wp = W + 2, HW = W * W, Sp = Wp * Wp;
+    static constexpr int NT = 64 * WGM * WGN;
+    static constexpr int WM = CT / (32 * WGM), WN = PT / (32 * WGN);        // 32x32 MFMA tiles per wave
+    static constexpr int WIMG = 9 * CB * CT;                                 // floats of one weight stage: [tap][half][CT][4]
+    // longest padded-flat span of PT consecutive pixels plus the halo: 2 pad columns per row crossed, 2 pad rows per image crossed
+    static constexpr int LMAX = PT + 2 * (PT / W + 2) + 2 * Wp * (PT / HW + 1) + 2 * (Wp + 1);
+    static constexpr int LX = LMAX;                                          // positions per channel half
+    static constexpr int NXE = (LMAX + NT - 1) / NT;                         // patch positions per thread
+    static constexpr int STAGE = WIMG + 2 * LX * 4;                          // floats
+    static constexpr int LDS_BYTES = 2 * STAGE * 4;
+    static constexpr int TILE = CT * PT;                                     // floats of one (partial) output tile
+    static constexpr int WGS_PER_CU = NT == 512 ? 1 : 2;                     // 8 waves per CU either way
+    static_assert(WM >= 1 && WN >= 1 && (NT == 512 || NT == 256) && LDS_BYTES * WGS_PER_CU <= 160 * 1024, "tile shape");
+};
+
+template <class C>
+__device__ __forceinline__ int padded_q(int p) {
+    const int b = p / C::HW, r = p - b * C::HW, y = r / C::W, x = r - y * C::W;
+    return b * C::Sp + (y + 1) * C::Wp + (x + 1);
+}
+
+// The tiles of the last, incomplete round of the grid are cut into equal spans of K-steps ("units").
+struct ConvSplit {
+    int rounds;          // whole rounds: workgroup g computes tiles r * G + g, r < rounds, completely
+    int tail_tiles;      // tiles rounds * G .. rounds * G + tail_tiles - 1 are shared
+    int per_wg;          // units (K-steps) of the shared tiles per workgroup
+};
+__host__ __device__ inline ConvSplit conv_split(int tiles, int nk, int G) {
+    ConvSplit s;
+    s.rounds = tiles / G;
+    s.tail_tiles = tiles - s.rounds * G;
+    s.per_wg = (int)(((long long)s.tail_tiles * nk + G - 1) / G);
+    return s;
+}
+
+// acc[r] of a 32x32 C/D tile is row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31
+template <class C>
+__device__ __forceinline__ void conv_store_tile(float* __restrict__ out, const f32x16 (&acc)[C::WM][C::WN], int tile, int nct, int npix,
+                                                int cout, int wm, int wn, int lane) {
+    const int pt = tile / nct, ct = tile - pt * nct;
+#pragma unroll
+    for (int j = 0; j < C::WN; ++j) {
+        const int p = pt * C::PT + (wn * C::WN + j) * 32 + (lane & 31);
+        if (p >= npix) continue;
+        const int b = p / C::HW, rem = p - b * C::HW;
+        float* ob = out + (size_t)b * cout * C::HW + rem;
+#pragma unroll
+        for (int i = 0; i < C::WM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = ct * C::CT + (wm * C::WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (co < cout) ob[(size_t)co * C::HW] = acc[i][j][r];
+            }
+    }
+}
+
+template <class C>
+__global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const float* __restrict__ x, const float* __restrict__ wpack,
+                                                             float* __restrict__ out, float* __restrict__ partial, int batch, int cin,
+                                                             int cout) {
+    constexpr int W = C::W, Wp = C::Wp, HW = C::HW, Sp = C::Sp, CT = C::CT, PT = C::PT, CB = C::CB, NT = C::NT;
+    constexpr int WM = C::WM, WN = C::WN, LX = C::LX, NXE = C::NXE;
+    extern __shared__ float4 conv_smem[];
+    float* S = reinterpret_cast<float*>(conv_smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int wm = wave / C::WGN, wn = wave % C::WGN;
+    const int npix = batch * HW, nct = (cout + CT - 1) / CT, tiles = ((npix + PT - 1) / PT) * nct;
+    const int nk = cin / CB, G = gridDim.x, g = blockIdx.x;
+    const ConvSplit sp = conv_split(tiles, nk, G);
+    // workgroup b runs on XCD b % 8: give every XCD a contiguous range of each round's tiles (shared patches / weights stay in its L2)
+    const int xq = G >> 3, xr = G & 7, xcd = g & 7;
+    const int gperm = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (g >> 3);
+    const long long unit_lo = (long long)g * sp.per_wg, unit_hi = min((long long)(g + 1) * sp.per_wg, (long long)sp.tail_tiles * nk);
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lptr_cv_t)S);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+    for (int it = 0; it < sp.rounds + 2; ++it) {
+        // the second workgroup of a CU starts with its shared tiles: the two never store / restart at the same time
+        const int item = (C::WGS_PER_CU == 2 && g >= (G >> 1)) ? (it + sp.rounds) % (sp.rounds + 2) : it;
+        int tile, kb0, kb1;
+        if (item < sp.rounds) {
+            tile = item * G + gperm, kb0 = 0, kb1 = nk;
+        } else if (item == sp.rounds) {                    // first shared tile of this workgroup's span
+            if (unit_lo >= unit_hi) continue;
+            const int t = (int)(unit_lo / nk);
+            tile = sp.rounds * G + t, kb0 = (int)(unit_lo - (long long)t * nk), kb1 = (int)min((long long)nk, unit_hi - (long long)t * nk);
+        } else {                                            // second one (a span is at most nk units long)
+            const int t = (int)(unit_lo / nk) + 1;
+            if (unit_lo >= unit_hi || (long long)t * nk >= unit_hi) continue;
+            tile = sp.rounds * G + t, kb0 = 0, kb1 = (int)(unit_hi - (long long)t * nk);
+        }
+        const int pt = tile / nct, ct = tile - pt * nct;
+        const int p0 = pt * PT;
+        const int q0 = padded_q<C>(p0), q_lo = q0 - Wp - 1;
+
+        // patch staging plan: position e of the patch is padded-flat position q_lo + e
+        int xoff[NXE];
+#pragma unroll
+        for (int i = 0; i < NXE; ++i) {
+            const int e = tid + i * NT, q = q_lo + e;
+            const int b = q / Sp, r = q - b * Sp, yp = r / Wp, xp = r - yp * Wp;
+            const bool valid = e < C::LMAX && b < batch && yp >= 1 && yp <= W && xp >= 1 && xp <= W;
+            xoff[i] = valid ? (b * cin * HW + (yp - 1) * W + (xp - 1)) : -1;
+        }
+        // operand offsets (floats): lane half h takes input channels 4 h .. 4 h + 3 of the K-step
+        int boff[WN], aoff[WM];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int p = min(p0 + (wn * WN + j) * 32 + (lane & 31), npix - 1);
+            boff[j] = (half * LX + padded_q<C>(p) - q0) * 4;
+        }
+#pragma unroll
+        for (int i = 0; i < WM; ++i) aoff[i] = (half * CT + (wm * WM + i) * 32 + (lane & 31)) * 4;
+
+        const float* wsrc = wpack + (size_t)ct * nk * C::WIMG;              // [ct][kb][tap][half][CT][4]
+        auto issue_w = [&](int kb, int stage) {
+            constexpr int CHUNKS = C::WIMG / 4;
+            const char* src = reinterpret_cast<const char*>(wsrc + (size_t)kb * C::WIMG);
+            const unsigned dst = lds0 + (unsigned)stage * (C::STAGE * 4);
+#pragma unroll
+            for (int c = 0; c < (CHUNKS + NT - 1) / NT; ++c) {
+                const int chunk0 = c * NT + wave_u * 64;                     // wave-uniform
+                if (chunk0 + lane < CHUNKS) conv_glds16(src + (size_t)(chunk0 + lane) * 16, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + chunk0 * 16)));
+            }
+        };
+        float xv[NXE][CB];
+        auto load_x = [&](int kb) {
+            const float* xb = x + (size_t)kb * CB * HW;
+#pragma unroll
+            for (int i = 0; i < NXE; ++i)
+#pragma unroll
+                for (int c = 0; c < CB; ++c) xv[i][c] = xoff[i] >= 0 ? xb[xoff[i] + c * HW] : 0.f;
+        };
+        auto store_x = [&](int stage) {
+            float4* Xs = reinterpret_cast<float4*>(S + stage * C::STAGE + C::WIMG);
+#pragma unroll
+            for (int i = 0; i < NXE; ++i) {
+                const int e = tid + i * NT;
+                if (e < C::LMAX) {
+                    Xs[e] = make_float4(xv[i][0], xv[i][1], xv[i][2], xv[i][3]);
+                    Xs[LX + e] = make_float4(xv[i][4], xv[i][5], xv[i][6], xv[i][7]);
+                }
+            }
+        };
+
+        f32x16 acc[WM][WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave is done with the previous item's stages
+        issue_w(kb0, 0);
+        load_x(kb0);
+        store_x(0);
+        for (int kb = kb0; kb < kb1; ++kb) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // this step's stage complete, the other one free
+            const int st = (kb - kb0) & 1;
+            if (kb + 1 < kb1) { issue_w(kb + 1, st ^ 1); load_x(kb + 1); }
+            const float* Ws = S + st * C::STAGE;
+            const float* Xs = Ws + C::WIMG;
+            float4 a[2][WM], b[2][WN];
+            auto frags = [&](int tap, float4 (&a2)[WM], float4 (&b2)[WN]) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i) a2[i] = *reinterpret_cast<const float4*>(Ws + aoff[i] + tap * 2 * CT * 4);
+#pragma unroll
+                for (int j = 0; j < WN; ++j) b2[j] = *reinterpret_cast<const float4*>(Xs + boff[j] + ((tap / 3) * Wp + (tap % 3)) * 4);
+            };
+            frags(0, a[0], b[0]);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap + 1 < 9) frags(tap + 1, a[(tap + 1) & 1], b[(tap + 1) & 1]);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j) {
+                            const float av = s == 0 ? a[tap & 1][i].x : s == 1 ? a[tap & 1][i].y : s == 2 ? a[tap & 1][i].z : a[tap & 1][i].w;
+                            const float bv = s == 0 ? b[tap & 1][j].x : s == 1 ? b[tap & 1][j].y : s == 2 ? b[tap & 1][j].z : b[tap & 1][j].w;
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                        }
+            }
+            if (kb + 1 < kb1) store_x(st ^ 1);
+        }
+
+        if (kb0 == 0 && kb1 == nk) {
+            conv_store_tile<C>(out, acc, tile, nct, npix, cout, wm, wn, lane);
+        } else {                                            // partial tile, in register order (coalesced 256-byte rows)
+            float* dst = partial + ((size_t)g * 2 + (item - sp.rounds)) * C::TILE;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dst[(((wave * WM + i) * WN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+        }
+    }
+}
+
+// Four workgroups per shared tile (each takes 4 of the 16 accumulator rows of every 32x32 block): add the partial tiles of the
+// workgroups whose spans cover it, in K order, and store the result.
+template <class C>
+__global__ __launch_bounds__(C::NT) void conv3x3_fixup_kernel(const float* __restrict__ partial, float* __restrict__ out, int batch,
+                                                              int cin, int cout, int G) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / C::WGN, wn = wave % C::WGN;
+    const int npix = batch * C::HW, nct = (cout + C::CT - 1) / C::CT, tiles = ((npix + C::PT - 1) / C::PT) * nct;
+    const int nk = cin / C::CB;
+    const ConvSplit sp = conv_split(tiles, nk, G);
+    const int t = blockIdx.x, r0 = 4 * blockIdx.y;
+    const long long u0 = (long long)t * nk, u1 = u0 + nk;
+    const int g_first = (int)(u0 / sp.per_wg), g_last = (int)((u1 - 1) / sp.per_wg);
+    if (g_first == g_last && (long long)g_first * sp.per_wg == u0 && sp.per_wg == nk) return;      // computed whole, already stored
+    float acc[C::WM][C::WN][4];
+#pragma unroll
+    for (int i = 0; i < C::WM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    for (int g = g_first; g <= g_last; ++g) {
+        const int which = (int)(((long long)g * sp.per_wg) / nk) == t ? 0 : 1;      // first or second tile of that workgroup's span
+        const float* src = partial + ((size_t)g * 2 + which) * C::TILE;
+#pragma unroll
+        for (int i = 0; i < C::WM; ++i)
+#pragma unroll
+            for (int j = 0; j < C::WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += src[(((wave * C::WM + i) * C::WN + j) * 16 + r0 + r) * 64 + lane];
+    }
+    const int tile = sp.rounds * G + t, pt = tile / nct, ct = tile - pt * nct;
+#pragma unroll
+    for (int j = 0; j < C::WN; ++j) {
+        const int p = pt * C::PT + (wn * C::WN + j) * 32 + (lane & 31);
+        if (p >= npix) continue;
+        const int b = p / C::HW, rem = p - b * C::HW;
+        float* ob = out + (size_t)b * cout * C::HW + rem;
+#pragma unroll
+        for (int i = 0; i < C::WM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = ct * C::CT + (wm * C::WM + i) * 32 + r + 2 * r0 + 4 * (lane >> 5);      // row of acc[r0 + r]: r + 8 (r0 / 4)
+                if (co < cout) ob[(size_t)co * C::HW] = acc[i][j][r];
+            }
+    }
+}
+
+// w [cout][cin][3][3] -> w_pack [ct][kb][tap][half][CT][4]: element (co = ct CT + cl, ci = 8 kb + 4 half + s).  transpose_flip: the filter
+// of the backward-data pass, w'[ci][co][ky][kx] = w[co][ci][2 - ky][2 - kx] (`cin` / `cout` are the channel counts of THAT convolution).
+template <class C>
+__global__ void conv3x3_pack_kernel(const float* __restrict__ w, float* __restrict__ wpack, int cin, int cout, int transpose_flip) {
+    const int nk = cin / C::CB, nct = (cout + C::CT - 1) / C::CT;
+    const long long total = (long long)nct * nk * C::WIMG;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int s = (int)(i & 3);
+        long long t = i >> 2;
+        const int cl = (int)(t % C::CT);
+        t /= C::CT;
+        const int h = (int)(t & 1);
+        t >>= 1;
+        const int tap = (int)(t % 9);
+        t /= 9;
+        const int kb = (int)(t % nk), ct = (int)(t / nk);
+        const int ci = kb * C::CB + 4 * h + s, co = ct * C::CT + cl;
+        float v = 0.f;
+        if (co < cout) v = transpose_flip ? w[((size_t)ci * cout + co) * 9 + (8 - tap)] : w[((size_t)co * cin + ci) * 9 + tap];
+        wpack[i] = v;
+    }
+}
+
+template <int V> struct Conv56V;
+template <> struct Conv56V<0> { using T = ConvCfg<56, 64, 512, 1, 8>; };
+template <> struct Conv56V<1> { using T = ConvCfg<56, 64, 256, 1, 4>; };
+template <int V> struct Conv28V;
+template <> struct Conv28V<0> { using T = ConvCfg<28, 128, 256, 2, 4>; };
+template <> struct Conv28V<1> { using T = ConvCfg<28, 64, 256, 1, 4>; };
+template <int V> struct Conv14V;
+template <> struct Conv14V<0> { using T = ConvCfg<14, 128, 256, 2, 4>; };
+template <> struct Conv14V<1> { using T = ConvCfg<14, 64, 256, 1, 4>; };
+template <int V> struct Conv7V;
+template <> struct Conv7V<0> { using T = ConvCfg<7, 128, 128, 2, 4>; };
+template <> struct Conv7V<1> { using T = ConvCfg<7, 64, 256, 1, 4>; };
+static int conv_variant() { const char* e = getenv("SC_CONV_VARIANT"); return e ? atoi(e) & 1 : 0; }
+
+template <class C>
+static long long pack_floats(int cin, int cout) { return cin % C::CB ? -1 : (long long)((cout + C::CT - 1) / C::CT) * (cin / C::CB) * C::WIMG; }
+
+// All filters of a network in ONE launch (they change once per optimizer step): table row e = {address of w, first float of its image
+// in dst, cin, cout, CT of the map side's tile shape, transpose_flip}; rows sorted by their first float, `total` = end of the last one.
+__global__ void conv3x3_pack_multi_kernel(const long long* __restrict__ table, int n, float* __restrict__ dst, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int lo = 0, hi = n - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (table[mid * 6 + 1] <= i) lo = mid; else hi = mid - 1;
+        }
+        const long long* row = table + lo * 6;
+        const float* w = reinterpret_cast<const float*>(row[0]);
+        const int cin = (int)row[2], cout = (int)row[3], CT = (int)row[4], flip = (int)row[5];
+        const int nk = cin / 8;
+        long long t = i - row[1];
+        const int s4 = (int)(t & 3);
+        t >>= 2;
+        const int cl = (int)(t % CT);
+        t /= CT;
+        const int h = (int)(t & 1);
+        t >>= 1;
+        const int tap = (int)(t % 9);
+        t /= 9;
+        const int kb = (int)(t % nk), ct = (int)(t / nk);
+        const int ci = kb * 8 + 4 * h + s4, co = ct * CT + cl;
+        float v = 0.f;
+        if (co < cout) v = flip ? w[((size_t)ci * cout + co) * 9 + (8 - tap)] : w[((size_t)co * cin + ci) * 9 + tap];
+        dst[i] = v;
+    }
+}
+
+static int conv_grid() {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus > 0 ? cus : 256;
+}
+
+template <class C>
+static long long workspace_floats() { return (long long)conv_grid() * C::WGS_PER_CU * 2 * C::TILE; }
+
+template <class C>
+static int launch_pack(const float* w, float* wpack, int cin, int cout, int tf, hipStream_t st) {
+    if (cin % C::CB) return (int)hipErrorInvalidValue;
+    const long long total = pack_floats<C>(cin, cout);
+    hipLaunchKernelGGL((conv3x3_pack_kernel<C>), dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), dim3(256), 0, st,
+                       w, wpack, cin, cout, tf);
+    return (int)hipGetLastError();
+}
+
+template <class C>
+static int launch_conv(const float* x, const float* wpack, float* out, float* workspace, int batch, int cin, int cout, hipStream_t st) {
+    if (cin % C::CB || batch <= 0) return (int)hipErrorInvalidValue;
+    const int tiles = ((batch * C::HW + C::PT - 1) / C::PT) * ((cout + C::CT - 1) / C::CT), nk = cin / C::CB;
+    const int G = getenv("SC_CONV_DP") ? tiles : getenv("SC_CONV_G1") ? conv_grid() : conv_grid() * C::WGS_PER_CU;
+    (void)hipFuncSetAttribute((const void*)conv3x3_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    hipLaunchKernelGGL((conv3x3_kernel<C>), dim3(G), dim3(C::NT), C::LDS_BYTES, st, x, wpack, out, workspace, batch, cin, cout);
+    const ConvSplit sp = conv_split(tiles, nk, G);
+    if (sp.tail_tiles > 0)
+        hipLaunchKernelGGL((conv3x3_fixup_kernel<C>), dim3(sp.tail_tiles, 4), dim3(C::NT), 0, st, workspace, out, batch, cin, cout, G);
+    return (int)hipGetLastError();
+}
+
+}  // namespace sc
+
+#define SC_CONV_V(F, CALL) if (sc::conv_variant()) return CALL(sc::F<1>::T); else return CALL(sc::F<0>::T);
+#define SC_CONV_DISPATCH(hw, CALL)                   \
+    switch (hw) {                                    \
+        case 56: SC_CONV_V(Conv56V, CALL)            \
+        case 28: SC_CONV_V(Conv28V, CALL)            \
+        case 14: SC_CONV_V(Conv14V, CALL)            \
+        case 7: SC_CONV_V(Conv7V, CALL)              \
+        default: return -1;                          \
+    }
+
+extern "C" long long sc_conv3x3_pack_floats(int cin, int cout, int hw) {
+#define CALL(C) sc::pack_floats<C>(cin, cout)
+    SC_CONV_DISPATCH(hw, CALL)
+#undef CALL
+}
+
+extern "C" long long sc_conv3x3_workspace_floats(int hw) {
+#define CALL(C) sc::workspace_floats<C>()
+    SC_CONV_DISPATCH(hw, CALL)
+#undef CALL
+}
+
+extern "C" int sc_conv3x3_tile_channels(int hw) {
+#define CALL(C) C::CT
+    SC_CONV_DISPATCH(hw, CALL)
+#undef CALL
+}
+
+extern "C" int sc_conv3x3_pack_multi(const long long* table, int n, float* dst, long long total, void* stream) {
+    if (n <= 0 || total <= 0) return 0;
+    const long long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(sc::conv3x3_pack_multi_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, table, n, dst,
+                       total);
+    return (int)hipGetLastError();
+}
+
+extern "C" int sc_conv3x3_pack(const float* w, float* w_pack, int cin, int cout, int hw, int transpose_flip, void* stream) {
+#define CALL(C) sc::launch_pack<C>(w, w_pack, cin, cout, transpose_flip, (hipStream_t)stream)
+    SC_CONV_DISPATCH(hw, CALL)
+#undef CALL
+}
+
+extern "C" int sc_conv3x3_forward(const float* x, const float* w_pack, float* out, float* workspace, int batch, int cin, int cout, int hw,
+                                  void* stream) {
+#define CALL(C) sc::launch_conv<C>(x, w_pack, out, workspace, batch, cin, cout, (hipStream_t)stream)
+    SC_CONV_DISPATCH(hw, CALL)
+#undef CALL
+}

@@ -211,6 +211,47 @@ def bn_relu_maxpool(bn, x, groups=1):
                                     training, float(bn.momentum), float(bn.eps), groups)
 
 
+class Conv3x3Function(torch.autograd.Function):
+    """F.conv2d(x, w, None, 1, 1) for the 3x3 / stride-1 layers of the ResNet trunks on csrc/conv3x3.hip (fp32 matrix pipe): forward
+    and backward-data are the same kernel (the latter with the transposed, flipped filter); the weight gradient stays on MIOpen.
+    pack_f / pack_b: the kernel-ready images of w from a Conv3x3PackSet (None: packed here, two extra launches)."""
+
+    @staticmethod
+    def forward(ctx, x, w, pack_f, pack_b):
+        x = ops._aligned(x)
+        ctx.save_for_backward(x, w, pack_b)
+        if pack_f is None:
+            pack_f = ops.conv3x3_pack(w, x.shape[2])
+        return ops.conv3x3_apply(x, pack_f, w.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, pack_b = ctx.saved_tensors
+        gy = ops._aligned(gy)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.conv3x3_apply(gy, pack_b if pack_b is not None else ops.conv3x3_pack(w, x.shape[2], True), w.shape[1])
+        gw = None
+        if ctx.needs_input_grad[1]:
+            gw = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        return gx, gw, None, None
+
+
+def conv3x3_takes(conv, x):
+    return (x.is_cuda and x.dtype == torch.float32 and conv.bias is None and conv.groups == 1 and conv.dilation == (1, 1)
+            and ops.conv3x3_supported(x.shape, conv.weight.shape, conv.stride, conv.padding))
+
+
+def conv3x3(conv, x, packs=None):
+    """nn.Conv2d `conv` applied to x: shapes the HIP kernel takes go through it (device tensors only), the rest through torch.
+    packs: the Conv3x3PackSet holding conv.weight's images (refreshed by the caller), or None."""
+    if not conv3x3_takes(conv, x):
+        return conv(x)
+    if packs is not None and id(conv.weight) in packs.index:
+        return Conv3x3Function.apply(x, conv.weight, packs.get(conv.weight, 0), packs.get(conv.weight, 1))
+    return Conv3x3Function.apply(x, conv.weight, None, None)
+
+
 class CameraRaysFunction(torch.autograd.Function):
     """pose [B,3,4], intr [B,3,3], ray_idx [B,R] | None -> cam_loc [B*R,3], ray_dirs [B*R,3] (unit), depth_fac [B*R]
     (reference utils/camera.py:157-196 + model/renderer.py:69-76, perspective camera) in one launch each way."""

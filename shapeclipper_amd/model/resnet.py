@@ -9,9 +9,10 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from ..functional import bn_act, bn_relu_maxpool
+from ..functional import bn_act, bn_relu_maxpool, conv3x3
 
 FUSED_BN = True
+HIP_CONV3X3 = True       # 3x3 / stride-1 convolutions on csrc/conv3x3.hip (`--hip.conv3x3!` keeps them on MIOpen)
 
 
 class BasicBlock(nn.Module):
@@ -26,7 +27,7 @@ class BasicBlock(nn.Module):
         self.bn2 = nn.BatchNorm2d(planes)
         self.downsample = downsample
 
-    def forward(self, x, groups=1):
+    def forward(self, x, groups=1, packs=None):
         if not FUSED_BN:
             assert groups == 1
             identity = x if self.downsample is None else self.downsample(x)
@@ -34,8 +35,9 @@ class BasicBlock(nn.Module):
             out = self.bn2(self.conv2(out))
             return self.relu(out + identity)
         identity = x if self.downsample is None else bn_act(self.downsample[1], self.downsample[0](x), relu=False, groups=groups)
-        out = bn_act(self.bn1, self.conv1(x), groups=groups)
-        return bn_act(self.bn2, self.conv2(out), residual=identity, groups=groups)
+        conv = (lambda m, t: conv3x3(m, t, packs)) if HIP_CONV3X3 else (lambda m, t: m(t))
+        out = bn_act(self.bn1, conv(self.conv1, x), groups=groups)
+        return bn_act(self.bn2, conv(self.conv2, out), residual=identity, groups=groups)
 
 
 class ResNet(nn.Module):
@@ -77,12 +79,40 @@ class ResNet(nn.Module):
             x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
             x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         else:
+            packs = self._conv_packs(x) if HIP_CONV3X3 else None
             x = bn_relu_maxpool(self.bn1, self.conv1(x), groups=groups)
             for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
                 for block in layer:
-                    x = block(x, groups=groups)
+                    x = block(x, groups=groups, packs=packs)
         return self.fc(torch.flatten(self.avgpool(x), 1))
 
+
+def _conv_packs(self, x):
+    """The kernel-ready images of every 3x3 / stride-1 filter csrc/conv3x3.hip takes at this input size, refreshed with one launch per
+    pass (the filters change once per optimizer step; a pass is cheap to re-pack: 2 x 21 M floats for ResNet-34)."""
+    from .. import ops
+    if not (x.is_cuda and x.dtype == torch.float32 and x.shape[2] == x.shape[3]):
+        return None
+    key = (x.shape[2], x.device.index)
+    cache = self.__dict__.setdefault("_pack_cache", {})
+    packs = cache.get(key)
+    if packs is None or (packs and packs.stale()):
+        side = ((x.shape[2] + 2 * 3 - 7) // 2 + 1 + 2 - 3) // 2 + 1           # after conv1 (7x7 / 2) and the 3x3 / 2 max-pool
+        items = []
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for block in layer:
+                if block.conv1.stride == (2, 2):
+                    side = (side + 2 - 3) // 2 + 1
+                for conv in ((block.conv2,) if block.conv1.stride != (1, 1) else (block.conv1, block.conv2)):
+                    if ops.conv3x3_supported((1, conv.in_channels, side, side), conv.weight.shape, conv.stride, conv.padding) and conv.bias is None:
+                        items.append((conv.weight, side))
+        packs = cache[key] = ops.Conv3x3PackSet(items) if items else False
+    if packs:
+        packs.refresh()
+    return packs or None
+
+
+ResNet._conv_packs = _conv_packs
 
 _LAYERS = {"resnet18": [2, 2, 2, 2], "resnet34": [3, 4, 6, 3]}
 

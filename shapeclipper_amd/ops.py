@@ -562,3 +562,106 @@ def pose_from_trig_backward(azim, elev, theta, scale_focal, scale_dist, cam_dist
                                               _lib.ptr(ge), _lib.ptr(gt), _lib.ptr(g[6]), _lib.ptr(g[7]), _lib.stream()),
                "sc_pose_from_trig_backward")
     return ga, ge, gt, g[6], g[7]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# 3x3 stride-1 convolutions of the ResNet trunks on the fp32 matrix pipe (csrc/conv3x3.hip)
+CONV3X3_SIDES = (56, 28, 14, 7)
+
+
+def conv3x3_supported(x_shape, w_shape, stride=1, padding=1) -> bool:
+    """Shapes sc_conv3x3_forward takes: square 56/28/14/7 maps, 3x3 filter, stride 1, pad 1, channel counts that are multiples of 8."""
+    return (len(x_shape) == 4 and tuple(w_shape[2:]) == (3, 3) and stride in (1, (1, 1)) and padding in (1, (1, 1))
+            and x_shape[2] == x_shape[3] and x_shape[2] in CONV3X3_SIDES and w_shape[1] == x_shape[1]
+            and w_shape[0] % 8 == 0 and w_shape[1] % 8 == 0)
+
+
+def conv3x3_pack(w, side, transpose_flip=False):
+    """Kernel-ready weight image of w [Cout, Cin, 3, 3] for `side` x `side` maps (transpose_flip: the backward-data filter)."""
+    lib = _lib.load()
+    w = _aligned(w)
+    cin, cout = (w.shape[0], w.shape[1]) if transpose_flip else (w.shape[1], w.shape[0])
+    n = lib.sc_conv3x3_pack_floats(cin, cout, side)
+    if n < 0:
+        raise RuntimeError("shapeclipper_amd: sc_conv3x3 does not take %dx%d maps with a %s filter" % (side, side, tuple(w.shape)))
+    w_pack = torch.empty(n, device=w.device, dtype=torch.float32)
+    _lib.check(lib.sc_conv3x3_pack(_lib.ptr(w), _lib.ptr(w_pack), cin, cout, side, int(transpose_flip), _lib.stream()), "sc_conv3x3_pack")
+    return w_pack
+
+
+_conv_ws = {}
+
+
+def _conv_workspace(dev, side):
+    """Scratch for the partial tiles of sc_conv3x3_forward, one per (device, stream, map side): calls on a stream are ordered."""
+    key = (dev.index, torch.cuda.current_stream().cuda_stream, side)
+    ws = _conv_ws.get(key)
+    if ws is None:
+        ws = _conv_ws[key] = torch.empty(_lib.load().sc_conv3x3_workspace_floats(side), device=dev, dtype=torch.float32)
+    return ws
+
+
+def conv3x3_apply(x, w_pack, cout):
+    lib = _lib.load()
+    x = _aligned(x)
+    B, cin, H, _ = x.shape
+    out = torch.empty(B, cout, H, H, device=x.device, dtype=torch.float32)
+    _lib.check(lib.sc_conv3x3_forward(_lib.ptr(x), _lib.ptr(w_pack), _lib.ptr(out), _lib.ptr(_conv_workspace(x.device, H)), B, cin, cout, H,
+                                      _lib.stream()), "sc_conv3x3_forward")
+    return out
+
+
+def _conv3x3(x, w, transpose_flip):
+    if x.dim() != 4 or x.shape[2] != x.shape[3]:
+        raise RuntimeError("shapeclipper_amd: sc_conv3x3 needs square NCHW maps, got %s" % (tuple(x.shape),))
+    return conv3x3_apply(x, conv3x3_pack(w, x.shape[2], transpose_flip), w.shape[1] if transpose_flip else w.shape[0])
+
+
+def conv3x3_forward(x, w):
+    """F.conv2d(x, w, None, 1, 1) for x [B, Cin, H, H], w [Cout, Cin, 3, 3]."""
+    return _conv3x3(x, w, False)
+
+
+def conv3x3_backward_data(gy, w):
+    """dL/dx of the above from gy [B, Cout, H, H]: the same kernel with the transposed, flipped filter."""
+    return _conv3x3(gy, w, True)
+
+
+class Conv3x3PackSet:
+    """Kernel-ready filter images (forward and backward-data orientation) of MANY 3x3 / stride-1 convolutions, rewritten by ONE launch
+    (sc_conv3x3_pack_multi): the filters of a network change once per optimizer step, so a trunk refreshes its set once per pass
+    instead of packing twice per layer.  `items`: [(weight [Cout, Cin, 3, 3], map side)]."""
+
+    def __init__(self, items):
+        lib = _lib.load()
+        self.weights = [w for w, _ in items]
+        self.ptrs = [w.data_ptr() for w in self.weights]
+        rows, off, self.where = [], 0, {}
+        for k, (w, side) in enumerate(items):
+            if not (w.is_cuda and w.is_contiguous() and w.dtype == torch.float32):
+                raise RuntimeError("shapeclipper_amd: Conv3x3PackSet needs contiguous fp32 device filters")
+            for flip in (0, 1):
+                cin, cout = (w.shape[0], w.shape[1]) if flip else (w.shape[1], w.shape[0])
+                n = lib.sc_conv3x3_pack_floats(cin, cout, side)
+                if n < 0:
+                    raise RuntimeError("shapeclipper_amd: sc_conv3x3 does not take %dx%d maps with a %s filter" % (side, side, tuple(w.shape)))
+                rows.append([w.data_ptr(), off, cin, cout, lib.sc_conv3x3_tile_channels(side), flip])
+                self.where[(k, flip)] = (off, n)
+                off += n
+        dev = self.weights[0].device
+        self.total = off
+        self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self.buf = torch.empty(off, device=dev, dtype=torch.float32)
+        self.index = {id(w): k for k, w in enumerate(self.weights)}
+
+    def stale(self):
+        """True when a filter was re-allocated since the table was built (in-place optimizer updates keep the addresses)."""
+        return any(w.data_ptr() != p for w, p in zip(self.weights, self.ptrs))
+
+    def refresh(self):
+        _lib.check(_lib.load().sc_conv3x3_pack_multi(_lib.ptr(self.table), len(self.where), _lib.ptr(self.buf), self.total, _lib.stream()),
+                   "sc_conv3x3_pack_multi")
+
+    def get(self, w, flip):
+        off, n = self.where[(self.index[id(w)], int(flip))]
+        return self.buf[off:off + n]

@@ -79,9 +79,12 @@ def main():
             line = "%-12s %-22s %5d | %8.3f %6.1f | %8.3f %6.1f | %8.3f %6.1f | %7.2f" % (
                 net, "%s %d>%d %d k%d/s%d" % (name, ci, co, h, k, s), count, t_f, flop / t_f / 1e9, t_d, flop / t_d / 1e9, t_w, flop / t_w / 1e9, per_step)
             if hip_conv is not None and k == 3 and s == 1:
-                t_hf = time_fn(lambda: hip_conv.conv3x3_forward(x.detach(), w.detach()))
-                t_hd = time_fn(lambda: hip_conv.conv3x3_backward_data(gy, w.detach()))
-                line += " | hip fwd %7.3f (%5.1f TF/s) bwdD %7.3f (%5.1f)" % (t_hf, flop / t_hf / 1e9, t_hd, flop / t_hd / 1e9)
+                xd, wd = x.detach(), w.detach()
+                wp_f, wp_b = hip_conv.conv3x3_pack(wd, h), hip_conv.conv3x3_pack(wd, h, True)
+                t_pk = time_fn(lambda: hip_conv.conv3x3_pack(wd, h))
+                t_hf = time_fn(lambda: hip_conv.conv3x3_apply(xd, wp_f, co))
+                t_hd = time_fn(lambda: hip_conv.conv3x3_apply(gy, wp_b, ci))
+                line += " | hip pack %6.3f fwd %7.3f (%5.1f TF/s) bwdD %7.3f (%5.1f)" % (t_pk, t_hf, flop / t_hf / 1e9, t_hd, flop / t_hd / 1e9)
                 if hasattr(hip_conv, "conv3x3_backward_weight"):
                     t_hw = time_fn(lambda: hip_conv.conv3x3_backward_weight(gy, x.detach()))
                     line += " bwdW %7.3f (%5.1f)" % (t_hw, flop / t_hw / 1e9)
