@@ -318,7 +318,7 @@ int sc_pose_from_trig_backward(const float* azim, const float* elev, const float
  *                           workspace: sc_conv3x3_workspace_floats(hw) floats of device scratch (partial tiles of the
  *                           workgroups that share the last round's tiles; summed in a fixed order by a second launch).
  *   sc_conv3x3_pack_multi   the same images for MANY filters in one launch (a network's filters change once per optimizer
- *                           step): table = n rows of 6 int64 on the device, {address of w, first float of the image inside dst,
+ *                           step): table = n <= 128 rows of 6 int64 on the device, {address of w, first float of the image inside dst,
  *                           cin, cout, sc_conv3x3_tile_channels(hw), transpose_flip}, rows sorted by first float; total = floats
  *                           of all images.  Image e is then  dst + row[1]  and has sc_conv3x3_pack_floats(cin, cout, hw) floats.  */
 long long sc_conv3x3_pack_floats(int cin, int cout, int hw);
@@ -328,6 +328,13 @@ int sc_conv3x3_pack_multi(const long long* table, int n, float* dst, long long t
 int sc_conv3x3_pack(const float* w, float* w_pack, int cin, int cout, int hw, int transpose_flip, void* stream);
 int sc_conv3x3_forward(const float* x, const float* w_pack, float* out, float* workspace, int batch, int cin, int cout, int hw,
                        void* stream);
+
+/* Weight gradient of the same convolution (csrc/conv3x3_wgrad.hip):  dw [cout][cin][3][3] = sum over the batch of gy (x) shifted x,
+ * gy [batch][cout][hw][hw], x [batch][cin][hw][hw], fully overwritten, fixed summation order.  cin and cout must be multiples of 64
+ * (otherwise hipErrorInvalidValue; sc_conv3x3_wgrad_workspace_floats returns -1): the caller keeps MIOpen for other shapes.
+ * workspace: sc_conv3x3_wgrad_workspace_floats(cin, cout) floats (one partial 64 x 64 x 9 block per workgroup).                       */
+long long sc_conv3x3_wgrad_workspace_floats(int cin, int cout);
+int sc_conv3x3_wgrad(const float* gy, const float* x, float* dw, float* workspace, int batch, int cin, int cout, int hw, void* stream);
 
 #ifdef __cplusplus
 }

@@ -337,7 +337,10 @@ static long long pack_floats(int cin, int cout) { return cin % C::CB ? -1 : (lon
 
 // All filters of a network in ONE launch (they change once per optimizer step): table row e = {address of w, first float of its image
 // in dst, cin, cout, CT of the map side's tile shape, transpose_flip}; rows sorted by their first float, `total` = end of the last one.
-__global__ void conv3x3_pack_multi_kernel(const long long* __restrict__ table, int n, float* __restrict__ dst, long long total) {
+__global__ void conv3x3_pack_multi_kernel(const long long* __restrict__ table_g, int n, float* __restrict__ dst, long long total) {
+    __shared__ long long table[128 * 6];                                    // n <= 128 rows (checked by the host)
+    for (int i = threadIdx.x; i < n * 6; i += blockDim.x) table[i] = table_g[i];
+    __syncthreads();
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         int lo = 0, hi = n - 1;
         while (lo < hi) {
@@ -428,8 +431,9 @@ extern "C" int sc_conv3x3_tile_channels(int hw) {
 
 extern "C" int sc_conv3x3_pack_multi(const long long* table, int n, float* dst, long long total, void* stream) {
     if (n <= 0 || total <= 0) return 0;
+    if (n > 128) return (int)hipErrorInvalidValue;
     const long long blocks = (total + 255) / 256;
-    hipLaunchKernelGGL(sc::conv3x3_pack_multi_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, table, n, dst,
+    hipLaunchKernelGGL(sc::conv3x3_pack_multi_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, table, n, dst,
                        total);
     return (int)hipGetLastError();
 }

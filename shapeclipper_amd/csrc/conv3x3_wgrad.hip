@@ -1,0 +1,266 @@
+// Weight gradient of the 3x3 / stride 1 / pad 1 convolutions of the ResNet trunks (autograd of the torchvision BasicBlock
+// convolutions behind model/graph.py:50-54 and model/view_estimator.py:40-42), fp32, NCHW, on the fp32 matrix pipe:
+//     dW[co][ci][ky][kx] = sum over images b and pixels (y, x) of  gy[b][co][y][x] * x[b][ci][y + ky - 1][x + kx - 1]
+// as nine GEMMs  D_tap[co][ci] = sum_p A[co][p] B_tap[p][ci]  that share A (= gy) and read B from ONE zero-padded patch of the input.
+// The reduction index is the pixel: a workgroup owns a 64 x 64 block of (co, ci) and a contiguous range of K-steps (K-step = 112 /
+// 112 / 196 / 98 pixels = 2 rows / 4 rows / 1 image / 2 images of a 56 / 28 / 14 / 7 wide map); its 8 waves are 2 x 2 MFMA tiles x 2
+// halves of the K-step's rows, each wave holding the 9 tap accumulators (144 registers) of its 32 x 32 tile.  MIOpen's fp32 weight
+// gradient kernels are NHWC-only (three layout transposes per call); this one reads NCHW as it lies.
+//
+// The inner loop follows the issue-cycle rule of DESIGN.md section 4 (every vector / LDS instruction costs ~4.5 cycles the matrix pipe
+// cannot hide): the k pair of an MFMA is (pixel x, pixel x + GS) of one row, so a lane needs GS consecutive pixels of gy -- one
+// ds_read_b128 / b64 / b32 -- and, per filter row ky, the GS + 2 consecutive patch values that serve all three kx: GS + 2 ds_read_b32
+// for 3 GS MFMAs, every address an immediate offset from two per-lane bases.
+// Staging: 56 consecutive floats of a channel are 1 / 2 / 4 rows (49 = one 7 x 7 image): every global load is one coalesced row
+// chunk per wave with scalar addressing, prefetched into registers during the MFMAs of the previous K-step; LDS is single-buffered
+// (two barriers per K-step of >= 16,000 MFMA cycles).
+//
+// Parallelism comes from the reduction: grid = (Cout / 64) (Cin / 64) blocks x S pixel ranges with S = 256 / blocks; every workgroup
+// writes its partial block and conv3x3_wgrad_reduce_kernel adds the S partials of an element in range order (fixed summation order).
+// Roofline: 2 * 9 * Cin * Cout FLOP per pixel on the 157.3 TFLOP/s fp32 matrix pipe; one read of gy and of x from HBM.
+#include <hip/hip_runtime.h>
+
+#include "shapeclipper_hip.h"
+
+namespace sc {
+
+typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
+
+template <int W_, int NR_, int NIMG_, int GS_>
+struct WgCfg {
+    static constexpr int W = W_, H = W_, NR = NR_, NIMG = NIMG_, GS = GS_;
+    static constexpr int HW = W * W, Wp = W + 2;
+    static constexpr bool WHOLE = NR == H;                                   // K-step = whole image(s): the halo rows are always zero
+    static constexpr int SLOTW = (W + 2 * GS - 1) / (2 * GS) * (2 * GS);     // k slots per row (7 -> 8: one zero slot)
+    static constexpr int ROWS = NIMG * NR;                                   // rows per K-step
+    static constexpr int NSLOT = ROWS * SLOTW;
+    static constexpr int GST = NSLOT + (((NSLOT / GS) & 1) ? 0 : GS);        // gy row stride: GST / GS odd -> conflict-free operand reads
+    static constexpr int PR = NR + 2;                                        // patch rows per image
+    static constexpr int PATCH = NIMG * PR * Wp;
+    static constexpr int LQ = PATCH | 1;                                     // odd channel stride; position PATCH may be read (x 0), kept zero
+    static constexpr int LDS_FLOATS = 64 * GST + 64 * LQ;
+    static constexpr int CHUNK = W == 7 ? 49 : 56;                           // floats per staging load: whole rows, contiguous in memory
+    static constexpr int RPC = CHUNK / W;                                    // rows per chunk
+    // x: rows y0 - 1 .. y0 + NR (halo rows may be real) unless the K-step is a whole image; gy: the K-step's rows
+    static constexpr int XROWS = WHOLE ? NR : PR;
+    static constexpr int XCH = (XROWS + RPC - 1) / RPC, GCH = (NR + RPC - 1) / RPC;          // chunks per channel and image
+    static constexpr int HR = ROWS / 2;                                      // rows per K-step half
+    static constexpr int GPR = SLOTW / (2 * GS);                             // MFMA groups per row
+    static constexpr int KH_A = HR * SLOTW;                                  // second half: offset in the gy tile ...
+    static constexpr int KH_B = NIMG == 2 ? PR * Wp : HR * Wp;               // ... and in the patch
+    static_assert(ROWS % 2 == 0 && H % NR == 0 && SLOTW % (2 * GS) == 0 && CHUNK % W == 0, "K-step shape");
+    static_assert(LDS_FLOATS * 4 <= 160 * 1024 && 4 * 48 * 64 <= LDS_FLOATS, "LDS");
+};
+
+template <class C>
+__global__ __launch_bounds__(512, 1) void conv3x3_wgrad_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                               float* __restrict__ partial, int batch, int cin, int cout, int S) {
+    constexpr int W = C::W, H = C::H, HW = C::HW, Wp = C::Wp, GS = C::GS, NIMG = C::NIMG, NR = C::NR;
+    extern __shared__ float4 wg_smem[];
+    float* As = reinterpret_cast<float*>(wg_smem);                           // gy tile  [64][GST]
+    float* Xs = As + 64 * C::GST;                                            // x patch  [64][LQ]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5;
+    const int wt = wave & 3, kh = wave >> 2;                                 // MFMA tile (co half, ci half) and K-step half
+    const int nti = cin / 64;
+    const int blk = blockIdx.x / S, s = blockIdx.x - blk * S;
+    const int co0 = (blk / nti) * 64, ci0 = (blk % nti) * 64;
+    const int nimg_steps = NIMG == 2 ? (batch + 1) / 2 : batch * (H / NR);  // K-steps of the whole batch
+    const int k_lo = (int)((long long)s * nimg_steps / S), k_hi = (int)((long long)(s + 1) * nimg_steps / S);
+
+    // zero what staging never writes: pad columns, always-zero halo rows, the extra position, the zero slots of 7-wide rows
+    for (int i = tid; i < C::LDS_FLOATS; i += 512) As[i] = 0.f;
+
+    // staging: wave w copies channels 8 w .. 8 w + 7 of both operands; lane = position inside a CHUNK of whole rows
+    const bool lane_on = lane < C::CHUNK;
+    const int lrow = lane / W, lx = lane - lrow * W;
+    float xv[8][C::XCH * NIMG], gv[8][C::GCH * NIMG];
+    auto load = [&](int kstep) {
+        int b, y0;
+        if (NIMG == 2) { b = 2 * kstep; y0 = 0; } else { b = kstep / (H / NR); y0 = (kstep - b * (H / NR)) * NR; }
+#pragma unroll
+        for (int im = 0; im < NIMG; ++im) {
+            const bool img_ok = b + im < batch;
+            const float* xb = x + ((size_t)(b + im) * cin + ci0 + 8 * wave) * HW;
+            const float* gb = gy + ((size_t)(b + im) * cout + co0 + 8 * wave) * HW;
+#pragma unroll
+            for (int c = 0; c < C::XCH; ++c) {
+                const int yr = (C::WHOLE ? 0 : y0 - 1) + c * C::RPC + lrow;          // image row of this lane's element
+                const bool ok = lane_on && img_ok && (unsigned)yr < (unsigned)H && c * C::RPC + lrow < C::XROWS;
+                const int off = yr * W + lx;
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch) xv[ch][im * C::XCH + c] = ok ? xb[ch * HW + off] : 0.f;
+            }
+#pragma unroll
+            for (int c = 0; c < C::GCH; ++c) {
+                const int yr = y0 + c * C::RPC + lrow;
+                const bool ok = lane_on && img_ok && c * C::RPC + lrow < NR;
+                const int off = yr * W + lx;
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch) gv[ch][im * C::GCH + c] = ok ? gb[ch * HW + off] : 0.f;
+            }
+        }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int im = 0; im < NIMG; ++im) {
+#pragma unroll
+            for (int c = 0; c < C::XCH; ++c) {
+                const int pr = (C::WHOLE ? 1 : 0) + c * C::RPC + lrow;               // patch row
+                if (lane_on && c * C::RPC + lrow < C::XROWS) {
+#pragma unroll
+                    for (int ch = 0; ch < 8; ++ch) Xs[(8 * wave + ch) * C::LQ + (im * C::PR + pr) * Wp + 1 + lx] = xv[ch][im * C::XCH + c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < C::GCH; ++c) {
+                if (lane_on && c * C::RPC + lrow < NR) {
+#pragma unroll
+                    for (int ch = 0; ch < 8; ++ch) As[(8 * wave + ch) * C::GST + (im * NR + c * C::RPC + lrow) * C::SLOTW + lx] = gv[ch][im * C::GCH + c];
+                }
+            }
+        }
+    };
+
+    wg_f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // operand bases: lane = (row of the 32 x 32 tile, k half): the k pair of an MFMA is (pixel, pixel + GS)
+    const float* Ab = As + ((wt >> 1) * 32 + (lane & 31)) * C::GST + half * GS + kh * C::KH_A;
+    const float* Bb = Xs + ((wt & 1) * 32 + (lane & 31)) * C::LQ + half * GS + kh * C::KH_B;
+
+    if (k_lo < k_hi) load(k_lo);
+    __syncthreads();                                                          // zero fill done
+    for (int kstep = k_lo; kstep < k_hi; ++kstep) {
+        store();
+        __syncthreads();
+        if (kstep + 1 < k_hi) load(kstep + 1);
+#pragma unroll
+        for (int yr = 0; yr < C::HR; ++yr) {
+            // the second image of a 2-image K-step starts PR patch rows (not NR) after the first: kh already carries that offset
+#pragma unroll
+            for (int gx = 0; gx < C::GPR; ++gx) {
+                float a[GS];
+                if constexpr (GS == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(Ab + yr * C::SLOTW + gx * 8);
+                    a[0] = t.x, a[1] = t.y, a[2] = t.z, a[3] = t.w;
+                } else if constexpr (GS == 2) {
+                    const float2 t = *reinterpret_cast<const float2*>(Ab + yr * C::SLOTW + gx * 4);
+                    a[0] = t.x, a[1] = t.y;
+                } else {
+                    a[0] = Ab[yr * C::SLOTW + gx * 2];
+                }
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    float bv[GS + 2];
+#pragma unroll
+                    for (int t = 0; t < GS + 2; ++t) bv[t] = Bb[(yr + ky) * Wp + gx * 2 * GS + t];
+#pragma unroll
+                    for (int ss = 0; ss < GS; ++ss)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx)
+                            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ss], bv[kx + ss], acc[ky * 3 + kx], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                                      // every wave is done reading this K-step's tiles
+    }
+
+    // add the second K-step half onto the first through LDS (three passes of 3 taps), then write the partial block in register order
+    float* R = As;
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+        if (kh == 1) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) R[((wt * 3 + t) * 16 + r) * 64 + lane] = acc[pass * 3 + t][r];
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[pass * 3 + t][r] += R[((wt * 3 + t) * 16 + r) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (kh == 0) {
+        float* dst = partial + (size_t)blockIdx.x * (64 * 64 * 9);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[((wt * 9 + t) * 16 + r) * 64 + lane] = acc[t][r];
+    }
+}
+
+// dW[co][ci][tap] = sum_s partial[block][s][...].  A workgroup handles 64 consecutive elements (register order: one coalesced 256-byte
+// row per partial); its four waves take the ranges s = w, w + 4, w + 8, ... and the four sums are added as (0 + 1) + (2 + 3): a
+// fixed summation order, independent of timing.
+__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int cin,
+                                                                  int cout, int S) {
+    __shared__ float part[4][64];
+    const int nti = cin / 64, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int blk = blockIdx.x / 576, e = (blockIdx.x - blk * 576) * 64 + lane;         // 576 * 64 = 36864 elements per block
+    const float* src = partial + (size_t)blk * S * 36864 + e;
+    float s0 = 0.f, s1 = 0.f;
+    int s = w;
+    for (; s + 4 < S; s += 8) {
+        s0 += src[(size_t)s * 36864];
+        s1 += src[(size_t)(s + 4) * 36864];
+    }
+    if (s < S) s0 += src[(size_t)s * 36864];
+    part[w][lane] = s0 + s1;
+    __syncthreads();
+    if (w == 0) {
+        const float sum = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        const int r = (e >> 6) & 15, t = (e >> 10) % 9, wt = e / (9 * 1024);
+        const int co = (blk / nti) * 64 + (wt >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int ci = (blk % nti) * 64 + (wt & 1) * 32 + (lane & 31);
+        dw[((size_t)co * cin + ci) * 9 + t] = sum;
+    }
+}
+
+using Wg56 = WgCfg<56, 2, 1, 4>;
+using Wg28 = WgCfg<28, 4, 1, 2>;
+using Wg14 = WgCfg<14, 14, 1, 1>;
+using Wg7 = WgCfg<7, 7, 2, 1>;
+
+static int wg_cus() {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus > 0 ? cus : 256;
+}
+static int wg_splits(int cin, int cout) {
+    const int nblk = (cin / 64) * (cout / 64), s = wg_cus() / nblk;
+    return s > 0 ? s : 1;
+}
+
+template <class C>
+static int launch_wgrad(const float* gy, const float* x, float* dw, float* workspace, int batch, int cin, int cout, hipStream_t st) {
+    if (cin % 64 || cout % 64 || batch <= 0) return (int)hipErrorInvalidValue;
+    const int nblk = (cin / 64) * (cout / 64), S = wg_splits(cin, cout);
+    (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_FLOATS * 4);
+    hipLaunchKernelGGL((conv3x3_wgrad_kernel<C>), dim3(nblk * S), dim3(512), C::LDS_FLOATS * 4, st, gy, x, workspace, batch, cin, cout, S);
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(nblk * 576), dim3(256), 0, st, workspace, dw, cin, cout, S);
+    return (int)hipGetLastError();
+}
+
+}  // namespace sc
+
+extern "C" long long sc_conv3x3_wgrad_workspace_floats(int cin, int cout) {
+    if (cin <= 0 || cout <= 0 || cin % 64 || cout % 64) return -1;
+    return (long long)(cin / 64) * (cout / 64) * sc::wg_splits(cin, cout) * 36864;
+}
+
+extern "C" int sc_conv3x3_wgrad(const float* gy, const float* x, float* dw, float* workspace, int batch, int cin, int cout, int hw, void* stream) {
+    switch (hw) {
+        case 56: return sc::launch_wgrad<sc::Wg56>(gy, x, dw, workspace, batch, cin, cout, (hipStream_t)stream);
+        case 28: return sc::launch_wgrad<sc::Wg28>(gy, x, dw, workspace, batch, cin, cout, (hipStream_t)stream);
+        case 14: return sc::launch_wgrad<sc::Wg14>(gy, x, dw, workspace, batch, cin, cout, (hipStream_t)stream);
+        case 7: return sc::launch_wgrad<sc::Wg7>(gy, x, dw, workspace, batch, cin, cout, (hipStream_t)stream);
+        default: return -1;
+    }
+}

@@ -213,7 +213,7 @@ def bn_relu_maxpool(bn, x, groups=1):
 
 class Conv3x3Function(torch.autograd.Function):
     """F.conv2d(x, w, None, 1, 1) for the 3x3 / stride-1 layers of the ResNet trunks on csrc/conv3x3.hip (fp32 matrix pipe): forward
-    and backward-data are the same kernel (the latter with the transposed, flipped filter); the weight gradient stays on MIOpen.
+    and backward-data are the same kernel (the latter with the transposed, flipped filter); the weight gradient is conv3x3_wgrad.hip.
     pack_f / pack_b: the kernel-ready images of w from a Conv3x3PackSet (None: packed here, two extra launches)."""
 
     @staticmethod
@@ -233,7 +233,10 @@ class Conv3x3Function(torch.autograd.Function):
             gx = ops.conv3x3_apply(gy, pack_b if pack_b is not None else ops.conv3x3_pack(w, x.shape[2], True), w.shape[1])
         gw = None
         if ctx.needs_input_grad[1]:
-            gw = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+            if ops.conv3x3_wgrad_supported(x.shape, w.shape):
+                gw = ops.conv3x3_backward_weight(gy, x)
+            else:           # channel counts that are not multiples of 64: MIOpen
+                gw = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
         return gx, gw, None, None
 
 

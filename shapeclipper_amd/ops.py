@@ -627,6 +627,28 @@ def conv3x3_backward_data(gy, w):
     return _conv3x3(gy, w, True)
 
 
+def conv3x3_wgrad_supported(x_shape, w_shape, stride=1, padding=1) -> bool:
+    return conv3x3_supported(x_shape, w_shape, stride, padding) and w_shape[0] % 64 == 0 and w_shape[1] % 64 == 0
+
+
+def conv3x3_backward_weight(gy, x):
+    """dL/dw [Cout, Cin, 3, 3] of F.conv2d(x, w, None, 1, 1) from gy [B, Cout, H, H] and x [B, Cin, H, H] (sc_conv3x3_wgrad)."""
+    lib = _lib.load()
+    gy, x = _aligned(gy), _aligned(x)
+    B, cout, H, _ = gy.shape
+    cin = x.shape[1]
+    n = lib.sc_conv3x3_wgrad_workspace_floats(cin, cout)
+    if n < 0 or H not in CONV3X3_SIDES or x.shape[0] != B or tuple(x.shape[2:]) != (H, H):
+        raise RuntimeError("shapeclipper_amd: sc_conv3x3_wgrad does not take gy %s with x %s" % (tuple(gy.shape), tuple(x.shape)))
+    key = (x.device.index, torch.cuda.current_stream().cuda_stream, "wgrad")
+    ws = _conv_ws.get(key)
+    if ws is None or ws.numel() < n:
+        ws = _conv_ws[key] = torch.empty(n, device=x.device, dtype=torch.float32)
+    dw = torch.empty(cout, cin, 3, 3, device=x.device, dtype=torch.float32)
+    _lib.check(lib.sc_conv3x3_wgrad(_lib.ptr(gy), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(ws), B, cin, cout, H, _lib.stream()), "sc_conv3x3_wgrad")
+    return dw
+
+
 class Conv3x3PackSet:
     """Kernel-ready filter images (forward and backward-data orientation) of MANY 3x3 / stride-1 convolutions, rewritten by ONE launch
     (sc_conv3x3_pack_multi): the filters of a network change once per optimizer step, so a trunk refreshes its set once per pass

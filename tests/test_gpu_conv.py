@@ -84,3 +84,22 @@ def test_pack_set_equals_single_packs():
         for flip in (False, True):
             assert torch.equal(packs.get(w, flip), ops.conv3x3_pack(w, side, flip)), (tuple(w.shape), side, flip)
     assert not packs.stale()
+
+
+@pytest.mark.parametrize("side,cin,cout,batch", [(56, 64, 64, 3), (28, 128, 128, 5), (14, 256, 256, 7), (7, 512, 512, 13), (7, 512, 512, 1),
+                                                  (14, 64, 128, 2), (28, 128, 64, 1), (56, 64, 64, 1), (7, 64, 64, 2)])
+def test_conv3x3_backward_weight(side, cin, cout, batch):
+    from shapeclipper_amd import ops
+    torch.manual_seed(side + cin + batch)
+    dev = torch.device("cuda:0")
+    x = torch.randn(batch, cin, side, side, device=dev)
+    gy = torch.randn(batch, cout, side, side, device=dev)
+    assert ops.conv3x3_wgrad_supported(x.shape, (cout, cin, 3, 3))
+    dw = ops.conv3x3_backward_weight(gy, x)
+    dw64 = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, 3, 3), gy.double(), 1, 1)
+    dw_t = torch.ops.aten.convolution_backward(gy, x, torch.zeros(cout, cin, 3, 3, device=dev), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                               [False, True, False])[1]
+    e_hip, e_torch = _rel(dw.double(), dw64), _rel(dw_t.double(), dw64)
+    print("conv3x3 wgrad %dx%d %d>%d B=%d: %.2e of max (torch/MIOpen: %.2e)" % (side, side, cin, cout, batch, e_hip, e_torch))
+    assert e_hip < 2e-5
+    assert torch.equal(dw, ops.conv3x3_backward_weight(gy, x))          # fixed summation order

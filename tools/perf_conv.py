@@ -85,8 +85,8 @@ def main():
                 t_hf = time_fn(lambda: hip_conv.conv3x3_apply(xd, wp_f, co))
                 t_hd = time_fn(lambda: hip_conv.conv3x3_apply(gy, wp_b, ci))
                 line += " | hip pack %6.3f fwd %7.3f (%5.1f TF/s) bwdD %7.3f (%5.1f)" % (t_pk, t_hf, flop / t_hf / 1e9, t_hd, flop / t_hd / 1e9)
-                if hasattr(hip_conv, "conv3x3_backward_weight"):
-                    t_hw = time_fn(lambda: hip_conv.conv3x3_backward_weight(gy, x.detach()))
+                if hip_conv.conv3x3_wgrad_supported(x.shape, w.shape):
+                    t_hw = time_fn(lambda: hip_conv.conv3x3_backward_weight(gy, xd))
                     line += " bwdW %7.3f (%5.1f)" % (t_hw, flop / t_hw / 1e9)
             print(line, flush=True)
             del x, w, y, gy
