@@ -27,7 +27,6 @@
 // Roofline: 2 * 9 * Cin FLOP per output element on the 157.3 TFLOP/s fp32 matrix pipe; HBM traffic is one read of x and one write of
 // out (<= 0.1 byte per FLOP), i.e. compute bound by two orders of magnitude.
 #include <hip/hip_runtime.h>
-#include <cstdlib>
 
 #include "shapeclipper_hip.h"
 
@@ -318,19 +317,13 @@ __global__ void conv3x3_pack_kernel(const float* __restrict__ w, float* __restri
     }
 }
 
-template <int V> struct Conv56V;
-template <> struct Conv56V<0> { using T = ConvCfg<56, 64, 512, 1, 8>; };
-template <> struct Conv56V<1> { using T = ConvCfg<56, 64, 256, 1, 4>; };
-template <int V> struct Conv28V;
-template <> struct Conv28V<0> { using T = ConvCfg<28, 128, 256, 2, 4>; };
-template <> struct Conv28V<1> { using T = ConvCfg<28, 64, 256, 1, 4>; };
-template <int V> struct Conv14V;
-template <> struct Conv14V<0> { using T = ConvCfg<14, 128, 256, 2, 4>; };
-template <> struct Conv14V<1> { using T = ConvCfg<14, 64, 256, 1, 4>; };
-template <int V> struct Conv7V;
-template <> struct Conv7V<0> { using T = ConvCfg<7, 128, 128, 2, 4>; };
-template <> struct Conv7V<1> { using T = ConvCfg<7, 64, 256, 1, 4>; };
-static int conv_variant() { const char* e = getenv("SC_CONV_VARIANT"); return e ? atoi(e) & 1 : 0; }
+// Tile shapes (measured, tools/perf_conv.py): 8 waves of 64 x 64 each.  Four-wave workgroups, two per CU (NT = 256: 64 x 256 tiles) reach
+// the same rates alone and in the training step; a plain one-tile-per-workgroup grid is 10-40 % slower (incomplete last round);
+// storing a finished tile under the next tile's first K-step (second accumulator set) spills and is 4-6 % slower.
+using Conv56 = ConvCfg<56, 64, 512, 1, 8>;       // 64 channels: the tile spans all of them
+using Conv28 = ConvCfg<28, 128, 256, 2, 4>;
+using Conv14 = ConvCfg<14, 128, 256, 2, 4>;
+using Conv7 = ConvCfg<7, 128, 128, 2, 4>;
 
 template <class C>
 static long long pack_floats(int cin, int cout) { return cin % C::CB ? -1 : (long long)((cout + C::CT - 1) / C::CT) * (cin / C::CB) * C::WIMG; }
@@ -390,7 +383,7 @@ template <class C>
 static int launch_conv(const float* x, const float* wpack, float* out, float* workspace, int batch, int cin, int cout, hipStream_t st) {
     if (cin % C::CB || batch <= 0) return (int)hipErrorInvalidValue;
     const int tiles = ((batch * C::HW + C::PT - 1) / C::PT) * ((cout + C::CT - 1) / C::CT), nk = cin / C::CB;
-    const int G = getenv("SC_CONV_DP") ? tiles : getenv("SC_CONV_G1") ? conv_grid() : conv_grid() * C::WGS_PER_CU;
+    const int G = conv_grid() * C::WGS_PER_CU;
     (void)hipFuncSetAttribute((const void*)conv3x3_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     hipLaunchKernelGGL((conv3x3_kernel<C>), dim3(G), dim3(C::NT), C::LDS_BYTES, st, x, wpack, out, workspace, batch, cin, cout);
     const ConvSplit sp = conv_split(tiles, nk, G);
@@ -401,13 +394,12 @@ static int launch_conv(const float* x, const float* wpack, float* out, float* wo
 
 }  // namespace sc
 
-#define SC_CONV_V(F, CALL) if (sc::conv_variant()) return CALL(sc::F<1>::T); else return CALL(sc::F<0>::T);
 #define SC_CONV_DISPATCH(hw, CALL)                   \
     switch (hw) {                                    \
-        case 56: SC_CONV_V(Conv56V, CALL)            \
-        case 28: SC_CONV_V(Conv28V, CALL)            \
-        case 14: SC_CONV_V(Conv14V, CALL)            \
-        case 7: SC_CONV_V(Conv7V, CALL)              \
+        case 56: return CALL(sc::Conv56);            \
+        case 28: return CALL(sc::Conv28);            \
+        case 14: return CALL(sc::Conv14);            \
+        case 7: return CALL(sc::Conv7);              \
         default: return -1;                          \
     }
 

@@ -670,6 +670,8 @@ class Conv3x3PackSet:
                 rows.append([w.data_ptr(), off, cin, cout, lib.sc_conv3x3_tile_channels(side), flip])
                 self.where[(k, flip)] = (off, n)
                 off += n
+        if len(rows) > 128:
+            raise RuntimeError("shapeclipper_amd: Conv3x3PackSet holds at most 64 filters (sc_conv3x3_pack_multi table limit)")
         dev = self.weights[0].device
         self.total = off
         self.table = torch.tensor(rows, dtype=torch.int64).to(dev)

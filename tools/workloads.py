@@ -6,6 +6,8 @@ which is the command the rocprofv3 summaries under profiles/ are taken from).
   clip_vit_b32               CLIP ViT-B/32 image tower, batch 32                   CLIP_anno.py:166-167
   render_eval_128            full-frame evaluation render 128x128, batch 32        model/renderer.py:57-152
   level_grid_100             SDF level grid, vox_res = 100, one image              utils/eval_3D.py:21-38
+  resnet_conv3x3             the 3x3 / stride-1 convolutions of one bs32 step's trunks  model/graph.py:50-54, view_estimator.py:40-42
+                             (ResNet-18 at 64 images + ResNet-34 at 96: forward, backward-data, backward-weight of 42 layers)
 
 Algorithmic work per unit is SURVEY 8(d)'s: 8 FLOP per ordered pair (Chamfer), 8.725 GFLOP per image (ViT-B/32),
 12,763,136 FLOP per ray (evaluation render), 80,640 FLOP per grid point.  `frac` = achieved / peak of the unit that
@@ -216,11 +218,55 @@ def level_grid_100(with_cpu=True):
     return out
 
 
+def resnet_conv3x3(with_cpu=True):
+    """csrc/conv3x3.hip + conv3x3_wgrad.hip on every 3x3 / stride-1 layer shape of the two trunks, weighted by how often a step runs
+    it, with MIOpen (torch's operators) on the same tensors beside it."""
+    from shapeclipper_amd import ops
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    shapes = []       # (channels, side, batch, layers)
+    for layers, batch in (([2, 2, 2, 2], 64), ([3, 4, 6, 3], 96)):
+        for li, (c, side) in enumerate(((64, 56), (128, 28), (256, 14), (512, 7))):
+            shapes.append((c, side, batch, 2 * layers[li] - (1 if li else 0)))
+    ms_hip = ms_lib = flop = 0.0
+    rows = []
+    for c, side, batch, count in shapes:
+        x = torch.randn(batch, c, side, side, device=dev)
+        w = torch.randn(c, c, 3, 3, device=dev) * 0.05
+        gy = torch.randn(batch, c, side, side, device=dev)
+        wp_f, wp_b = ops.conv3x3_pack(w, side), ops.conv3x3_pack(w, side, True)
+        t = [_gpu_ms(f, iters=10)[0] for f in (lambda: ops.conv3x3_apply(x, wp_f, c), lambda: ops.conv3x3_apply(gy, wp_b, c),
+                                               lambda: ops.conv3x3_backward_weight(gy, x))]
+        bw = lambda m: torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, m)
+        tl = [_gpu_ms(f, iters=10)[0] for f in (lambda: torch.nn.functional.conv2d(x, w, None, 1, 1), lambda: bw([True, False, False]),
+                                                lambda: bw([False, True, False]))]
+        f1 = 2.0 * batch * side * side * c * c * 9
+        ms_hip += count * sum(t)
+        ms_lib += count * sum(tl)
+        flop += count * 3 * f1
+        rows.append(dict(channels=c, side=side, batch=batch, layers=count, hip_ms=[round(v, 3) for v in t], miopen_ms=[round(v, 3) for v in tl],
+                         hip_tflops=[round(f1 / v / 1e9, 1) for v in t]))
+        del x, w, gy
+    tf = flop / (ms_hip * 1e-3) / 1e12
+    out = dict(workload="3x3 stride-1 convolutions of one bs32 step (ResNet-18 x 64 images, ResNet-34 x 96): fwd + bwd-data + bwd-weight of 42 layers",
+               ms=round(ms_hip, 3), ms_miopen=round(ms_lib, 3), algorithmic_flop=flop, achieved=round(tf, 2), peak=PEAK_FP32, unit="TFLOP/s",
+               bound="fp32 MFMA", frac=round(tf / PEAK_FP32, 4), layers=rows)
+    if with_cpu:
+        torch.set_num_threads(cpu_threads())
+        c, side, batch = 128, 28, 8
+        xc, wc = torch.randn(batch, c, side, side), torch.randn(c, c, 3, 3) * 0.05
+        dt, k = _cpu_time(lambda: torch.nn.functional.conv2d(xc, wc, None, 1, 1), budget_s=4.0)
+        out["cpu"] = dict(value=round(2.0 * batch * side * side * c * c * 9 / dt / 1e12, 4), unit="TFLOP/s", cores=cpu_threads(), kind="port",
+                          sample="torch conv2d forward, 128 channels 28x28, 8 images, %d timed runs" % k, gpu_value=out["achieved"])
+    return out
+
+
 def run_all(with_cpu=True):
     out = {}
     for name, fn in (("chamfer_b1", lambda: chamfer(1, with_cpu=with_cpu)), ("chamfer_b32", lambda: chamfer(32, with_cpu=False)),
                      ("clip_vit_b32", lambda: clip_vit(32, with_cpu=with_cpu)), ("render_eval_128", lambda: render_eval_128(32, with_cpu=with_cpu)),
-                     ("level_grid_100", lambda: level_grid_100(with_cpu=with_cpu))):
+                     ("level_grid_100", lambda: level_grid_100(with_cpu=with_cpu)),
+                     ("resnet_conv3x3", lambda: resnet_conv3x3(with_cpu=with_cpu))):
         out[name] = fn()
         torch.cuda.empty_cache()
     return out
