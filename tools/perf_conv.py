@@ -1,6 +1,6 @@
 """Per-layer table of the ResNet-18/34 convolutions of one bs32 training step: every distinct
-(Cin, Cout, H, kernel, stride) shape at the batch the step runs it with (encoder: 2 passes x 32 = 64 images in one grouped pass,
-estimator: 3 x 32 = 96), forward / backward-data / backward-weight timed separately through torch (= MIOpen's pick), with the
+(Cin, Cout, H, kernel, stride) shape at the batch the step runs it with (ResNet-34 encoder: 2 passes x 32 = 64 images in one grouped
+pass, ResNet-18 view estimator: 3 x 32 = 96), forward / backward-data / backward-weight timed separately through torch (= MIOpen's pick), with the
 effective TFLOP/s against the 157.3 TFLOP/s fp32 MFMA peak and the share of the step each shape carries.
 
     python tools/perf_conv.py [--hip]      --hip: time shapeclipper_amd's own convolution kernels beside MIOpen
@@ -60,7 +60,7 @@ def main():
         from shapeclipper_amd import ops
         hip_conv = ops
     print("%-12s %-22s %5s | %8s %6s | %8s %6s | %8s %6s | %7s" % ("net", "layer Cin>Cout HxH k/s", "count", "fwd ms", "TF/s", "bwdD ms", "TF/s", "bwdW ms", "TF/s", "ms/step"))
-    for net, layers, batch in (("resnet18 B=64", [2, 2, 2, 2], 64), ("resnet34 B=96", [3, 4, 6, 3], 96)):
+    for net, layers, batch in (("resnet18 B=96", [2, 2, 2, 2], 96), ("resnet34 B=64", [3, 4, 6, 3], 64)):
         for (name, ci, co, h, k, s, count, b) in shapes(layers, batch):
             x = torch.randn(b, ci, h, h, device=dev, requires_grad=True)
             w = torch.randn(co, ci, k, k, device=dev, requires_grad=True) * 0.05

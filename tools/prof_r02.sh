@@ -5,6 +5,7 @@ R=$PWD
 O=$R/gpurun_out/r02_profiles
 mkdir -p $O
 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -E "passed|failed|Error" | tail -3 > $O/gputest.log
+python tools/perf_conv.py --hip 2>&1 | grep -v -i "warn\|amdgpu" > $O/conv_layers.txt
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bench -o bench -- python $R/bench.py --no-workloads --no-cpu-baseline --sustained 0 --steps 10 > $O/bench_under_rocprof.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_wl -o wl -- python $R/bench.py --workloads-only --no-cpu-baseline > $O/workloads_under_rocprof.log 2>&1

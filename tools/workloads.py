@@ -7,7 +7,7 @@ which is the command the rocprofv3 summaries under profiles/ are taken from).
   render_eval_128            full-frame evaluation render 128x128, batch 32        model/renderer.py:57-152
   level_grid_100             SDF level grid, vox_res = 100, one image              utils/eval_3D.py:21-38
   resnet_conv3x3             the 3x3 / stride-1 convolutions of one bs32 step's trunks  model/graph.py:50-54, view_estimator.py:40-42
-                             (ResNet-18 at 64 images + ResNet-34 at 96: forward, backward-data, backward-weight of 42 layers)
+                             (ResNet-34 encoder at 64 images + ResNet-18 estimator at 96: forward, backward-data, backward-weight of 42 layers)
 
 Algorithmic work per unit is SURVEY 8(d)'s: 8 FLOP per ordered pair (Chamfer), 8.725 GFLOP per image (ViT-B/32),
 12,763,136 FLOP per ray (evaluation render), 80,640 FLOP per grid point.  `frac` = achieved / peak of the unit that
@@ -225,7 +225,7 @@ def resnet_conv3x3(with_cpu=True):
     dev = torch.device("cuda")
     torch.manual_seed(0)
     shapes = []       # (channels, side, batch, layers)
-    for layers, batch in (([2, 2, 2, 2], 64), ([3, 4, 6, 3], 96)):
+    for layers, batch in (([2, 2, 2, 2], 96), ([3, 4, 6, 3], 64)):       # view estimator: 3 x 32 images, encoder: 2 x 32
         for li, (c, side) in enumerate(((64, 56), (128, 28), (256, 14), (512, 7))):
             shapes.append((c, side, batch, 2 * layers[li] - (1 if li else 0)))
     ms_hip = ms_lib = flop = 0.0
@@ -248,7 +248,7 @@ def resnet_conv3x3(with_cpu=True):
                          hip_tflops=[round(f1 / v / 1e9, 1) for v in t]))
         del x, w, gy
     tf = flop / (ms_hip * 1e-3) / 1e12
-    out = dict(workload="3x3 stride-1 convolutions of one bs32 step (ResNet-18 x 64 images, ResNet-34 x 96): fwd + bwd-data + bwd-weight of 42 layers",
+    out = dict(workload="3x3 stride-1 convolutions of one bs32 step (ResNet-34 encoder x 64 images, ResNet-18 estimator x 96): fwd + bwd-data + bwd-weight of 42 layers",
                ms=round(ms_hip, 3), ms_miopen=round(ms_lib, 3), algorithmic_flop=flop, achieved=round(tf, 2), peak=PEAK_FP32, unit="TFLOP/s",
                bound="fp32 MFMA", frac=round(tf / PEAK_FP32, 4), layers=rows)
     if with_cpu:
