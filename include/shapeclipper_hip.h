@@ -25,7 +25,7 @@ extern "C" {
 
 /* ---------------------------------------------------------------------------------------------
  * Chamfer3D.  xyz1 [b,n,3], xyz2 [b,m,3] fp32 contiguous.  dist1 [b,n], dist2 [b,m]: SQUARED
- * nearest-neighbour distance d = fma(dz,dz,fma(dx,dx,dy*dy)) (contraction order: see oracle/chamfer_ref.c); idx1 [b,n], idx2 [b,m] int32: index
+ * nearest-neighbour distance d = fma(dy,dy,dx*dx) + dz*dz (the reference extension's arithmetic on this GPU: oracle/chamfer_ref.c); idx1 [b,n], idx2 [b,m] int32: index
  * of the nearest neighbour, lowest index among exact ties (chamfer3D.cu:36,126).  Outputs are
  * fully overwritten (if n==0 or m==0 they are left untouched, as the reference does).
  * Launches on `stream` (the reference used the legacy default stream).                          */

@@ -14,12 +14,13 @@ container against the reference's own modules imported from ``/root/reference``
 (``model/implicit.py``, ``model/renderer.py``, ``model/loss.py``,
 ``utils/camera.py``); the frozen input/output vectors live in
 ``tests/golden/*.npz`` next to the script that made them
-(``tests/golden/make_golden.py``).  Two pieces are restated from source that
-cannot run here and are therefore pinned only by known-answer vectors:
+(``tests/golden/make_golden.py``).
 
-  * Chamfer3D (``external/chamfer3D/chamfer3D.cu`` needs nvcc + a GPU) --
-    ``chamfer_ref.c`` follows the kernel line by line (fp32, fma contraction
-    as nvcc's default ``-fmad=true``, strict ``<`` lowest-index tie rule);
+  * Chamfer3D: ``build_chamfer_ref.py`` builds the reference's OWN extension
+    (``external/chamfer3D``: chamfer_cuda.cpp + chamfer3D.cu, untouched) for
+    gfx950 into ``oracle/_ref/chamfer_3D_ref.so``; ``chamfer_ref.c`` (fp32,
+    d = fmaf(y, y, x*x) + z*z, strict ``<`` lowest-index tie rule) and the HIP
+    kernels agree with it bit for bit (``tests/test_gpu_chamfer_ref.py``);
   * ``utils/eval_3D.py`` metric helpers (module imports mcubes/trimesh, absent
     here) -- restated from the file and checked with sys.modules stubs.
 

@@ -6,19 +6,19 @@
  *   sc_ref_chamfer_forward  <- NmDistanceKernel           (chamfer3D.cu:12-134, launches :142-143)
  *   sc_ref_chamfer_backward <- NmDistanceGradKernel       (chamfer3D.cu:155-174, launches :184-185)
  *
- * PARITY UNPINNED for the last bit of `dist`: the .cu needs nvcc + a GPU, neither exists here, and the reference
- * holds no vectors for this kernel.  What IS pinned: the algorithm (known-answer vectors in tests/golden/g9_chamfer.npz:
- * float64 brute force within 1e-6, engineered exact ties) and the tie rule.  Arithmetic:
+ * PINNED against the reference itself: oracle/build_chamfer_ref.py builds the reference's own extension (chamfer_cuda.cpp +
+ * chamfer3D.cu, untouched, where they lie under /root/reference) for gfx950 into oracle/_ref/chamfer_3D_ref.so, and
+ * tests/test_gpu_chamfer_ref.py runs it on the GPU beside this restatement and the HIP kernels: dist and idx agree bit for bit
+ * (uniform clouds up to 100,000 x 100,000, lattice clouds with thousands of exact ties, ragged sizes), the gradients to 1e-6
+ * (float atomics).  Also pinned: known-answer vectors in tests/golden/g9_chamfer.npz (float64 brute force within 1e-6,
+ * engineered exact ties).  Arithmetic:
  *   - fp32 throughout; the source expression is  d = x2*x2 + y2*y2 + z2*z2  (chamfer3D.cu:35, x2 = target - query,
- *     :32-34), parsed as (x2*x2 + y2*y2) + z2*z2, and nvcc's default -fmad=true contracts it.  WHICH products are
- *     fused is a compiler choice that cannot be observed here.  This restatement (and the HIP kernel, which uses the
- *     same chain so that the two agree bit for bit) follows the LLVM/NVPTX DAG combiner order -- fadd(fmul a, fmul b)
- *     -> fma(a.0, a.1, b): the FIRST product is fused, the second stays a rounded product; then fadd(t, fmul c) ->
- *     fma(c.0, c.1, t):
- *         d = fmaf(z2, z2, fmaf(x2, x2, y2*y2))
- *     The alternative fmaf(z2, z2, fmaf(y2, y2, x2*x2)) differs by <= 1 ulp of d and can flip idx only between two
- *     targets whose distances differ by < 2 ulp.  Tests therefore assert bit-equality only between this oracle and
- *     the kernel (same chain), and 1-ulp / near-tie tolerance against the float64 brute force.
+ *     :32-34), parsed as (x2*x2 + y2*y2) + z2*z2 and contracted by the compiler.  The reference build for this GPU computes
+ *         d = fmaf(y2, y2, x2*x2) + z2*z2
+ *     (x2*x2 rounded and fused into the y product, z2*z2 rounded, one rounded add: v_pk_mul / v_fma / v_add in its disassembly;
+ *     of the eight candidate contractions only this one reproduces its output, tools/probe_chamfer_ref.py).  What nvcc emits
+ *     for NVIDIA hardware may differ in the last bit of d (<= 1 ulp; idx can then differ only between targets whose distances
+ *     differ by < 2 ulp) -- on THIS platform the reference's results are the ones above.
  *   - strict '<' inside a 512-target tile, first element unconditionally (k==0), so the lowest
  *     index among equal minima wins inside a tile (chamfer3D.cu:36, :46 ...);
  *   - across tiles: overwrite only if previous best > tile best (chamfer3D.cu:126) -> again the
@@ -42,7 +42,8 @@ static void nm_distance(int b, int n, const float *xyz, int m, const float *xyz2
                 const float x2 = xyz2[(i * (int64_t)m + k) * 3 + 0] - x1;
                 const float y2 = xyz2[(i * (int64_t)m + k) * 3 + 1] - y1;
                 const float z2 = xyz2[(i * (int64_t)m + k) * 3 + 2] - z1;
-                const float d = fmaf(z2, z2, fmaf(x2, x2, y2 * y2));
+                const float xx = x2 * x2, zz = z2 * z2;
+                const float d = fmaf(y2, y2, xx) + zz;
                 if (k == 0 || d < best) { best = d; best_i = k; }
             }
             /* m == 0: the reference leaves the caller's zero-filled outputs untouched */

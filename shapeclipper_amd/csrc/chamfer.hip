@@ -4,11 +4,10 @@
 //   NmDistanceKernel      (chamfer3D.cu:12-134)  -> chamfer_nn_kernel + chamfer_nn_index_kernel
 //   NmDistanceGradKernel  (chamfer3D.cu:155-174) -> chamfer_grad_kernel
 //
-// Roofline: FP32 VALU bound (8 algorithmic FLOP per ordered pair: 3 sub, 1 mul, 2 fma; no exact
+// Roofline: FP32 VALU bound (8 algorithmic FLOP per ordered pair: 3 sub, 2 mul, 1 fma, 1 add; no exact
 // MFMA form exists because |a|^2+|b|^2-2ab changes rounding and therefore argmin ties).
-// Measured (round 2): the inner loop is 6.5 vector instructions per pair (3 v_sub, 1 v_mul, 2 v_fmac, half a v_min3) at the
-// ~2.7 cycles per wave64 VALU instruction this chip sustains: 7.9 Tpairs/s = 0.40 of the fp32 FLOP peak = ~96 % of that issue
-// rate.  8 queries per lane instead of 4 (half the LDS reads per pair): no faster.
+// The inner loop works on TWO targets per instruction with the packed fp32 VALU forms (v_pk_add / v_pk_mul / v_pk_fma: 7 packed
+// instructions + one v_min3 per two pairs = 4 vector instructions per pair; the scalar form of round 1 needed 7).
 //
 // Design (wave64, 256 CUs):
 //   * a lane owns Q query points in registers; targets stream through LDS as float4 and are read
@@ -19,10 +18,11 @@
 //     and takes the first exact match.  "First sub-block whose min is strictly smaller" + "first
 //     index inside it" == the reference's "lowest index among equal minima" rule
 //     (chamfer3D.cu:36,46,126), bit for bit.
-//   * d = fmaf(dz,dz, fmaf(dx,dx, dy*dy)) with dx = target - query: the LLVM/NVPTX contraction order of
-//     chamfer3D.cu:35 `x2*x2+y2*y2+z2*z2` under nvcc's default -fmad=true (first product of an add fused, second
-//     rounded), written explicitly so host oracle and device agree exactly.  Which products nvcc really fuses
-//     cannot be verified without nvcc: the last bit of d is parity-unpinned (oracle/chamfer_ref.c header).
+//   * d = fmaf(dy, dy, dx*dx) + dz*dz with dx = target - query: what the reference's own extension computes for
+//     chamfer3D.cu:35 `x2*x2+y2*y2+z2*z2` when it is built for this GPU (oracle/build_chamfer_ref.py -> oracle/_ref: the
+//     first product rounded, fused into the second, the third product rounded and added; identified instruction by
+//     instruction in its disassembly and bit for bit on 100,000 x 100,000 points, tests/test_gpu_chamfer_ref.py), written
+//     with explicit fma and contraction switched off so that host oracle, packed and scalar device code agree exactly.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -34,10 +34,43 @@ constexpr int CH_TCHUNK = 2048;  // targets per LDS chunk (32 KiB as float4)
 constexpr int CH_SUB = 16;       // targets per min-only sub-block
 constexpr float CH_FAR = 1.0e18f;  // padding coordinate: d ~ 3e36, finite, never wins
 
+typedef float ch_f2 __attribute__((ext_vector_type(2)));
+
+#pragma clang fp contract(off)
 __device__ __forceinline__ float dist2(float tx, float ty, float tz, float qx, float qy, float qz) {
     const float dx = tx - qx, dy = ty - qy, dz = tz - qz;
-    return __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));
+    const float xx = dx * dx, zz = dz * dz;
+    return __builtin_fmaf(dy, dy, xx) + zz;
 }
+// the same arithmetic for two targets at once (packed fp32: IEEE results per component, identical to dist2)
+__device__ __forceinline__ ch_f2 dist2_pk(ch_f2 tx, ch_f2 ty, ch_f2 tz, float qx, float qy, float qz) {
+    const ch_f2 dx = tx - qx, dy = ty - qy, dz = tz - qz;
+    const ch_f2 xx = dx * dx, zz = dz * dz;
+    return __builtin_elementwise_fma(dy, dy, xx) + zz;
+}
+// LDS image of a target pair (a, b): {xa, xb, ya, yb} {za, zb, -, -}
+struct ChPair { float4 xy, z; };
+__device__ __forceinline__ void stage_targets(float4* tgt, const float* t_ptr, int k0, int cnt, int cnt_pad, int tid) {
+    for (int j = tid; j < cnt_pad; j += CH_THREADS) {
+        float x = CH_FAR, y = CH_FAR, z = CH_FAR;
+        if (j < cnt) {
+            const float* p = t_ptr + (size_t)(k0 + j) * 3;
+            x = p[0]; y = p[1]; z = p[2];
+        }
+        float* e = reinterpret_cast<float*>(tgt + (j >> 1) * 2) + (j & 1);
+        e[0] = x; e[2] = y; e[4] = z;
+    }
+}
+// running minimum of one query over the CH_SUB targets of sub-block sb (pair images sb .. sb + CH_SUB - 1)
+#define CH_MIN_SUBBLOCK(mn)                                                                              \
+    _Pragma("unroll") for (int t = 0; t < CH_SUB; t += 2) {                                              \
+        const float4 Txy = tgt[sb + t], Tz = tgt[sb + t + 1];                                            \
+        const ch_f2 tx = {Txy.x, Txy.y}, ty = {Txy.z, Txy.w}, tz = {Tz.x, Tz.y};                         \
+        _Pragma("unroll") for (int q = 0; q < CH_Q; ++q) {                                               \
+            const ch_f2 d = dist2_pk(tx, ty, tz, qx[q], qy[q], qz[q]);                                   \
+            mn[q] = __builtin_fminf(__builtin_fminf(mn[q], d.x), d.y);   /* v_min3_f32: inputs are finite */ \
+        }                                                                                                \
+    }
 
 // One direction: for every query j of cloud `xyz` [b,n,3], min_k d(q_j, t_k) over `xyz2` [b,m,3].
 // Writes the squared distance and the 16-target sub-block id that first reached it.
@@ -68,28 +101,13 @@ __global__ __launch_bounds__(CH_THREADS) void chamfer_nn_kernel(
         const int cnt = min(CH_TCHUNK, m - k0);
         const int cnt_pad = (cnt + CH_SUB - 1) & ~(CH_SUB - 1);
         __syncthreads();
-        for (int j = tid; j < cnt_pad; j += CH_THREADS) {
-            float4 t = make_float4(CH_FAR, CH_FAR, CH_FAR, 0.f);
-            if (j < cnt) {
-                const float* p = t_ptr + (size_t)(k0 + j) * 3;
-                t.x = p[0]; t.y = p[1]; t.z = p[2];
-            }
-            tgt[j] = t;
-        }
+        stage_targets(tgt, t_ptr, k0, cnt, cnt_pad, tid);
         __syncthreads();
         for (int sb = 0; sb < cnt_pad; sb += CH_SUB) {
             float mn[CH_Q];
 #pragma unroll
             for (int q = 0; q < CH_Q; ++q) mn[q] = __builtin_inff();
-#pragma unroll
-            for (int t = 0; t < CH_SUB; ++t) {
-                const float4 T = tgt[sb + t];
-#pragma unroll
-                for (int q = 0; q < CH_Q; ++q) {
-                    const float d = dist2(T.x, T.y, T.z, qx[q], qy[q], qz[q]);
-                    mn[q] = __builtin_fminf(mn[q], d);     // one v_min_f32 per pair (inputs are finite: no NaN semantics needed)
-                }
-            }
+            CH_MIN_SUBBLOCK(mn)
             const int blk = (k0 + sb) / CH_SUB;
 #pragma unroll
             for (int q = 0; q < CH_Q; ++q) {
@@ -137,22 +155,13 @@ __global__ __launch_bounds__(CH_THREADS) void chamfer_nn_split_kernel(
         const int cnt = min(CH_TCHUNK, t_end - k0);
         const int cnt_pad = (cnt + CH_SUB - 1) & ~(CH_SUB - 1);
         __syncthreads();
-        for (int j = tid; j < cnt_pad; j += CH_THREADS) {
-            float4 t = make_float4(CH_FAR, CH_FAR, CH_FAR, 0.f);
-            if (j < cnt) { const float* p = t_ptr + (size_t)(k0 + j) * 3; t.x = p[0]; t.y = p[1]; t.z = p[2]; }
-            tgt[j] = t;
-        }
+        stage_targets(tgt, t_ptr, k0, cnt, cnt_pad, tid);
         __syncthreads();
         for (int sb = 0; sb < cnt_pad; sb += CH_SUB) {
             float mn[CH_Q];
 #pragma unroll
             for (int q = 0; q < CH_Q; ++q) mn[q] = __builtin_inff();
-#pragma unroll
-            for (int t = 0; t < CH_SUB; ++t) {
-                const float4 T = tgt[sb + t];
-#pragma unroll
-                for (int q = 0; q < CH_Q; ++q) mn[q] = __builtin_fminf(mn[q], dist2(T.x, T.y, T.z, qx[q], qy[q], qz[q]));
-            }
+            CH_MIN_SUBBLOCK(mn)
             const int blk = (k0 + sb) / CH_SUB;      // slices start at multiples of CH_SUB
 #pragma unroll
             for (int q = 0; q < CH_Q; ++q) {

@@ -1,0 +1,26 @@
+import sys, os, numpy as np, torch
+sys.path.insert(0, os.getcwd())
+from oracle import build_chamfer_ref
+ref = build_chamfer_ref.load_module()
+rng = np.random.RandomState(0)
+for (N, M) in ((100000, 100000), (1000, 700), (17, 5), (7001, 3000)):
+    a = torch.tensor(rng.uniform(-0.5, 0.5, (1, N, 3)).astype(np.float32)).cuda()
+    b = torch.tensor(rng.uniform(-0.5, 0.5, (1, M, 3)).astype(np.float32)).cuda()
+    d1 = torch.zeros(1, N).cuda(); d2 = torch.zeros(1, M).cuda()
+    i1 = torch.zeros(1, N, dtype=torch.int32).cuda(); i2 = torch.zeros(1, M, dtype=torch.int32).cuda()
+    ref.forward(a, b, d1, d2, i1, i2); torch.cuda.synchronize()
+    nb = b[0][i1[0].long()]
+    diff = (nb - a[0])            # fp32 subtraction as in the kernel: buf - x1
+    x, y, z = [diff[:, k].double() for k in range(3)]
+    r = lambda t: t.float().double()
+    cand = {
+        "A fma(x,x,y2)+z2": r(r(x * x + r(y * y)) + r(z * z)),
+        "B fma(y,y,x2)+z2": r(r(y * y + r(x * x)) + r(z * z)),
+        "C fma(z,z,fma(x,x,y2))": r(z * z + r(x * x + r(y * y))),
+        "D plain": r(r(r(x * x) + r(y * y)) + r(z * z)),
+        "E fma(z,z,fma(y,y,x2))": r(z * z + r(y * y + r(x * x))),
+        "F fma(x,x,y2+z2)": r(x * x + r(r(y * y) + r(z * z))),
+        "G fma(y,y,z2)+x2": r(r(y * y + r(z * z)) + r(x * x)),
+        "H x2 + fma(y,y,z2)": r(r(x * x) + r(y * y + r(z * z))),
+    }
+    print(N, M, {k: int((v.float() != d1[0]).sum()) for k, v in cand.items()})
