@@ -13,7 +13,8 @@ Algorithmic work per unit is SURVEY 8(d)'s: 8 FLOP per ordered pair (Chamfer), 8
 12,763,136 FLOP per ray (evaluation render), 80,640 FLOP per grid point.  `frac` = achieved / peak of the unit that
 bounds the kernel (fp32 VALU / bf16 MFMA / fp32 MFMA, MI355X_MICROARCH.md).  CPU legs ("cpu"): the oracle
 (oracle/reference_ops.py), a chunked torch.cdist brute force, and transformers' CLIP vision model, on a bounded sample
-of the same workload with min(os.cpu_count(), 32) threads -- reported baselines, not targets.
+of the same workload with min(os.cpu_count(), 32) threads -- reported baselines, not targets.  Chamfer also carries
+`reference_gpu`: the reference's own CUDA extension built for gfx950 (oracle/_ref), timed on the same tensors.
 """
 import os
 import sys
@@ -88,6 +89,19 @@ def chamfer(B, N=100000, with_cpu=True):
         out["cpu"] = dict(value=round(2.0 * n * n / dt / 1e9, 3), unit="Gpairs/s", cores=cpu_threads(), kind="port",
                           sample="chunked torch.cdist + min/argmin, N=M=%d, both directions, %d timed runs" % (n, k),
                           gpu_value=round(pairs / (ms * 1e-3) / 1e9, 1))
+    # baseline leg: the reference's OWN extension built for this GPU (oracle/_ref, checker of tests/test_gpu_chamfer_ref.py),
+    # same tensors, same device -- what a user of the reference would get here without this build
+    try:
+        from oracle import build_chamfer_ref
+        ref = build_chamfer_ref.load_module()
+    except Exception:        # noqa: BLE001
+        ref = None
+    if ref is not None:
+        e1, e2, j1, j2 = torch.zeros_like(d1), torch.zeros_like(d2), torch.zeros_like(i1), torch.zeros_like(i2)
+        rms, _ = _gpu_ms(lambda: ref.forward(a, b, e1, e2, j1, j2), iters=3, warm=1)
+        out["reference_gpu"] = dict(ms=round(rms, 3), kind="reference", speedup=round(rms / ms, 2), same_results=bool(
+            torch.equal(e1, d1) and torch.equal(e2, d2) and torch.equal(j1, i1) and torch.equal(j2, i2)),
+            sample="external/chamfer3D of the reference built for gfx950 (oracle/build_chamfer_ref.py), same tensors on the same GPU")
     return out
 
 
