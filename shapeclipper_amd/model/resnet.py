@@ -27,7 +27,7 @@ class BasicBlock(nn.Module):
         self.bn2 = nn.BatchNorm2d(planes)
         self.downsample = downsample
 
-    def forward(self, x, groups=1, packs=None):
+    def forward(self, x, groups=1, packs=None, hip_conv=None):
         if not FUSED_BN:
             assert groups == 1
             identity = x if self.downsample is None else self.downsample(x)
@@ -35,7 +35,7 @@ class BasicBlock(nn.Module):
             out = self.bn2(self.conv2(out))
             return self.relu(out + identity)
         identity = x if self.downsample is None else bn_act(self.downsample[1], self.downsample[0](x), relu=False, groups=groups)
-        conv = (lambda m, t: conv3x3(m, t, packs)) if HIP_CONV3X3 else (lambda m, t: m(t))
+        conv = (lambda m, t: conv3x3(m, t, packs)) if (HIP_CONV3X3 if hip_conv is None else hip_conv) else (lambda m, t: m(t))
         out = bn_act(self.bn1, conv(self.conv1, x), groups=groups)
         return bn_act(self.bn2, conv(self.conv2, out), residual=identity, groups=groups)
 
@@ -79,11 +79,12 @@ class ResNet(nn.Module):
             x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
             x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         else:
-            packs = self._conv_packs(x) if HIP_CONV3X3 else None
+            use_hip = HIP_CONV3X3 if getattr(self, "hip_conv3x3", None) is None else self.hip_conv3x3      # per-network override
+            packs = self._conv_packs(x) if use_hip else None
             x = bn_relu_maxpool(self.bn1, self.conv1(x), groups=groups)
             for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
                 for block in layer:
-                    x = block(x, groups=groups, packs=packs)
+                    x = block(x, groups=groups, packs=packs, hip_conv=use_hip)
         return self.fc(torch.flatten(self.avgpool(x), 1))
 
 
