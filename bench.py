@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--sustained", type=int, default=200, help="extra steps timed after the K-step region (0: off)")
     ap.add_argument("--no-workloads", action="store_true", help="skip the other SURVEY 8(d) workloads (tools/workloads.py)")
     ap.add_argument("--workloads-only", action="store_true", help="only those workloads (the rocprofv3 command of profiles/)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the second measurement with --hip.conv3x3_split")
+    ap.add_argument("--alt-steps", type=int, default=60)
     ap.add_argument("--opt", action="append", default=[], help="extra option override(s), e.g. --opt=--hip.fused_backward!")
     return ap.parse_args()
 
@@ -200,6 +202,27 @@ def main():
             sdt = t.item()
         sustained = dict(steps=a.sustained, ms_per_step=round(sdt / a.sustained * 1e3, 3),
                          value=round(a.batch * world / (sdt / a.sustained), 2))
+    # Second measurement, NOT the headline: the same step with `--hip.conv3x3_split` (forward / backward-data products of the 3x3
+    # convolutions as exact three-piece bf16 splits on the bf16 matrix pipe, fp32 accumulate; error against float64 no larger than the
+    # fp32-MFMA kernels', tests/test_gpu_conv.py).  `value` above is measured with fp32 MFMA arithmetic throughout.
+    alt = None
+    if world == 1 and not a.no_alt and not any("conv3x3_split" in o for o in a.opt):
+        from shapeclipper_amd.model import resnet
+        resnet.HIP_CONV3X3_SPLIT = True
+        try:
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.time()
+            for _ in range(a.alt_steps):
+                step()
+            torch.cuda.synchronize()
+            adt = (time.time() - t1) / a.alt_steps
+            alt = dict(steps=a.alt_steps, ms_per_step=round(adt * 1e3, 3), value=round(a.batch / adt, 2),
+                       note="same step with --hip.conv3x3_split: 3x3 convolution forward/backward-data on the bf16 matrix pipe with exact "
+                            "3-piece operand splits (fp32-accurate, opt-in); not the headline")
+        finally:
+            resnet.HIP_CONV3X3_SPLIT = False
     allreduce = None
     if world > 1 and runner.reducer is not None:      # the step's only exchange: one flat all-reduce
         flat = runner.reducer.flat
@@ -274,6 +297,8 @@ def main():
                    sustained=sustained)
         if allreduce is not None:
             out["allreduce"] = allreduce
+        if alt is not None:
+            out["with_conv3x3_split"] = alt
         if not a.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks must not wait for rank 0)
             out["cpu_baseline"] = cpu_baseline(a.cpu_batch or a.batch)
         if not a.no_workloads and world == 1:

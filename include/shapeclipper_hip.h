@@ -329,6 +329,17 @@ int sc_conv3x3_pack(const float* w, float* w_pack, int cin, int cout, int hw, in
 int sc_conv3x3_forward(const float* x, const float* w_pack, float* out, float* workspace, int batch, int cin, int cout, int hw,
                        void* stream);
 
+/* The same convolution with fp32-ACCURATE products on the bf16 matrix pipe (opt-in, `--hip.conv3x3_split`): every operand is split
+ * exactly into three bf16 pieces (x = p0 + p1 + p2), the six products a_p b_q with p + q <= 2 are accumulated in fp32 (what is dropped
+ * is < 2^-23 |a||b| per product); 6 bf16 MFMAs replace 16 fp32-MFMA passes.  Same tensors and semantics as sc_conv3x3_forward; the
+ * filter image is written by sc_conv3x3_pack with bit 1 of transpose_flip set (or flags | 2 in a sc_conv3x3_pack_multi row) and has
+ * sc_conv3x3_pack_floats_split floats; tile width / workspace: the _split queries.                                                   */
+long long sc_conv3x3_pack_floats_split(int cin, int cout, int hw);
+long long sc_conv3x3_workspace_floats_split(int hw);
+int sc_conv3x3_tile_channels_split(int hw);
+int sc_conv3x3_forward_split(const float* x, const float* w_pack, float* out, float* workspace, int batch, int cin, int cout, int hw,
+                             void* stream);
+
 /* Weight gradient of the same convolution (csrc/conv3x3_wgrad.hip):  dw [cout][cin][3][3] = sum over the batch of gy (x) shifted x,
  * gy [batch][cout][hw][hw], x [batch][cin][hw][hw], fully overwritten, fixed summation order.  cin and cout must be multiples of 64
  * (otherwise hipErrorInvalidValue; sc_conv3x3_wgrad_workspace_floats returns -1): the caller keeps MIOpen for other shapes.

@@ -33,6 +33,8 @@
 namespace sc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 cv_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 cv_bf16x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lptr_cv_t;
 
 __device__ __forceinline__ void conv_glds16(const void* gsrc, unsigned lds_dst) {
@@ -41,18 +43,20 @@ __device__ __forceinline__ void conv_glds16(const void* gsrc, unsigned lds_dst) 
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-template <int W_, int CT_, int PT_, int WGM_, int WGN_>
+template <int W_, int CT_, int PT_, int WGM_, int WGN_, bool SPLIT_ = false>
 struct ConvCfg {
     static constexpr int W = W_, CT = CT_, PT = PT_, WGM = WGM_, WGN = WGN_, CB = 8;
+    static constexpr bool SPLIT = SPLIT_;            // operands as three bf16 pieces on the bf16 matrix pipe (see conv3x3 SPLIT below)
     static constexpr int Wp = W + 2, HW = W * W, Sp = Wp * Wp;
     static constexpr int NT = 64 * WGM * WGN;
     static constexpr int WM = CT / (32 * WGM), WN = PT / (32 * WGN);        // 32x32 MFMA tiles per wave
-    static constexpr int WIMG = 9 * CB * CT;                                 // floats of one weight stage: [tap][half][CT][4]
+    // floats (4-byte units) of one weight stage: fp32 [tap][half][CT][4]; SPLIT [tap pair (5)][piece (3)][half][CT][8 bf16]
+    static constexpr int WIMG = SPLIT ? 5 * 3 * 2 * CT * 4 : 9 * CB * CT;
     // longest padded-flat span of PT consecutive pixels plus the halo: 2 pad columns per row crossed, 2 pad rows per image crossed
     static constexpr int LMAX = PT + 2 * (PT / W + 2) + 2 * Wp * (PT / HW + 1) + 2 * (Wp + 1);
     static constexpr int LX = LMAX;                                          // positions per channel half
     static constexpr int NXE = (LMAX + NT - 1) / NT;                         // patch positions per thread
-    static constexpr int STAGE = WIMG + 2 * LX * 4;                          // floats
+    static constexpr int STAGE = WIMG + (SPLIT ? 3 : 2) * LX * 4;            // floats: patch [half][LX][4 fp32] or [piece][LX][8 bf16]
     static constexpr int LDS_BYTES = 2 * STAGE * 4;
     static constexpr int TILE = CT * PT;                                     // floats of one (partial) output tile
     static constexpr int WGS_PER_CU = NT == 512 ? 1 : 2;                     // 8 waves per CU either way
@@ -157,6 +161,10 @@ __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const flo
         }
 #pragma unroll
         for (int i = 0; i < WM; ++i) aoff[i] = (half * CT + (wm * WM + i) * 32 + (lane & 31)) * 4;
+        if constexpr (C::SPLIT) {       // the patch holds one 16-byte chunk (8 channels of one piece) per position: no half term
+#pragma unroll
+            for (int j = 0; j < WN; ++j) boff[j] -= half * LX * 4;
+        }
 
         const float* wsrc = wpack + (size_t)ct * nk * C::WIMG;              // [ct][kb][tap][half][CT][4]
         auto issue_w = [&](int kb, int stage) {
@@ -183,8 +191,24 @@ __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const flo
             for (int i = 0; i < NXE; ++i) {
                 const int e = tid + i * NT;
                 if (e < C::LMAX) {
-                    Xs[e] = make_float4(xv[i][0], xv[i][1], xv[i][2], xv[i][3]);
-                    Xs[LX + e] = make_float4(xv[i][4], xv[i][5], xv[i][6], xv[i][7]);
+                    if constexpr (C::SPLIT) {       // x = p0 + p1 + p2 exactly, each piece a bf16 (round to nearest even, residuals exact)
+                        cv_bf16x8 p0, p1, p2;
+#pragma unroll
+                        for (int c = 0; c < CB; ++c) {
+                            const float v = xv[i][c];
+                            const __bf16 h0 = (__bf16)v;
+                            const float r1 = v - (float)h0;
+                            const __bf16 h1 = (__bf16)r1;
+                            const float r2 = r1 - (float)h1;
+                            p0[c] = h0, p1[c] = h1, p2[c] = (__bf16)r2;
+                        }
+                        Xs[e] = __builtin_bit_cast(float4, p0);
+                        Xs[LX + e] = __builtin_bit_cast(float4, p1);
+                        Xs[2 * LX + e] = __builtin_bit_cast(float4, p2);
+                    } else {
+                        Xs[e] = make_float4(xv[i][0], xv[i][1], xv[i][2], xv[i][3]);
+                        Xs[LX + e] = make_float4(xv[i][4], xv[i][5], xv[i][6], xv[i][7]);
+                    }
                 }
             }
         };
@@ -207,6 +231,36 @@ __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const flo
             if (kb + 1 < kb1) { issue_w(kb + 1, st ^ 1); load_x(kb + 1); }
             const float* Ws = S + st * C::STAGE;
             const float* Xs = Ws + C::WIMG;
+            if constexpr (C::SPLIT) {
+                // k block of an MFMA (32x32x16): lane half h holds the 8 channels of tap 2 tp + h (tap 9: zero weights).  Per tap pair:
+                // WM + WN operand tiles x 3 pieces, six products a_p b_q with p + q <= 2 (what is dropped is < 2^-23 of |a||b|)
+                float4 a[WM][3], b[WN][3];
+#pragma unroll
+                for (int tp = 0; tp < 5; ++tp) {
+                    constexpr int DUMMY = 8;                                   // the 10th "tap" reads tap 8's patch values (finite), weights 0
+                    const int t0 = 2 * tp, t1 = 2 * tp + 1 < 9 ? 2 * tp + 1 : DUMMY;
+                    const int o0 = (t0 / 3) * Wp + t0 % 3, o1 = (t1 / 3) * Wp + t1 % 3;
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc) a[i][pc] = *reinterpret_cast<const float4*>(Ws + aoff[i] + (tp * 3 + pc) * 2 * CT * 4);
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc)
+                            b[j][pc] = *reinterpret_cast<const float4*>(Xs + boff[j] + (pc * LX + o0) * 4 + half * (o1 - o0) * 4);
+#pragma unroll
+                    for (int term = 0; term < 6; ++term) {
+                        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};      // small terms first
+#pragma unroll
+                        for (int i = 0; i < WM; ++i)
+#pragma unroll
+                            for (int j = 0; j < WN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cv_bf16x8, a[i][PA[term]]),
+                                                                                    __builtin_bit_cast(cv_bf16x8, b[j][PB[term]]), acc[i][j], 0, 0, 0);
+                    }
+                }
+            } else {
             float4 a[2][WM], b[2][WN];
             auto frags = [&](int tap, float4 (&a2)[WM], float4 (&b2)[WN]) {
 #pragma unroll
@@ -228,6 +282,7 @@ __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const flo
                             const float bv = s == 0 ? b[tap & 1][j].x : s == 1 ? b[tap & 1][j].y : s == 2 ? b[tap & 1][j].z : b[tap & 1][j].w;
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
                         }
+            }
             }
             if (kb + 1 < kb1) store_x(st ^ 1);
         }
@@ -296,25 +351,62 @@ __global__ __launch_bounds__(C::NT) void conv3x3_fixup_kernel(const float* __res
 
 // w [cout][cin][3][3] -> w_pack [ct][kb][tap][half][CT][4]: element (co = ct CT + cl, ci = 8 kb + 4 half + s).  transpose_flip: the filter
 // of the backward-data pass, w'[ci][co][ky][kx] = w[co][ci][2 - ky][2 - kx] (`cin` / `cout` are the channel counts of THAT convolution).
-template <class C>
-__global__ void conv3x3_pack_kernel(const float* __restrict__ w, float* __restrict__ wpack, int cin, int cout, int transpose_flip) {
-    const int nk = cin / C::CB, nct = (cout + C::CT - 1) / C::CT;
-    const long long total = (long long)nct * nk * C::WIMG;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int s = (int)(i & 3);
-        long long t = i >> 2;
-        const int cl = (int)(t % C::CT);
-        t /= C::CT;
+// value of filter element (co, ci, tap) in the orientation of this pass
+__device__ __forceinline__ float conv_w_at(const float* __restrict__ w, int cin, int cout, int co, int ci, int tap, int transpose_flip) {
+    return transpose_flip ? w[((size_t)ci * cout + co) * 9 + (8 - tap)] : w[((size_t)co * cin + ci) * 9 + tap];
+}
+// piece pc (0, 1, 2) of the exact three-way bf16 split v = p0 + p1 + p2
+__device__ __forceinline__ unsigned conv_bf16_piece(float v, int pc) {
+    const __bf16 h0 = (__bf16)v;
+    const float r1 = v - (float)h0;
+    const __bf16 h1 = (__bf16)r1;
+    const __bf16 h2 = (__bf16)(r1 - (float)h1);
+    const __bf16 h = pc == 0 ? h0 : pc == 1 ? h1 : h2;
+    return (unsigned)__builtin_bit_cast(unsigned short, h);
+}
+// one 4-byte word of a packed filter image.  fp32: [tap][half][CT][4]: element (co = ct CT + cl, ci = 8 kb + 4 half + s).
+// split: [tap pair][piece][half][CT][8 bf16]: lane half h of tap pair tp holds tap 2 tp + h (tap 9 = zeros), channels 8 kb .. 8 kb + 7.
+__device__ __forceinline__ float conv_pack_word(const float* __restrict__ w, long long t, int CT, int nk, int cin, int cout, int flip,
+                                                bool split) {
+    if (!split) {
+        const int s4 = (int)(t & 3);
+        t >>= 2;
+        const int cl = (int)(t % CT);
+        t /= CT;
         const int h = (int)(t & 1);
         t >>= 1;
         const int tap = (int)(t % 9);
         t /= 9;
         const int kb = (int)(t % nk), ct = (int)(t / nk);
-        const int ci = kb * C::CB + 4 * h + s, co = ct * C::CT + cl;
-        float v = 0.f;
-        if (co < cout) v = transpose_flip ? w[((size_t)ci * cout + co) * 9 + (8 - tap)] : w[((size_t)co * cin + ci) * 9 + tap];
-        wpack[i] = v;
+        const int ci = kb * 8 + 4 * h + s4, co = ct * CT + cl;
+        return co < cout ? conv_w_at(w, cin, cout, co, ci, tap, flip) : 0.f;
     }
+    const int wi = (int)(t & 3);
+    t >>= 2;
+    const int cl = (int)(t % CT);
+    t /= CT;
+    const int h = (int)(t & 1);
+    t >>= 1;
+    const int pc = (int)(t % 3);
+    t /= 3;
+    const int tp = (int)(t % 5);
+    t /= 5;
+    const int kb = (int)(t % nk), ct = (int)(t / nk);
+    const int tap = 2 * tp + h, co = ct * CT + cl, ci = kb * 8 + 2 * wi;
+    unsigned lo = 0, hi = 0;
+    if (tap < 9 && co < cout) {
+        lo = conv_bf16_piece(conv_w_at(w, cin, cout, co, ci, tap, flip), pc);
+        hi = conv_bf16_piece(conv_w_at(w, cin, cout, co, ci + 1, tap, flip), pc);
+    }
+    return __uint_as_float(lo | (hi << 16));
+}
+
+template <class C>
+__global__ void conv3x3_pack_kernel(const float* __restrict__ w, float* __restrict__ wpack, int cin, int cout, int transpose_flip) {
+    const int nk = cin / C::CB, nct = (cout + C::CT - 1) / C::CT;
+    const long long total = (long long)nct * nk * C::WIMG;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+        wpack[i] = conv_pack_word(w, i, C::CT, nk, cin, cout, transpose_flip, C::SPLIT);
 }
 
 // Tile shapes (measured, tools/perf_conv.py): 8 waves of 64 x 64 each.  Four-wave workgroups, two per CU (NT = 256: 64 x 256 tiles) reach
@@ -324,6 +416,11 @@ using Conv56 = ConvCfg<56, 64, 512, 1, 8>;       // 64 channels: the tile spans 
 using Conv28 = ConvCfg<28, 128, 256, 2, 4>;
 using Conv14 = ConvCfg<14, 128, 256, 2, 4>;
 using Conv7 = ConvCfg<7, 128, 128, 2, 4>;
+// SPLIT (fp32-accurate products on the bf16 matrix pipe): 64 channels x 512 pixels, 8 waves of 64 x 64
+using Conv56S = ConvCfg<56, 64, 512, 1, 8, true>;
+using Conv28S = ConvCfg<28, 64, 512, 1, 8, true>;
+using Conv14S = ConvCfg<14, 64, 512, 1, 8, true>;
+using Conv7S = ConvCfg<7, 64, 256, 1, 8, true>;
 
 template <class C>
 static long long pack_floats(int cin, int cout) { return cin % C::CB ? -1 : (long long)((cout + C::CT - 1) / C::CT) * (cin / C::CB) * C::WIMG; }
@@ -342,22 +439,8 @@ __global__ void conv3x3_pack_multi_kernel(const long long* __restrict__ table_g,
         }
         const long long* row = table + lo * 6;
         const float* w = reinterpret_cast<const float*>(row[0]);
-        const int cin = (int)row[2], cout = (int)row[3], CT = (int)row[4], flip = (int)row[5];
-        const int nk = cin / 8;
-        long long t = i - row[1];
-        const int s4 = (int)(t & 3);
-        t >>= 2;
-        const int cl = (int)(t % CT);
-        t /= CT;
-        const int h = (int)(t & 1);
-        t >>= 1;
-        const int tap = (int)(t % 9);
-        t /= 9;
-        const int kb = (int)(t % nk), ct = (int)(t / nk);
-        const int ci = kb * 8 + 4 * h + s4, co = ct * CT + cl;
-        float v = 0.f;
-        if (co < cout) v = flip ? w[((size_t)ci * cout + co) * 9 + (8 - tap)] : w[((size_t)co * cin + ci) * 9 + tap];
-        dst[i] = v;
+        const int cin = (int)row[2], cout = (int)row[3], CT = (int)row[4], flags = (int)row[5];     // flags: 1 transpose_flip, 2 split
+        dst[i] = conv_pack_word(w, i - row[1], CT, cin / 8, cin, cout, flags & 1, (flags & 2) != 0);
     }
 }
 
@@ -403,6 +486,37 @@ static int launch_conv(const float* x, const float* wpack, float* out, float* wo
         default: return -1;                          \
     }
 
+#define SC_CONV_DISPATCH_SPLIT(hw, CALL)              \
+    switch (hw) {                                    \
+        case 56: return CALL(sc::Conv56S);           \
+        case 28: return CALL(sc::Conv28S);           \
+        case 14: return CALL(sc::Conv14S);           \
+        case 7: return CALL(sc::Conv7S);             \
+        default: return -1;                          \
+    }
+
+extern "C" long long sc_conv3x3_pack_floats_split(int cin, int cout, int hw) {
+#define CALL(C) sc::pack_floats<C>(cin, cout)
+    SC_CONV_DISPATCH_SPLIT(hw, CALL)
+#undef CALL
+}
+extern "C" long long sc_conv3x3_workspace_floats_split(int hw) {
+#define CALL(C) sc::workspace_floats<C>()
+    SC_CONV_DISPATCH_SPLIT(hw, CALL)
+#undef CALL
+}
+extern "C" int sc_conv3x3_tile_channels_split(int hw) {
+#define CALL(C) C::CT
+    SC_CONV_DISPATCH_SPLIT(hw, CALL)
+#undef CALL
+}
+extern "C" int sc_conv3x3_forward_split(const float* x, const float* w_pack, float* out, float* workspace, int batch, int cin, int cout,
+                                        int hw, void* stream) {
+#define CALL(C) sc::launch_conv<C>(x, w_pack, out, workspace, batch, cin, cout, (hipStream_t)stream)
+    SC_CONV_DISPATCH_SPLIT(hw, CALL)
+#undef CALL
+}
+
 extern "C" long long sc_conv3x3_pack_floats(int cin, int cout, int hw) {
 #define CALL(C) sc::pack_floats<C>(cin, cout)
     SC_CONV_DISPATCH(hw, CALL)
@@ -431,7 +545,12 @@ extern "C" int sc_conv3x3_pack_multi(const long long* table, int n, float* dst, 
 }
 
 extern "C" int sc_conv3x3_pack(const float* w, float* w_pack, int cin, int cout, int hw, int transpose_flip, void* stream) {
-#define CALL(C) sc::launch_pack<C>(w, w_pack, cin, cout, transpose_flip, (hipStream_t)stream)
+    if (transpose_flip & 2) {           /* bit 1: the three-piece bf16 image of sc_conv3x3_forward_split */
+#define CALL(C) sc::launch_pack<C>(w, w_pack, cin, cout, transpose_flip & 1, (hipStream_t)stream)
+        SC_CONV_DISPATCH_SPLIT(hw, CALL)
+#undef CALL
+    }
+#define CALL(C) sc::launch_pack<C>(w, w_pack, cin, cout, transpose_flip & 1, (hipStream_t)stream)
     SC_CONV_DISPATCH(hw, CALL)
 #undef CALL
 }

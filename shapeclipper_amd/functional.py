@@ -214,15 +214,17 @@ def bn_relu_maxpool(bn, x, groups=1):
 class Conv3x3Function(torch.autograd.Function):
     """F.conv2d(x, w, None, 1, 1) for the 3x3 / stride-1 layers of the ResNet trunks on csrc/conv3x3.hip (fp32 matrix pipe): forward
     and backward-data are the same kernel (the latter with the transposed, flipped filter); the weight gradient is conv3x3_wgrad.hip.
-    pack_f / pack_b: the kernel-ready images of w from a Conv3x3PackSet (None: packed here, two extra launches)."""
+    pack_f / pack_b: the kernel-ready images of w from a Conv3x3PackSet (None: packed here, two extra launches).
+    split: forward / backward-data with fp32-accurate products on the bf16 matrix pipe (sc_conv3x3_forward_split)."""
 
     @staticmethod
-    def forward(ctx, x, w, pack_f, pack_b):
+    def forward(ctx, x, w, pack_f, pack_b, split):
         x = ops._aligned(x)
         ctx.save_for_backward(x, w, pack_b)
+        ctx.split = split
         if pack_f is None:
-            pack_f = ops.conv3x3_pack(w, x.shape[2])
-        return ops.conv3x3_apply(x, pack_f, w.shape[0])
+            pack_f = ops.conv3x3_pack(w, x.shape[2], False, split)
+        return ops.conv3x3_apply(x, pack_f, w.shape[0], split)
 
     @staticmethod
     def backward(ctx, gy):
@@ -230,14 +232,14 @@ class Conv3x3Function(torch.autograd.Function):
         gy = ops._aligned(gy)
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = ops.conv3x3_apply(gy, pack_b if pack_b is not None else ops.conv3x3_pack(w, x.shape[2], True), w.shape[1])
+            gx = ops.conv3x3_apply(gy, pack_b if pack_b is not None else ops.conv3x3_pack(w, x.shape[2], True, ctx.split), w.shape[1], ctx.split)
         gw = None
         if ctx.needs_input_grad[1]:
             if ops.conv3x3_wgrad_supported(x.shape, w.shape):
                 gw = ops.conv3x3_backward_weight(gy, x)
             else:           # channel counts that are not multiples of 64: MIOpen
                 gw = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
-        return gx, gw, None, None
+        return gx, gw, None, None, None
 
 
 def conv3x3_takes(conv, x):
@@ -251,8 +253,8 @@ def conv3x3(conv, x, packs=None):
     if not conv3x3_takes(conv, x):
         return conv(x)
     if packs is not None and id(conv.weight) in packs.index:
-        return Conv3x3Function.apply(x, conv.weight, packs.get(conv.weight, 0), packs.get(conv.weight, 1))
-    return Conv3x3Function.apply(x, conv.weight, None, None)
+        return Conv3x3Function.apply(x, conv.weight, packs.get(conv.weight, 0), packs.get(conv.weight, 1), packs.split)
+    return Conv3x3Function.apply(x, conv.weight, None, None, False)
 
 
 class CameraRaysFunction(torch.autograd.Function):

@@ -13,6 +13,7 @@ from ..functional import bn_act, bn_relu_maxpool, conv3x3
 
 FUSED_BN = True
 HIP_CONV3X3 = True       # 3x3 / stride-1 convolutions on csrc/conv3x3.hip (`--hip.conv3x3!` keeps them on MIOpen)
+HIP_CONV3X3_SPLIT = False  # `--hip.conv3x3_split`: their forward / backward-data products on the bf16 matrix pipe (three-piece exact split)
 
 
 class BasicBlock(nn.Module):
@@ -94,7 +95,7 @@ def _conv_packs(self, x):
     from .. import ops
     if not (x.is_cuda and x.dtype == torch.float32 and x.shape[2] == x.shape[3]):
         return None
-    key = (x.shape[2], x.device.index)
+    key = (x.shape[2], x.device.index, HIP_CONV3X3_SPLIT)
     cache = self.__dict__.setdefault("_pack_cache", {})
     packs = cache.get(key)
     if packs is None or (packs and packs.stale()):
@@ -107,7 +108,7 @@ def _conv_packs(self, x):
                 for conv in ((block.conv2,) if block.conv1.stride != (1, 1) else (block.conv1, block.conv2)):
                     if ops.conv3x3_supported((1, conv.in_channels, side, side), conv.weight.shape, conv.stride, conv.padding) and conv.bias is None:
                         items.append((conv.weight, side))
-        packs = cache[key] = ops.Conv3x3PackSet(items) if items else False
+        packs = cache[key] = ops.Conv3x3PackSet(items, split=HIP_CONV3X3_SPLIT) if items else False
     if packs:
         packs.refresh()
     return packs or None

@@ -576,55 +576,60 @@ def conv3x3_supported(x_shape, w_shape, stride=1, padding=1) -> bool:
             and w_shape[0] % 8 == 0 and w_shape[1] % 8 == 0)
 
 
-def conv3x3_pack(w, side, transpose_flip=False):
-    """Kernel-ready weight image of w [Cout, Cin, 3, 3] for `side` x `side` maps (transpose_flip: the backward-data filter)."""
+def conv3x3_pack(w, side, transpose_flip=False, split=False):
+    """Kernel-ready weight image of w [Cout, Cin, 3, 3] for `side` x `side` maps (transpose_flip: the backward-data filter;
+    split: the three-piece bf16 image of sc_conv3x3_forward_split)."""
     lib = _lib.load()
     w = _aligned(w)
     cin, cout = (w.shape[0], w.shape[1]) if transpose_flip else (w.shape[1], w.shape[0])
-    n = lib.sc_conv3x3_pack_floats(cin, cout, side)
+    n = (lib.sc_conv3x3_pack_floats_split if split else lib.sc_conv3x3_pack_floats)(cin, cout, side)
     if n < 0:
         raise RuntimeError("shapeclipper_amd: sc_conv3x3 does not take %dx%d maps with a %s filter" % (side, side, tuple(w.shape)))
     w_pack = torch.empty(n, device=w.device, dtype=torch.float32)
-    _lib.check(lib.sc_conv3x3_pack(_lib.ptr(w), _lib.ptr(w_pack), cin, cout, side, int(transpose_flip), _lib.stream()), "sc_conv3x3_pack")
+    _lib.check(lib.sc_conv3x3_pack(_lib.ptr(w), _lib.ptr(w_pack), cin, cout, side, int(transpose_flip) | (2 if split else 0), _lib.stream()),
+               "sc_conv3x3_pack")
     return w_pack
 
 
 _conv_ws = {}
 
 
-def _conv_workspace(dev, side):
+def _conv_workspace(dev, side, split=False):
     """Scratch for the partial tiles of sc_conv3x3_forward, one per (device, stream, map side): calls on a stream are ordered."""
-    key = (dev.index, torch.cuda.current_stream().cuda_stream, side)
+    key = (dev.index, torch.cuda.current_stream().cuda_stream, side, split)
     ws = _conv_ws.get(key)
     if ws is None:
-        ws = _conv_ws[key] = torch.empty(_lib.load().sc_conv3x3_workspace_floats(side), device=dev, dtype=torch.float32)
+        lib = _lib.load()
+        n = (lib.sc_conv3x3_workspace_floats_split if split else lib.sc_conv3x3_workspace_floats)(side)
+        ws = _conv_ws[key] = torch.empty(n, device=dev, dtype=torch.float32)
     return ws
 
 
-def conv3x3_apply(x, w_pack, cout):
+def conv3x3_apply(x, w_pack, cout, split=False):
     lib = _lib.load()
     x = _aligned(x)
     B, cin, H, _ = x.shape
     out = torch.empty(B, cout, H, H, device=x.device, dtype=torch.float32)
-    _lib.check(lib.sc_conv3x3_forward(_lib.ptr(x), _lib.ptr(w_pack), _lib.ptr(out), _lib.ptr(_conv_workspace(x.device, H)), B, cin, cout, H,
-                                      _lib.stream()), "sc_conv3x3_forward")
+    fn = lib.sc_conv3x3_forward_split if split else lib.sc_conv3x3_forward
+    _lib.check(fn(_lib.ptr(x), _lib.ptr(w_pack), _lib.ptr(out), _lib.ptr(_conv_workspace(x.device, H, split)), B, cin, cout, H, _lib.stream()),
+               "sc_conv3x3_forward")
     return out
 
 
-def _conv3x3(x, w, transpose_flip):
+def _conv3x3(x, w, transpose_flip, split=False):
     if x.dim() != 4 or x.shape[2] != x.shape[3]:
         raise RuntimeError("shapeclipper_amd: sc_conv3x3 needs square NCHW maps, got %s" % (tuple(x.shape),))
-    return conv3x3_apply(x, conv3x3_pack(w, x.shape[2], transpose_flip), w.shape[1] if transpose_flip else w.shape[0])
+    return conv3x3_apply(x, conv3x3_pack(w, x.shape[2], transpose_flip, split), w.shape[1] if transpose_flip else w.shape[0], split)
 
 
-def conv3x3_forward(x, w):
-    """F.conv2d(x, w, None, 1, 1) for x [B, Cin, H, H], w [Cout, Cin, 3, 3]."""
-    return _conv3x3(x, w, False)
+def conv3x3_forward(x, w, split=False):
+    """F.conv2d(x, w, None, 1, 1) for x [B, Cin, H, H], w [Cout, Cin, 3, 3].  split: fp32-accurate products on the bf16 matrix pipe."""
+    return _conv3x3(x, w, False, split)
 
 
-def conv3x3_backward_data(gy, w):
+def conv3x3_backward_data(gy, w, split=False):
     """dL/dx of the above from gy [B, Cout, H, H]: the same kernel with the transposed, flipped filter."""
-    return _conv3x3(gy, w, True)
+    return _conv3x3(gy, w, True, split)
 
 
 def conv3x3_wgrad_supported(x_shape, w_shape, stride=1, padding=1) -> bool:
@@ -654,8 +659,9 @@ class Conv3x3PackSet:
     (sc_conv3x3_pack_multi): the filters of a network change once per optimizer step, so a trunk refreshes its set once per pass
     instead of packing twice per layer.  `items`: [(weight [Cout, Cin, 3, 3], map side)]."""
 
-    def __init__(self, items):
+    def __init__(self, items, split=False):
         lib = _lib.load()
+        self.split = bool(split)
         self.weights = [w for w, _ in items]
         self.ptrs = [w.data_ptr() for w in self.weights]
         rows, off, self.where = [], 0, {}
@@ -664,10 +670,11 @@ class Conv3x3PackSet:
                 raise RuntimeError("shapeclipper_amd: Conv3x3PackSet needs contiguous fp32 device filters")
             for flip in (0, 1):
                 cin, cout = (w.shape[0], w.shape[1]) if flip else (w.shape[1], w.shape[0])
-                n = lib.sc_conv3x3_pack_floats(cin, cout, side)
+                n = (lib.sc_conv3x3_pack_floats_split if split else lib.sc_conv3x3_pack_floats)(cin, cout, side)
                 if n < 0:
                     raise RuntimeError("shapeclipper_amd: sc_conv3x3 does not take %dx%d maps with a %s filter" % (side, side, tuple(w.shape)))
-                rows.append([w.data_ptr(), off, cin, cout, lib.sc_conv3x3_tile_channels(side), flip])
+                ct = (lib.sc_conv3x3_tile_channels_split if split else lib.sc_conv3x3_tile_channels)(side)
+                rows.append([w.data_ptr(), off, cin, cout, ct, flip | (2 if split else 0)])
                 self.where[(k, flip)] = (off, n)
                 off += n
         if len(rows) > 128:

@@ -44,8 +44,10 @@ def test_conv3x3_rejects_other_shapes():
         ops.conv3x3_forward(x, torch.randn(64, 64, 3, 3, device="cuda:0"))
 
 
-def test_resnet34_hip_convolutions_equal_miopen():
-    """The whole trunk, forward and backward, with the 3x3 / stride-1 layers on csrc/conv3x3.hip vs on MIOpen (resnet.HIP_CONV3X3)."""
+@pytest.mark.parametrize("split", [False, True])
+def test_resnet34_hip_convolutions_equal_miopen(split):
+    """The whole trunk, forward and backward, with the 3x3 / stride-1 layers on csrc/conv3x3.hip vs on MIOpen (resnet.HIP_CONV3X3);
+    split: their forward / backward-data products on the bf16 matrix pipe (resnet.HIP_CONV3X3_SPLIT)."""
     import copy
     from shapeclipper_amd.model import resnet
     torch.manual_seed(5)
@@ -53,7 +55,7 @@ def test_resnet34_hip_convolutions_equal_miopen():
     x = torch.randn(6, 3, 224, 224, device="cuda")
     res = []
     for hip in (False, True):
-        resnet.HIP_CONV3X3 = hip
+        resnet.HIP_CONV3X3, resnet.HIP_CONV3X3_SPLIT = hip, hip and split
         try:
             m = copy.deepcopy(net)
             xi = x.clone().requires_grad_(True)
@@ -62,11 +64,11 @@ def test_resnet34_hip_convolutions_equal_miopen():
             res.append((y.detach(), xi.grad.clone(), m.conv1.weight.grad.clone(), m.layer1[0].conv1.weight.grad.clone(),
                         m.layer3[2].conv2.weight.grad.clone(), m.layer4[2].conv2.weight.grad.clone()))
         finally:
-            resnet.HIP_CONV3X3 = True
+            resnet.HIP_CONV3X3, resnet.HIP_CONV3X3_SPLIT = True, False
     for a, b, name in zip(res[1], res[0], ("logits", "d input", "d conv1.weight", "d layer1.0.conv1.weight", "d layer3.2.conv2.weight",
                                            "d layer4.2.conv2.weight")):
         rel = float((a - b).norm() / b.norm().clamp_min(1e-12))
-        print("resnet34 hip-conv vs MIOpen, %s: relative L2 difference %.2e" % (name, rel))
+        print("resnet34 hip-conv%s vs MIOpen, %s: relative L2 difference %.2e" % (" (bf16 split)" if split else "", name, rel))
         # 33 BN layers deep with 2 images per BN group: rounding differences (and the odd ReLU-kink flip) are amplified on the way back
         assert rel < (1e-4 if name == "logits" else 3e-2), name
 
@@ -103,3 +105,23 @@ def test_conv3x3_backward_weight(side, cin, cout, batch):
     print("conv3x3 wgrad %dx%d %d>%d B=%d: %.2e of max (torch/MIOpen: %.2e)" % (side, side, cin, cout, batch, e_hip, e_torch))
     assert e_hip < 2e-5
     assert torch.equal(dw, ops.conv3x3_backward_weight(gy, x))          # fixed summation order
+
+
+@pytest.mark.parametrize("side,cin,cout,batch", [(56, 64, 64, 3), (28, 128, 128, 5), (14, 256, 256, 7), (7, 512, 512, 13), (7, 512, 512, 1),
+                                                  (14, 64, 128, 2), (28, 64, 72, 1), (56, 8, 64, 1)])
+def test_conv3x3_split_bf16_is_fp32_accurate(side, cin, cout, batch):
+    """--hip.conv3x3_split: three-piece bf16 operands, six products, fp32 accumulate.  The bar is the fp32 kernels' own: 2e-5 of the
+    output scale against float64, and no worse than 2x the fp32-MFMA kernel's error on the same tensors (printed)."""
+    from shapeclipper_amd import ops
+    torch.manual_seed(side + cin + batch)
+    dev = torch.device("cuda:0")
+    x = torch.randn(batch, cin, side, side, device=dev) * torch.rand(batch, cin, 1, 1, device=dev) * 4       # mixed magnitudes
+    w = torch.randn(cout, cin, 3, 3, device=dev) * (2.0 / (9 * cin)) ** 0.5
+    y64 = torch.nn.functional.conv2d(x.double(), w.double(), None, 1, 1)
+    e_fp32 = _rel(ops.conv3x3_forward(x, w).double(), y64)
+    e_split = _rel(ops.conv3x3_forward(x, w, split=True).double(), y64)
+    gy = torch.randn_like(y64, dtype=torch.float32)
+    gx64 = torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), 1, 1)
+    e_bwd = _rel(ops.conv3x3_backward_data(gy, w, split=True).double(), gx64)
+    print("conv3x3 split %dx%d %d>%d B=%d: forward %.2e of max (fp32 MFMA kernel %.2e), backward-data %.2e" % (side, side, cin, cout, batch, e_split, e_fp32, e_bwd))
+    assert e_split < 2e-5 and e_bwd < 2e-5 and e_split < 2 * e_fp32 + 2e-7

@@ -50,6 +50,7 @@ def time_fn(fn, iters=20):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--hip", action="store_true")
+    ap.add_argument("--split", action="store_true", help="also time the bf16-split forward kernel")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
@@ -85,6 +86,10 @@ def main():
                 t_hf = time_fn(lambda: hip_conv.conv3x3_apply(xd, wp_f, co))
                 t_hd = time_fn(lambda: hip_conv.conv3x3_apply(gy, wp_b, ci))
                 line += " | hip pack %6.3f fwd %7.3f (%5.1f TF/s) bwdD %7.3f (%5.1f)" % (t_pk, t_hf, flop / t_hf / 1e9, t_hd, flop / t_hd / 1e9)
+                if args.split:
+                    ws_f = hip_conv.conv3x3_pack(wd, h, False, True)
+                    t_sf = time_fn(lambda: hip_conv.conv3x3_apply(xd, ws_f, co, True))
+                    line += " split fwd %7.3f (%5.1f)" % (t_sf, flop / t_sf / 1e9)
                 if hip_conv.conv3x3_wgrad_supported(x.shape, w.shape):
                     t_hw = time_fn(lambda: hip_conv.conv3x3_backward_weight(gy, xd))
                     line += " bwdW %7.3f (%5.1f)" % (t_hw, flop / t_hw / 1e9)
