@@ -7,7 +7,7 @@ mkdir -p $O
 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | grep -E "passed|failed|Error" | tail -3 > $O/gputest.log
 python tools/perf_conv.py --hip 2>&1 | grep -v -i "warn\|amdgpu" > $O/conv_layers.txt
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bench -o bench -- python $R/bench.py --no-workloads --no-cpu-baseline --sustained 0 --steps 10 > $O/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bench -o bench -- python $R/bench.py --no-workloads --no-cpu-baseline --no-alt --sustained 0 --steps 10 > $O/bench_under_rocprof.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_wl -o wl -- python $R/bench.py --workloads-only --no-cpu-baseline > $O/workloads_under_rocprof.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch -o f -- python $R/tools/perf_render.py --B 32 --iters 1 --yaml $R/options/pix3d/config.yaml > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/p_write -o w -- python $R/tools/perf_render.py --B 32 --iters 1 --yaml $R/options/pix3d/config.yaml > /dev/null 2>&1
