@@ -12,6 +12,10 @@ import gc
 if mode == ['nogc']:
     gc.collect(); gc.freeze(); gc.disable()
 ts = []
+mem = []
 for i in range(40):
     torch.cuda.synchronize(); t0 = time.time(); step(); torch.cuda.synchronize(); ts.append((time.time() - t0) * 1e3)
+    st = torch.cuda.memory_stats()
+    mem.append((st["reserved_bytes.all.current"] >> 20, st["segment.all.allocated"], st["num_device_alloc"] if "num_device_alloc" in st else -1))
 print(" ".join("%.1f" % t for t in ts))
+print("reserved MiB / segments allocated / device allocs per step:", " ".join("%d/%d/%d" % m for m in mem))
