@@ -347,6 +347,14 @@ int sc_conv3x3_forward_split(const float* x, const float* w_pack, float* out, fl
 long long sc_conv3x3_wgrad_workspace_floats(int cin, int cout);
 int sc_conv3x3_wgrad(const float* gy, const float* x, float* dw, float* workspace, int batch, int cin, int cout, int hw, void* stream);
 
+/* The stem of the trunks (torchvision ResNet.conv1: 7x7 / stride 2 / pad 3, 3 -> 64 channels, 224 x 224 inputs only; csrc/conv_stem.hip):
+ *   sc_conv_stem_forward   out [batch][64][112][112] = conv(x [batch][3][224][224], w [64][3][7][7]), fully overwritten
+ *   sc_conv_stem_wgrad     dw [64][3][7][7] = weight gradient from gy [batch][64][112][112] and x, fixed summation order;
+ *                          workspace: sc_conv_stem_wgrad_workspace_floats() floats.  (The input is data: no backward-data.)          */
+long long sc_conv_stem_wgrad_workspace_floats(void);
+int sc_conv_stem_forward(const float* x, const float* w, float* out, int batch, void* stream);
+int sc_conv_stem_wgrad(const float* gy, const float* x, float* dw, float* workspace, int batch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

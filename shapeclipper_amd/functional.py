@@ -242,6 +242,35 @@ class Conv3x3Function(torch.autograd.Function):
         return gx, gw, None, None, None
 
 
+class ConvStemFunction(torch.autograd.Function):
+    """ResNet.conv1 (7x7 / 2, 3 -> 64, 224 x 224 inputs) on csrc/conv_stem.hip: forward and weight gradient; the input is data, a
+    requested input gradient falls back to MIOpen's backward-data."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        x = ops._aligned(x)
+        ctx.save_for_backward(x, w)
+        return ops.conv_stem_forward(x, w)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = ops._aligned(gy)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.ops.aten.convolution_backward(gy, x, w, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        gw = ops.conv_stem_backward_weight(gy, x) if ctx.needs_input_grad[1] else None
+        return gx, gw
+
+
+def conv_stem(conv, x):
+    """nn.Conv2d `conv` (the ResNet stem) applied to x through the HIP kernel when the shapes are the ones it takes."""
+    if (x.is_cuda and x.dtype == torch.float32 and conv.bias is None and conv.groups == 1 and conv.dilation == (1, 1)
+            and ops.conv_stem_supported(x.shape, conv.weight.shape, conv.stride, conv.padding)):
+        return ConvStemFunction.apply(x, conv.weight)
+    return conv(x)
+
+
 def conv3x3_takes(conv, x):
     return (x.is_cuda and x.dtype == torch.float32 and conv.bias is None and conv.groups == 1 and conv.dilation == (1, 1)
             and ops.conv3x3_supported(x.shape, conv.weight.shape, conv.stride, conv.padding))

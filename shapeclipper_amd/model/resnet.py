@@ -9,10 +9,11 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from ..functional import bn_act, bn_relu_maxpool, conv3x3
+from ..functional import bn_act, bn_relu_maxpool, conv3x3, conv_stem
 
 FUSED_BN = True
 HIP_CONV3X3 = True       # 3x3 / stride-1 convolutions on csrc/conv3x3.hip (`--hip.conv3x3!` keeps them on MIOpen)
+HIP_CONV_STEM = True      # the 7x7 / 2 stem on csrc/conv_stem.hip (`--hip.conv_stem!` keeps it on MIOpen)
 HIP_CONV3X3_SPLIT = False  # `--hip.conv3x3_split`: their forward / backward-data products on the bf16 matrix pipe (three-piece exact split)
 
 
@@ -82,7 +83,7 @@ class ResNet(nn.Module):
         else:
             use_hip = HIP_CONV3X3 if getattr(self, "hip_conv3x3", None) is None else self.hip_conv3x3      # per-network override
             packs = self._conv_packs(x) if use_hip else None
-            x = bn_relu_maxpool(self.bn1, self.conv1(x), groups=groups)
+            x = bn_relu_maxpool(self.bn1, conv_stem(self.conv1, x) if HIP_CONV_STEM else self.conv1(x), groups=groups)
             for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
                 for block in layer:
                     x = block(x, groups=groups, packs=packs, hip_conv=use_hip)

@@ -654,6 +654,31 @@ def conv3x3_backward_weight(gy, x):
     return dw
 
 
+def conv_stem_supported(x_shape, w_shape, stride=2, padding=3) -> bool:
+    """Shapes sc_conv_stem_* take: [B, 3, 224, 224] inputs, a [64, 3, 7, 7] filter, stride 2, pad 3."""
+    return (tuple(x_shape[1:]) == (3, 224, 224) and tuple(w_shape) == (64, 3, 7, 7) and stride in (2, (2, 2)) and padding in (3, (3, 3)))
+
+
+def conv_stem_forward(x, w):
+    lib = _lib.load()
+    x, w = _aligned(x), _aligned(w)
+    out = torch.empty(x.shape[0], 64, 112, 112, device=x.device, dtype=torch.float32)
+    _lib.check(lib.sc_conv_stem_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(out), x.shape[0], _lib.stream()), "sc_conv_stem_forward")
+    return out
+
+
+def conv_stem_backward_weight(gy, x):
+    lib = _lib.load()
+    gy, x = _aligned(gy), _aligned(x)
+    key = (x.device.index, torch.cuda.current_stream().cuda_stream, "stem")
+    ws = _conv_ws.get(key)
+    if ws is None:
+        ws = _conv_ws[key] = torch.empty(lib.sc_conv_stem_wgrad_workspace_floats(), device=x.device, dtype=torch.float32)
+    dw = torch.empty(64, 3, 7, 7, device=x.device, dtype=torch.float32)
+    _lib.check(lib.sc_conv_stem_wgrad(_lib.ptr(gy), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(ws), x.shape[0], _lib.stream()), "sc_conv_stem_wgrad")
+    return dw
+
+
 class Conv3x3PackSet:
     """Kernel-ready filter images (forward and backward-data orientation) of MANY 3x3 / stride-1 convolutions, rewritten by ONE launch
     (sc_conv3x3_pack_multi): the filters of a network change once per optimizer step, so a trunk refreshes its set once per pass

@@ -125,3 +125,27 @@ def test_conv3x3_split_bf16_is_fp32_accurate(side, cin, cout, batch):
     e_bwd = _rel(ops.conv3x3_backward_data(gy, w, split=True).double(), gx64)
     print("conv3x3 split %dx%d %d>%d B=%d: forward %.2e of max (fp32 MFMA kernel %.2e), backward-data %.2e" % (side, side, cin, cout, batch, e_split, e_fp32, e_bwd))
     assert e_split < 2e-5 and e_bwd < 2e-5 and e_split < 2 * e_fp32 + 2e-7
+
+
+@pytest.mark.parametrize("batch", [1, 3, 64])
+def test_conv_stem_forward_and_weight_gradient(batch):
+    """ResNet.conv1 (7x7 / 2, 3 -> 64) on csrc/conv_stem.hip against float64 and against torch / MIOpen."""
+    from shapeclipper_amd import ops
+    torch.manual_seed(batch)
+    dev = torch.device("cuda:0")
+    x = torch.randn(batch, 3, 224, 224, device=dev)
+    w = torch.randn(64, 3, 7, 7, device=dev) * 0.1
+    assert ops.conv_stem_supported(x.shape, w.shape)
+    nref = min(batch, 4)
+    y = ops.conv_stem_forward(x, w)
+    y64 = torch.nn.functional.conv2d(x[:nref].double(), w.double(), None, 2, 3)
+    y_t = torch.nn.functional.conv2d(x[:nref], w, None, 2, 3)
+    e_f, e_ft = _rel(y[:nref].double(), y64), _rel(y_t.double(), y64)
+    gy = torch.randn_like(y)
+    dw = ops.conv_stem_backward_weight(gy, x)
+    dw64 = torch.nn.grad.conv2d_weight(x.double(), w.shape, gy.double(), 2, 3)
+    dw_t = torch.ops.aten.convolution_backward(gy, x, w, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    e_w, e_wt = _rel(dw.double(), dw64), _rel(dw_t.double(), dw64)
+    print("conv stem B=%d: forward %.2e of max (torch/MIOpen %.2e), weight gradient %.2e (torch/MIOpen %.2e)" % (batch, e_f, e_ft, e_w, e_wt))
+    assert e_f < 2e-5 and e_w < 2e-5
+    assert torch.equal(dw, ops.conv_stem_backward_weight(gy, x))

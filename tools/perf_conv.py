@@ -79,6 +79,11 @@ def main():
             total["bwd_weight"] += count * t_w
             line = "%-12s %-22s %5d | %8.3f %6.1f | %8.3f %6.1f | %8.3f %6.1f | %7.2f" % (
                 net, "%s %d>%d %d k%d/s%d" % (name, ci, co, h, k, s), count, t_f, flop / t_f / 1e9, t_d, flop / t_d / 1e9, t_w, flop / t_w / 1e9, per_step)
+            if hip_conv is not None and name == "stem":
+                xd, wd = x.detach(), w.detach()
+                t_hf = time_fn(lambda: hip_conv.conv_stem_forward(xd, wd))
+                t_hw = time_fn(lambda: hip_conv.conv_stem_backward_weight(gy, xd))
+                line += " | hip fwd %7.3f (%5.1f TF/s) bwdW %7.3f (%5.1f)" % (t_hf, flop / t_hf / 1e9, t_hw, flop / t_hw / 1e9)
             if hip_conv is not None and k == 3 and s == 1:
                 xd, wd = x.detach(), w.detach()
                 wp_f, wp_b = hip_conv.conv3x3_pack(wd, h), hip_conv.conv3x3_pack(wd, h, True)
