@@ -355,6 +355,16 @@ long long sc_conv_stem_wgrad_workspace_floats(void);
 int sc_conv_stem_forward(const float* x, const float* w, float* out, int batch, void* stream);
 int sc_conv_stem_wgrad(const float* gy, const float* x, float* dw, float* workspace, int batch, void* stream);
 
+/* The 1x1 / stride 2 shortcut convolutions of the trunks (torchvision BasicBlock.downsample[0]; csrc/conv1x1s2.hip), NCHW fp32,
+ * hin = side of the (square, even) input map, cin and cout multiples of 64 (otherwise hipErrorInvalidValue / -1):
+ *   sc_conv1x1s2_forward        out [batch][cout][hin/2][hin/2] = sum_ci w[cout][cin] x[batch][cin][2y][2x]
+ *   sc_conv1x1s2_backward_data  gx [batch][cin][hin][hin] from gy [batch][cout][hin/2][hin/2]: fully written (zeros at odd positions)
+ *   sc_conv1x1s2_wgrad          dw [cout][cin] from gy and x, fixed summation order; workspace: the _workspace_floats query.        */
+long long sc_conv1x1s2_wgrad_workspace_floats(int cin, int cout);
+int sc_conv1x1s2_forward(const float* x, const float* w, float* out, int batch, int cin, int cout, int hin, void* stream);
+int sc_conv1x1s2_backward_data(const float* gy, const float* w, float* gx, int batch, int cin, int cout, int hin, void* stream);
+int sc_conv1x1s2_wgrad(const float* gy, const float* x, float* dw, float* workspace, int batch, int cin, int cout, int hin, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -271,6 +271,32 @@ def conv_stem(conv, x):
     return conv(x)
 
 
+class Conv1x1S2Function(torch.autograd.Function):
+    """BasicBlock.downsample[0] (1x1 / stride 2) on csrc/conv1x1s2.hip: forward, backward-data (writes the zeros itself), backward-weight."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        x = ops._aligned(x)
+        ctx.save_for_backward(x, w)
+        return ops.conv1x1s2_forward(x, w)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = ops._aligned(gy)
+        gx = ops.conv1x1s2_backward_data(gy, w) if ctx.needs_input_grad[0] else None
+        gw = ops.conv1x1s2_backward_weight(gy, x) if ctx.needs_input_grad[1] else None
+        return gx, gw
+
+
+def conv1x1s2(conv, x):
+    """nn.Conv2d `conv` (a 1x1 / stride-2 shortcut) applied to x through the HIP kernels when the shapes are the ones they take."""
+    if (x.is_cuda and x.dtype == torch.float32 and conv.bias is None and conv.groups == 1 and conv.dilation == (1, 1)
+            and ops.conv1x1s2_supported(x.shape, conv.weight.shape, conv.stride, conv.padding)):
+        return Conv1x1S2Function.apply(x, conv.weight)
+    return conv(x)
+
+
 def conv3x3_takes(conv, x):
     return (x.is_cuda and x.dtype == torch.float32 and conv.bias is None and conv.groups == 1 and conv.dilation == (1, 1)
             and ops.conv3x3_supported(x.shape, conv.weight.shape, conv.stride, conv.padding))

@@ -9,11 +9,12 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from ..functional import bn_act, bn_relu_maxpool, conv3x3, conv_stem
+from ..functional import bn_act, bn_relu_maxpool, conv1x1s2, conv3x3, conv_stem
 
 FUSED_BN = True
 HIP_CONV3X3 = True       # 3x3 / stride-1 convolutions on csrc/conv3x3.hip (`--hip.conv3x3!` keeps them on MIOpen)
 HIP_CONV_STEM = True      # the 7x7 / 2 stem on csrc/conv_stem.hip (`--hip.conv_stem!` keeps it on MIOpen)
+HIP_CONV_1X1 = True       # the 1x1 / stride-2 shortcuts on csrc/conv1x1s2.hip (`--hip.conv1x1!`)
 HIP_CONV3X3_SPLIT = False  # `--hip.conv3x3_split`: their forward / backward-data products on the bf16 matrix pipe (three-piece exact split)
 
 
@@ -36,7 +37,9 @@ class BasicBlock(nn.Module):
             out = self.relu(self.bn1(self.conv1(x)))
             out = self.bn2(self.conv2(out))
             return self.relu(out + identity)
-        identity = x if self.downsample is None else bn_act(self.downsample[1], self.downsample[0](x), relu=False, groups=groups)
+        use_hip = HIP_CONV3X3 if hip_conv is None else hip_conv
+        identity = x if self.downsample is None else bn_act(
+            self.downsample[1], conv1x1s2(self.downsample[0], x) if (use_hip and HIP_CONV_1X1) else self.downsample[0](x), relu=False, groups=groups)
         conv = (lambda m, t: conv3x3(m, t, packs)) if (HIP_CONV3X3 if hip_conv is None else hip_conv) else (lambda m, t: m(t))
         out = bn_act(self.bn1, conv(self.conv1, x), groups=groups)
         return bn_act(self.bn2, conv(self.conv2, out), residual=identity, groups=groups)

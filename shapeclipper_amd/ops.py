@@ -679,6 +679,46 @@ def conv_stem_backward_weight(gy, x):
     return dw
 
 
+def conv1x1s2_supported(x_shape, w_shape, stride=2, padding=0) -> bool:
+    """Shapes sc_conv1x1s2_* take: a 1x1 filter, stride 2, no padding, square even maps, channel counts that are multiples of 64."""
+    return (len(x_shape) == 4 and tuple(w_shape[2:]) == (1, 1) and stride in (2, (2, 2)) and padding in (0, (0, 0)) and x_shape[2] == x_shape[3]
+            and x_shape[2] % 2 == 0 and w_shape[1] == x_shape[1] and w_shape[0] % 64 == 0 and w_shape[1] % 64 == 0)
+
+
+def conv1x1s2_forward(x, w):
+    lib = _lib.load()
+    x, w = _aligned(x), _aligned(w)
+    B, cin, H, _ = x.shape
+    out = torch.empty(B, w.shape[0], H // 2, H // 2, device=x.device, dtype=torch.float32)
+    _lib.check(lib.sc_conv1x1s2_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(out), B, cin, w.shape[0], H, _lib.stream()), "sc_conv1x1s2_forward")
+    return out
+
+
+def conv1x1s2_backward_data(gy, w):
+    lib = _lib.load()
+    gy, w = _aligned(gy), _aligned(w)
+    B, cout, Ho, _ = gy.shape
+    gx = torch.empty(B, w.shape[1], 2 * Ho, 2 * Ho, device=gy.device, dtype=torch.float32)
+    _lib.check(lib.sc_conv1x1s2_backward_data(_lib.ptr(gy), _lib.ptr(w), _lib.ptr(gx), B, w.shape[1], cout, 2 * Ho, _lib.stream()),
+               "sc_conv1x1s2_backward_data")
+    return gx
+
+
+def conv1x1s2_backward_weight(gy, x):
+    lib = _lib.load()
+    gy, x = _aligned(gy), _aligned(x)
+    B, cin, H, _ = x.shape
+    cout = gy.shape[1]
+    n = lib.sc_conv1x1s2_wgrad_workspace_floats(cin, cout)
+    key = (x.device.index, torch.cuda.current_stream().cuda_stream, "1x1s2")
+    ws = _conv_ws.get(key)
+    if ws is None or ws.numel() < n:
+        ws = _conv_ws[key] = torch.empty(n, device=x.device, dtype=torch.float32)
+    dw = torch.empty(cout, cin, 1, 1, device=x.device, dtype=torch.float32)
+    _lib.check(lib.sc_conv1x1s2_wgrad(_lib.ptr(gy), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(ws), B, cin, cout, H, _lib.stream()), "sc_conv1x1s2_wgrad")
+    return dw
+
+
 class Conv3x3PackSet:
     """Kernel-ready filter images (forward and backward-data orientation) of MANY 3x3 / stride-1 convolutions, rewritten by ONE launch
     (sc_conv3x3_pack_multi): the filters of a network change once per optimizer step, so a trunk refreshes its set once per pass

@@ -149,3 +149,25 @@ def test_conv_stem_forward_and_weight_gradient(batch):
     print("conv stem B=%d: forward %.2e of max (torch/MIOpen %.2e), weight gradient %.2e (torch/MIOpen %.2e)" % (batch, e_f, e_ft, e_w, e_wt))
     assert e_f < 2e-5 and e_w < 2e-5
     assert torch.equal(dw, ops.conv_stem_backward_weight(gy, x))
+
+
+@pytest.mark.parametrize("hin,cin,cout,batch", [(56, 64, 128, 3), (28, 128, 256, 5), (14, 256, 512, 7), (14, 256, 512, 1), (56, 64, 128, 64), (6, 64, 64, 2)])
+def test_conv1x1_stride2_forward_backward(hin, cin, cout, batch):
+    """BasicBlock.downsample[0] on csrc/conv1x1s2.hip against float64 (and torch / MIOpen beside it)."""
+    from shapeclipper_amd import ops
+    torch.manual_seed(hin + cin + batch)
+    dev = torch.device("cuda:0")
+    x = torch.randn(batch, cin, hin, hin, device=dev)
+    w = torch.randn(cout, cin, 1, 1, device=dev) * (1.0 / cin) ** 0.5
+    assert ops.conv1x1s2_supported(x.shape, w.shape)
+    y = ops.conv1x1s2_forward(x, w)
+    y64 = torch.nn.functional.conv2d(x.double(), w.double(), None, 2, 0)
+    gy = torch.randn_like(y)
+    gx = ops.conv1x1s2_backward_data(gy, w)
+    gx64 = torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), 2, 0)
+    dw = ops.conv1x1s2_backward_weight(gy, x)
+    dw64 = torch.nn.grad.conv2d_weight(x.double(), w.shape, gy.double(), 2, 0)
+    e = (_rel(y.double(), y64), _rel(gx.double(), gx64), _rel(dw.double(), dw64))
+    print("conv1x1/2 %dx%d %d>%d B=%d: forward %.2e, backward-data %.2e, backward-weight %.2e of max" % ((hin, hin, cin, cout, batch) + e))
+    assert max(e) < 2e-5
+    assert torch.equal(dw, ops.conv1x1s2_backward_weight(gy, x))
