@@ -33,9 +33,11 @@ _lib: Optional[ctypes.CDLL] = None
 # Optional per-entry-point GPU timing (bench.py): when TIMING is a dict every C-ABI call is bracketed by
 # two events on torch's current stream (the stream the kernels are enqueued on).
 TIMING = None
-TIMING_SKIP = ("sc_bn_splits", "sc_bn_act_forward", "sc_bn_act_backward", "sc_bn_relu_pool_forward",
-               "sc_bn_relu_pool_backward")       # ~500 tiny calls per step: not worth two events each
-
+TIMING_SKIP = ("sc_bn_splits", "sc_bn_act_forward", "sc_bn_act_backward", "sc_bn_relu_pool_forward", "sc_bn_relu_pool_backward",
+               # the trunks' convolutions: ~250 calls per step -- two events each cost the step ~1 ms (rocprofv3 covers them: profiles/)
+               "sc_conv3x3_forward", "sc_conv3x3_forward_split", "sc_conv3x3_wgrad", "sc_conv3x3_pack", "sc_conv3x3_pack_multi",
+               "sc_conv_stem_forward", "sc_conv_stem_wgrad", "sc_conv1x1s2_forward", "sc_conv1x1s2_backward_data", "sc_conv1x1s2_wgrad",
+               "sc_conv3x3_tile_channels", "sc_conv3x3_tile_channels_split")
 
 class _Timed:
     """Wraps a ctypes function: records (start, end) events around the call when TIMING is enabled."""
