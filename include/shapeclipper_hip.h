@@ -340,6 +340,13 @@ int sc_conv3x3_tile_channels_split(int hw);
 int sc_conv3x3_forward_split(const float* x, const float* w_pack, float* out, float* workspace, int batch, int cin, int cout, int hw,
                              void* stream);
 
+/* 3x3 / stride 2 / pad 1 (BasicBlock.conv1 of layer2-4), forward only, same kernel family: hw = side of the INPUT map (56, 28 or 14),
+ * out [batch][cout][hw/2][hw/2].  Filter image: sc_conv3x3_pack with bit 2 (value 4) of transpose_flip set, sc_conv3x3s2_pack_floats floats. */
+long long sc_conv3x3s2_pack_floats(int cin, int cout, int hw);
+long long sc_conv3x3s2_workspace_floats(int hw);
+int sc_conv3x3s2_forward(const float* x, const float* w_pack, float* out, float* workspace, int batch, int cin, int cout, int hw,
+                         void* stream);
+
 /* Weight gradient of the same convolution (csrc/conv3x3_wgrad.hip):  dw [cout][cin][3][3] = sum over the batch of gy (x) shifted x,
  * gy [batch][cout][hw][hw], x [batch][cin][hw][hw], fully overwritten, fixed summation order.  cin and cout must be multiples of 64
  * (otherwise hipErrorInvalidValue; sc_conv3x3_wgrad_workspace_floats returns -1): the caller keeps MIOpen for other shapes.

@@ -43,17 +43,20 @@ __device__ __forceinline__ void conv_glds16(const void* gsrc, unsigned lds_dst) 
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-template <int W_, int CT_, int PT_, int WGM_, int WGN_, bool SPLIT_ = false>
+template <int W_, int CT_, int PT_, int WGM_, int WGN_, bool SPLIT_ = false, int S_ = 1>
 struct ConvCfg {
     static constexpr int W = W_, CT = CT_, PT = PT_, WGM = WGM_, WGN = WGN_, CB = 8;
     static constexpr bool SPLIT = SPLIT_;            // operands as three bf16 pieces on the bf16 matrix pipe (see conv3x3 SPLIT below)
-    static constexpr int Wp = W + 2, HW = W * W, Sp = Wp * Wp;
+    static constexpr int Wp = W + 2, HW = W * W, Sp = Wp * Wp;             // geometry of the INPUT map (W x W, one pad ring)
+    static constexpr int S = S_, WO = W / S, HWO = WO * WO;                  // stride and output map (stride 2: the three conv1 of layer2-4)
     static constexpr int NT = 64 * WGM * WGN;
     static constexpr int WM = CT / (32 * WGM), WN = PT / (32 * WGN);        // 32x32 MFMA tiles per wave
     // floats (4-byte units) of one weight stage: fp32 [tap][half][CT][4]; SPLIT [tap pair (5)][piece (3)][half][CT][8 bf16]
     static constexpr int WIMG = SPLIT ? 5 * 3 * 2 * CT * 4 : 9 * CB * CT;
-    // longest padded-flat span of PT consecutive pixels plus the halo: 2 pad columns per row crossed, 2 pad rows per image crossed
-    static constexpr int LMAX = PT + 2 * (PT / W + 2) + 2 * Wp * (PT / HW + 1) + 2 * (Wp + 1);
+    // longest padded-flat span of PT consecutive (output) pixels plus the halo.  Stride 1: 2 pad columns per row crossed, 2 pad rows
+    // per image crossed.  Stride S: S positions per pixel, S (Wp - WO) extra per row crossed, Sp - S (WO - 1)(Wp + 1) per image crossed.
+    static constexpr int LMAX = S == 1 ? PT + 2 * (PT / W + 2) + 2 * Wp * (PT / HW + 1) + 2 * (Wp + 1)
+                                       : S * PT + (PT / WO + 2) * S * (Wp - WO) + (PT / HWO + 1) * (Sp - S * (WO - 1) * (Wp + 1)) + 2 * (Wp + 1);
     static constexpr int LX = LMAX;                                          // positions per channel half
     static constexpr int NXE = (LMAX + NT - 1) / NT;                         // patch positions per thread
     static constexpr int STAGE = WIMG + (SPLIT ? 3 : 2) * LX * 4;            // floats: patch [half][LX][4 fp32] or [piece][LX][8 bf16]
@@ -65,8 +68,8 @@ struct ConvCfg {
 
 template <class C>
 __device__ __forceinline__ int padded_q(int p) {
-    const int b = p / C::HW, r = p - b * C::HW, y = r / C::W, x = r - y * C::W;
-    return b * C::Sp + (y + 1) * C::Wp + (x + 1);
+    const int b = p / C::HWO, r = p - b * C::HWO, y = r / C::WO, x = r - y * C::WO;          // output pixel -> centre tap in the input
+    return b * C::Sp + (C::S * y + 1) * C::Wp + (C::S * x + 1);
 }
 
 // The tiles of the last, incomplete round of the grid are cut into equal spans of K-steps ("units").
@@ -92,14 +95,14 @@ __device__ __forceinline__ void conv_store_tile(float* __restrict__ out, const f
     for (int j = 0; j < C::WN; ++j) {
         const int p = pt * C::PT + (wn * C::WN + j) * 32 + (lane & 31);
         if (p >= npix) continue;
-        const int b = p / C::HW, rem = p - b * C::HW;
-        float* ob = out + (size_t)b * cout * C::HW + rem;
+        const int b = p / C::HWO, rem = p - b * C::HWO;
+        float* ob = out + (size_t)b * cout * C::HWO + rem;
 #pragma unroll
         for (int i = 0; i < C::WM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = ct * C::CT + (wm * C::WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (co < cout) ob[(size_t)co * C::HW] = acc[i][j][r];
+                if (co < cout) ob[(size_t)co * C::HWO] = acc[i][j][r];
             }
     }
 }
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const flo
     float* S = reinterpret_cast<float*>(conv_smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const int wm = wave / C::WGN, wn = wave % C::WGN;
-    const int npix = batch * HW, nct = (cout + CT - 1) / CT, tiles = ((npix + PT - 1) / PT) * nct;
+    const int npix = batch * C::HWO, nct = (cout + CT - 1) / CT, tiles = ((npix + PT - 1) / PT) * nct;
     const int nk = cin / CB, G = gridDim.x, g = blockIdx.x;
     const ConvSplit sp = conv_split(tiles, nk, G);
     // workgroup b runs on XCD b % 8: give every XCD a contiguous range of each round's tiles (shared patches / weights stay in its L2)
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(C::NT) void conv3x3_fixup_kernel(const float* __res
                                                               int cin, int cout, int G) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / C::WGN, wn = wave % C::WGN;
-    const int npix = batch * C::HW, nct = (cout + C::CT - 1) / C::CT, tiles = ((npix + C::PT - 1) / C::PT) * nct;
+    const int npix = batch * C::HWO, nct = (cout + C::CT - 1) / C::CT, tiles = ((npix + C::PT - 1) / C::PT) * nct;
     const int nk = cin / C::CB;
     const ConvSplit sp = conv_split(tiles, nk, G);
     const int t = blockIdx.x, r0 = 4 * blockIdx.y;
@@ -337,14 +340,14 @@ __global__ __launch_bounds__(C::NT) void conv3x3_fixup_kernel(const float* __res
     for (int j = 0; j < C::WN; ++j) {
         const int p = pt * C::PT + (wn * C::WN + j) * 32 + (lane & 31);
         if (p >= npix) continue;
-        const int b = p / C::HW, rem = p - b * C::HW;
-        float* ob = out + (size_t)b * cout * C::HW + rem;
+        const int b = p / C::HWO, rem = p - b * C::HWO;
+        float* ob = out + (size_t)b * cout * C::HWO + rem;
 #pragma unroll
         for (int i = 0; i < C::WM; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = ct * C::CT + (wm * C::WM + i) * 32 + r + 2 * r0 + 4 * (lane >> 5);      // row of acc[r0 + r]: r + 8 (r0 / 4)
-                if (co < cout) ob[(size_t)co * C::HW] = acc[i][j][r];
+                if (co < cout) ob[(size_t)co * C::HWO] = acc[i][j][r];
             }
     }
 }
@@ -416,6 +419,10 @@ using Conv56 = ConvCfg<56, 64, 512, 1, 8>;       // 64 channels: the tile spans 
 using Conv28 = ConvCfg<28, 128, 256, 2, 4>;
 using Conv14 = ConvCfg<14, 128, 256, 2, 4>;
 using Conv7 = ConvCfg<7, 128, 128, 2, 4>;
+// stride 2 (BasicBlock.conv1 of layer2-4, forward only): 64 channels x 256 output pixels, 8 waves of 64 x 32
+using Conv56S2 = ConvCfg<56, 64, 256, 1, 8, false, 2>;
+using Conv28S2 = ConvCfg<28, 64, 256, 1, 8, false, 2>;
+using Conv14S2 = ConvCfg<14, 64, 256, 1, 8, false, 2>;
 // SPLIT (fp32-accurate products on the bf16 matrix pipe): 64 channels x 512 pixels, 8 waves of 64 x 64
 using Conv56S = ConvCfg<56, 64, 512, 1, 8, true>;
 using Conv28S = ConvCfg<28, 64, 512, 1, 8, true>;
@@ -465,7 +472,7 @@ static int launch_pack(const float* w, float* wpack, int cin, int cout, int tf, 
 template <class C>
 static int launch_conv(const float* x, const float* wpack, float* out, float* workspace, int batch, int cin, int cout, hipStream_t st) {
     if (cin % C::CB || batch <= 0) return (int)hipErrorInvalidValue;
-    const int tiles = ((batch * C::HW + C::PT - 1) / C::PT) * ((cout + C::CT - 1) / C::CT), nk = cin / C::CB;
+    const int tiles = ((batch * C::HWO + C::PT - 1) / C::PT) * ((cout + C::CT - 1) / C::CT), nk = cin / C::CB;
     const int G = conv_grid() * C::WGS_PER_CU;
     (void)hipFuncSetAttribute((const void*)conv3x3_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     hipLaunchKernelGGL((conv3x3_kernel<C>), dim3(G), dim3(C::NT), C::LDS_BYTES, st, x, wpack, out, workspace, batch, cin, cout);
@@ -494,6 +501,31 @@ static int launch_conv(const float* x, const float* wpack, float* out, float* wo
         case 7: return CALL(sc::Conv7S);             \
         default: return -1;                          \
     }
+
+#define SC_CONV_DISPATCH_S2(hw, CALL)                 \
+    switch (hw) {                                    \
+        case 56: return CALL(sc::Conv56S2);          \
+        case 28: return CALL(sc::Conv28S2);          \
+        case 14: return CALL(sc::Conv14S2);          \
+        default: return -1;                          \
+    }
+
+extern "C" long long sc_conv3x3s2_pack_floats(int cin, int cout, int hw) {
+#define CALL(C) sc::pack_floats<C>(cin, cout)
+    SC_CONV_DISPATCH_S2(hw, CALL)
+#undef CALL
+}
+extern "C" long long sc_conv3x3s2_workspace_floats(int hw) {
+#define CALL(C) sc::workspace_floats<C>()
+    SC_CONV_DISPATCH_S2(hw, CALL)
+#undef CALL
+}
+extern "C" int sc_conv3x3s2_forward(const float* x, const float* w_pack, float* out, float* workspace, int batch, int cin, int cout, int hw,
+                                    void* stream) {
+#define CALL(C) sc::launch_conv<C>(x, w_pack, out, workspace, batch, cin, cout, (hipStream_t)stream)
+    SC_CONV_DISPATCH_S2(hw, CALL)
+#undef CALL
+}
 
 extern "C" long long sc_conv3x3_pack_floats_split(int cin, int cout, int hw) {
 #define CALL(C) sc::pack_floats<C>(cin, cout)
@@ -545,6 +577,11 @@ extern "C" int sc_conv3x3_pack_multi(const long long* table, int n, float* dst, 
 }
 
 extern "C" int sc_conv3x3_pack(const float* w, float* w_pack, int cin, int cout, int hw, int transpose_flip, void* stream) {
+    if (transpose_flip & 4) {           /* bit 2: the image of sc_conv3x3s2_forward (hw = side of the INPUT map) */
+#define CALL(C) sc::launch_pack<C>(w, w_pack, cin, cout, transpose_flip & 1, (hipStream_t)stream)
+        SC_CONV_DISPATCH_S2(hw, CALL)
+#undef CALL
+    }
     if (transpose_flip & 2) {           /* bit 1: the three-piece bf16 image of sc_conv3x3_forward_split */
 #define CALL(C) sc::launch_pack<C>(w, w_pack, cin, cout, transpose_flip & 1, (hipStream_t)stream)
         SC_CONV_DISPATCH_SPLIT(hw, CALL)

@@ -297,6 +297,30 @@ def conv1x1s2(conv, x):
     return conv(x)
 
 
+class Conv3x3S2Function(torch.autograd.Function):
+    """BasicBlock.conv1 of layer2-4 (3x3 / stride 2): forward on csrc/conv3x3.hip (stride-2 instance), both gradients on MIOpen."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        x = ops._aligned(x)
+        ctx.save_for_backward(x, w)
+        return ops.conv3x3s2_forward(x, w)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx, gw, _ = torch.ops.aten.convolution_backward(ops._aligned(gy), x, w, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
+                                                        [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        return gx, gw
+
+
+def conv3x3s2(conv, x):
+    if (x.is_cuda and x.dtype == torch.float32 and conv.bias is None and conv.groups == 1 and conv.dilation == (1, 1)
+            and ops.conv3x3s2_supported(x.shape, conv.weight.shape, conv.stride, conv.padding)):
+        return Conv3x3S2Function.apply(x, conv.weight)
+    return conv(x)
+
+
 def conv3x3_takes(conv, x):
     return (x.is_cuda and x.dtype == torch.float32 and conv.bias is None and conv.groups == 1 and conv.dilation == (1, 1)
             and ops.conv3x3_supported(x.shape, conv.weight.shape, conv.stride, conv.padding))

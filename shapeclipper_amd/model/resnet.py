@@ -9,11 +9,12 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from ..functional import bn_act, bn_relu_maxpool, conv1x1s2, conv3x3, conv_stem
+from ..functional import bn_act, bn_relu_maxpool, conv1x1s2, conv3x3, conv3x3s2, conv_stem
 
 FUSED_BN = True
 HIP_CONV3X3 = True       # 3x3 / stride-1 convolutions on csrc/conv3x3.hip (`--hip.conv3x3!` keeps them on MIOpen)
 HIP_CONV_STEM = True      # the 7x7 / 2 stem on csrc/conv_stem.hip (`--hip.conv_stem!` keeps it on MIOpen)
+HIP_CONV3X3_S2 = True    # forward of the 3x3 / stride-2 conv1 of layer2-4 on the stride-2 instance of conv3x3.hip (`--hip.conv3x3s2!`)
 HIP_CONV_1X1 = True       # the 1x1 / stride-2 shortcuts on csrc/conv1x1s2.hip (`--hip.conv1x1!`)
 HIP_CONV3X3_SPLIT = False  # `--hip.conv3x3_split`: their forward / backward-data products on the bf16 matrix pipe (three-piece exact split)
 
@@ -40,7 +41,7 @@ class BasicBlock(nn.Module):
         use_hip = HIP_CONV3X3 if hip_conv is None else hip_conv
         identity = x if self.downsample is None else bn_act(
             self.downsample[1], conv1x1s2(self.downsample[0], x) if (use_hip and HIP_CONV_1X1) else self.downsample[0](x), relu=False, groups=groups)
-        conv = (lambda m, t: conv3x3(m, t, packs)) if (HIP_CONV3X3 if hip_conv is None else hip_conv) else (lambda m, t: m(t))
+        conv = (lambda m, t: conv3x3s2(m, t) if (m.stride == (2, 2) and HIP_CONV3X3_S2) else conv3x3(m, t, packs)) if use_hip else (lambda m, t: m(t))
         out = bn_act(self.bn1, conv(self.conv1, x), groups=groups)
         return bn_act(self.bn2, conv(self.conv2, out), residual=identity, groups=groups)
 

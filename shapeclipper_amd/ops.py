@@ -719,6 +719,33 @@ def conv1x1s2_backward_weight(gy, x):
     return dw
 
 
+def conv3x3s2_supported(x_shape, w_shape, stride=2, padding=1) -> bool:
+    """Shapes sc_conv3x3s2_forward takes: 3x3 filter, stride 2, pad 1, square 56 / 28 / 14 maps, channel counts that are multiples of 8."""
+    return (len(x_shape) == 4 and tuple(w_shape[2:]) == (3, 3) and stride in (2, (2, 2)) and padding in (1, (1, 1)) and x_shape[2] == x_shape[3]
+            and x_shape[2] in (56, 28, 14) and w_shape[1] == x_shape[1] and w_shape[0] % 8 == 0 and w_shape[1] % 8 == 0)
+
+
+def conv3x3s2_forward(x, w):
+    """F.conv2d(x, w, None, 2, 1) for x [B, Cin, H, H], w [Cout, Cin, 3, 3] (the stride-1 kernel with strided pixel offsets)."""
+    lib = _lib.load()
+    x, w = _aligned(x), _aligned(w)
+    B, cin, H, _ = x.shape
+    cout = w.shape[0]
+    n = lib.sc_conv3x3s2_pack_floats(cin, cout, H)
+    if n < 0:
+        raise RuntimeError("shapeclipper_amd: sc_conv3x3s2 does not take [%d, %d, %d, %d] * %s" % (B, cin, H, H, tuple(w.shape)))
+    w_pack = torch.empty(n, device=x.device, dtype=torch.float32)
+    _lib.check(lib.sc_conv3x3_pack(_lib.ptr(w), _lib.ptr(w_pack), cin, cout, H, 4, _lib.stream()), "sc_conv3x3_pack")
+    key = (x.device.index, torch.cuda.current_stream().cuda_stream, H, "s2")
+    ws = _conv_ws.get(key)
+    if ws is None:
+        ws = _conv_ws[key] = torch.empty(lib.sc_conv3x3s2_workspace_floats(H), device=x.device, dtype=torch.float32)
+    out = torch.empty(B, cout, H // 2, H // 2, device=x.device, dtype=torch.float32)
+    _lib.check(lib.sc_conv3x3s2_forward(_lib.ptr(x), _lib.ptr(w_pack), _lib.ptr(out), _lib.ptr(ws), B, cin, cout, H, _lib.stream()),
+               "sc_conv3x3s2_forward")
+    return out
+
+
 class Conv3x3PackSet:
     """Kernel-ready filter images (forward and backward-data orientation) of MANY 3x3 / stride-1 convolutions, rewritten by ONE launch
     (sc_conv3x3_pack_multi): the filters of a network change once per optimizer step, so a trunk refreshes its set once per pass

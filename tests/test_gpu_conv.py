@@ -171,3 +171,19 @@ def test_conv1x1_stride2_forward_backward(hin, cin, cout, batch):
     print("conv1x1/2 %dx%d %d>%d B=%d: forward %.2e, backward-data %.2e, backward-weight %.2e of max" % ((hin, hin, cin, cout, batch) + e))
     assert max(e) < 2e-5
     assert torch.equal(dw, ops.conv1x1s2_backward_weight(gy, x))
+
+
+@pytest.mark.parametrize("hin,cin,cout,batch", [(56, 64, 128, 3), (28, 128, 256, 5), (14, 256, 512, 7), (14, 256, 512, 1), (56, 64, 128, 33), (28, 64, 72, 2)])
+def test_conv3x3_stride2_forward(hin, cin, cout, batch):
+    """BasicBlock.conv1 of layer2-4 (3x3 / stride 2 / pad 1): the stride-2 instance of csrc/conv3x3.hip against float64."""
+    from shapeclipper_amd import ops
+    torch.manual_seed(hin + cin + batch)
+    dev = torch.device("cuda:0")
+    x = torch.randn(batch, cin, hin, hin, device=dev)
+    w = torch.randn(cout, cin, 3, 3, device=dev) * (2.0 / (9 * cin)) ** 0.5
+    assert ops.conv3x3s2_supported(x.shape, w.shape)
+    y = ops.conv3x3s2_forward(x, w)
+    y64 = torch.nn.functional.conv2d(x.double(), w.double(), None, 2, 1)
+    e, e_t = _rel(y.double(), y64), _rel(torch.nn.functional.conv2d(x, w, None, 2, 1).double(), y64)
+    print("conv3x3/2 %dx%d %d>%d B=%d: forward %.2e of max (torch/MIOpen %.2e)" % (hin, hin, cin, cout, batch, e, e_t))
+    assert y.shape == y64.shape and e < 2e-5

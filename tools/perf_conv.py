@@ -84,6 +84,10 @@ def main():
                 t_hf = time_fn(lambda: hip_conv.conv_stem_forward(xd, wd))
                 t_hw = time_fn(lambda: hip_conv.conv_stem_backward_weight(gy, xd))
                 line += " | hip fwd %7.3f (%5.1f TF/s) bwdW %7.3f (%5.1f)" % (t_hf, flop / t_hf / 1e9, t_hw, flop / t_hw / 1e9)
+            if hip_conv is not None and k == 3 and s == 2:
+                xd, wd = x.detach(), w.detach()
+                t_hf = time_fn(lambda: hip_conv.conv3x3s2_forward(xd, wd))
+                line += " | hip fwd (incl. pack) %7.3f (%5.1f TF/s)" % (t_hf, flop / t_hf / 1e9)
             if hip_conv is not None and k == 1 and s == 2:
                 xd, wd = x.detach(), w.detach()
                 t_hf = time_fn(lambda: hip_conv.conv1x1s2_forward(xd, wd))
