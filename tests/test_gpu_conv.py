@@ -187,3 +187,27 @@ def test_conv3x3_stride2_forward(hin, cin, cout, batch):
     e, e_t = _rel(y.double(), y64), _rel(torch.nn.functional.conv2d(x, w, None, 2, 1).double(), y64)
     print("conv3x3/2 %dx%d %d>%d B=%d: forward %.2e of max (torch/MIOpen %.2e)" % (hin, hin, cin, cout, batch, e, e_t))
     assert y.shape == y64.shape and e < 2e-5
+
+
+@pytest.mark.parametrize("kind,cin,cout,side,k,stride,pad", [("conv3x3", 64, 64, 56, 3, 1, 1), ("conv3x3", 256, 256, 14, 3, 1, 1),
+                                                               ("conv3x3s2", 64, 128, 56, 3, 2, 1), ("conv3x3s2", 256, 512, 14, 3, 2, 1),
+                                                               ("conv1x1s2", 128, 256, 28, 1, 2, 0), ("conv_stem", 3, 64, 224, 7, 2, 3)])
+def test_autograd_wrappers_match_torch(kind, cin, cout, side, k, stride, pad):
+    """functional.conv3x3 / conv3x3s2 / conv1x1s2 / conv_stem on an nn.Conv2d: output, input gradient and weight gradient against the
+    same module through torch's own operator (wiring of the autograd Functions: argument order, which gradients are requested)."""
+    from shapeclipper_amd import functional as F_
+    torch.manual_seed(cin + side)
+    conv = torch.nn.Conv2d(cin, cout, k, stride, pad, bias=False).cuda()
+    x = torch.randn(4, cin, side, side, device="cuda")
+    res = []
+    for hip in (False, True):
+        conv.weight.grad = None
+        xi = x.clone().requires_grad_(True)
+        y = getattr(F_, kind)(conv, xi) if hip else conv(xi)
+        g = torch.Generator(device="cpu").manual_seed(1)
+        (y * torch.randn(y.shape, generator=g).cuda()).sum().backward()
+        res.append((y.detach(), xi.grad.clone(), conv.weight.grad.clone()))
+    for a, b, name in zip(res[1], res[0], ("output", "input gradient", "weight gradient")):
+        e = _rel(a.double(), b.double())
+        print("%s %d>%d %dx%d: %s differs from torch's by %.2e of max" % (kind, cin, cout, side, side, name, e))
+        assert e < 2e-5, name
