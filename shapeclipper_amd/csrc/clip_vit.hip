@@ -82,6 +82,9 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(
 // grid would leave most CUs without a workgroup -- batch 32: 78 tiles for N = 768 -- instead of round 1's split-K with fp32
 // atomics, which also made the summation order run-dependent).  Two LDS stages: the tile of K-step k+1 is in flight while k is
 // consumed; large grids put two (BT = 128) or more workgroups on a CU and they hide the rest of the latency.
+#ifndef SC_GEMM64_STAGES
+#define SC_GEMM64_STAGES 3
+#endif
 template <int EPI, int BT>
 __global__ __launch_bounds__(256, BT == 128 ? 2 : 4) void gemm_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
                                                                            const float* __restrict__ bias, void* __restrict__ out,
@@ -89,7 +92,11 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 4) void gemm_bf16_kernel(const
     constexpr int MI = BT / 64;                // MFMA tiles per wave and dimension
     constexpr int CH = BT * 8;                 // 16-byte chunks per operand tile (BT rows x 64 K)
     constexpr int QN = CH / 256;               // DMA instructions per thread and operand
-    extern __shared__ uint4 Sbuf[];            // [2 stages][A: BT rows x 8 chunks | B: BT rows x 8 chunks]
+    // LDS stages.  The 64 x 64 kernel serves grids whose 128-wide form would leave CUs idle (batch 32): its K-step is 4 MFMAs per wave,
+    // shorter than the DMA round trip, so it keeps SC_GEMM64_STAGES - 1 steps in flight (measured at batch 32: 3 stages 1.05 ms per
+    // tower, 2 stages 1.09, 4 stages 1.08, 6 stages 1.58 -- these launches are mostly launch latency, 12-17 us whatever the shape).
+    constexpr int NS = BT == 64 ? SC_GEMM64_STAGES : 2, PD = NS - 1;
+    extern __shared__ uint4 Sbuf[];            // [NS stages][A: BT rows x 8 chunks | B: BT rows x 8 chunks]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     // XCD-aware tile order.  Workgroup b runs on XCD b % 8 and every XCD has its own 4 MiB L2: with the plain (n, m) grid each
@@ -160,11 +167,18 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 4) void gemm_bf16_kernel(const
     // Tile kt is complete for every wave once each wave has waited for its own DMA (issued from asm: counted by hand) and all
     // have met at the barrier; the same barrier says that everybody has finished reading the stage the next DMA overwrites.
 #define SC_GEMM_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
-    if (kt1 > 0) issue(0, 0);
+#pragma unroll
+    for (int d = 0; d < PD; ++d)
+        if (d < kt1) issue(d, d);
     for (int kt = 0; kt < kt1; ++kt) {
-        SC_GEMM_SYNC();
-        if (kt + 1 < kt1) issue(kt + 1, (kt + 1) & 1);
-        compute(kt & 1);
+        // step kt has landed once at most min(PD - 1, steps issued after it) DMA groups (2 QN instructions each) are outstanding
+        const int later = min(PD - 1, kt1 - 1 - kt);
+        if (later <= 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * QN) : "memory");
+        else if (later == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(4 * QN) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(6 * QN) : "memory");
+        if (kt + PD < kt1) issue(kt + PD, (kt + PD) % NS);       // into the stage read at step kt - 1: everybody is past it
+        compute(kt % NS);
     }
     // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     // Fast path (full-width tile, row pitch a multiple of 16 bytes): the tile goes through the (now free) LDS stages and leaves
@@ -605,8 +619,10 @@ static int launch_gemm(int epi, const bf16_t* A, const bf16_t* Wt, const float* 
     const bool small = t128 < 384;
 #define SC_LAUNCH(E)                                                                                                          \
     if (small) {                                                                                                              \
-        hipLaunchKernelGGL((gemm_bf16_kernel<E, 64>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 2 * 2 * 64 * 8 * 16, st, \
-                           A, Wt, bias, out, M, N, K);                                                                        \
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<E, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,           \
+                                   SC_GEMM64_STAGES * 2 * 64 * 8 * 16);                                                       \
+        hipLaunchKernelGGL((gemm_bf16_kernel<E, 64>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256),                          \
+                           SC_GEMM64_STAGES * 2 * 64 * 8 * 16, st, A, Wt, bias, out, M, N, K);                                \
     } else if ((N % 8) == 0) {          /* persistent: 2 resident workgroups per CU walk the tile list */                     \
         (void)hipFuncSetAttribute((const void*)gemm_bf16_persist_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); \
         hipLaunchKernelGGL((gemm_bf16_persist_kernel<E>), dim3(512), dim3(256), 65536, st, A, Wt, bias, out, M, N, K,         \
