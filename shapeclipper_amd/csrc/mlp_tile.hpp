@@ -83,6 +83,37 @@ __device__ __forceinline__ void mm_act_t(const float* wl, const float (&in)[ACT_
         for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(wl[kp(s) * LD + 16 * mt], in[s], acc[mt]);
     __builtin_amdgcn_sched_barrier(0);
 }
+// The same product with the column-wise weight reads software-pipelined one block of 4 K-steps (16 ds_read_b32, merged into 8
+// ds_read2_b32) ahead of the MFMAs that consume them, the order pinned by scheduling barriers.  For a wave that has its SIMD to
+// itself while it runs a transposed layer (the chain waves of sdf_bwdw in the V sweep: the wgrad partner is parked at a barrier)
+// hipcc's own schedule -- one ds_read2_b32, s_waitcnt lgkmcnt(0), two MFMAs, 32 times -- exposes an LDS round trip per MFMA pair
+// (measured 5.5 k cycles for the 64 MFMAs = 2 k of a layer).  Kernels with two chain waves per SIMD keep mm_act_t: there the partner
+// hides the latency and the 32 extra live registers cost more.
+template <int LD, int MT>
+__device__ __forceinline__ void mm_act_t_pipe(const float* wl, const float (&in)[ACT_STEPS], f32x4 (&acc)[MT]) {
+    float wa[4 * MT], wb[4 * MT];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) wa[r * MT + mt] = wl[kp(r) * LD + 16 * mt];
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+        float (&cur)[4 * MT] = (T & 1) ? wb : wa;
+        float (&nxt)[4 * MT] = (T & 1) ? wa : wb;
+        if (T + 1 < NT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) nxt[r * MT + mt] = wl[kp(4 * (T + 1) + r) * LD + 16 * mt];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(cur[r * MT + mt], in[4 * T + r], acc[mt]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
 
 // acc[mt] += W[row0 + 16*mt + i][col0 + 4*(S0+s) + g] * in[s]      wl = W + (row0+i)*LD + col0 + g
 template <int LD, int MT, int S0, int NS>
@@ -175,18 +206,32 @@ __device__ __forceinline__ void pe_slots(float x0, float x1, float x2, int g, bo
 // (1024 floats per 16-point tile).  In C/D layout a lane holds 4 consecutive channels per
 // accumulator, so a tile is written/read with 4 fully coalesced dwordx4 accesses per lane, and the
 // weight-gradient kernel restages the same image through LDS.  v[4T+r] <-> channel 16T + 4g + r.
-__device__ __forceinline__ void tbl_store(float* base, int tile, int p, int g, const float (&v)[ACT_STEPS]) {
-    float4* dst = reinterpret_cast<float4*>(base) + (size_t)tile * 256;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-        dst[(4 * t + g) * 16 + p] = make_float4(v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]);
+// Addressing: a wave owns one tile, so `tile` is wave-uniform.  Saying so (readfirstlane) and going through a buffer resource
+// (base = the 4 KiB tile in 4 SGPRs built by a handful of scalar instructions, ONE per-lane 32-bit offset shared by every tensor,
+// the quarter of the tile as the instruction's immediate) keeps all of the addressing out of the vector registers.  With plain
+// pointers hipcc held a 64-bit VGPR pointer per tensor and layer across the tile loop: 75 spilled registers in sdf_bwdw, and
+// every scratch reload is followed by `s_waitcnt vmcnt(0)`, which drains the stash prefetches (measured: tools/prof_bwdw.py).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tbl_rsrc(const float* base, int tile) {
+    const char* tb = reinterpret_cast<const char*>(base) + (size_t)__builtin_amdgcn_readfirstlane(tile) * 4096;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(tb), 0, 4096, 0x00020000);       // raw buffer, 4096 bytes, gfx9 dword 3
 }
-__device__ __forceinline__ void tbl_load(const float* base, int tile, int p, int g, float (&v)[ACT_STEPS]) {
-    const float4* src = reinterpret_cast<const float4*>(base) + (size_t)tile * 256;
+__device__ __forceinline__ void tbl_store(float* base, int tile, int p, int g, const float (&v)[ACT_STEPS]) {
+    const __amdgpu_buffer_rsrc_t rs = tbl_rsrc(base, tile);
+    const int lo = (g * 16 + p) * 16;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const float4 q = src[(4 * t + g) * 16 + p];
-        v[4 * t] = q.x; v[4 * t + 1] = q.y; v[4 * t + 2] = q.z; v[4 * t + 3] = q.w;
+        const f32x4 q = {v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q), rs, lo, 1024 * t, 0);
+    }
+}
+__device__ __forceinline__ void tbl_load(const float* base, int tile, int p, int g, float (&v)[ACT_STEPS]) {
+    const __amdgpu_buffer_rsrc_t rs = tbl_rsrc(base, tile);
+    const int lo = (g * 16 + p) * 16;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lo, 1024 * t, 0));
+        v[4 * t] = q[0]; v[4 * t + 1] = q[1]; v[4 * t + 2] = q[2]; v[4 * t + 3] = q[3];
     }
 }
 __device__ __forceinline__ void acc_to_regs(const f32x4 (&acc)[NT], float (&v)[ACT_STEPS]) {

@@ -44,7 +44,16 @@ struct SdfBwdwArgs {
     float* park;           // [gridDim.x * 4][4][1024] floats of per-wave scratch (L2-resident)
     float* partial;        // [gridDim.x][SdfPack::TOTAL]: one partial gradient image per workgroup (fully written)
     float* g_cbias;        // [n_images][5][64], zero-filled by the caller (atomicAdd)
+#ifdef SC_BWDW_PROFILE
+    unsigned long long* prof;   // [8 waves][64] s_memtime stamps of one iteration of one workgroup (tools/prof_bwdw.py)
+    int prof_block, prof_iter;
+#endif
 };
+#ifdef SC_BWDW_PROFILE
+#define BW_STAMP(ID) if (prof_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) a.prof[wave * 64 + (ID)] = t_; }
+#else
+#define BW_STAMP(ID)
+#endif
 
 constexpr int BW_CHAIN = 4;                          // chain waves (= wgrad waves) per workgroup
 constexpr int BW_WLDS = (SdfLds::TOTAL + 3) & ~3;    // weight image, floats
@@ -154,38 +163,80 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
         // =====================================================================================================
         // chain role
         // =====================================================================================================
-        const int cw = wave, p = lane & 15, g = lane >> 4;
+        const int cw = __builtin_amdgcn_readfirstlane(wave), p = lane & 15, g = lane >> 4;     // cw in an SGPR: scalar tile addressing
         float* slotA = lds + BW_XCH + (cw * 2 + 0) * 1024;
         float* slotB = lds + BW_XCH + (cw * 2 + 1) * 1024;
         float* ptsw = lds + BW_PTS + cw * 16 * 8;
-        float* red = lds + BW_RED;
         int wr[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) wr[r] = (((p >> 2) * 64 + 4 * g + (r ^ (p >> 2))) << 2) + (p & 3);
         float* park = a.park + (size_t)(blockIdx.x * BW_CHAIN + cw) * 4 * 1024;
 
-        const float* w0 = lds + SdfLds::W0 + p * SdfLds::LD0 + g;
-        const float* w1h = lds + SdfLds::W1 + p * SdfLds::LD1 + 4 * g;
-        const float* w1e = lds + SdfLds::W1 + p * SdfLds::LD1 + 64 + g;
-        const float* w2h = lds + SdfLds::W2 + p * SdfLds::LD1 + 4 * g;
-        const float* w2e = lds + SdfLds::W2 + p * SdfLds::LD1 + 64 + g;
-        const float* w3 = lds + SdfLds::W3 + p * SdfLds::LD3 + 4 * g;
-        const float* w4 = lds + SdfLds::W4 + p * SdfLds::LD3 + 4 * g;
-        const float* w5s = lds + SdfLds::W5 + 4 * g;
-        const float* w5ft = lds + SdfLds::W5 + (1 + 4 * g) * SdfLds::LD3 + p;
-        const float* w4t = lds + SdfLds::W4 + 4 * g * SdfLds::LD3 + p;
-        const float* w3t = lds + SdfLds::W3 + 4 * g * SdfLds::LD3 + p;
-        const float* w2t = lds + SdfLds::W2 + 4 * g * SdfLds::LD1 + p;
-        const float* w1t = lds + SdfLds::W1 + 4 * g * SdfLds::LD1 + p;
+        // Seven lane-dependent LDS offsets (made opaque so that hipcc keeps ONE register each and puts the matrix / column constants
+        // into the 16-bit immediate of the ds_read -- it otherwise hoists a full address per matrix and orientation out of the tile
+        // loop, 13 registers that end up in scratch; every group of matrices below spans less than 64 KiB from its first one).
+        int o52 = p * SdfLds::LD0 + g, o116h = p * SdfLds::LD1 + 4 * g, o116e = p * SdfLds::LD1 + g, o68 = p * SdfLds::LD3 + 4 * g,
+            o4g = 4 * g, c68 = 4 * g * SdfLds::LD3 + p, c116 = 4 * g * SdfLds::LD1 + p;
+        asm volatile("" : "+v"(o52), "+v"(o116h), "+v"(o116e), "+v"(o68), "+v"(o4g), "+v"(c68), "+v"(c116));
+        const float* w0 = lds + SdfLds::W0 + o52;
+        const float* w1h = lds + SdfLds::W1 + o116h;
+        const float* w1e = lds + SdfLds::W1 + 64 + o116e;
+        const float* w2h = lds + SdfLds::W2 + o116h;
+        const float* w2e = lds + SdfLds::W2 + 64 + o116e;
+        const float* w3 = lds + SdfLds::W3 + o68;
+        const float* w4 = lds + SdfLds::W4 + o68;
+        const float* w5s = lds + SdfLds::W5 + o4g;
+        const float* w5ft = lds + SdfLds::W5 + SdfLds::LD3 + c68;
+        const float* w4t = lds + SdfLds::W4 + c68;
+        const float* w3t = lds + SdfLds::W3 + c68;
+        const float* w2t = lds + SdfLds::W2 + c116;
+        const float* w1t = lds + SdfLds::W1 + c116;
 
 // the write phase of one step: B1 (the wgrad waves have finished reading the previous pair), write, B2 (visible)
-#define BW_EXCHANGE(WRITES)                                                                 \
+#define BW_EXCHANGE(K, WRITES)                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        BW_STAMP(4 * (K) + 1)                                                                \
         lds_barrier();                                                                       \
+        BW_STAMP(4 * (K) + 2)                                                                \
         { WRITES }                                                                           \
-        lds_barrier();
+        lds_barrier();                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        BW_STAMP(4 * (K) + 3)
 
+        // The per-tile inputs -- point, upstream gradients, layer-0 stash -- are fetched ONE TILE AHEAD (issued before the last two
+        // exchanges of the previous tile, whose waits hide the HBM round trip).  Buffer loads: the 16 points of a tile are one
+        // bounds-checked resource (lanes past n_points read 0 and are masked below).
+        float nx[3] = {0.f, 0.f, 0.f}, ngam[3] = {0.f, 0.f, 0.f}, nGs = 0.f;
+#define BW_FETCH(TILE)                                                                      \
+        {                                                                                    \
+            const int ft_ = __builtin_amdgcn_readfirstlane(TILE);                             \
+            const int left_ = min(TP, a.n_points - ft_ * TP);                                 \
+            const __amdgpu_buffer_rsrc_t rp_ = __builtin_amdgcn_make_buffer_rsrc(             \
+                const_cast<float*>(a.points) + (size_t)ft_ * TP * 3, 0, left_ * 12, 0x00020000); \
+            const __amdgpu_buffer_rsrc_t rg_ = __builtin_amdgcn_make_buffer_rsrc(             \
+                const_cast<float*>(a.g_grad) + (size_t)ft_ * TP * 3, 0, left_ * 12, 0x00020000); \
+            _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                   \
+                nx[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rp_, p * 12, 4 * c, 0));   \
+                ngam[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg_, p * 12, 4 * c, 0)); \
+            }                                                                                \
+            nGs = 0.f;                                                                       \
+            if (a.g_sdf) {                                                                   \
+                const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(         \
+                    const_cast<float*>(a.g_sdf) + (size_t)ft_ * TP, 0, left_ * 4, 0x00020000); \
+                nGs = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_, p * 4, 0, 0)); \
+            }                                                                                \
+            __builtin_amdgcn_sched_barrier(0);                                               \
+        }
+        if (t_begin + cw < t_end) BW_FETCH(t_begin + cw)
+#ifdef SC_BWDW_PROFILE
+        int prof_it = 0;
+#endif
 #pragma unroll 1
         for (int base = t_begin; base < t_end; base += BW_CHAIN) {
+#ifdef SC_BWDW_PROFILE
+            const bool prof_on = (int)blockIdx.x == a.prof_block && prof_it++ == a.prof_iter;
+#endif
+            BW_STAMP(60)
             const int tile = base + cw;
             if (tile >= t_end) {            // tail: nothing to do but keep the barrier count (11 steps) and feed zeros
                 for (int k = 0; k < 11; ++k) {
@@ -201,18 +252,57 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
             const int pt = tile * TP + p;
             const bool valid = pt < a.n_points;
             const float vmask = valid ? 1.f : 0.f;
-            const int ptc = valid ? pt : a.n_points - 1;
-            const float x0 = a.points[(size_t)ptc * 3 + 0], x1 = a.points[(size_t)ptc * 3 + 1], x2 = a.points[(size_t)ptc * 3 + 2];
-            float gam[3] = {0.f, 0.f, 0.f};
-            if (valid) { gam[0] = a.g_grad[(size_t)pt * 3]; gam[1] = a.g_grad[(size_t)pt * 3 + 1]; gam[2] = a.g_grad[(size_t)pt * 3 + 2]; }
-            float d1[PE_STEPS];
+            const float x0 = nx[0], x1 = nx[1], x2 = nx[2], Gs = nGs;       // (zeros for the lanes past n_points)
+            const float gam[3] = {ngam[0], ngam[1], ngam[2]};
             float j_av[ACT_STEPS], j_pend[ACT_STEPS], j_u[ACT_STEPS];      // R -> V junction registers
+            float r0v[ACT_STEPS];                                          // dW5 row-0 operand: leaves with step 10
+            float gx[3] = {0.f, 0.f, 0.f};                                 // d L / d point
+// Point-gradient terms that need only one operand of a step and the PE derivatives of the point:
+//   gx_c += sum_ch V[ch] * (W_le * DV[4c..4c+3])[ch]     V = q_l, DV = Gg_c d2E/dx_c^2 (steps 0-2);  V = Ga_l, DV = dE/dx_c (layers 2-0)
+// They sit where this wave would otherwise wait for the wgrad waves (which carry the PE outer products of the same steps).
+#define BW_PE_DOT2(WE, LD, V)                                                               \
+            if (a.g_points) {                                                                \
+                _Pragma("unroll") for (int c = 0; c < 3; ++c) {                               \
+                    f32x4 tacc[NT];                                                          \
+                    acc_zero(tacc);                                                          \
+                    BW_D2(c)                                                                 \
+                    if (c == 0) mm_pe<LD, NT, 0, 4>(WE, dv, tacc);                           \
+                    if (c == 1) mm_pe<LD, NT, 4, 4>(WE, dv, tacc);                           \
+                    if (c == 2) mm_pe<LD, NT, 8, 4>(WE, dv, tacc);                           \
+                    float dsum = 0.f;                                                        \
+                    _Pragma("unroll") for (int s = 0; s < ACT_STEPS; ++s)                     \
+                        dsum = __builtin_fmaf(V[s], tacc[s >> 2][s & 3], dsum);              \
+                    gx[c] += dsum;                                                           \
+                }                                                                            \
+            }
+#define BW_PE_DOT(WE, LD, V, DV)                                                            \
+            if (a.g_points) {                                                                \
+                _Pragma("unroll") for (int c = 0; c < 3; ++c) {                               \
+                    f32x4 tacc[NT];                                                          \
+                    acc_zero(tacc);                                                          \
+                    if (c == 0) mm_pe<LD, NT, 0, 4>(WE, DV + 0, tacc);                       \
+                    if (c == 1) mm_pe<LD, NT, 4, 4>(WE, DV + 4, tacc);                       \
+                    if (c == 2) mm_pe<LD, NT, 8, 4>(WE, DV + 8, tacc);                       \
+                    float dsum = 0.f;                                                        \
+                    _Pragma("unroll") for (int s = 0; s < ACT_STEPS; ++s)                     \
+                        dsum = __builtin_fmaf(V[s], tacc[s >> 2][s & 3], dsum);              \
+                    gx[c] += dsum;                                                           \
+                }                                                                            \
+            }
             // ================= R sweep =================
             {
-                float e[PE_STEPS], d2[PE_STEPS], eps[PE_STEPS];
+                float e[PE_STEPS], d1[PE_STEPS], d2[PE_STEPS], eps[PE_STEPS];
                 pe_slots<true, false, true>(x0, x1, x2, g, symmetric, e, d1, d2);
 #pragma unroll
                 for (int j = 0; j < PE_STEPS; ++j) eps[j] = gam[j >> 2] * d1[j];
+                // Gg_c d2E/dx_c^2 of the point terms is rebuilt from eps where it is used (12 registers less across the sweep): a
+                // slot pair is (sin, cos) of one argument f |x_c|, so  d2 sin = -f^2 sin sg^2 = +f sg * (d1 cos)  and
+                // d2 cos = -f sg * (d1 sin);  raw-coordinate lanes (g == 3) have no second derivative.
+                const float fb = g == 3 ? 0.f : (g == 0 ? 1.f : (g == 1 ? 4.f : 16.f));
+                const float fb0 = (symmetric ? (x0 > 0.f ? 1.f : (x0 < 0.f ? -1.f : 0.f)) : 1.f) * fb;
+#define BW_D2(C)                                                                            \
+                const float fs_ = (C) == 0 ? fb0 : fb;                                       \
+                const float dv[4] = {fs_ * eps[4 * (C) + 1], -fs_ * eps[4 * (C)], 2.f * fs_ * eps[4 * (C) + 3], -2.f * fs_ * eps[4 * (C) + 2]};
                 f32x4 acc[NT];
                 float avA[ACT_STEPS], pvA[ACT_STEPS], avB[ACT_STEPS], pvB[ACT_STEPS], gpA[ACT_STEPS], gpB[ACT_STEPS];
 #define BW_R_LOAD(L, av, pv)                                                                \
@@ -238,33 +328,41 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
                 BW_R_LOAD(0, avA, pvA)
                 BW_R_LOAD(1, avB, pvB)
                 mm_pe<SdfLds::LD0, NT, 0, PE_STEPS>(w0, eps, acc);                 // Gq0
+                BW_STAMP(0)
                 BW_R_ELEM(0, avA, pvA, gpA)
-                BW_EXCHANGE(                                                        // step 0: A = q0 (pairs with eps)
+                BW_PE_DOT2(w0, SdfLds::LD0, pvA)
+                BW_EXCHANGE(0,                                                         // step 0: A = q0 (pairs with eps)
                     xch_write(slotA, wr, pvA, vmask);
                     if (g == 0) {
                         *reinterpret_cast<float4*>(ptsw + p * 8) = make_float4(x0, x1, x2, gam[0]);
-                        *reinterpret_cast<float4*>(ptsw + p * 8 + 4) = make_float4(gam[1], gam[2], vmask, 0.f);
+                        *reinterpret_cast<float4*>(ptsw + p * 8 + 4) = make_float4(gam[1], gam[2], vmask, Gs);
                     })
                 acc_zero(acc);
                 BW_R_LOAD(2, avA, pvA)
                 mm_act<SdfLds::LD1, NT>(w1h, gpA, acc);
                 mm_pe<SdfLds::LD1, NT, 0, PE_STEPS>(w1e, eps, acc);                // Gq1
+                BW_STAMP(4)
                 BW_R_ELEM(1, avB, pvB, gpB)
-                BW_EXCHANGE(xch_write(slotA, wr, pvB, vmask); xch_write(slotB, wr, gpA, vmask);)      // step 1: (q1, Gp0)
+                BW_PE_DOT2(w1e, SdfLds::LD1, pvB)
+                BW_EXCHANGE(1, xch_write(slotA, wr, pvB, vmask); xch_write(slotB, wr, gpA, vmask);)      // step 1: (q1, Gp0)
                 acc_zero(acc);
                 BW_R_LOAD(3, avB, pvB)
                 mm_act<SdfLds::LD1, NT>(w2h, gpB, acc);
                 mm_pe<SdfLds::LD1, NT, 0, PE_STEPS>(w2e, eps, acc);                // Gq2
+                BW_STAMP(8)
                 BW_R_ELEM(2, avA, pvA, gpA)
-                BW_EXCHANGE(xch_write(slotA, wr, pvA, vmask); xch_write(slotB, wr, gpB, vmask);)      // step 2: (q2, Gp1)
+                BW_PE_DOT2(w2e, SdfLds::LD1, pvA)
+                BW_EXCHANGE(2, xch_write(slotA, wr, pvA, vmask); xch_write(slotB, wr, gpB, vmask);)      // step 2: (q2, Gp1)
                 acc_zero(acc);
                 tbl_load(a.stash_a + 4 * tbl, tile, p, g, j_av);
                 __builtin_amdgcn_sched_barrier(0);
                 mm_act<SdfLds::LD3, NT>(w3, gpA, acc);                             // Gq3
+                BW_STAMP(12)
                 BW_R_ELEM(3, avB, pvB, gpB)
-                BW_EXCHANGE(xch_write(slotA, wr, pvB, vmask); xch_write(slotB, wr, gpA, vmask);)      // step 3: (q3, Gp2)
+                BW_EXCHANGE(3, xch_write(slotA, wr, pvB, vmask); xch_write(slotB, wr, gpA, vmask);)      // step 3: (q3, Gp2)
                 acc_zero(acc);
                 mm_act<SdfLds::LD3, NT>(w4, gpB, acc);                             // Gq4
+                BW_STAMP(16)
                 {
                     float q4[ACT_STEPS];
 #pragma unroll
@@ -276,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
                         j_u[s] = gq * ds;
                         q4[s] = w5 * ds;
                     }
-                    BW_EXCHANGE(xch_write(slotA, wr, q4, vmask); xch_write(slotB, wr, gpB, vmask);)   // step 4: (q4, Gp3)
+                    BW_EXCHANGE(4, xch_write(slotA, wr, q4, vmask); xch_write(slotB, wr, gpB, vmask);)   // step 4: (q4, Gp3)
                 }
 #undef BW_R_ELEM
 #undef BW_R_LOAD
@@ -284,7 +382,6 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             // ================= V sweep =================
             {
-                const float Gs = (valid && a.g_sdf) ? a.g_sdf[pt] : 0.f;
                 f32x4 acc[NT];
                 float av[ACT_STEPS], pv[ACT_STEPS], avB[ACT_STEPS], pvB[ACT_STEPS], gaA[ACT_STEPS], gaB[ACT_STEPS], hv[ACT_STEPS];
 #define BW_V_LOAD(L, av, pv)                                                                \
@@ -303,15 +400,14 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
                 float gf[ACT_STEPS];
                 if (a.g_feat) {
                     tbl_load(a.g_feat, tile, p, g, gf);
-                    mm_act_t<SdfLds::LD3, NT>(w5ft, gf, acc);
+                    mm_act_t_pipe<SdfLds::LD3, NT>(w5ft, gf, acc);
                 } else {
 #pragma unroll
                     for (int s = 0; s < ACT_STEPS; ++s) gf[s] = 0.f;
                 }
                 BW_V_LOAD(3, av, pv)
-                BW_V_LOAD(2, avB, pvB)
+                BW_STAMP(20)
                 {
-                    float r0v[ACT_STEPS];
 #pragma unroll
                     for (int s = 0; s < ACT_STEPS; ++s) {
                         float t, r;
@@ -321,91 +417,72 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
                         r0v[s] = (Gs * hv[s] + j_u[s]) * vmask;
                         gaA[s] = gh * softplus_d1(j_av[s], t, r) + j_pend[s];
                     }
-                    // dW5 row 0 = sum over points of r0, db5[0] = sum Gs: row reduction + one LDS atomic per channel
-#pragma unroll
-                    for (int s = 0; s < ACT_STEPS; ++s) {
-                        const float tot = row_sum16(r0v[s]);
-                        if (p == 0) atomicAdd(&red[16 * (s >> 2) + 4 * g + (s & 3)], tot);
-                    }
-                    const float gs_tot = row_sum16(Gs);
-                    if (lane == 0) atomicAdd(&red[64], gs_tot);
+                    // dW5 row 0 = sum over points of r0 and db5[0] = sum Gs are row sums the wgrad waves take on the way: r0 rides in
+                    // the idle slot B of step 10, Gs in the point stash.  (They used to be reduced here with DPP adds and 16 LDS
+                    // atomics whose spilled addresses came back through `s_waitcnt vmcnt(0)`: 13 k cycles per tile, measured.)
                 }
-                BW_EXCHANGE(xch_write(slotA, wr, gf, vmask); xch_write(slotB, wr, hv, vmask);)        // step 5: (Gf, h4)
+                BW_EXCHANGE(5, xch_write(slotA, wr, gf, vmask); xch_write(slotB, wr, hv, vmask);)        // step 5: (Gf, h4)
                 acc_zero(acc);
-                mm_act_t<SdfLds::LD3, NT>(w4t, gaA, acc);
+                mm_act_t_pipe<SdfLds::LD3, NT>(w4t, gaA, acc);
+                BW_V_LOAD(2, avB, pvB)          // (after the MFMAs: a scratch reload in front of them would drain the fresh loads)
+                BW_STAMP(24)
                 BW_V_ELEM(av, pv, gaB)                                                              // Ga3, h3
-                BW_EXCHANGE(xch_write(slotA, wr, gaA, vmask); xch_write(slotB, wr, hv, vmask);)       // step 6: (Ga4, h3)
+                BW_EXCHANGE(6, xch_write(slotA, wr, gaA, vmask); xch_write(slotB, wr, hv, vmask);)       // step 6: (Ga4, h3)
+                acc_zero(acc);
+                mm_act_t_pipe<SdfLds::LD3, NT>(w3t, gaB, acc);
                 BW_V_LOAD(1, av, pv)
-                acc_zero(acc);
-                mm_act_t<SdfLds::LD3, NT>(w3t, gaB, acc);
+                BW_STAMP(28)
                 BW_V_ELEM(avB, pvB, gaA)                                                            // Ga2, h2
-                BW_EXCHANGE(xch_write(slotA, wr, gaB, vmask); xch_write(slotB, wr, hv, vmask);)       // step 7: (Ga3, h2)
+                BW_EXCHANGE(7, xch_write(slotA, wr, gaB, vmask); xch_write(slotB, wr, hv, vmask);)       // step 7: (Ga3, h2)
+                acc_zero(acc);
+                mm_act_t_pipe<SdfLds::LD1, NT>(w2t, gaA, acc);
                 BW_V_LOAD(0, avB, pvB)
-                acc_zero(acc);
-                mm_act_t<SdfLds::LD1, NT>(w2t, gaA, acc);
+                BW_STAMP(32)
                 BW_V_ELEM(av, pv, gaB)                                                              // Ga1, h1
-                BW_EXCHANGE(xch_write(slotA, wr, gaA, vmask); xch_write(slotB, wr, hv, vmask);)       // step 8: (Ga2, h1)
+                BW_EXCHANGE(8, xch_write(slotA, wr, gaA, vmask); xch_write(slotB, wr, hv, vmask);)       // step 8: (Ga2, h1)
+                float e[PE_STEPS], d1[PE_STEPS], d2[PE_STEPS];
+                pe_slots<true, false, true>(x0, x1, x2, g, symmetric, e, d1, d2);
+                BW_PE_DOT(w2e, SdfLds::LD1, gaA, d1)                                                // Ga2 (gaA is overwritten below)
                 acc_zero(acc);
-                mm_act_t<SdfLds::LD1, NT>(w1t, gaB, acc);
+                mm_act_t_pipe<SdfLds::LD1, NT>(w1t, gaB, acc);
+                BW_STAMP(36)
                 BW_V_ELEM(avB, pvB, gaA)                                                            // Ga0, h0
-                BW_EXCHANGE(xch_write(slotA, wr, gaB, vmask); xch_write(slotB, wr, hv, vmask);)       // step 9: (Ga1, h0)
-                BW_EXCHANGE(xch_write(slotA, wr, gaA, vmask);)                                      // step 10: Ga0 (pairs with e)
+                if (tile + BW_CHAIN < t_end) BW_FETCH(tile + BW_CHAIN)                              // next tile's inputs
+                BW_EXCHANGE(9, xch_write(slotA, wr, gaB, vmask); xch_write(slotB, wr, hv, vmask);)       // step 9: (Ga1, h0)
+                BW_PE_DOT(w1e, SdfLds::LD1, gaB, d1)                                                // Ga1
+                BW_PE_DOT(w0, SdfLds::LD0, gaA, d1)                                                 // Ga0
+                if (a.g_points) {
+                    const float o0 = group_sum(gx[0]), o1 = group_sum(gx[1]), o2 = group_sum(gx[2]);
+                    if (valid && g == 0) {
+                        a.g_points[(size_t)pt * 3 + 0] = o0;
+                        a.g_points[(size_t)pt * 3 + 1] = o1;
+                        a.g_points[(size_t)pt * 3 + 2] = o2;
+                    }
+                }
+                BW_EXCHANGE(10, xch_write(slotA, wr, gaA, vmask); xch_write(slotB, wr, r0v, 1.f);)      // step 10: Ga0 (pairs with e) | r0
 #undef BW_V_ELEM
 #undef BW_V_LOAD
             }
         }
 #undef BW_EXCHANGE
-        __syncthreads();        // all sums are in LDS
-        float* out = a.partial + (size_t)blockIdx.x * SdfPack::TOTAL;
-        if (tid < 64) out[SdfPack::W5 + tid] = lds[BW_RED + tid];
-        if (tid == 64) out[SdfPack::B5] = lds[BW_RED + 64];
+#undef BW_FETCH
+#undef BW_PE_DOT
+#undef BW_PE_DOT2
+#undef BW_D2
+        __syncthreads();        // the wgrad waves' sum of Gs is in LDS
+        if (tid == 0) a.partial[(size_t)blockIdx.x * SdfPack::TOTAL + SdfPack::B5] = lds[BW_RED + 64];
     } else {
         // =====================================================================================================
         // wgrad role: wave w owns rows 16w..16w+15 of every matrix
         // =====================================================================================================
         const int w = wave - BW_CHAIN, i = lane & 15, kg = lane >> 4;
         const int rd = (kg * 64 + (i ^ kg)) << 2;            // this lane's float4 chunk of channel tile 0 (+ 64 floats per tile)
-        // Besides the outer products, wave w evaluates the point-gradient terms of chain tile w that only need the A operand
-        // of a step and the PE derivatives of the point:  gx_c += Gg_c * q_l . (W_le d2E/dx_c^2)  (steps 0-2) and
-        // gx_c += Ga_l . (W_le dE/dx_c)  (steps 8-10) -- 288 of the 1008 chain MFMAs move from the latency-bound chain wave to
-        // this one.  In this view the lane is point p = i of the tile, channel group g = kg (the chain waves' layout).
-        const float* w0 = lds + SdfLds::W0 + i * SdfLds::LD0 + kg;
-        const float* w1e = lds + SdfLds::W1 + i * SdfLds::LD1 + 64 + kg;
-        const float* w2e = lds + SdfLds::W2 + i * SdfLds::LD1 + 64 + kg;
-        const float* slotAw = lds + BW_XCH + (w * 2 + 0) * 1024;
         const float* ptsw = lds + BW_PTS + w * 16 * 8;
-        int wr[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) wr[r] = (((i >> 2) * 64 + 4 * kg + (r ^ (i >> 2))) << 2) + (i & 3);
-        float gx[3] = {0.f, 0.f, 0.f}, gam[3] = {0.f, 0.f, 0.f};
-        float pd1[PE_STEPS], pd2[PE_STEPS];
-        float pvalid = 0.f;
-// gx_c += scale_c * sum_s V[s] * (W_le * DV[4c..4c+3])[s]
-#define BW_PE_DOT(WE, LD, V, DV, SCALE)                                                     \
-        _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                      \
-            f32x4 tacc[NT];                                                                  \
-            acc_zero(tacc);                                                                  \
-            if (c == 0) mm_pe<LD, NT, 0, 4>(WE, DV + 0, tacc);                               \
-            if (c == 1) mm_pe<LD, NT, 4, 4>(WE, DV + 4, tacc);                               \
-            if (c == 2) mm_pe<LD, NT, 8, 4>(WE, DV + 8, tacc);                               \
-            float dsum = 0.f;                                                                \
-            _Pragma("unroll") for (int s = 0; s < ACT_STEPS; ++s)                             \
-                dsum = __builtin_fmaf(V[s], tacc[s >> 2][s & 3], dsum);                      \
-            gx[c] = __builtin_fmaf(SCALE, dsum, gx[c]);                                      \
-        }
-// the A operand of chain tile w back in the chain layout (v[4T+r] = channel 16T+4g+r of point p), then the PE dot products
-#define BW_POINT_TERMS(WE, LD, DV, SCALE)                                                   \
-        if (a.g_points) {                                                                    \
-            float vv[ACT_STEPS];                                                             \
-            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                    \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) vv[4 * t + r] = slotAw[wr[r] + 64 * t]; \
-            BW_PE_DOT(WE, LD, vv, DV, SCALE)                                                 \
-        }
-
         f32x4 d0e[3], d1h[4], d1e[3], d2h[4], d2e[3], d3[4], d4[4], d5[4];
         acc_zero(d0e); acc_zero(d1h); acc_zero(d1e); acc_zero(d2h); acc_zero(d2e); acc_zero(d3); acc_zero(d4); acc_zero(d5);
         float rs[5] = {0.f, 0.f, 0.f, 0.f, 0.f};            // per-image bias-gradient partials (this lane's 4 points of every tile)
         float rsf = 0.f;                                     // sum over all points of Gf (db5 feature rows)
+        float rs0 = 0.f, gss = 0.f;                          // sum over all points of r0 (dW5 row 0, channel 16w + i) and of Gs (db5[0], tile w)
         int cur_img = -1;                                    // >= 0: rs[] belongs to this image; -2: mixed iteration (direct atomics)
         auto flush = [&]() {
             if (cur_img >= 0) {
@@ -419,7 +496,11 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
                 }
             }
         };
+#ifdef SC_BWDW_PROFILE
+#define BW_STEP_BEGIN BW_STAMP(prof_k) lds_barrier(); lds_barrier(); BW_STAMP(prof_k + 1) prof_k += 2;
+#else
 #define BW_STEP_BEGIN lds_barrier(); lds_barrier();
+#endif
 // one step over the four chain tiles.  HP: 64-wide B operand in slot B; PEM: 0 none, 1 E, 2 eps; RS: bias layer (-1 none, 5 = Gf)
 #define BW_CONSUME(ACCH, ACCE, HP, PEM, RS)                                                 \
         _Pragma("unroll") for (int c = 0; c < BW_CHAIN; ++c) {                               \
@@ -450,8 +531,16 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
                 }                                                                            \
             }                                                                                \
         }
+#ifdef SC_BWDW_PROFILE
+        int prof_it = 0, prof_k = 0;
+#endif
 #pragma unroll 1
         for (int base = t_begin; base < t_end; base += BW_CHAIN) {
+#ifdef SC_BWDW_PROFILE
+            const bool prof_on = (int)blockIdx.x == a.prof_block && prof_it++ == a.prof_iter;
+            prof_k = 0;
+#endif
+            BW_STAMP(60)
             const int img0 = min(base / tiles_per_image, a.n_images - 1);
             const int img3 = min(min(base + BW_CHAIN - 1, t_end - 1) / tiles_per_image, a.n_images - 1);
             if (img0 != cur_img || img3 != img0) {
@@ -459,49 +548,41 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
                 cur_img = img0 == img3 ? img0 : -2;
             }
             BW_STEP_BEGIN
-            if (a.g_points) {                                       // PE derivatives of this wave's tile (point stash written in step 0)
-                const float4 xa = *reinterpret_cast<const float4*>(ptsw + i * 8);
-                const float4 xb = *reinterpret_cast<const float4*>(ptsw + i * 8 + 4);
-                float pe[PE_STEPS];
-                pe_slots<true, true, true>(xa.x, xa.y, xa.z, kg, symmetric, pe, pd1, pd2);
-                gam[0] = xa.w; gam[1] = xb.x; gam[2] = xb.y; pvalid = xb.z;
-                gx[0] = gx[1] = gx[2] = 0.f;
-            }
+            gss += kg == 0 ? ptsw[i * 8 + 7] : 0.f;                 // db5[0] = sum of Gs (point i of chain tile w; stash written in step 0)
             BW_CONSUME(d3, d0e, false, 2, -1)                      // 0: q0 x eps
-            BW_POINT_TERMS(w0, SdfLds::LD0, pd2, gam[c])
             BW_STEP_BEGIN BW_CONSUME(d1h, d1e, true, 2, -1)         // 1: q1 x (Gp0 | eps)
-            BW_POINT_TERMS(w1e, SdfLds::LD1, pd2, gam[c])
             BW_STEP_BEGIN BW_CONSUME(d2h, d2e, true, 2, -1)         // 2: q2 x (Gp1 | eps)
-            BW_POINT_TERMS(w2e, SdfLds::LD1, pd2, gam[c])
             BW_STEP_BEGIN BW_CONSUME(d3, d0e, true, 0, -1)          // 3: q3 x Gp2
             BW_STEP_BEGIN BW_CONSUME(d4, d0e, true, 0, -1)          // 4: q4 x Gp3
             BW_STEP_BEGIN BW_CONSUME(d5, d0e, true, 0, 5)           // 5: Gf x h4
             BW_STEP_BEGIN BW_CONSUME(d4, d0e, true, 0, 4)           // 6: Ga4 x h3
             BW_STEP_BEGIN BW_CONSUME(d3, d0e, true, 0, 3)           // 7: Ga3 x h2
             BW_STEP_BEGIN BW_CONSUME(d2h, d2e, true, 1, 2)          // 8: Ga2 x (h1 | E)
-            BW_POINT_TERMS(w2e, SdfLds::LD1, pd1, 1.f)
             BW_STEP_BEGIN BW_CONSUME(d1h, d1e, true, 1, 1)          // 9: Ga1 x (h0 | E)
-            BW_POINT_TERMS(w1e, SdfLds::LD1, pd1, 1.f)
             BW_STEP_BEGIN BW_CONSUME(d3, d0e, false, 1, 0)          // 10: Ga0 x E
-            BW_POINT_TERMS(w0, SdfLds::LD0, pd1, 1.f)
-            if (a.g_points) {
-                const float o0 = group_sum(gx[0]), o1 = group_sum(gx[1]), o2 = group_sum(gx[2]);
-                const size_t pt = (size_t)(base + w) * TP + i;
-                if (base + w < t_end && pvalid != 0.f && kg == 0) {
-                    a.g_points[pt * 3 + 0] = o0;
-                    a.g_points[pt * 3 + 1] = o1;
-                    a.g_points[pt * 3 + 2] = o2;
-                }
+#pragma unroll
+            for (int c = 0; c < BW_CHAIN; ++c) {                    //     slot B of step 10 carries r0: its row sums are dW5 row 0
+                const float4 rf = xch_frag(lds + BW_XCH + (c * 2 + 1) * 1024, rd, w);
+                rs0 += (rf.x + rf.y) + (rf.z + rf.w);
             }
+            BW_STAMP(prof_k)
         }
 #undef BW_CONSUME
-#undef BW_POINT_TERMS
-#undef BW_PE_DOT
 #undef BW_STEP_BEGIN
         flush();
+        {
+            const float gs = row_sum16(gss);
+            if (lane == 0) atomicAdd(&lds[BW_RED + 64], gs);
+        }
         __syncthreads();
         // ---- this workgroup's partial image: rows 16w + 4kg + r, columns 16n + i of every matrix ----
         float* out = a.partial + (size_t)blockIdx.x * SdfPack::TOTAL;
+        {
+            float v0 = rs0;
+            v0 += __shfl_xor(v0, 16);
+            v0 += __shfl_xor(v0, 32);
+            if (kg == 0) out[SdfPack::W5 + 16 * w + i] = v0;
+        }
         auto put = [&](const f32x4* acc, int ntile, int off, int ld, int col0) {
             for (int n = 0; n < ntile; ++n)
 #pragma unroll
@@ -527,6 +608,12 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
 
 extern "C" {
 
+#ifdef SC_BWDW_PROFILE
+static unsigned long long* sc_bwdw_prof_buf = nullptr;
+static int sc_bwdw_prof_block = -1, sc_bwdw_prof_iter = -1;
+void sc_bwdw_set_prof(unsigned long long* buf, int block, int iter) { sc_bwdw_prof_buf = buf; sc_bwdw_prof_block = block; sc_bwdw_prof_iter = iter; }
+#endif
+
 // Number of workgroups (= partial images, = 4-wave park slots / 4) sc_sdf_backward_fused launches for n_points.
 int sc_sdf_backward_fused_parts(int n_points) {
     const int ntiles = (n_points + sc::TP - 1) / sc::TP;
@@ -541,6 +628,9 @@ int sc_sdf_backward_fused(const float* points, const float* w_pack, int n_points
     if (!g_grad || !stash_p || n_per_image <= 0 || n_per_image % sc::TP != 0 || n_images <= 0) return (int)hipErrorInvalidValue;
     sc::SdfBwdwArgs a{points, w_pack, n_points, n_per_image, n_images, symmetric, stash_a, stash_p, g_sdf, g_grad, g_feat,
                       g_points, park, partial, g_cbias};
+#ifdef SC_BWDW_PROFILE
+    a.prof = sc_bwdw_prof_buf; a.prof_block = sc_bwdw_prof_block; a.prof_iter = sc_bwdw_prof_iter;
+#endif
     const int blocks = sc_sdf_backward_fused_parts(n_points);
     const size_t lds_bytes = (size_t)sc::BW_LDS_FLOATS * sizeof(float);
     (void)hipFuncSetAttribute((const void*)sc::sdf_bwdw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
