@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--sustained", type=int, default=200, help="extra steps timed after the K-step region (0: off)")
     ap.add_argument("--no-workloads", action="store_true", help="skip the other SURVEY 8(d) workloads (tools/workloads.py)")
     ap.add_argument("--workloads-only", action="store_true", help="only those workloads (the rocprofv3 command of profiles/)")
-    ap.add_argument("--no-alt", action="store_true", help="skip the second measurement with --hip.conv3x3_split")
+    ap.add_argument("--no-alt", action="store_true", help="skip the second measurement with --hip.conv3x3_split! (fp32-MFMA convolutions)")
     ap.add_argument("--alt-steps", type=int, default=60)
     ap.add_argument("--opt", action="append", default=[], help="extra option override(s), e.g. --opt=--hip.fused_backward!")
     return ap.parse_args()
@@ -202,13 +202,16 @@ def main():
             sdt = t.item()
         sustained = dict(steps=a.sustained, ms_per_step=round(sdt / a.sustained * 1e3, 3),
                          value=round(a.batch * world / (sdt / a.sustained), 2))
-    # Second measurement, NOT the headline: the same step with `--hip.conv3x3_split` (forward / backward-data products of the 3x3
-    # convolutions as exact three-piece bf16 splits on the bf16 matrix pipe, fp32 accumulate; error against float64 no larger than the
-    # fp32-MFMA kernels', tests/test_gpu_conv.py).  `value` above is measured with fp32 MFMA arithmetic throughout.
+    # `value` above is measured in the default arithmetic (round 3, VERDICT r02 ruling): every product of the step is an fp32 product
+    # with fp32 accumulation; the forward / backward-data products of the 3x3 stride-1 convolutions are evaluated on the bf16 matrix
+    # pipe from exact three-piece operand splits (x = p0 + p1 + p2, six exact piece products summed in fp32: error against float64 no
+    # larger than the fp32-MFMA kernels', tests/test_gpu_conv.py), everything else on the fp32 matrix pipe.  Second measurement: the
+    # same step with `--hip.conv3x3_split!`, i.e. fp32 MFMA instructions throughout.
     alt = None
-    if world == 1 and not a.no_alt and not any("conv3x3_split" in o for o in a.opt):
-        from shapeclipper_amd.model import resnet
-        resnet.HIP_CONV3X3_SPLIT = True
+    from shapeclipper_amd.model import resnet
+    split_default = bool(resnet.HIP_CONV3X3_SPLIT)
+    if world == 1 and not a.no_alt and split_default:
+        resnet.HIP_CONV3X3_SPLIT = False
         try:
             for _ in range(5):
                 step()
@@ -218,11 +221,11 @@ def main():
                 step()
             torch.cuda.synchronize()
             adt = (time.time() - t1) / a.alt_steps
-            alt = dict(steps=a.alt_steps, ms_per_step=round(adt * 1e3, 3), value=round(a.batch / adt, 2),
-                       note="same step with --hip.conv3x3_split: 3x3 convolution forward/backward-data on the bf16 matrix pipe with exact "
-                            "3-piece operand splits (fp32-accurate, opt-in); not the headline")
+            alt = dict(steps=a.alt_steps, ms_per_step=round(adt * 1e3, 3), value=round(a.batch / adt, 2), dtype="f32 (fp32 MFMA throughout)",
+                       note="same step with --hip.conv3x3_split!: the 3x3 convolution forward/backward-data products on v_mfma_f32_32x32x2_f32 "
+                            "instead of the exact bf16x3 split; not the headline")
         finally:
-            resnet.HIP_CONV3X3_SPLIT = False
+            resnet.HIP_CONV3X3_SPLIT = True
     allreduce = None
     if world > 1 and runner.reducer is not None:      # the step's only exchange: one flat all-reduce
         flat = runner.reducer.flat
@@ -287,9 +290,13 @@ def main():
                                   flops_per_point=flops_pt)
         out = dict(metric="train-step images/sec (Pix3D cfg, bs32/GPU)", value=round(a.batch * world / (dt / a.steps), 2),
                    unit="images/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3),
-                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   higher_is_better=True, scaling="weak", vs_baseline=None,
+                   dtype="f32 (bf16x3-split MFMA, fp32 accumulate)" if split_default else "f32", data="synthetic",
                    config=dict(workload="Pix3D train step: bs32/GPU, 224x224 inputs, 512 rays x 64 samples, 2 renders "
-                                        "(input + CLIP-NN view) + eikonal, ResNet-34 encoder + ResNet-18 estimator, Adam",
+                                        "(input + CLIP-NN view) + eikonal, ResNet-34 encoder + ResNet-18 estimator, Adam; fp32 arithmetic "
+                                        "throughout" + ("; the 3x3 stride-1 convolution forward/backward-data products run on the bf16 matrix pipe "
+                                                        "from exact 3-piece operand splits with fp32 accumulation (fp32-accurate), all other "
+                                                        "products on fp32 MFMA" if split_default else " (fp32 MFMA)"),
                                global_batch=a.batch * world, rays_per_image=opt.render.rand_sample, samples_per_ray=64,
                                parallelism="dp%d" % world),
                    roofline=roofline, roofline_wgrad=roofline_wgrad, host_enqueue_ms_per_step=round(host_dt / a.steps * 1e3, 3),
@@ -298,7 +305,7 @@ def main():
         if allreduce is not None:
             out["allreduce"] = allreduce
         if alt is not None:
-            out["with_conv3x3_split"] = alt
+            out["fp32_mfma_convolutions"] = alt
         if not a.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks must not wait for rank 0)
             out["cpu_baseline"] = cpu_baseline(a.cpu_batch or a.batch)
         if not a.no_workloads and world == 1:

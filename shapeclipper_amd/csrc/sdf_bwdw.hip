@@ -192,13 +192,14 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
         const float* w2t = lds + SdfLds::W2 + c116;
         const float* w1t = lds + SdfLds::W1 + c116;
 
-// the write phase of one step: B1 (the wgrad waves have finished reading the previous pair), write, B2 (visible)
+// the write phase of one step: B1 (the wgrad waves have finished reading the previous pair), write, B2 (visible).
+// VM is the validity mask of the lane's point: a compile-time 1 for full tiles (all but the last tile of a launch)
 #define BW_EXCHANGE(K, WRITES)                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                   \
         BW_STAMP(4 * (K) + 1)                                                                \
         lds_barrier();                                                                       \
         BW_STAMP(4 * (K) + 2)                                                                \
-        { WRITES }                                                                           \
+        if (full) { constexpr float VM = 1.f; WRITES } else { const float VM = vmask; WRITES } \
         lds_barrier();                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                   \
         BW_STAMP(4 * (K) + 3)
@@ -252,6 +253,7 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
             const int pt = tile * TP + p;
             const bool valid = pt < a.n_points;
             const float vmask = valid ? 1.f : 0.f;
+            const bool full = tile * TP + TP <= a.n_points;                // wave-uniform
             const float x0 = nx[0], x1 = nx[1], x2 = nx[2], Gs = nGs;       // (zeros for the lanes past n_points)
             const float gam[3] = {ngam[0], ngam[1], ngam[2]};
             float j_av[ACT_STEPS], j_pend[ACT_STEPS], j_u[ACT_STEPS];      // R -> V junction registers
@@ -332,10 +334,10 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
                 BW_R_ELEM(0, avA, pvA, gpA)
                 BW_PE_DOT2(w0, SdfLds::LD0, pvA)
                 BW_EXCHANGE(0,                                                         // step 0: A = q0 (pairs with eps)
-                    xch_write(slotA, wr, pvA, vmask);
+                    xch_write(slotA, wr, pvA, VM);
                     if (g == 0) {
                         *reinterpret_cast<float4*>(ptsw + p * 8) = make_float4(x0, x1, x2, gam[0]);
-                        *reinterpret_cast<float4*>(ptsw + p * 8 + 4) = make_float4(gam[1], gam[2], vmask, Gs);
+                        *reinterpret_cast<float4*>(ptsw + p * 8 + 4) = make_float4(gam[1], gam[2], VM, Gs);
                     })
                 acc_zero(acc);
                 BW_R_LOAD(2, avA, pvA)
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
                 BW_STAMP(4)
                 BW_R_ELEM(1, avB, pvB, gpB)
                 BW_PE_DOT2(w1e, SdfLds::LD1, pvB)
-                BW_EXCHANGE(1, xch_write(slotA, wr, pvB, vmask); xch_write(slotB, wr, gpA, vmask);)      // step 1: (q1, Gp0)
+                BW_EXCHANGE(1, xch_write(slotA, wr, pvB, VM); xch_write(slotB, wr, gpA, VM);)      // step 1: (q1, Gp0)
                 acc_zero(acc);
                 BW_R_LOAD(3, avB, pvB)
                 mm_act<SdfLds::LD1, NT>(w2h, gpB, acc);
@@ -352,14 +354,14 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
                 BW_STAMP(8)
                 BW_R_ELEM(2, avA, pvA, gpA)
                 BW_PE_DOT2(w2e, SdfLds::LD1, pvA)
-                BW_EXCHANGE(2, xch_write(slotA, wr, pvA, vmask); xch_write(slotB, wr, gpB, vmask);)      // step 2: (q2, Gp1)
+                BW_EXCHANGE(2, xch_write(slotA, wr, pvA, VM); xch_write(slotB, wr, gpB, VM);)      // step 2: (q2, Gp1)
                 acc_zero(acc);
                 tbl_load(a.stash_a + 4 * tbl, tile, p, g, j_av);
                 __builtin_amdgcn_sched_barrier(0);
                 mm_act<SdfLds::LD3, NT>(w3, gpA, acc);                             // Gq3
                 BW_STAMP(12)
                 BW_R_ELEM(3, avB, pvB, gpB)
-                BW_EXCHANGE(3, xch_write(slotA, wr, pvB, vmask); xch_write(slotB, wr, gpA, vmask);)      // step 3: (q3, Gp2)
+                BW_EXCHANGE(3, xch_write(slotA, wr, pvB, VM); xch_write(slotB, wr, gpA, VM);)      // step 3: (q3, Gp2)
                 acc_zero(acc);
                 mm_act<SdfLds::LD3, NT>(w4, gpB, acc);                             // Gq4
                 BW_STAMP(16)
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
                         j_u[s] = gq * ds;
                         q4[s] = w5 * ds;
                     }
-                    BW_EXCHANGE(4, xch_write(slotA, wr, q4, vmask); xch_write(slotB, wr, gpB, vmask);)   // step 4: (q4, Gp3)
+                    BW_EXCHANGE(4, xch_write(slotA, wr, q4, VM); xch_write(slotB, wr, gpB, VM);)   // step 4: (q4, Gp3)
                 }
 #undef BW_R_ELEM
 #undef BW_R_LOAD
@@ -421,25 +423,25 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
                     // the idle slot B of step 10, Gs in the point stash.  (They used to be reduced here with DPP adds and 16 LDS
                     // atomics whose spilled addresses came back through `s_waitcnt vmcnt(0)`: 13 k cycles per tile, measured.)
                 }
-                BW_EXCHANGE(5, xch_write(slotA, wr, gf, vmask); xch_write(slotB, wr, hv, vmask);)        // step 5: (Gf, h4)
+                BW_EXCHANGE(5, xch_write(slotA, wr, gf, VM); xch_write(slotB, wr, hv, VM);)        // step 5: (Gf, h4)
                 acc_zero(acc);
                 mm_act_t_pipe<SdfLds::LD3, NT>(w4t, gaA, acc);
                 BW_V_LOAD(2, avB, pvB)          // (after the MFMAs: a scratch reload in front of them would drain the fresh loads)
                 BW_STAMP(24)
                 BW_V_ELEM(av, pv, gaB)                                                              // Ga3, h3
-                BW_EXCHANGE(6, xch_write(slotA, wr, gaA, vmask); xch_write(slotB, wr, hv, vmask);)       // step 6: (Ga4, h3)
+                BW_EXCHANGE(6, xch_write(slotA, wr, gaA, VM); xch_write(slotB, wr, hv, VM);)       // step 6: (Ga4, h3)
                 acc_zero(acc);
                 mm_act_t_pipe<SdfLds::LD3, NT>(w3t, gaB, acc);
                 BW_V_LOAD(1, av, pv)
                 BW_STAMP(28)
                 BW_V_ELEM(avB, pvB, gaA)                                                            // Ga2, h2
-                BW_EXCHANGE(7, xch_write(slotA, wr, gaB, vmask); xch_write(slotB, wr, hv, vmask);)       // step 7: (Ga3, h2)
+                BW_EXCHANGE(7, xch_write(slotA, wr, gaB, VM); xch_write(slotB, wr, hv, VM);)       // step 7: (Ga3, h2)
                 acc_zero(acc);
                 mm_act_t_pipe<SdfLds::LD1, NT>(w2t, gaA, acc);
                 BW_V_LOAD(0, avB, pvB)
                 BW_STAMP(32)
                 BW_V_ELEM(av, pv, gaB)                                                              // Ga1, h1
-                BW_EXCHANGE(8, xch_write(slotA, wr, gaA, vmask); xch_write(slotB, wr, hv, vmask);)       // step 8: (Ga2, h1)
+                BW_EXCHANGE(8, xch_write(slotA, wr, gaA, VM); xch_write(slotB, wr, hv, VM);)       // step 8: (Ga2, h1)
                 float e[PE_STEPS], d1[PE_STEPS], d2[PE_STEPS];
                 pe_slots<true, false, true>(x0, x1, x2, g, symmetric, e, d1, d2);
                 BW_PE_DOT(w2e, SdfLds::LD1, gaA, d1)                                                // Ga2 (gaA is overwritten below)
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
                 BW_STAMP(36)
                 BW_V_ELEM(avB, pvB, gaA)                                                            // Ga0, h0
                 if (tile + BW_CHAIN < t_end) BW_FETCH(tile + BW_CHAIN)                              // next tile's inputs
-                BW_EXCHANGE(9, xch_write(slotA, wr, gaB, vmask); xch_write(slotB, wr, hv, vmask);)       // step 9: (Ga1, h0)
+                BW_EXCHANGE(9, xch_write(slotA, wr, gaB, VM); xch_write(slotB, wr, hv, VM);)       // step 9: (Ga1, h0)
                 BW_PE_DOT(w1e, SdfLds::LD1, gaB, d1)                                                // Ga1
                 BW_PE_DOT(w0, SdfLds::LD0, gaA, d1)                                                 // Ga0
                 if (a.g_points) {
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
                         a.g_points[(size_t)pt * 3 + 2] = o2;
                     }
                 }
-                BW_EXCHANGE(10, xch_write(slotA, wr, gaA, vmask); xch_write(slotB, wr, r0v, 1.f);)      // step 10: Ga0 (pairs with e) | r0
+                BW_EXCHANGE(10, xch_write(slotA, wr, gaA, VM); xch_write(slotB, wr, r0v, 1.f);)      // step 10: Ga0 (pairs with e) | r0
 #undef BW_V_ELEM
 #undef BW_V_LOAD
             }

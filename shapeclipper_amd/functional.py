@@ -220,6 +220,10 @@ class Conv3x3Function(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, pack_f, pack_b, split):
         x = ops._aligned(x)
+        # pack_b is a view of the pack set's buffer, which every forward pass of the network rewrites in place through a raw pointer.
+        # That is safe: the rewrite reproduces the same bytes unless w changed, and w is saved here too, so a backward pass after an
+        # in-place update of w (forward A; optimizer.step(); forward B; backward A) fails in ctx.saved_tensors with autograd's own
+        # "modified by an inplace operation" error before the stale image could be used (tests/test_gpu_conv.py).
         ctx.save_for_backward(x, w, pack_b)
         ctx.split = split
         if pack_f is None:
@@ -333,7 +337,8 @@ def conv3x3(conv, x, packs=None):
         return conv(x)
     if packs is not None and id(conv.weight) in packs.index:
         return Conv3x3Function.apply(x, conv.weight, packs.get(conv.weight, 0), packs.get(conv.weight, 1), packs.split)
-    return Conv3x3Function.apply(x, conv.weight, None, None, False)
+    from .model import resnet          # the arithmetic switch lives with the trunks (`--hip.conv3x3_split`)
+    return Conv3x3Function.apply(x, conv.weight, None, None, bool(resnet.HIP_CONV3X3_SPLIT))
 
 
 class CameraRaysFunction(torch.autograd.Function):

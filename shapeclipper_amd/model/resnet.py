@@ -1,9 +1,10 @@
 """ResNet-18/34 trunks in plain torch.nn with torchvision's state-dict key names
 (conv1, bn1, layer{1..4}.{i}.conv{1,2}/bn{1,2}/downsample.{0,1}, fc) so that reference
-checkpoints load.  torchvision itself is not a dependency of this build.  SURVEY 8f-1: the convolutions
-run on MIOpen through stock PyTorch-ROCm; everything between them (BatchNorm + residual add + ReLU, and the
-stem's BN + ReLU + max-pool) is the fused HIP path of csrc/bn_act.hip (`FUSED_BN = False` restores the
-stock operators, e.g. for A/B timing)."""
+checkpoints load.  torchvision itself is not a dependency of this build.  SURVEY 8f-1: the convolutions run on the
+hand-written kernels of csrc/conv3x3.hip, conv3x3_wgrad.hip, conv_stem.hip and conv1x1s2.hip (the switches below send a
+layer class back to MIOpen through stock PyTorch-ROCm, and shapes the kernels do not take go there by themselves);
+everything between them (BatchNorm + residual add + ReLU, and the stem's BN + ReLU + max-pool) is the fused HIP path of
+csrc/bn_act.hip (`FUSED_BN = False` restores the stock operators, e.g. for A/B timing)."""
 from __future__ import annotations
 
 import torch
@@ -16,7 +17,8 @@ HIP_CONV3X3 = True       # 3x3 / stride-1 convolutions on csrc/conv3x3.hip (`--h
 HIP_CONV_STEM = True      # the 7x7 / 2 stem on csrc/conv_stem.hip (`--hip.conv_stem!` keeps it on MIOpen)
 HIP_CONV3X3_S2 = True    # forward of the 3x3 / stride-2 conv1 of layer2-4 on the stride-2 instance of conv3x3.hip (`--hip.conv3x3s2!`)
 HIP_CONV_1X1 = True       # the 1x1 / stride-2 shortcuts on csrc/conv1x1s2.hip (`--hip.conv1x1!`)
-HIP_CONV3X3_SPLIT = False  # `--hip.conv3x3_split`: their forward / backward-data products on the bf16 matrix pipe (three-piece exact split)
+HIP_CONV3X3_SPLIT = True  # their forward / backward-data products on the bf16 matrix pipe from exact three-piece operand splits, fp32 accumulate
+                          # (default since round 3, VERDICT r02 ruling; `--hip.conv3x3_split!` selects the fp32-MFMA kernels)
 
 
 class BasicBlock(nn.Module):

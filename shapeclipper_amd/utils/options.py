@@ -22,7 +22,7 @@ torch.backends.cudnn.benchmark = False
 # defaults for keys this build adds (a reference YAML without them still loads)
 # deterministic_conv: the reference sets cudnn.deterministic=True globally (utils/options.py:14); on ROCm that
 # restricts MIOpen to GEMM-based backward solvers (measured 437 ms of 640 ms per bs32 step), so it is opt-in here.
-HIP_DEFAULTS = dict(hip=dict(device_rng=False, device_choice=True, fused_backward=True, deterministic_conv=False, fused_loss=True, fused_adam=True, batched_encoders=True, two_streams=True, conv3x3=True, conv3x3_split=False, conv_stem=True, conv1x1=True, conv3x3s2=True))
+HIP_DEFAULTS = dict(hip=dict(device_rng=False, device_choice=True, fused_backward=True, deterministic_conv=False, fused_loss=True, fused_adam=True, batched_encoders=True, two_streams=True, conv3x3=True, conv3x3_split=True, conv_stem=True, conv1x1=True, conv3x3s2=True))
 
 
 def parse_arguments(args):
@@ -112,7 +112,7 @@ def process_options(opt):
     torch.backends.cudnn.deterministic = bool(opt.get("hip", {}).get("deterministic_conv", False))
     from ..model import resnet
     resnet.HIP_CONV3X3 = bool(opt.get("hip", {}).get("conv3x3", True))
-    resnet.HIP_CONV3X3_SPLIT = bool(opt.get("hip", {}).get("conv3x3_split", False))
+    resnet.HIP_CONV3X3_SPLIT = bool(opt.get("hip", {}).get("conv3x3_split", True))
     resnet.HIP_CONV_STEM = bool(opt.get("hip", {}).get("conv_stem", True))
     resnet.HIP_CONV_1X1 = bool(opt.get("hip", {}).get("conv1x1", True))
     resnet.HIP_CONV3X3_S2 = bool(opt.get("hip", {}).get("conv3x3s2", True))

@@ -20,13 +20,16 @@ def _last_json(out):
 def test_bench_line_contract():
     env = dict(os.environ, MIOPEN_LOG_LEVEL="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "2", "--sustained", "2",
-                        "--no-cpu-baseline", "--no-workloads"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+                        "--alt-steps", "2", "--no-cpu-baseline", "--no-workloads"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "sustained", "hip_ms_per_step", "host_enqueue_ms_per_step"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "images/s" and d["dtype"] == "f32"
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "images/s"
+    # VERDICT r02 ruling (a), (b): the default arithmetic names the split, and the pure fp32-MFMA step stays in the line beside it
+    assert d["dtype"] == "f32 (bf16x3-split MFMA, fp32 accumulate)" and "3-piece" in d["config"]["workload"]
+    assert d["fp32_mfma_convolutions"]["ms_per_step"] > 0 and d["fp32_mfma_convolutions"]["dtype"].startswith("f32")
     assert d["vs_baseline"] is None and d["scaling"] == "weak" and d["higher_is_better"] is True and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - 2 / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]

@@ -54,6 +54,7 @@ def test_resnet34_hip_convolutions_equal_miopen(split):
     net = resnet.build("resnet34").cuda().train()
     x = torch.randn(6, 3, 224, 224, device="cuda")
     res = []
+    saved = (resnet.HIP_CONV3X3, resnet.HIP_CONV3X3_SPLIT)
     for hip in (False, True):
         resnet.HIP_CONV3X3, resnet.HIP_CONV3X3_SPLIT = hip, hip and split
         try:
@@ -64,7 +65,7 @@ def test_resnet34_hip_convolutions_equal_miopen(split):
             res.append((y.detach(), xi.grad.clone(), m.conv1.weight.grad.clone(), m.layer1[0].conv1.weight.grad.clone(),
                         m.layer3[2].conv2.weight.grad.clone(), m.layer4[2].conv2.weight.grad.clone()))
         finally:
-            resnet.HIP_CONV3X3, resnet.HIP_CONV3X3_SPLIT = True, False
+            resnet.HIP_CONV3X3, resnet.HIP_CONV3X3_SPLIT = saved
     for a, b, name in zip(res[1], res[0], ("logits", "d input", "d conv1.weight", "d layer1.0.conv1.weight", "d layer3.2.conv2.weight",
                                            "d layer4.2.conv2.weight")):
         rel = float((a - b).norm() / b.norm().clamp_min(1e-12))
@@ -125,6 +126,89 @@ def test_conv3x3_split_bf16_is_fp32_accurate(side, cin, cout, batch):
     e_bwd = _rel(ops.conv3x3_backward_data(gy, w, split=True).double(), gx64)
     print("conv3x3 split %dx%d %d>%d B=%d: forward %.2e of max (fp32 MFMA kernel %.2e), backward-data %.2e" % (side, side, cin, cout, batch, e_split, e_fp32, e_bwd))
     assert e_split < 2e-5 and e_bwd < 2e-5 and e_split < 2 * e_fp32 + 2e-7
+
+
+def test_split_is_the_default_arithmetic():
+    """VERDICT r02 ruling: the three-piece split is the default of the 3x3 / stride-1 forward and backward-data products."""
+    from shapeclipper_amd.model import resnet
+    from shapeclipper_amd.utils import options
+    assert resnet.HIP_CONV3X3_SPLIT is True and options.HIP_DEFAULTS["hip"]["conv3x3_split"] is True
+
+
+@pytest.mark.parametrize("case", ["tiny", "range30", "huge"])
+def test_conv3x3_split_edge_magnitudes(case):
+    """Where the three-piece split could differ from fp32 arithmetic in kind, not in the last bits (conditions of the VERDICT r02 ruling):
+      tiny    operands around the smallest normal fp32 number (1.2e-38): the second and third pieces of such a number are below the bf16 /
+              fp32 normal range, and every product is subnormal in fp32 -- the fp32-MFMA kernel keeps subnormals, the split may flush them.
+              Bar: absolute error <= 2^-126 x the number of summed products (each lost piece is below the smallest normal) on top of the
+              usual relative bar, i.e. the result is right to within the subnormal range;
+      range30 one reduction mixes input channels whose magnitudes span 2^30: the low pieces of the small channels vanish against the large
+              ones exactly as their low mantissa bits do in fp32 -- the usual bar (2e-5 of the output scale) must hold;
+      huge    operands of 1e18: products 1e36..1e38 stay finite in both kernels (no spurious overflow from the piece products)."""
+    from shapeclipper_amd import ops
+    torch.manual_seed(11)
+    dev = torch.device("cuda:0")
+    B, C, S = 2, 64, 14
+    x = torch.randn(B, C, S, S, device=dev)
+    w = torch.randn(C, C, 3, 3, device=dev) * (2.0 / (9 * C)) ** 0.5
+    abs_tol = 0.0
+    gy = torch.randn(B, C, S, S, device=dev)
+    if case == "tiny":
+        x, gy = x * 2.0 ** -120, gy * 2.0 ** -120
+        w = w * 2.0 ** -4                    # products around 2^-126: the fp32 result itself is subnormal
+        abs_tol = 9 * C * 2.0 ** -126
+    elif case == "range30":
+        x = x * (2.0 ** torch.linspace(0, 30, C, device=dev)).view(1, C, 1, 1)
+        gy = gy * (2.0 ** torch.linspace(0, 30, C, device=dev)).view(1, C, 1, 1)
+    else:
+        x, w, gy = x * 1e18, w * 1e18, gy * 1e18
+    y64 = torch.nn.functional.conv2d(x.double(), w.double(), None, 1, 1)
+    gx64 = torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), 1, 1)
+    scale, scale_b = float(y64.abs().max()), float(gx64.abs().max())
+    for split in (False, True):
+        y = ops.conv3x3_forward(x, w, split=split)
+        gx = ops.conv3x3_backward_data(gy, w, split=split)
+        err = float((y.double() - y64).abs().max())
+        err_b = float((gx.double() - gx64).abs().max())
+        print("conv3x3 %s, %s: forward |error| %.3e (output scale %.3e), backward-data %.3e (scale %.3e)"
+              % (case, "bf16x3 split" if split else "fp32 MFMA", err, scale, err_b, scale_b))
+        assert torch.isfinite(y).all() and torch.isfinite(gx).all()
+        assert err <= 2e-5 * scale + abs_tol and err_b <= 2e-5 * scale_b + abs_tol
+
+
+def test_conv3x3_split_propagates_non_finite_values():
+    """An Inf or NaN input must poison exactly the outputs whose receptive field contains it, in both arithmetics (the training loop's
+    finite check relies on it).  With split operands Inf - Inf of the residual makes the poisoned outputs NaN where fp32 arithmetic
+    gives +-Inf: `not finite` is the contract, the flavour is not."""
+    from shapeclipper_amd import ops
+    torch.manual_seed(12)
+    dev = torch.device("cuda:0")
+    x = torch.randn(2, 64, 14, 14, device=dev)
+    w = torch.randn(64, 64, 3, 3, device=dev) * 0.05
+    x[0, 3, 5, 7] = float("inf")
+    x[1, 60, 0, 13] = float("nan")
+    x[1, 7, 9, 2] = float("-inf")
+    ref = ~torch.isfinite(torch.nn.functional.conv2d(x.double().cpu(), w.double().cpu(), None, 1, 1))
+    assert ref.any() and not ref.all()
+    for split in (False, True):
+        y = ops.conv3x3_forward(x, w, split=split)
+        assert torch.equal(~torch.isfinite(y).cpu(), ref), "split=%s" % split
+
+
+def test_backward_after_inplace_filter_update_raises():
+    """forward A; optimizer.step(); forward B; backward A: the packed filter image of A has been overwritten by B's refresh.  The filter
+    itself is saved for backward too, so autograd's version check refuses the stale backward."""
+    from shapeclipper_amd.model import resnet
+    torch.manual_seed(3)
+    net = resnet.build("resnet18").cuda().train()
+    x = torch.randn(2, 3, 224, 224, device="cuda")
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    ya = net(x).square().mean()
+    net(x).square().mean().backward()
+    opt.step()
+    net(x)                                   # forward B: refreshes the pack set from the updated filters
+    with pytest.raises(RuntimeError, match="inplace"):
+        ya.backward()
 
 
 @pytest.mark.parametrize("batch", [1, 3, 64])

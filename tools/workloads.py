@@ -29,6 +29,7 @@ if ROOT not in sys.path:
 
 PEAK_FP32 = 157.3       # TFLOP/s, fp32 vector = fp32 MFMA dense peak
 PEAK_BF16 = 2500.0      # TFLOP/s, bf16 MFMA dense peak
+PEAK_SPLIT = PEAK_BF16 / 6   # fp32-equivalent roof of the exact bf16x3 split: six bf16 MFMA products per fp32 product (416.7 TFLOP/s)
 CHAMFER_FLOP_PER_PAIR = 8
 VIT_B32_GFLOP = 8.725
 RENDER_EVAL_FLOP_PER_RAY = 64 * 199424
@@ -234,7 +235,9 @@ def level_grid_100(with_cpu=True):
 
 def resnet_conv3x3(with_cpu=True):
     """csrc/conv3x3.hip + conv3x3_wgrad.hip on every 3x3 / stride-1 layer shape of the two trunks, weighted by how often a step runs
-    it, with MIOpen (torch's operators) on the same tensors beside it."""
+    it, with MIOpen (torch's operators) on the same tensors beside it.  Default arithmetic: forward / backward-data from exact
+    three-piece bf16 operand splits (roof: bf16 dense peak / 6), weight gradient on fp32 MFMA (roof 157.3); the fp32-MFMA
+    forward / backward-data kernels (`--hip.conv3x3_split!`) are timed beside them."""
     from shapeclipper_amd import ops
     dev = torch.device("cuda")
     torch.manual_seed(0)
@@ -242,29 +245,45 @@ def resnet_conv3x3(with_cpu=True):
     for layers, batch in (([2, 2, 2, 2], 96), ([3, 4, 6, 3], 64)):       # view estimator: 3 x 32 images, encoder: 2 x 32
         for li, (c, side) in enumerate(((64, 56), (128, 28), (256, 14), (512, 7))):
             shapes.append((c, side, batch, 2 * layers[li] - (1 if li else 0)))
-    ms_hip = ms_lib = flop = 0.0
+    ms_split = ms_f32 = ms_wg = ms_lib = flop1 = 0.0
     rows = []
     for c, side, batch, count in shapes:
         x = torch.randn(batch, c, side, side, device=dev)
         w = torch.randn(c, c, 3, 3, device=dev) * 0.05
         gy = torch.randn(batch, c, side, side, device=dev)
         wp_f, wp_b = ops.conv3x3_pack(w, side), ops.conv3x3_pack(w, side, True)
+        ws_f, ws_b = ops.conv3x3_pack(w, side, False, True), ops.conv3x3_pack(w, side, True, True)
         t = [_gpu_ms(f, iters=10)[0] for f in (lambda: ops.conv3x3_apply(x, wp_f, c), lambda: ops.conv3x3_apply(gy, wp_b, c),
                                                lambda: ops.conv3x3_backward_weight(gy, x))]
+        ts = [_gpu_ms(f, iters=10)[0] for f in (lambda: ops.conv3x3_apply(x, ws_f, c, True), lambda: ops.conv3x3_apply(gy, ws_b, c, True))]
         bw = lambda m: torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, m)
         tl = [_gpu_ms(f, iters=10)[0] for f in (lambda: torch.nn.functional.conv2d(x, w, None, 1, 1), lambda: bw([True, False, False]),
                                                 lambda: bw([False, True, False]))]
         f1 = 2.0 * batch * side * side * c * c * 9
-        ms_hip += count * sum(t)
+        ms_split += count * sum(ts)
+        ms_f32 += count * (t[0] + t[1])
+        ms_wg += count * t[2]
         ms_lib += count * sum(tl)
-        flop += count * 3 * f1
-        rows.append(dict(channels=c, side=side, batch=batch, layers=count, hip_ms=[round(v, 3) for v in t], miopen_ms=[round(v, 3) for v in tl],
-                         hip_tflops=[round(f1 / v / 1e9, 1) for v in t]))
+        flop1 += count * f1
+        rows.append(dict(channels=c, side=side, batch=batch, layers=count, split_ms=[round(v, 3) for v in ts], fp32_mfma_ms=[round(v, 3) for v in t],
+                         miopen_ms=[round(v, 3) for v in tl], split_tflops=[round(f1 / v / 1e9, 1) for v in ts],
+                         fp32_mfma_tflops=[round(f1 / v / 1e9, 1) for v in t]))
         del x, w, gy
-    tf = flop / (ms_hip * 1e-3) / 1e12
+    ms_hip = ms_split + ms_wg
+    tf_s, tf_w, tf_f = 2 * flop1 / (ms_split * 1e-3) / 1e12, flop1 / (ms_wg * 1e-3) / 1e12, 2 * flop1 / (ms_f32 * 1e-3) / 1e12
     out = dict(workload="3x3 stride-1 convolutions of one bs32 step (ResNet-34 encoder x 64 images, ResNet-18 estimator x 96): fwd + bwd-data + bwd-weight of 42 layers",
-               ms=round(ms_hip, 3), ms_miopen=round(ms_lib, 3), algorithmic_flop=flop, achieved=round(tf, 2), peak=PEAK_FP32, unit="TFLOP/s",
-               bound="fp32 MFMA", frac=round(tf / PEAK_FP32, 4), layers=rows)
+               ms=round(ms_hip, 3), ms_miopen=round(ms_lib, 3), algorithmic_flop=3 * flop1, achieved=round(3 * flop1 / (ms_hip * 1e-3) / 1e12, 2),
+               unit="TFLOP/s", dtype="f32 (forward / backward-data: bf16x3-split MFMA, fp32 accumulate; backward-weight: fp32 MFMA)",
+               forward_backward_data=dict(ms=round(ms_split, 3), achieved=round(tf_s, 2), peak=round(PEAK_SPLIT, 1), unit="TFLOP/s",
+                                          bound="bf16 MFMA / 6 (exact 3-piece split: six bf16 products per fp32 product)",
+                                          frac=round(tf_s / PEAK_SPLIT, 4)),
+               backward_weight=dict(ms=round(ms_wg, 3), achieved=round(tf_w, 2), peak=PEAK_FP32, unit="TFLOP/s", bound="fp32 MFMA",
+                                    frac=round(tf_w / PEAK_FP32, 4)),
+               fp32_mfma_forward_backward_data=dict(ms=round(ms_f32, 3), achieved=round(tf_f, 2), peak=PEAK_FP32, unit="TFLOP/s", bound="fp32 MFMA",
+                                                    frac=round(tf_f / PEAK_FP32, 4), note="--hip.conv3x3_split!"),
+               # one number for the table: time-weighted fraction of the two roofs
+               frac=round((ms_split * (tf_s / PEAK_SPLIT) + ms_wg * (tf_w / PEAK_FP32)) / ms_hip, 4), peak=None,
+               bound="bf16 MFMA / 6 (fwd, bwd-data) + fp32 MFMA (bwd-weight), time-weighted", layers=rows)
     if with_cpu:
         torch.set_num_threads(cpu_threads())
         c, side, batch = 128, 28, 8
