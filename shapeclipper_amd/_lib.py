@@ -13,7 +13,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libshapeclipper_hip.so")
+# SHAPECLIPPER_HIP_LIB: load another build of the same C ABI (tuning / A-B experiments, e.g. tools/micro variants)
+LIB_PATH = os.environ.get("SHAPECLIPPER_HIP_LIB") or os.path.join(_HERE, "lib", "libshapeclipper_hip.so")
 
 SYMBOLS = (
     "sc_chamfer3d_forward", "sc_chamfer3d_forward_split", "sc_chamfer3d_backward", "sc_sdf_forward", "sc_rgb_composite_forward",

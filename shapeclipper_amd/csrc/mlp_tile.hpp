@@ -185,8 +185,12 @@ __device__ __forceinline__ void pe_slots(float x0, float x1, float x2, int g, bo
         for (int m = 0; m < 2; ++m) {
             const float f = fbase * (float)(1 << m);
             float sn, cs;
+#ifdef SC_NO_FAST_TRIG                       // experiment switch: accurate sincosf everywhere (tools/ab_fast_trig.sh)
+            sincosf(xs[c] * f, &sn, &cs);
+#else
             if (FAST) __sincosf(xs[c] * f, &sn, &cs);
             else sincosf(xs[c] * f, &sn, &cs);
+#endif
             e[4 * c + 2 * m] = raw ? (m == 0 ? xs[c] : 0.f) : sn;
             e[4 * c + 2 * m + 1] = raw ? 0.f : cs;
             if (D1) {
