@@ -27,6 +27,7 @@ class NN_annotator:
         if name not in ("ViT-B/32", "ViT-L/14"):
             raise NotImplementedError("clip_model '%s' (available: ViT-B/32, ViT-L/14)" % name)
         cfg = VIT_L14 if name == "ViT-L/14" else VIT_B32
+        cfg = dict(cfg, dtype=str(opt.get("clip_dtype", "fp16")))       # fp16: the reference's arithmetic on a GPU (:16); or bf16
         self.tower = ClipVisionTower(**cfg)
         ckpt = opt.get("clip_ckpt", None)
         if ckpt:

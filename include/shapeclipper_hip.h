@@ -161,6 +161,15 @@ int sc_clip_vit_forward(const float* image, int B, int C, int H, int W, int patc
  * 3: bf16.  K % 64 == 0.                                                                               */
 int sc_gemm_bf16(int epi, const uint16_t* A, const uint16_t* Wt, const float* bias, void* out, int M, int N, int K, void* stream);
 int sc_f32_to_bf16(const float* x, uint16_t* y, long long n, void* stream);
+/* The same three entry points with IEEE fp16 operands instead of bf16 (16-bit images / activations are fp16 bit patterns, fp32
+ * accumulation, LayerNorm / softmax statistics / residual stream in fp32): the arithmetic the reference's dependency uses on a GPU --
+ * clip.load("ViT-L/14", device="cuda") keeps weights and activations in fp16 with fp32 LayerNorm (CLIP_anno.py:16,166-167).  Default
+ * of shapeclipper_amd.model.clip_vit.ClipVisionTower since round 3.                                          */
+int sc_clip_vit_forward_f16(const float* image, int B, int C, int H, int W, int patch, int D, int mlp, int layers,
+                            int heads, int proj_dim, const uint16_t* w_f16, const float* w_f32, float ln_eps,
+                            float* out, void* workspace, long long workspace_bytes, void* stream);
+int sc_gemm_f16(int epi, const uint16_t* A, const uint16_t* Wt, const float* bias, void* out, int M, int N, int K, void* stream);
+int sc_f32_to_f16(const float* x, uint16_t* y, long long n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Ray sampling (UniformSampler.get_z_vals + point generation, model/renderer.py:13-37,84-86).

@@ -37,8 +37,24 @@ __device__ __forceinline__ bf16_t f2bf(float f) {      // round-to-nearest-even
 }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
+// 16-bit operand format of the tower: H = false bf16 (8-bit mantissa), H = true IEEE fp16 (11-bit mantissa: what openai/CLIP runs its
+// weights and activations in on a GPU, CLIP_anno.py:16 -> clip.load(..., device="cuda")).  Same MFMA rate (2.5 PFLOP/s dense), same
+// storage width: every kernel below is a template over H and differs only in the conversion and in the MFMA opcode.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+template <bool H>
+__device__ __forceinline__ bf16_t cvt16(float f) {
+    if (H) return __builtin_bit_cast(bf16_t, (_Float16)f);       // v_cvt_f16_f32, round to nearest even (saturates to +-inf past 65504)
+    return f2bf(f);
+}
+template <bool H>
+__device__ __forceinline__ f32x16 mfma16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    if (H) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // out [B*np][Kpad]: columns >= C*P*P are zero (the GEMM wants K % 64 == 0; ViT-L/14 has 3*14*14 = 588 -> 640)
+template <bool H16>
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, bf16_t* __restrict__ out,
                                                        int B, int C, int H, int W, int P, int Kpad) {
     const int gw = W / P, gh = H / P, np = gw * gh, K = C * P * P;
@@ -50,7 +66,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
         const int pidx = (int)(row % np), b = (int)(row / np);
         const int c = k / (P * P), ky = (k / P) % P, kx = k % P;
         const int py = pidx / gw, px = pidx % gw;
-        out[idx] = f2bf(img[(((size_t)b * C + c) * H + py * P + ky) * W + px * P + kx]);
+        out[idx] = cvt16<H16>(img[(((size_t)b * C + c) * H + py * P + ky) * W + px * P + kx]);
     }
 }
 
@@ -85,7 +101,7 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(
 #ifndef SC_GEMM64_STAGES
 #define SC_GEMM64_STAGES 3
 #endif
-template <int EPI, int BT>
+template <int EPI, int BT, bool H16>
 __global__ __launch_bounds__(256, BT == 128 ? 2 : 4) void gemm_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
                                                                            const float* __restrict__ bias, void* __restrict__ out,
                                                                            int M, int N, int K) {
@@ -161,7 +177,7 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 4) void gemm_bf16_kernel(const
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < MI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma16<H16>(af[kk & 1][i], bf[kk & 1][j], acc[i][j]);
         }
     };
     // Tile kt is complete for every wave once each wave has waited for its own DMA (issued from asm: counted by hand) and all
@@ -201,8 +217,8 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 4) void gemm_bf16_kernel(const
                 for (int r = 0; r < 16; ++r) {
                     const int rl = (BT / 2) * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     const float v = acc[i][j][r] + bv;
-                    if (EPI == EPI_GELU_BF16) Ch[rl * BT + cl] = f2bf(v / (1.f + __expf(-1.702f * v)));
-                    else if (EPI == EPI_BF16) Ch[rl * BT + cl] = f2bf(v);
+                    if (EPI == EPI_GELU_BF16) Ch[rl * BT + cl] = cvt16<H16>(v / (1.f + __expf(-1.702f * v)));
+                    else if (EPI == EPI_BF16) Ch[rl * BT + cl] = cvt16<H16>(v);
                     else Cf[rl * BT + cl] = v;
                 }
             }
@@ -268,8 +284,8 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 4) void gemm_bf16_kernel(const
                 const size_t o = (size_t)row * N + col;
                 if (EPI == EPI_F32) reinterpret_cast<float*>(out)[o] = v;
                 else if (EPI == EPI_RESID) reinterpret_cast<float*>(out)[o] = res[i][j][r] + v;
-                else if (EPI == EPI_GELU_BF16) reinterpret_cast<bf16_t*>(out)[o] = f2bf(v / (1.f + __expf(-1.702f * v)));
-                else reinterpret_cast<bf16_t*>(out)[o] = f2bf(v);
+                else if (EPI == EPI_GELU_BF16) reinterpret_cast<bf16_t*>(out)[o] = cvt16<H16>(v / (1.f + __expf(-1.702f * v)));
+                else reinterpret_cast<bf16_t*>(out)[o] = cvt16<H16>(v);
             }
         }
 }
@@ -279,7 +295,7 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 4) void gemm_bf16_kernel(const
 // one, so its DMA round trip (~1.3 us under load) and the pointer set-up run under the epilogue instead of in front of an idle
 // matrix pipe, and no workgroup is re-launched per tile.  The epilogue stages the tile through the LDS stage that was consumed
 // last (the other one is receiving the next tile): 32 KiB = the whole bf16 tile, or the fp32 tile in two 64-row halves.
-template <int EPI>
+template <int EPI, bool H16>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_persist_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt,
                                                                    const float* __restrict__ bias, void* __restrict__ out,
                                                                    int M, int N, int K, int ntn, int tiles) {
@@ -354,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_persist_kernel(const bf16_t*
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma16<H16>(af[kk & 1][i], bf[kk & 1][j], acc[i][j]);
             }
         }
         // ---- epilogue through the stage consumed last, (g - 1) & 1; the other one may be receiving the next tile ----
@@ -373,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_persist_kernel(const bf16_t*
                     for (int r = 0; r < 16; ++r) {
                         const int rl = 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                         const float v = acc[i][j][r] + bv;
-                        Ch[rl * BT + cl] = EPI == EPI_GELU_BF16 ? f2bf(v / (1.f + __expf(-1.702f * v))) : f2bf(v);
+                        Ch[rl * BT + cl] = EPI == EPI_GELU_BF16 ? cvt16<H16>(v / (1.f + __expf(-1.702f * v))) : cvt16<H16>(v);
                     }
                 }
             SC_LDS_SYNC();
@@ -429,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_persist_kernel(const bf16_t*
 
 // ---------------------------------------------------------------------------------------------------
 // LayerNorm over D (multiple of 64, <= 1024 here) per row; x rows are `stride` floats apart.
-template <bool OUT_BF16>
+template <bool OUT_BF16, bool H16>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int stride, const float* __restrict__ g,
                                                         const float* __restrict__ b, void* __restrict__ out, int rows, int D,
                                                         float eps) {
@@ -464,7 +480,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                 const float o0 = v[k].x * inv * gg.x + bb.x, o1 = v[k].y * inv * gg.y + bb.y;
                 const float o2 = v[k].z * inv * gg.z + bb.z, o3 = v[k].w * inv * gg.w + bb.w;
                 if (OUT_BF16) {
-                    const uint2 pk = make_uint2((uint32_t)f2bf(o0) | ((uint32_t)f2bf(o1) << 16), (uint32_t)f2bf(o2) | ((uint32_t)f2bf(o3) << 16));
+                    const uint2 pk = make_uint2((uint32_t)cvt16<H16>(o0) | ((uint32_t)cvt16<H16>(o1) << 16),
+                                                (uint32_t)cvt16<H16>(o2) | ((uint32_t)cvt16<H16>(o3) << 16));
                     *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (size_t)row * D + d) = pk;
                 } else {
                     *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)row * D + d) = make_float4(o0, o1, o2, o3);
@@ -480,7 +497,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const float inv = rsqrtf(var + eps);
     for (int d = lane; d < D; d += 64) {
         const float v = (xr[d] - mean) * inv * g[d] + b[d];
-        if (OUT_BF16) reinterpret_cast<bf16_t*>(out)[(size_t)row * D + d] = f2bf(v);
+        if (OUT_BF16) reinterpret_cast<bf16_t*>(out)[(size_t)row * D + d] = cvt16<H16>(v);
         else reinterpret_cast<float*>(out)[(size_t)row * D + d] = v;
     }
 }
@@ -508,6 +525,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ pa
 //                                K-step are 8 keys); B = V with keys contiguous per lane -> V is staged once per
 //                                workgroup TRANSPOSED in LDS (Vt[d][key]), the K-step's key order follows the C/D layout
 // fp32 scores / statistics / accumulation, bf16 probabilities (openai/CLIP on GPU keeps them in fp16).
+template <bool H16>
 __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int T, int D,
                                                         int heads, float scale) {
     extern __shared__ bf16_t Vt[];                   // [64][ldv], ldv = Tp + 4 (row stride = odd multiple of 2 words)
@@ -541,7 +559,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) S[r] = 0.f;
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(kc + n, D + 16 * s4), qf[s4], S, 0, 0, 0);
+            for (int s4 = 0; s4 < 4; ++s4) S = mfma16<H16>(frag(kc + n, D + 16 * s4), qf[s4], S);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kc + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -582,7 +600,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float x = v[8 * j + e];
-                    tmp[e] = f2bf(x > NEG ? __expf(x - m) * inv : 0.f);
+                    tmp[e] = cvt16<H16>(x > NEG ? __expf(x - m) * inv : 0.f);
                 }
                 pf[j] = __builtin_bit_cast(bf16x8, tmp);
             }
@@ -594,7 +612,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
                     const bf16_t* vp = Vt + (32 * t + n) * ldv + kc + 16 * j + 4 * h;
                     const uint2 lo = *reinterpret_cast<const uint2*>(vp), hi = *reinterpret_cast<const uint2*>(vp + 8);
                     const uint4 pk = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                    O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[j], __builtin_bit_cast(bf16x8, pk), O[t], 0, 0, 0);
+                    O[t] = mfma16<H16>(pf[j], __builtin_bit_cast(bf16x8, pk), O[t]);
                 }
         }
 #pragma unroll
@@ -602,15 +620,17 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int qq = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (qq < T) out[((size_t)b * T + qq) * D + hd * 64 + 32 * t + n] = f2bf(O[t][r]);
+                if (qq < T) out[((size_t)b * T + qq) * D + hd * 64 + 32 * t + n] = cvt16<H16>(O[t][r]);
             }
     }
 }
 
+template <bool H16>
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = f2bf(x[i]);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = cvt16<H16>(x[i]);
 }
 
+template <bool H16>
 static int launch_gemm(int epi, const bf16_t* A, const bf16_t* Wt, const float* bias, void* out, int M, int N, int K,
                        hipStream_t st) {
     if (K % 64) return (int)hipErrorInvalidValue;
@@ -619,17 +639,17 @@ static int launch_gemm(int epi, const bf16_t* A, const bf16_t* Wt, const float* 
     const bool small = t128 < 384;
 #define SC_LAUNCH(E)                                                                                                          \
     if (small) {                                                                                                              \
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<E, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,           \
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<E, 64, H16>, hipFuncAttributeMaxDynamicSharedMemorySize,           \
                                    SC_GEMM64_STAGES * 2 * 64 * 8 * 16);                                                       \
-        hipLaunchKernelGGL((gemm_bf16_kernel<E, 64>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256),                          \
+        hipLaunchKernelGGL((gemm_bf16_kernel<E, 64, H16>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256),                          \
                            SC_GEMM64_STAGES * 2 * 64 * 8 * 16, st, A, Wt, bias, out, M, N, K);                                \
     } else if ((N % 8) == 0) {          /* persistent: 2 resident workgroups per CU walk the tile list */                     \
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_persist_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); \
-        hipLaunchKernelGGL((gemm_bf16_persist_kernel<E>), dim3(512), dim3(256), 65536, st, A, Wt, bias, out, M, N, K,         \
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_persist_kernel<E, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); \
+        hipLaunchKernelGGL((gemm_bf16_persist_kernel<E, H16>), dim3(512), dim3(256), 65536, st, A, Wt, bias, out, M, N, K,         \
                            (N + 127) / 128, (int)t128);                                                                       \
     } else {                                                                                                                  \
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<E, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);  \
-        hipLaunchKernelGGL((gemm_bf16_kernel<E, 128>), dim3((N + 127) / 128, (M + 127) / 128), dim3(256), 65536, st,          \
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<E, 128, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);  \
+        hipLaunchKernelGGL((gemm_bf16_kernel<E, 128, H16>), dim3((N + 127) / 128, (M + 127) / 128), dim3(256), 65536, st,          \
                            A, Wt, bias, out, M, N, K);                                                                        \
     }
     switch (epi) {
@@ -642,40 +662,11 @@ static int launch_gemm(int epi, const bf16_t* A, const bf16_t* Wt, const float* 
     return (int)hipGetLastError();
 }
 
-}  // namespace sc
-
-extern "C" {
-
-// y[n] = bf16(x[n])  (weight preparation, once per model)
-int sc_f32_to_bf16(const float* x, uint16_t* y, long long n, void* stream_) {
-    if (n <= 0) return 0;
-    int blocks = (int)((n + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(sc::f32_to_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, x, y, (size_t)n);
-    return (int)hipGetLastError();
-}
-
-// Generic bf16 GEMM used by the tower (exported for tests): out[M,N] (epi 0 fp32 / 1 fp32 += / 2 quick_gelu bf16 / 3 bf16)
-int sc_gemm_bf16(int epi, const uint16_t* A, const uint16_t* Wt, const float* bias, void* out, int M, int N, int K, void* stream_) {
-    return sc::launch_gemm(epi, A, Wt, bias, out, M, N, K, (hipStream_t)stream_);
-}
-
-// Bytes of device workspace sc_clip_vit_forward carves for this geometry (same carve order and 256-byte alignment).
-long long sc_clip_vit_workspace_bytes(int B, int C, int H, int W, int patch, int D, int mlp) {
-    const long long np = (long long)(H / patch) * (W / patch), T = np + 1, M = (long long)B * T;
-    const long long Kp = ((long long)C * patch * patch + 63) & ~63LL;
-    const long long sizes[8] = {B * np * Kp * 2, B * np * D * 4, M * D * 4, M * D * 2, M * 3 * D * 2, M * D * 2, M * mlp * 2,
-                                (long long)B * D * 2};
-    long long total = 0;
-    for (long long s : sizes) total += (s + 255) & ~255LL;
-    return total;
-}
-
-// Full image tower.  See include/shapeclipper_hip.h for the weight image layout.
-int sc_clip_vit_forward(const float* image, int B, int C, int H, int W, int patch, int D, int mlp, int layers, int heads,
-                        int proj_dim, const uint16_t* w_bf16, const float* w_f32, float ln_eps, float* out,
-                        void* workspace, long long workspace_bytes, void* stream_) {
-    using namespace sc;
+// Full image tower (H16: fp16 instead of bf16 operands).  See include/shapeclipper_hip.h for the weight image layout.
+template <bool H16>
+static int clip_vit_forward(const float* image, int B, int C, int H, int W, int patch, int D, int mlp, int layers, int heads,
+                            int proj_dim, const uint16_t* w_bf16, const float* w_f32, float ln_eps, float* out,
+                            void* workspace, long long workspace_bytes, void* stream_) {
     hipStream_t st = (hipStream_t)stream_;
     if (D % 64 || D / heads != 64 || mlp % 64) return (int)hipErrorInvalidValue;
     const int np = (H / patch) * (W / patch), T = np + 1, M = B * T;
@@ -702,15 +693,15 @@ int sc_clip_vit_forward(const float* image, int B, int C, int H, int W, int patc
     const float* lnpre_g = wf; wf += D;
     const float* lnpre_b = wf; wf += D;
 
-    hipLaunchKernelGGL(patchify_kernel, dim3(2048), dim3(256), 0, st, image, a_patch, B, C, H, W, patch, Kp);
+    hipLaunchKernelGGL(patchify_kernel<H16>, dim3(2048), dim3(256), 0, st, image, a_patch, B, C, H, W, patch, Kp);
     const int att_lds = 64 * (((T + 31) & ~31) + 4) * (int)sizeof(bf16_t);
     if (att_lds > 160 * 1024) return (int)hipErrorInvalidValue;
     if (att_lds > 48 * 1024)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, att_lds);
-    int rc = launch_gemm(EPI_F32, a_patch, w_patch, nullptr, patch_out, B * np, D, Kp, st);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<H16>), hipFuncAttributeMaxDynamicSharedMemorySize, att_lds);
+    int rc = launch_gemm<H16>(EPI_F32, a_patch, w_patch, nullptr, patch_out, B * np, D, Kp, st);
     if (rc) return rc;
     hipLaunchKernelGGL(embed_kernel, dim3(1024), dim3(256), 0, st, patch_out, cls, pos, x, B, T, D);
-    hipLaunchKernelGGL(layernorm_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, x, D, lnpre_g, lnpre_b, (void*)x, M, D, ln_eps);
+    hipLaunchKernelGGL((layernorm_kernel<false, H16>), dim3((M + 3) / 4), dim3(256), 0, st, x, D, lnpre_g, lnpre_b, (void*)x, M, D, ln_eps);
     for (int l = 0; l < layers; ++l) {
         const bf16_t* w_qkv = wb; wb += (size_t)3 * D * D;
         const bf16_t* w_o = wb; wb += (size_t)D * D;
@@ -724,20 +715,77 @@ int sc_clip_vit_forward(const float* image, int B, int C, int H, int W, int patc
         const float* ln2_b = wf; wf += D;
         const float* b_fc1 = wf; wf += mlp;
         const float* b_fc2 = wf; wf += D;
-        hipLaunchKernelGGL(layernorm_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, x, D, ln1_g, ln1_b, (void*)xn, M, D, ln_eps);
-        if ((rc = launch_gemm(EPI_BF16, xn, w_qkv, b_qkv, qkv, M, 3 * D, D, st))) return rc;
-        hipLaunchKernelGGL(attention_kernel, dim3(B * heads), dim3(256), att_lds, st, qkv, att, T, D, heads, 0.125f);
-        if ((rc = launch_gemm(EPI_RESID, att, w_o, b_o, x, M, D, D, st))) return rc;
-        hipLaunchKernelGGL(layernorm_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, x, D, ln2_g, ln2_b, (void*)xn, M, D, ln_eps);
-        if ((rc = launch_gemm(EPI_GELU_BF16, xn, w_fc1, b_fc1, hbuf, M, mlp, D, st))) return rc;
-        if ((rc = launch_gemm(EPI_RESID, hbuf, w_fc2, b_fc2, x, M, D, mlp, st))) return rc;
+        hipLaunchKernelGGL((layernorm_kernel<true, H16>), dim3((M + 3) / 4), dim3(256), 0, st, x, D, ln1_g, ln1_b, (void*)xn, M, D, ln_eps);
+        if ((rc = launch_gemm<H16>(EPI_BF16, xn, w_qkv, b_qkv, qkv, M, 3 * D, D, st))) return rc;
+        hipLaunchKernelGGL(attention_kernel<H16>, dim3(B * heads), dim3(256), att_lds, st, qkv, att, T, D, heads, 0.125f);
+        if ((rc = launch_gemm<H16>(EPI_RESID, att, w_o, b_o, x, M, D, D, st))) return rc;
+        hipLaunchKernelGGL((layernorm_kernel<true, H16>), dim3((M + 3) / 4), dim3(256), 0, st, x, D, ln2_g, ln2_b, (void*)xn, M, D, ln_eps);
+        if ((rc = launch_gemm<H16>(EPI_GELU_BF16, xn, w_fc1, b_fc1, hbuf, M, mlp, D, st))) return rc;
+        if ((rc = launch_gemm<H16>(EPI_RESID, hbuf, w_fc2, b_fc2, x, M, D, mlp, st))) return rc;
     }
     const bf16_t* w_proj = wb;
     const float* lnpost_g = wf; wf += D;
     const float* lnpost_b = wf; wf += D;
     // ln_post on the class token of every image (row stride T*D), then the projection (no bias)
-    hipLaunchKernelGGL(layernorm_kernel<true>, dim3((B + 3) / 4), dim3(256), 0, st, x, T * D, lnpost_g, lnpost_b, (void*)pooled, B, D, ln_eps);
-    return launch_gemm(EPI_F32, pooled, w_proj, nullptr, out, B, proj_dim, D, st);
+    hipLaunchKernelGGL((layernorm_kernel<true, H16>), dim3((B + 3) / 4), dim3(256), 0, st, x, T * D, lnpost_g, lnpost_b, (void*)pooled, B, D, ln_eps);
+    return launch_gemm<H16>(EPI_F32, pooled, w_proj, nullptr, out, B, proj_dim, D, st);
+}
+
+}  // namespace sc
+
+extern "C" {
+
+// y[n] = bf16(x[n])  (weight preparation, once per model)
+int sc_f32_to_bf16(const float* x, uint16_t* y, long long n, void* stream_) {
+    if (n <= 0) return 0;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sc::f32_to_bf16_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, x, y, (size_t)n);
+    return (int)hipGetLastError();
+}
+// y[n] = fp16(x[n]), round to nearest even
+int sc_f32_to_f16(const float* x, uint16_t* y, long long n, void* stream_) {
+    if (n <= 0) return 0;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sc::f32_to_bf16_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, x, y, (size_t)n);
+    return (int)hipGetLastError();
+}
+
+// Generic bf16 GEMM used by the tower (exported for tests): out[M,N] (epi 0 fp32 / 1 fp32 += / 2 quick_gelu bf16 / 3 bf16)
+int sc_gemm_bf16(int epi, const uint16_t* A, const uint16_t* Wt, const float* bias, void* out, int M, int N, int K, void* stream_) {
+    return sc::launch_gemm<false>(epi, A, Wt, bias, out, M, N, K, (hipStream_t)stream_);
+}
+// The same GEMM with IEEE fp16 operands (A, Wt and the 16-bit outputs of epilogues 2 / 3 are fp16 bit patterns)
+int sc_gemm_f16(int epi, const uint16_t* A, const uint16_t* Wt, const float* bias, void* out, int M, int N, int K, void* stream_) {
+    return sc::launch_gemm<true>(epi, A, Wt, bias, out, M, N, K, (hipStream_t)stream_);
+}
+
+// Bytes of device workspace sc_clip_vit_forward carves for this geometry (same carve order and 256-byte alignment).
+long long sc_clip_vit_workspace_bytes(int B, int C, int H, int W, int patch, int D, int mlp) {
+    const long long np = (long long)(H / patch) * (W / patch), T = np + 1, M = (long long)B * T;
+    const long long Kp = ((long long)C * patch * patch + 63) & ~63LL;
+    const long long sizes[8] = {B * np * Kp * 2, B * np * D * 4, M * D * 4, M * D * 2, M * 3 * D * 2, M * D * 2, M * mlp * 2,
+                                (long long)B * D * 2};
+    long long total = 0;
+    for (long long s : sizes) total += (s + 255) & ~255LL;
+    return total;
+}
+
+// Full image tower, bf16 operands.  See include/shapeclipper_hip.h for the weight image layout.
+int sc_clip_vit_forward(const float* image, int B, int C, int H, int W, int patch, int D, int mlp, int layers, int heads,
+                        int proj_dim, const uint16_t* w_bf16, const float* w_f32, float ln_eps, float* out,
+                        void* workspace, long long workspace_bytes, void* stream_) {
+    return sc::clip_vit_forward<false>(image, B, C, H, W, patch, D, mlp, layers, heads, proj_dim, w_bf16, w_f32, ln_eps, out, workspace,
+                                       workspace_bytes, stream_);
+}
+// The same tower with IEEE fp16 operands (`w_f16`: the 16-bit weight image as fp16 bit patterns, same order) -- the arithmetic
+// openai/CLIP uses on a GPU (CLIP_anno.py:16: fp16 weights and activations, fp32 LayerNorm); fp32 accumulation in the MFMAs.
+int sc_clip_vit_forward_f16(const float* image, int B, int C, int H, int W, int patch, int D, int mlp, int layers, int heads,
+                            int proj_dim, const uint16_t* w_f16, const float* w_f32, float ln_eps, float* out,
+                            void* workspace, long long workspace_bytes, void* stream_) {
+    return sc::clip_vit_forward<true>(image, B, C, H, W, patch, D, mlp, layers, heads, proj_dim, w_f16, w_f32, ln_eps, out, workspace,
+                                      workspace_bytes, stream_);
 }
 
 }  // extern "C"

@@ -4,8 +4,9 @@ Drop-in for the one call the reference makes into the un-vendored openai/CLIP pa
 `clip_encoder.encode_image(image).float()` (CLIP_anno.py:166).  Parameters carry the
 transformers.CLIPVisionModelWithProjection names so a converted checkpoint loads with
 load_state_dict; `from_openai_state_dict` maps the original openai/CLIP `visual.*` names.
-Compute: bf16 MFMA GEMMs with fp32 accumulation, fp32 LayerNorm / softmax / residual stream
-(openai/CLIP on GPU runs fp16 weights+activations with fp32 LayerNorm)."""
+Compute: 16-bit MFMA GEMMs with fp32 accumulation, fp32 LayerNorm / softmax statistics / residual stream.
+`dtype="fp16"` (default): IEEE fp16 operands, the arithmetic openai/CLIP itself uses on a GPU (fp16 weights and
+activations with fp32 LayerNorm, CLIP_anno.py:16); `dtype="bf16"`: bf16 operands (8-bit mantissa, fp32's range)."""
 from __future__ import annotations
 
 import ctypes
@@ -21,8 +22,11 @@ VIT_L14 = dict(image_size=224, patch=14, width=1024, layers=24, heads=16, mlp=40
 
 class ClipVisionTower(nn.Module):
 
-    def __init__(self, image_size=224, patch=32, width=768, layers=12, heads=12, mlp=3072, proj=512, channels=3):
+    def __init__(self, image_size=224, patch=32, width=768, layers=12, heads=12, mlp=3072, proj=512, channels=3, dtype="fp16"):
         super().__init__()
+        if dtype not in ("fp16", "bf16"):
+            raise ValueError("ClipVisionTower dtype must be 'fp16' or 'bf16', got %r" % (dtype,))
+        self.dtype16 = dtype
         self.cfg = dict(image_size=image_size, patch=patch, width=width, layers=layers, heads=heads, mlp=mlp, proj=proj,
                         channels=channels)
         T = (image_size // patch) ** 2 + 1
@@ -83,7 +87,7 @@ class ClipVisionTower(nn.Module):
                      g(pre + "mlp.fc1.bias"), g(pre + "mlp.fc2.bias")]
         mats.append(g("visual_projection.weight"))
         vecs += [g(vm + "post_layernorm.weight"), g(vm + "post_layernorm.bias")]
-        w_bf16 = torch.cat([m.reshape(-1) for m in mats]).to(torch.bfloat16).contiguous()
+        w_bf16 = torch.cat([m.reshape(-1) for m in mats]).to(torch.float16 if self.dtype16 == "fp16" else torch.bfloat16).contiguous()
         w_f32 = torch.cat([v.reshape(-1).float() for v in vecs]).contiguous()
         return w_bf16, w_f32
 
@@ -107,7 +111,8 @@ class ClipVisionTower(nn.Module):
         out = torch.empty(B, c["proj"], device=image.device, dtype=torch.float32)
         nbytes = self.workspace_bytes(B)
         ws = torch.empty(nbytes, device=image.device, dtype=torch.uint8)
-        code = lib.sc_clip_vit_forward(_lib.ptr(image), ctypes.c_int(B), ctypes.c_int(c["channels"]),
+        fwd = lib.sc_clip_vit_forward_f16 if self.dtype16 == "fp16" else lib.sc_clip_vit_forward
+        code = fwd(_lib.ptr(image), ctypes.c_int(B), ctypes.c_int(c["channels"]),
                                        ctypes.c_int(c["image_size"]), ctypes.c_int(c["image_size"]), ctypes.c_int(c["patch"]),
                                        ctypes.c_int(c["width"]), ctypes.c_int(c["mlp"]), ctypes.c_int(c["layers"]),
                                        ctypes.c_int(c["heads"]), ctypes.c_int(c["proj"]), _lib.ptr(w_bf16), _lib.ptr(w_f32),

@@ -2,7 +2,13 @@
 seeded random weights -- architecture-level oracle; parity with the reference is unpinned (openai/CLIP is an
 un-vendored dependency of CLIP_anno.py:16 and no weights are available offline).
 
-Bar: bf16 GEMM inputs, fp32 accumulate: cosine similarity of embeddings > 0.999, max abs error < 3 % of max |ref|."""
+Arithmetic: the tower's default is IEEE fp16 operands with fp32 accumulation and fp32 LayerNorm / softmax statistics -- what the
+reference's dependency runs on a GPU (clip.load(..., device="cuda"), CLIP_anno.py:16); bf16 operands are the other option.
+Bars (embedding vs the fp32 architecture oracle; measured values are printed): fp16  cos > 0.99999 and max abs error < 0.4 % of
+max |ref| (measured round 3: cos >= 0.9999980, <= 0.18 %, ViT-L/14 at full depth 0.9999998 / 0.07 %);  bf16  cos > 0.9999 and
+< 2.5 % (measured: cos >= 0.99993, <= 1.3 %).
+What the reference USES the embeddings for is a cosine k-NN (CLIP_anno.py:29-41): test_clip_knn_indices_match_fp32_oracle checks the
+neighbour INDICES on a 256-image set."""
 import numpy as np
 import pytest
 import torch
@@ -25,47 +31,117 @@ def _hf(width, layers, heads, mlp, patch, image, proj, seed):
     return m
 
 
+BARS = {"fp16": (0.99999, 0.004), "bf16": (0.9999, 0.025)}
+
+
+def _check(got, ref, dtype, what):
+    cos = torch.nn.functional.cosine_similarity(got, ref, dim=-1)
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    print("CLIP tower %s, %s: min cosine %.7f, max abs error %.3f %% of max |ref|" % (what, dtype, cos.min().item(), 100 * err))
+    assert torch.isfinite(got).all()
+    assert cos.min().item() > BARS[dtype][0], cos
+    assert err < BARS[dtype][1]
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
 @pytest.mark.parametrize("width,layers,heads,mlp,patch,image,proj,B", [
     (128, 2, 2, 256, 32, 64, 64, 3),             # 5 tokens
     (768, 12, 12, 3072, 32, 224, 512, 4),        # ViT-B/32: 50 tokens
-    (768, 12, 12, 3072, 32, 224, 512, 32),       # ViT-B/32 at the BASELINE config[2] batch (1600 token rows: split-K proj / fc2)
+    (768, 12, 12, 3072, 32, 224, 512, 32),       # ViT-B/32 at the BASELINE config[2] batch (1600 token rows: 64-wide tiles)
     (128, 2, 2, 256, 14, 112, 64, 2),            # 65 tokens (> one key chunk... and 2 query blocks + 1), patch K = 588 (padded)
     (192, 2, 3, 384, 8, 112, 96, 2),             # 197 tokens: 7 key chunks, query blocks wrap over the 4 waves
     (1024, 2, 16, 4096, 14, 224, 768, 2),        # ViT-L/14 geometry (257 tokens), 2 layers
 ])
-def test_clip_tower_vs_transformers(width, layers, heads, mlp, patch, image, proj, B):
+def test_clip_tower_vs_transformers(width, layers, heads, mlp, patch, image, proj, B, dtype):
     from shapeclipper_amd.model.clip_vit import ClipVisionTower
     hf = _hf(width, layers, heads, mlp, patch, image, proj, seed=width)
     x = torch.randn(B, 3, image, image)
     with torch.no_grad():
         ref = hf(pixel_values=x).image_embeds
-    tower = ClipVisionTower(image_size=image, patch=patch, width=width, layers=layers, heads=heads, mlp=mlp, proj=proj)
+    tower = ClipVisionTower(image_size=image, patch=patch, width=width, layers=layers, heads=heads, mlp=mlp, proj=proj, dtype=dtype)
     tower.load_state_dict(hf.state_dict())
     tower = tower.cuda()
     got = tower.encode_image(x.cuda()).cpu()
-    cos = torch.nn.functional.cosine_similarity(got, ref, dim=-1)
-    assert cos.min().item() > 0.999, cos
-    assert (got - ref).abs().max().item() < 0.03 * ref.abs().max().item()
+    _check(got, ref, dtype, "%d x %d layers, patch %d, B=%d" % (width, layers, patch, B))
 
 
-def test_gemm_bf16_transpose_detecting():
-    """C = A W^T with asymmetric operands (catches swapped row/col in the MFMA C/D mapping)."""
+def test_clip_vit_l14_full_depth():
+    """The model the reference loads (CLIP_anno.py:16): ViT-L/14, all 24 layers, 257 tokens, in its own fp16 arithmetic."""
+    import os
+    from shapeclipper_amd.model.clip_vit import VIT_L14, ClipVisionTower
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    hf = _hf(1024, 24, 16, 4096, 14, 224, 768, seed=14)
+    x = torch.randn(2, 3, 224, 224)
+    with torch.no_grad():
+        ref = hf(pixel_values=x).image_embeds
+    tower = ClipVisionTower(**VIT_L14)
+    assert tower.dtype16 == "fp16"
+    tower.load_state_dict(hf.state_dict())
+    got = tower.cuda().encode_image(x.cuda()).cpu()
+    _check(got, ref, "fp16", "ViT-L/14, 24 layers, B=2")
+
+
+def test_clip_knn_indices_match_fp32_oracle():
+    """The reference uses the tower for ONE thing: L2-normalise the embeddings, cosine similarity of all pairs, top-k (CLIP_anno.py:
+    29-41,166-167).  256 synthetic images in 32 loose clusters, ViT-B/32: the neighbour lists computed from the HIP fp16 embeddings
+    must equal those computed from the fp32 architecture oracle's embeddings -- position by position, except where the oracle's own
+    similarities of two adjacent candidates are closer than 4x the largest similarity error (a genuine near-tie; counted, printed)."""
+    import os
+    from shapeclipper_amd.model.clip_vit import VIT_B32, ClipVisionTower
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    hf = _hf(768, 12, 12, 3072, 32, 224, 512, seed=7)
+    g = torch.Generator().manual_seed(3)
+    centres = torch.randn(32, 3, 224, 224, generator=g)
+    imgs = (centres[:, None] + 0.6 * torch.randn(32, 8, 3, 224, 224, generator=g)).reshape(256, 3, 224, 224)
+    with torch.no_grad():
+        ref = torch.cat([hf(pixel_values=imgs[i:i + 32]).image_embeds for i in range(0, 256, 32)])
+    tower = ClipVisionTower(**VIT_B32)
+    tower.load_state_dict(hf.state_dict())
+    tower = tower.cuda()
+    got = torch.cat([tower.encode_image(imgs[i:i + 32].cuda()) for i in range(0, 256, 32)]).cpu()
+    k = 6                                            # options/clip/pix3d.yaml: k_nearest
+    nrm = lambda e: torch.nn.functional.normalize(e.double(), dim=-1)
+    s_ref, s_got = nrm(ref) @ nrm(ref).t(), nrm(got) @ nrm(got).t()
+    sim_err = float((s_ref - s_got).abs().max())
+    v_ref, i_ref = s_ref.topk(k + 1, dim=1)
+    _, i_got = s_got.topk(k, dim=1)
+    exact = (i_ref[:, :k] == i_got)
+    gaps = (v_ref[:, :-1] - v_ref[:, 1:])            # oracle gap between candidate j and j + 1
+    near_tie = torch.zeros_like(exact)
+    near_tie[:, 1:] |= gaps[:, :k - 1] < 4 * sim_err
+    near_tie |= gaps[:, :k] < 4 * sim_err
+    bad = ~exact & ~near_tie
+    print("CLIP k-NN on 256 images: %d / %d neighbour positions identical, %d differ at oracle near-ties (< %.1e), %d wrong; "
+          "max |cos_hip - cos_fp32| %.2e, smallest / median top-%d gap %.2e / %.2e"
+          % (int(exact.sum()), exact.numel(), int((~exact & near_tie).sum()), 4 * sim_err, int(bad.sum()), sim_err, k,
+             float(gaps[:, :k].min()), float(gaps[:, :k].median())))
+    assert (i_got[:, 0] == torch.arange(256)).all()             # a query's first neighbour is itself
+    assert not bad.any()
+    assert exact.float().mean() > 0.97
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,N,K", [(200, 192, 128), (1600, 768, 768), (12800, 2304, 768)])       # 64-wide tiles / persistent 128-wide tiles
+def test_gemm_16bit_transpose_detecting(M, N, K, dtype):
+    """C = A W^T with asymmetric operands (catches swapped row/col in the MFMA C/D mapping); the 16-bit operands are exact inputs,
+    so the only error is the fp32 accumulation order."""
     import ctypes
     from shapeclipper_amd import _lib
     lib = _lib.load()
     dev = torch.device("cuda:0")
     torch.manual_seed(1)
-    M, N, K = 200, 192, 128
-    A = torch.randn(M, K, device=dev).to(torch.bfloat16)
-    W = (torch.randn(N, K, device=dev) + torch.arange(N, device=dev)[:, None] * 0.01).to(torch.bfloat16)
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    A = torch.randn(M, K, device=dev).to(td)
+    W = (torch.randn(N, K, device=dev) + torch.arange(N, device=dev)[:, None] * 0.01).to(td)
     bias = torch.randn(N, device=dev)
     out = torch.zeros(M, N, device=dev)
-    rc = lib.sc_gemm_bf16(ctypes.c_int(0), _lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(out), ctypes.c_int(M),
-                          ctypes.c_int(N), ctypes.c_int(K), _lib.stream())
+    fn = lib.sc_gemm_bf16 if dtype == "bf16" else lib.sc_gemm_f16
+    rc = fn(ctypes.c_int(0), _lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(out), ctypes.c_int(M), ctypes.c_int(N), ctypes.c_int(K),
+            _lib.stream())
     assert rc == 0
     torch.cuda.synchronize()
-    ref = A.float() @ W.float().t() + bias
-    assert (out - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
+    ref = (A.double() @ W.double().t() + bias.double()).float()
+    assert (out - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
 
 
 def test_clip_tower_golden_fixture():
@@ -77,6 +153,4 @@ def test_clip_tower_golden_fixture():
     tower = ClipVisionTower(image_size=image, patch=patch, width=width, layers=layers, heads=heads, mlp=mlp, proj=proj)
     tower.load_state_dict({k[2:]: torch.tensor(g[k]) for k in g.files if k.startswith("w.")})
     got = tower.cuda().encode_image(torch.tensor(g["input"]).cuda()).cpu()
-    ref = torch.tensor(g["embedding"])
-    assert torch.nn.functional.cosine_similarity(got, ref, dim=-1).min().item() > 0.999
-    assert (got - ref).abs().max().item() < 0.03 * ref.abs().max().item()
+    _check(got, torch.tensor(g["embedding"]), "fp16", "G11 fixture")

@@ -32,6 +32,7 @@ PEAK_BF16 = 2500.0      # TFLOP/s, bf16 MFMA dense peak
 PEAK_SPLIT = PEAK_BF16 / 6   # fp32-equivalent roof of the exact bf16x3 split: six bf16 MFMA products per fp32 product (416.7 TFLOP/s)
 CHAMFER_FLOP_PER_PAIR = 8
 VIT_B32_GFLOP = 8.725
+VIT_L14_GFLOP = 155.5   # the model the reference loads (CLIP_anno.py:16)
 RENDER_EVAL_FLOP_PER_RAY = 64 * 199424
 GRID_FLOP_PER_POINT = 80640
 
@@ -106,16 +107,21 @@ def chamfer(B, N=100000, with_cpu=True):
     return out
 
 
-def clip_vit(B=32, with_cpu=True):
-    from shapeclipper_amd.model.clip_vit import VIT_B32, ClipVisionTower
+def clip_vit(B=32, with_cpu=True, model="ViT-B/32"):
+    """The tower in its default arithmetic: fp16 operands (what openai/CLIP runs on a GPU), fp32 accumulate; same 2.5 PFLOP/s dense
+    MFMA peak as bf16."""
+    from shapeclipper_amd.model.clip_vit import VIT_B32, VIT_L14, ClipVisionTower
     torch.manual_seed(0)
-    tower = ClipVisionTower(**VIT_B32).cuda()
+    cfg, gflop = (VIT_L14, VIT_L14_GFLOP) if model == "ViT-L/14" else (VIT_B32, VIT_B32_GFLOP)
+    tower = ClipVisionTower(**cfg).cuda()
     x = torch.randn(B, 3, 224, 224, device="cuda")
-    ms, best = _gpu_ms(lambda: tower.encode_image(x), iters=20, warm=3)
-    tf = B * VIT_B32_GFLOP * 1e9 / (ms * 1e-3) / 1e12
-    out = dict(workload="CLIP ViT-B/32 image tower forward, B=%d, 224x224" % B, ms=round(ms, 3), ms_best=round(best, 3),
-               algorithmic_flop=B * VIT_B32_GFLOP * 1e9, achieved=round(tf, 1), peak=PEAK_BF16, unit="TFLOP/s", bound="bf16 MFMA",
+    ms, best = _gpu_ms(lambda: tower.encode_image(x), iters=10 if model == "ViT-L/14" else 20, warm=3)
+    tf = B * gflop * 1e9 / (ms * 1e-3) / 1e12
+    out = dict(workload="CLIP %s image tower forward, B=%d, 224x224" % (model, B), ms=round(ms, 3), ms_best=round(best, 3), dtype=tower.dtype16,
+               algorithmic_flop=B * gflop * 1e9, achieved=round(tf, 1), peak=PEAK_BF16, unit="TFLOP/s", bound="fp16 MFMA (dense peak = bf16's)",
                frac=round(tf / PEAK_BF16, 4), images_per_s=round(B / (ms * 1e-3), 1))
+    if with_cpu and model != "ViT-B/32":
+        with_cpu = False
     if with_cpu:
         try:
             from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
@@ -297,7 +303,8 @@ def resnet_conv3x3(with_cpu=True):
 def run_all(with_cpu=True):
     out = {}
     for name, fn in (("chamfer_b1", lambda: chamfer(1, with_cpu=with_cpu)), ("chamfer_b32", lambda: chamfer(32, with_cpu=False)),
-                     ("clip_vit_b32", lambda: clip_vit(32, with_cpu=with_cpu)), ("render_eval_128", lambda: render_eval_128(32, with_cpu=with_cpu)),
+                     ("clip_vit_b32", lambda: clip_vit(32, with_cpu=with_cpu)), ("clip_vit_b32_batch256", lambda: clip_vit(256, with_cpu=False)),
+                     ("clip_vit_l14_b32", lambda: clip_vit(32, with_cpu=False, model="ViT-L/14")), ("render_eval_128", lambda: render_eval_128(32, with_cpu=with_cpu)),
                      ("level_grid_100", lambda: level_grid_100(with_cpu=with_cpu)),
                      ("resnet_conv3x3", lambda: resnet_conv3x3(with_cpu=with_cpu))):
         out[name] = fn()
