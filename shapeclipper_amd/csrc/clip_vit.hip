@@ -23,6 +23,7 @@
 // Bound: the four GEMMs per layer -> bf16 MFMA (dense peak 2.5 PFLOP/s).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace sc {
 
@@ -636,7 +637,8 @@ static int launch_gemm(int epi, const bf16_t* A, const bf16_t* Wt, const float* 
     if (K % 64) return (int)hipErrorInvalidValue;
     // 128-wide tiles when they give every CU work (>= 1.5 workgroups per CU), 64-wide ones otherwise
     const long long t128 = (long long)((N + 127) / 128) * ((M + 127) / 128);
-    const bool small = t128 < 384;
+    static const long long t128_min = [] { const char* e = getenv("SC_GEMM_T128_MIN"); return e ? atoll(e) : 384LL; }();   // tuning override
+    const bool small = t128 < t128_min;
 #define SC_LAUNCH(E)                                                                                                          \
     if (small) {                                                                                                              \
         (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<E, 64, H16>, hipFuncAttributeMaxDynamicSharedMemorySize,           \

@@ -122,10 +122,10 @@ class SDFNetwork(nn.Module):
         built once and shared by the main render, the NN-view render and the eikonal calls (4 uses per step)."""
         cache = getattr(self, "_pack_cache", None)
         if cache is not None and cache[0] == torch.is_grad_enabled():
-            return cache[1], packing.sdf_cbias(self.weight_dict(), proj_latent)
-        w_pack, cbias = packing.pack_sdf(self.weight_dict(), proj_latent)
+            return cache[1], packing.sdf_cbias(None, proj_latent, gathered=cache[2])
+        w_pack, cbias, gathered = packing.pack_sdf(self.weight_dict(), proj_latent, return_gathered=True)
         if getattr(self, "_pack_cache_on", False):
-            self._pack_cache = (torch.is_grad_enabled(), w_pack)
+            self._pack_cache = (torch.is_grad_enabled(), w_pack, gathered)
         return w_pack, cbias
 
     def begin_step(self, enable=True):
@@ -178,10 +178,10 @@ class RGBNetwork(nn.Module):
     def packed(self, proj_latent):
         cache = getattr(self, "_pack_cache", None)
         if cache is not None and cache[0] == torch.is_grad_enabled():
-            return cache[1], packing.rgb_dbias(self.weight_dict(), proj_latent)
-        v_pack, dbias = packing.pack_rgb(self.weight_dict(), proj_latent)
+            return cache[1], packing.rgb_dbias(None, proj_latent, gathered=cache[2])
+        v_pack, dbias, gathered = packing.pack_rgb(self.weight_dict(), proj_latent, return_gathered=True)
         if getattr(self, "_pack_cache_on", False):
-            self._pack_cache = (torch.is_grad_enabled(), v_pack)
+            self._pack_cache = (torch.is_grad_enabled(), v_pack, gathered)
         return v_pack, dbias
 
     def begin_step(self, enable=True):

@@ -64,61 +64,151 @@ def check_arch(opt) -> None:
             "(impl_sdf: 5x64, pos_enc 6, skip [1,2]; impl_rgb: 3x64, pos_enc 6; no weight_norm)")
 
 
-def sdf_cbias(W: Dict[str, torch.Tensor], z: torch.Tensor) -> torch.Tensor:
-    """Per-image biases c_l = b_l + W_l[:, latent] @ z (skip layers scaled by 1/sqrt2) -> [B, 5, 64]."""
+# ---- gather plans ---------------------------------------------------------------------------------------------------------
+# Packing used to be ~70 small torch operators per forward pass (slices, cats, the slot permutation, three latent matmuls) and ~300
+# in backward (every Select / Slice backward is a fill + a copy): a tenth of the launches of a training step.  Now ONE index_select
+# over the concatenated raw parameters builds, in a single vector,   [ packed weight image | latent columns of the conditioned layers
+# | bias rows ],   with the 1/sqrt(2) skip scale as one element-wise multiply: 3 launches forward and 3 backward (every source element is
+# gathered at most once, so the index_add_ of the backward pass has no colliding addresses besides the shared zero pad and is
+# deterministic); the per-image biases are one matmul on the gathered latent block.  The result is bit-identical to the operator-by-
+# operator construction (each element is still `parameter` or `parameter * r`, the bias sums are evaluated in the same order).
+_PLANS = {}
+
+
+def _plan(kind: str, Z: int, device):
+    key = (kind, Z, str(device))
+    if key in _PLANS:
+        return _PLANS[key]
     r = 1.0 / math.sqrt(2.0)
-    w0, w1, w2 = W["lin0.weight"], W["lin1.weight"], W["lin2.weight"]
-    B = z.shape[0]
-    c0 = W["lin0.bias"] + z @ w0[:, 39:].t()
-    c1 = W["lin1.bias"] + (z @ w1[:, 103:].t()) * r
-    c2 = W["lin2.bias"] + (z @ w2[:, 103:].t()) * r
-    c3 = W["lin3.bias"].unsqueeze(0).expand(B, 64)
-    c4 = W["lin4.bias"].unsqueeze(0).expand(B, 64)
-    return torch.stack([c0, c1, c2, c3, c4], dim=1).contiguous()
+    idx, scl = [], []
+    if kind == "sdf":
+        shapes = [(64, 39 + Z), (64,), (64, 103 + Z), (64,), (64, 103 + Z), (64,), (64, 64), (64,), (64, 64), (64,), (65, 64), (65,)]
+    else:
+        shapes = [(64, 39 + Z + 64), (64,), (64, 64), (64,), (64, 64), (64,), (3, 64), (3,)]
+    offs, o = [], 0
+    for sh in shapes:
+        offs.append(o)
+        o += int(torch.Size(sh).numel())
+    zero = o                                           # index of the appended exact zero
+
+    def mat(k, row, col):                              # flat index of element (row, col) of parameter k
+        return offs[k] + row * shapes[k][1] + col
+
+    def put(i, sc=1.0):
+        idx.append(i); scl.append(sc)
+    if kind == "sdf":
+        for row in range(64):                          # W0: PE slots
+            for c in range(PE_COLS):
+                put(mat(0, row, _SLOT_IDX[c]) if _SLOT_IDX[c] < 39 else zero)
+        for k in (2, 4):                               # W1, W2: [hidden 64 | PE slots 48], both scaled
+            for row in range(64):
+                for c in range(64):
+                    put(mat(k, row, c), r)
+                for c in range(PE_COLS):
+                    put(mat(k, row, 64 + _SLOT_IDX[c]) if _SLOT_IDX[c] < 39 else zero, r)
+        for k, rows in ((6, 64), (8, 64), (10, 65)):   # W3, W4, W5
+            for row in range(rows):
+                for c in range(64):
+                    put(mat(k, row, c))
+        for row in range(65):                          # b5
+            put(offs[11] + row)
+        n_pack = len(idx)
+        assert n_pack == SDF_PACK_FLOATS
+        for k, c0 in ((0, 39), (2, 103), (4, 103)):    # latent columns [3 x 64 rows][Z]
+            for row in range(64):
+                for c in range(Z):
+                    put(mat(k, row, c0 + c))
+        for k in (1, 3, 5, 7, 9):                      # bias rows b0..b4
+            for row in range(64):
+                put(offs[k] + row)
+        n_lat, n_bias = 3 * 64 * Z, 5 * 64
+        post = torch.tensor([1.0, r, r], device=device).view(1, 3, 1)       # (z @ W_lat^T) * r for the skip layers, as before
+    else:
+        for row in range(64):                          # V0: [PE slots 48 | sdf feature 64]
+            for c in range(PE_COLS):
+                put(mat(0, row, _SLOT_IDX[c]) if _SLOT_IDX[c] < 39 else zero)
+            for c in range(64):
+                put(mat(0, row, 39 + Z + c))
+        for k, rows in ((2, 64), (4, 64), (6, 3)):
+            for row in range(rows):
+                for c in range(64):
+                    put(mat(k, row, c))
+        for row in range(3):
+            put(offs[7] + row)
+        put(zero)
+        n_pack = len(idx)
+        assert n_pack == RGB_PACK_FLOATS
+        for row in range(64):
+            for c in range(Z):
+                put(mat(0, row, 39 + c))
+        for k in (1, 3, 5):
+            for row in range(64):
+                put(offs[k] + row)
+        n_lat, n_bias = 64 * Z, 3 * 64
+        post = None
+    scale = torch.tensor(scl, dtype=torch.float32)
+    plan = dict(idx=torch.tensor(idx, dtype=torch.int64).to(device), scale=None if bool((scale == 1).all()) else scale.to(device),
+                n_pack=n_pack, n_lat=n_lat, n_bias=n_bias, post=post, shapes=shapes, total=zero)
+    _PLANS[key] = plan
+    return plan
 
 
-def pack_sdf(W: Dict[str, torch.Tensor], z: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+def _names(kind):
+    n = 6 if kind == "sdf" else 4
+    return [k for l in range(n) for k in ("lin%d.weight" % l, "lin%d.bias" % l)]
+
+
+def gather_params(kind: str, W: Dict[str, torch.Tensor], Z: int) -> torch.Tensor:
+    """[ packed image | latent block | bias rows ] of a network in one gather (differentiable w.r.t. every parameter)."""
+    names = _names(kind)
+    dev = W[names[0]].device
+    plan = _plan(kind, Z, dev)
+    for n, sh in zip(names, plan["shapes"]):
+        assert tuple(W[n].shape) == tuple(sh), (n, tuple(W[n].shape), sh)
+    src = torch.cat([W[n].reshape(-1) for n in names] + [W[names[0]].new_zeros(1)])
+    out = torch.index_select(src, 0, plan["idx"])
+    return out * plan["scale"] if plan["scale"] is not None else out
+
+
+def _bias_from(kind: str, g: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+    B, Z = z.shape
+    plan = _plan(kind, Z, g.device)
+    n_pack, n_lat = plan["n_pack"], plan["n_lat"]
+    L = n_lat // (64 * Z)                               # conditioned layers: 3 (sdf) / 1 (rgb)
+    lat = g[n_pack:n_pack + n_lat].view(L * 64, Z)
+    bias = g[n_pack + n_lat:].view(1, -1, 64)
+    zw = (z @ lat.t()).view(B, L, 64)
+    if plan["post"] is not None:
+        zw = zw * plan["post"]
+    NL = bias.shape[1]
+    return torch.nn.functional.pad(zw, (0, 0, 0, NL - L)) + bias                 # = bias + z-term (fp32 addition commutes)
+
+
+def sdf_cbias(W: Dict[str, torch.Tensor], z: torch.Tensor, gathered: torch.Tensor = None) -> torch.Tensor:
+    """Per-image biases c_l = b_l + W_l[:, latent] @ z (skip layers scaled by 1/sqrt2) -> [B, 5, 64]."""
+    g = gathered if gathered is not None else gather_params("sdf", W, z.shape[1])
+    return _bias_from("sdf", g, z)
+
+
+def pack_sdf(W: Dict[str, torch.Tensor], z: torch.Tensor, return_gathered: bool = False):
     """SDFNetwork parameters (state-dict names lin{l}.weight/.bias) + latent z [B, Z]
     -> (w_pack [SDF_PACK_FLOATS], cbias [B, 5, 64])."""
-    r = 1.0 / math.sqrt(2.0)
-    w0, w1, w2 = W["lin0.weight"], W["lin1.weight"], W["lin2.weight"]
-    Z = z.shape[1]
-    assert w0.shape == (64, 39 + Z) and w1.shape == (64, 64 + 39 + Z)
-    cbias = sdf_cbias(W, z)
-    pack = torch.cat([
-        _slots(w0[:, :39]).reshape(-1),
-        torch.cat([w1[:, :64] * r, _slots(w1[:, 64:103]) * r], dim=1).reshape(-1),
-        torch.cat([w2[:, :64] * r, _slots(w2[:, 64:103]) * r], dim=1).reshape(-1),
-        W["lin3.weight"].reshape(-1), W["lin4.weight"].reshape(-1),
-        W["lin5.weight"].reshape(-1), W["lin5.bias"].reshape(-1),
-    ]).contiguous()
-    assert pack.numel() == SDF_PACK_FLOATS
-    return pack, cbias
+    g = gather_params("sdf", W, z.shape[1])
+    out = (g[:SDF_PACK_FLOATS], _bias_from("sdf", g, z))
+    return out + (g,) if return_gathered else out
 
 
-def rgb_dbias(W: Dict[str, torch.Tensor], z: torch.Tensor) -> torch.Tensor:
-    v0 = W["lin0.weight"]
-    Z, B = z.shape[1], z.shape[0]
-    d0 = W["lin0.bias"] + z @ v0[:, 39:39 + Z].t()
-    d1 = W["lin1.bias"].unsqueeze(0).expand(B, 64)
-    d2 = W["lin2.bias"].unsqueeze(0).expand(B, 64)
-    return torch.stack([d0, d1, d2], dim=1).contiguous()
+def rgb_dbias(W: Dict[str, torch.Tensor], z: torch.Tensor, gathered: torch.Tensor = None) -> torch.Tensor:
+    g = gathered if gathered is not None else gather_params("rgb", W, z.shape[1])
+    return _bias_from("rgb", g, z)
 
 
-def pack_rgb(W: Dict[str, torch.Tensor], z: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+def pack_rgb(W: Dict[str, torch.Tensor], z: torch.Tensor, return_gathered: bool = False):
     """RGBNetwork parameters + latent z_rgb [B, Z] -> (v_pack [RGB_PACK_FLOATS], dbias [B, 3, 64]).
     lin0 input order is [PE(39), z_rgb(Z), sdf_feature(64)] (model/implicit.py:231)."""
-    v0 = W["lin0.weight"]
-    Z = z.shape[1]
-    assert v0.shape == (64, 39 + Z + 64)
-    dbias = rgb_dbias(W, z)
-    pack = torch.cat([
-        torch.cat([_slots(v0[:, :39]), v0[:, 39 + Z:]], dim=1).reshape(-1),
-        W["lin1.weight"].reshape(-1), W["lin2.weight"].reshape(-1),
-        W["lin3.weight"].reshape(-1), W["lin3.bias"].reshape(-1), v0.new_zeros(1),
-    ]).contiguous()
-    assert pack.numel() == RGB_PACK_FLOATS
-    return pack, dbias
+    g = gather_params("rgb", W, z.shape[1])
+    out = (g[:RGB_PACK_FLOATS], _bias_from("rgb", g, z))
+    return out + (g,) if return_gathered else out
 
 
 def n_tiles(n_points: int) -> int:
