@@ -91,8 +91,11 @@ int sc_rgb_composite_forward(const float* points, const float* z_vals, const flo
                              float* rgb, float* mask, float* mask_hard, float* depth, float* normal,
                              float* weights, float* alpha, float* rgb_flat, void* stream);
 
-/* Reverse pass.  G_* are the upstream per-ray gradients (NULL = zero).  g_beta [1] must be zero-filled
- * (atomicAdd).  gy (3 x TBL64), rr (3 x TBL64), gy3 [P][3]: operands for the RGB weight gradients.      */
+/* Reverse pass.  G_* are the upstream per-ray gradients (NULL = zero).  g_beta: SC_RGB_BWD_BETA_PARTS floats, fully
+ * written: one partial of d/d(raw beta parameter) per wave of the grid; the gradient is their sum in index order
+ * (sc_partial_reduce(g_beta, SC_RGB_BWD_BETA_PARTS, 1, 1, out)) -- a fixed summation order, no float atomics.
+ * gy (3 x TBL64), rr (3 x TBL64), gy3 [P][3]: operands for the RGB weight gradients.                          */
+#define SC_RGB_BWD_BETA_PARTS 2048
 int sc_rgb_composite_backward(
     const float* points, const float* z_vals, const float* depth_fac, const float* sdf, const float* grad,
     const float* feat, const float* v_pack, const float* dbias, const float* beta_param, const float* rgb_flat,
@@ -107,34 +110,42 @@ int sc_rgb_composite_backward(
  * 5 positional encoding of the point (48 columns), 6 g_grad-weighted PE Jacobian (48 columns).
  * Every one of the `nparts` workgroups writes its partial result at
  * partial[part*partial_stride + out_offset + row*out_ld + col]; sc_partial_reduce sums the parts.
- * rowsum (may be NULL): [n_images][64], zero-filled by the caller; receives, per image, the sum over its points of
- * term 0's A operand (= the bias / per-image latent gradient of that layer) -- the operand is in registers anyway.
- * Requires n_per_image % 16 == 0 (a 16-point tile never straddles two images).                          */
+ * rowsum (may be NULL): [nparts * 4][n_images][64], fully written: per WAVE of the grid and per image, the sum over
+ * the wave's points of term 0's A operand (= the bias / per-image latent gradient of that layer) -- the operand is in
+ * registers anyway; the caller adds the nparts * 4 partial images in index order (sc_partial_reduce): a fixed summation
+ * order instead of float atomics.  Requires n_per_image % 16 == 0 (a 16-point tile never straddles two images).       */
 int sc_wgrad(int nterms,
              const float* a0_0, const float* a1_0, int aop_0, const float* b0_0, int bop0_0, const float* b1_0, int bop1_0,
              const float* a0_1, const float* a1_1, int aop_1, const float* b0_1, int bop0_1, const float* b1_1, int bop1_1,
              const float* points, const float* g_grad, const float* w5row, int n_points, int symmetric,
              int nb0, int nb1, float* partial, int nparts, int partial_stride, int out_offset, int out_ld,
              float* rowsum, int n_per_image, int n_images, void* stream);
-/* out[i] += sum_part partial[part*stride + i], i < n.  out must be zero-filled (16 atomic chunks per element). */
+/* out[i] = sum_part partial[part*stride + i], i < n, in a fixed order (interleaved sequential sums combined by a fixed binary tree):
+ * results do not depend on timing.  out is assigned (need not be zero-filled).                              */
 int sc_partial_reduce(const float* partial, int nparts, int stride, int n, float* out, void* stream);
 
 /* out_t[img][k][ch] += sum_{p in img} coef[p][k] * x_t[ch][p] for t < n_tensors (<= 8) TBL64 tensors in ONE
  * launch (coef NULL: K = 1, coefficient 1; else K = 3).  xs / outs are HOST arrays of device pointers; every
- * out must be zero-filled.  Used for bias / latent gradients and the 3-row output layer of the RGB net. */
+ * Two modes.  part != NULL (needs n_per_image % 16 == 0): fixed summation order -- every block writes a partial image into
+ * `part` (sc_tbl_sum_blocks(n_points) * n_tensors * n_images * K * 64 floats of workspace) and a second launch adds them in
+ * block order into outs[0], which must be ONE buffer holding all tensors back to back ([n_tensors][n_images][K][64], fully
+ * written).  part == NULL: every outs[t] must be zero-filled, float atomicAdd (summation order depends on timing).
+ * Used for bias / latent gradients and the 3-row output layer of the RGB net.                                   */
+int sc_tbl_sum_blocks(int n_points);
 int sc_tbl_sum(const float* const* xs, int n_tensors, const float* coef, int n_points, int n_per_image,
-               int n_images, float* const* outs, void* stream);
+               int n_images, float* const* outs, float* part, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Loss reductions of one render in one launch (Loss.MSE_loss / mask_loss / normal_loss, model/loss.py:19-97
  * as called from Graph.compute_loss, model/graph.py:224-236, 252-264).
  * rgb, rgb_t, normal, normal_t [B][R][3]; mask, mask_t [B][R]; eik [B][E] or NULL.
  * normal mask = (mask_t > 0.5) & (mask > 0.5); keep_frac = 1 - reg.normal_tol (double: the cut is
- * int(n * keep_frac) as in loss.py:62).  out4 (zero-filled by the caller) receives
- * (render MSE, IoU + mask_mse*MSE, robust normal loss, eikonal MSE); g_* receive d loss_k / d prediction;
+ * int(n * keep_frac) as in loss.py:62).  out4: EIGHT floats, zero-filled by the caller: [0..3] receive
+ * (render MSE, IoU + mask_mse*MSE, robust normal loss, eikonal MSE), [4] is the arrival counter of the fixed-order
+ * reduction over the images (results do not depend on timing), [5..7] pad; g_* receive d loss_k / d prediction;
  * g_normal_t [B][R][3] (or NULL) receives d normal loss / d normal_t -- the target is
  * camera.transform_normal(input normal, predicted pose) (graph.py:85,260), so autograd carries it into the estimator.
- * ang_ws: [B*R] floats of workspace.                                                               */
+ * ang_ws: B*R + 4*B floats of workspace.                                                           */
 int sc_loss_fused_forward(const float* rgb, const float* rgb_t, const float* mask, const float* mask_t,
                           const float* normal, const float* normal_t, const float* eik, int B, int R, int E,
                           float normal_l1, float mask_mse, double keep_frac, float* out4, float* g_rgb,
@@ -230,11 +241,14 @@ int sc_sdf_grid_forward(const float* sdf_pack, const float* sdf_cbias, float lo,
  * weight-gradient waves of a workgroup exchange operands through LDS).  Requires g_grad and stash_p (the d sdf/dx output
  * is differentiated: every training render) and n_per_image % 16 == 0.
  *   park     workspace, sc_sdf_backward_fused_parts(n_points) * 4 * 4 * 1024 floats (per-wave scratch, stays in L2)
- *   partial  [sc_sdf_backward_fused_parts(n_points)][SdfPack floats]: one partial image of d/d(w_pack) per workgroup,
- *            fully written; sum them with sc_partial_reduce(partial, parts, SdfPack floats, SdfPack floats, g_w_pack)
- *   g_cbias  [n_images][5][64], zero-filled by the caller: d/d(per-image biases)
+ *   partial  [sc_sdf_backward_fused_parts(n_points)][S], S = sc_sdf_backward_fused_partial_floats(n_images): one partial image
+ *            per workgroup, fully written: SdfPack floats of d/d(w_pack) followed (n_images <= 256) by [n_images][5][64] of
+ *            d/d(per-image biases); sum them with sc_partial_reduce(partial, parts, S, S, out) -- a fixed summation order
+ *   g_cbias  only for n_images > 256 (S == SdfPack floats): [n_images][5][64], zero-filled by the caller, float atomicAdd;
+ *            ignored (may be NULL) otherwise
  *   g_points [n_points][3] or NULL.                                                                              */
 int sc_sdf_backward_fused_parts(int n_points);
+int sc_sdf_backward_fused_partial_floats(int n_images);
 int sc_sdf_backward_fused(const float* points, const float* w_pack, int n_points, int n_per_image, int n_images,
                           int symmetric, const float* stash_a, const float* stash_p, const float* g_sdf,
                           const float* g_grad, const float* g_feat, float* g_points, float* park, float* partial,

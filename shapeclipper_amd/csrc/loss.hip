@@ -9,8 +9,9 @@
 // The reference spends ~60 launch-bound torch kernels (+ a full sort and two boolean-index syncs)
 // on this per render; here blocks 0..B-1 do the per-image sums (IoU needs per-image numerators) and
 // block B does the robust normal selection with a 4-pass radix select instead of a sort.
-// Loss values are accumulated with atomicAdd into out[4] (pre-zeroed); the gradients of each loss
-// w.r.t. its prediction are written alongside (the backward is then 4 scalings).
+// Loss values: every image block publishes its three partial sums, the block that arrives last adds the B partials in image
+// order (a fixed summation order: results do not depend on timing -- they used to be float atomicAdds into out[]); the gradients
+// of each loss w.r.t. its prediction are written alongside (the backward is then 4 scalings).
 // Bound: latency (tensors are tens of KB); the metric is microseconds and launch count.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -25,7 +26,8 @@ struct LossArgs {
     int B, R, E;
     float normal_l1, mask_mse;
     double keep_frac;                            // 1 - reg.normal_tol
-    float* out;                                  // [4]: render, mask, normal, eikonal (pre-zeroed)
+    float* out;                                  // [8]: render, mask, normal, eikonal | arrival counter (one word, ZERO at launch) | pad
+    float* part;                                 // [B][4] workspace: per-image partial sums
     float* g_rgb; float* g_mask; float* g_normal; float* g_eik;
     float* g_normal_t;                           // d normal loss / d normal_t (the target is differentiable in the pose) or null
     float* ang_ws;                               // [B*R] workspace (angular error of masked rays)
@@ -87,9 +89,25 @@ __global__ __launch_bounds__(1024) void loss_fused_kernel(LossArgs a) {
                                             + a.mask_mse * 2.f * (p - t) * inv_m;
         }
         if (tid == 0) {
-            atomicAdd(&a.out[0], s_rgb * inv_rgb);
-            atomicAdd(&a.out[1], (1.f - I / U) / (float)a.B + a.mask_mse * s_mm * inv_m);
-            if (a.eik) atomicAdd(&a.out[3], s_e / ((float)a.B * a.E));
+            a.part[b * 4 + 0] = s_rgb * inv_rgb;
+            a.part[b * 4 + 1] = (1.f - I / U) / (float)a.B + a.mask_mse * s_mm * inv_m;
+            a.part[b * 4 + 2] = a.eik ? s_e / ((float)a.B * a.E) : 0.f;
+            // publish (agent-scope release; the explicit wait keeps the counter from overtaking the write-back), take a ticket
+            __threadfence();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned int ticket = atomicAdd(reinterpret_cast<unsigned int*>(a.out + 4), 1u);
+            if (ticket == (unsigned int)a.B - 1u) {         // last image block: all partials are published
+                __threadfence();                             // acquire
+                float t0 = 0.f, t1 = 0.f, t3 = 0.f;
+                for (int k = 0; k < a.B; ++k) {
+                    t0 += __builtin_nontemporal_load(&a.part[k * 4 + 0]);
+                    t1 += __builtin_nontemporal_load(&a.part[k * 4 + 1]);
+                    t3 += __builtin_nontemporal_load(&a.part[k * 4 + 2]);
+                }
+                a.out[0] = t0;
+                a.out[1] = t1;
+                if (a.eik) a.out[3] = t3;
+            }
         }
         return;
     }
@@ -210,8 +228,9 @@ extern "C" int sc_loss_fused_forward(const float* rgb, const float* rgb_t, const
                                      float normal_l1, float mask_mse, double keep_frac, float* out4, float* g_rgb,
                                      float* g_mask, float* g_normal, float* g_eik, float* g_normal_t, float* ang_ws, void* stream_) {
     if (B <= 0 || R <= 0) return 0;
+    // out4: 8 floats, zero-filled by the caller ([4] is the arrival counter); ang_ws: B*R + 4*B floats of workspace
     sc::LossArgs a{rgb, rgb_t, mask, mask_t, normal, normal_t, eik, B, R, E, normal_l1, mask_mse, keep_frac,
-                   out4, g_rgb, g_mask, g_normal, g_eik, g_normal_t, ang_ws};
+                   out4, ang_ws + (size_t)B * R, g_rgb, g_mask, g_normal, g_eik, g_normal_t, ang_ws};
     hipLaunchKernelGGL(sc::loss_fused_kernel, dim3(B + 1), dim3(1024), 0, (hipStream_t)stream_, a);
     return (int)hipGetLastError();
 }

@@ -17,14 +17,16 @@ namespace sc {
 
 enum { W_OP_NONE = 0, W_OP_PLAIN = 1, W_OP_SP = 2, W_OP_Q = 3, W_OP_Q4 = 4, W_OP_PE = 5, W_OP_EPS = 6 };
 constexpr int RB_PARTS = 512;
+constexpr int RB_MAX_IMAGES = 64;      // the fixed-order partial images of the per-image sums are carved for up to this many images
 
 __global__ __launch_bounds__(256) void rb_add_kernel(float* __restrict__ a, const float* __restrict__ b, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) a[i] += b[i];
 }
 
-// out[k] += sum_i x[i*stride + k], k < K <= 4 (out zero-filled); used for sum(g_sdf) (K = 1) and the column sums of gy3 (K = 3)
+// part[block][k] = sum over the block's rows of x[i*stride + k], k < K <= 4 (every block writes its 4 floats; sc_partial_reduce adds the
+// blocks in index order: fixed summation order); used for the column sums of gy3 (K = 3)
 __global__ __launch_bounds__(256) void rb_colsum_kernel(const float* __restrict__ x, size_t n, int stride, int K,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ part) {
     __shared__ float red[4][4];
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
@@ -35,7 +37,8 @@ __global__ __launch_bounds__(256) void rb_colsum_kernel(const float* __restrict_
         if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
     }
     __syncthreads();
-    if (threadIdx.x < K) atomicAdd(&out[threadIdx.x], red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+    if (threadIdx.x < 4)
+        part[blockIdx.x * 4 + threadIdx.x] = threadIdx.x < K ? (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]) : 0.f;
 }
 
 // [n_images][5][64] -> [5][n_images][64]
@@ -62,8 +65,11 @@ static size_t rb_workspace_floats(int n_rays, int* T_out) {
     add(5 * T > (size_t)256 * 4 * 4 * 1024 ? 5 * T : (size_t)256 * 4 * 4 * 1024);   // park scratch of the fused SDF backward (was Ga)
     add(4 * T > (size_t)5 * 4096 * 64 ? 4 * T : (size_t)5 * 4096 * 64);             // per-image bias-gradient staging (was Gp)
     add(T);                                                                          // (unused, kept for layout stability)
-    add((size_t)RB_PARTS * SdfPack::TOTAL);                        // partial images (the larger of the two networks)
-    add(2 * 64);                                                   // tbl_sum outputs for [r0, g_feat]
+    add((size_t)RB_PARTS * SdfPack::TOTAL);                        // partial images of the RGB weight gradients
+    add(2 * 64);                                                   // (unused, kept for layout stability)
+    add((size_t)RB_PARTS * 4 * RB_MAX_IMAGES * 64);                // per-wave row-sum partials of sc_wgrad
+    add((size_t)256 * (SdfPack::TOTAL + RB_MAX_IMAGES * 320));     // partial images of the fused SDF backward (weights + per-image biases)
+    add(SC_RGB_BWD_BETA_PARTS); add(512 * 4); add((size_t)1024 * 3 * 64);    // beta partials, column-sum partials, tbl_sum partials
     return n;
 }
 
@@ -102,35 +108,45 @@ extern "C" int sc_render_backward(
     float* gp = ws.f(4 * T > (size_t)5 * 4096 * 64 ? 4 * T : (size_t)5 * 4096 * 64);
     float* r0 = ws.f(T);
     (void)r0;
-    if (n_images > 4096) return (int)hipErrorInvalidValue;
+    if (n_images > RB_MAX_IMAGES) return (int)hipErrorInvalidValue;
     float* partial = ws.f((size_t)RB_PARTS * SdfPack::TOTAL);
     float* tot = ws.f(2 * 64);
     (void)tot;
+    float* rs_part = ws.f((size_t)RB_PARTS * 4 * RB_MAX_IMAGES * 64);
+    float* sdf_partial = ws.f((size_t)256 * (SdfPack::TOTAL + RB_MAX_IMAGES * 320));
+    float* beta_part = ws.f(SC_RGB_BWD_BETA_PARTS);
+    float* col_part = ws.f(512 * 4);
+    float* tbl_part = ws.f((size_t)1024 * 3 * 64);
+    const int E = n_images * 64;                        // floats of one per-image row-sum image
     int rc;
 #define SC_TRY(x) if ((rc = (x))) return rc
     // ---------------- RGB network + compositing ----------------
-    hipMemsetAsync(g_beta, 0, 4, st);
     SC_TRY(sc_rgb_composite_backward(points, z_vals, depth_fac, sdf, grad, feat, rgb_pack, rgb_dbias, beta_param, rgb_flat, n_rays,
                                      rays_per_image, n_images, symmetric, beta_min, bgcolor, normal_pow, G_rgb, G_mask, G_depth,
-                                     G_normal, g_sdf, g_grad, g_feat, gpts_rgb, g_z, g_depth_fac, g_beta, gy, rr, gy3, stream_));
+                                     G_normal, g_sdf, g_grad, g_feat, gpts_rgb, g_z, g_depth_fac, beta_part, gy, rr, gy3, stream_));
+    SC_TRY(sc_partial_reduce(beta_part, SC_RGB_BWD_BETA_PARTS, 1, 1, g_beta, stream_));
     hipMemsetAsync(g_dbias, 0, (size_t)3 * n_images * 64 * 4, st);       // [3][n_images][64]
     hipMemsetAsync(g_rgb_pack, 0, (size_t)RgbPack::TOTAL * 4, st);
     const int rs = RgbPack::TOTAL;
     // V0 = [PE 48 | sdf feature 64] in one pass over Gy0
     SC_TRY(sc_wgrad(1, gy, nullptr, W_OP_PLAIN, nullptr, W_OP_PE, feat, W_OP_PLAIN, nullptr, nullptr, W_OP_NONE, nullptr, W_OP_NONE, nullptr,
-                    W_OP_NONE, points, nullptr, nullptr, P, symmetric, 48, 64, partial, RB_PARTS, rs, RgbPack::V0, 112, g_dbias, npi, n_images,
+                    W_OP_NONE, points, nullptr, nullptr, P, symmetric, 48, 64, partial, RB_PARTS, rs, RgbPack::V0, 112, rs_part, npi, n_images,
                     stream_));
-    SC_TRY(wgrad1(gy + T, rr, W_OP_PLAIN, points, P, symmetric, 64, partial, rs, RgbPack::V1, 64, g_dbias + (size_t)n_images * 64, npi, n_images, stream_));
-    SC_TRY(wgrad1(gy + 2 * T, rr + T, W_OP_PLAIN, points, P, symmetric, 64, partial, rs, RgbPack::V2, 64, g_dbias + (size_t)2 * n_images * 64, npi, n_images, stream_));
+    SC_TRY(sc_partial_reduce(rs_part, RB_PARTS * 4, E, E, g_dbias, stream_));                    // per-wave row sums, index order
+    SC_TRY(wgrad1(gy + T, rr, W_OP_PLAIN, points, P, symmetric, 64, partial, rs, RgbPack::V1, 64, rs_part, npi, n_images, stream_));
+    SC_TRY(sc_partial_reduce(rs_part, RB_PARTS * 4, E, E, g_dbias + (size_t)E, stream_));
+    SC_TRY(wgrad1(gy + 2 * T, rr + T, W_OP_PLAIN, points, P, symmetric, 64, partial, rs, RgbPack::V2, 64, rs_part, npi, n_images, stream_));
+    SC_TRY(sc_partial_reduce(rs_part, RB_PARTS * 4, E, E, g_dbias + (size_t)2 * E, stream_));
     // the 3-row output layer: V3 via the coefficient form of tbl_sum, its bias via column sums (both accumulate into zeros);
     // the partial images only cover V0..V2 -- reduce exactly that prefix so V3/B3 are not overwritten with garbage
     SC_TRY(sc_partial_reduce(partial, RB_PARTS, rs, RgbPack::V3, g_rgb_pack, stream_));
     {
         const float* xs[1] = {rr + 2 * T};
         float* outs[1] = {g_rgb_pack + RgbPack::V3};
-        SC_TRY(sc_tbl_sum(xs, 1, gy3, P, P, 1, outs, stream_));
+        SC_TRY(sc_tbl_sum(xs, 1, gy3, P, P, 1, outs, tbl_part, stream_));
     }
-    hipLaunchKernelGGL(rb_colsum_kernel, dim3(512), dim3(256), 0, st, gy3, (size_t)P, 3, 3, g_rgb_pack + RgbPack::B3);
+    hipLaunchKernelGGL(rb_colsum_kernel, dim3(512), dim3(256), 0, st, gy3, (size_t)P, 3, 3, col_part);
+    SC_TRY(sc_partial_reduce(col_part, 512, 4, 3, g_rgb_pack + RgbPack::B3, stream_));
     // ---------------- SDF network (first and second order): one workgroup-cooperative launch ----------------
     // (csrc/sdf_bwdw.hip: input gradients + all weight / bias gradients, no Ga/Gp/r0 hand-off tensors; g_cbias comes out as
     //  [n_images][5][64] and is transposed into this entry point's [5][n_images][64] below)
@@ -138,11 +154,11 @@ extern "C" int sc_render_backward(
     const int parts = sc_sdf_backward_fused_parts(P);
     float* park = ga;                                   // 256 x 4 x 4 KiB x ... : carved from the (now unused) Ga region
     float* g_c_img = gp;                                // [n_images][5][64] staging
-    hipMemsetAsync(g_c_img, 0, (size_t)5 * n_images * 64 * 4, st);
+    const int S = sc_sdf_backward_fused_partial_floats(n_images);       // weight image + [n_images][5][64] per workgroup (n_images <= 256)
     SC_TRY(sc_sdf_backward_fused(points, sdf_pack, P, npi, n_images, symmetric, stash_a, stash_p, g_sdf, g_grad, g_feat, gpts_sdf,
-                                 park, partial, g_c_img, stream_));
-    hipMemsetAsync(g_sdf_pack, 0, (size_t)SdfPack::TOTAL * 4, st);
-    SC_TRY(sc_partial_reduce(partial, parts, SdfPack::TOTAL, SdfPack::TOTAL, g_sdf_pack, stream_));
+                                 park, sdf_partial, nullptr, stream_));
+    SC_TRY(sc_partial_reduce(sdf_partial, parts, S, SdfPack::TOTAL, g_sdf_pack, stream_));
+    SC_TRY(sc_partial_reduce(sdf_partial + SdfPack::TOTAL, parts, S, 5 * E, g_c_img, stream_));
     hipLaunchKernelGGL(rb_transpose_cbias_kernel, dim3((5 * n_images * 64 + 255) / 256), dim3(256), 0, st, g_c_img, g_cbias, n_images);
     // ---------------- points -> camera ----------------
     hipLaunchKernelGGL(rb_add_kernel, dim3(2048), dim3(256), 0, st, gpts_sdf, gpts_rgb, (size_t)3 * P);

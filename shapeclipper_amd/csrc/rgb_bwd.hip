@@ -30,7 +30,8 @@ struct RgbBwdArgs {
     float* g_points;     // [P][3]   (RGB net's own dependence on the point; sdf_bwd adds the rest)
     float* g_z;          // [n_rays][64]
     float* g_depth_fac;  // [n_rays]
-    float* g_beta;       // [1], pre-zeroed, atomicAdd (gradient wrt the raw parameter)
+    float* g_beta;       // [SC_RGB_BWD_BETA_PARTS = 2048]: one partial per wave of the grid (gradient wrt the raw parameter), fully written;
+                         // the gradient is their sum in index order (sc_partial_reduce) -- it used to be one float atomicAdd per wave
     float* gy;           // 3 x TBL64: pre-activation gradients Gy0, Gy1, Gy2
     float* rr;           // 3 x TBL64: post-ReLU activations r0, r1, r2
     float* gy3;          // [P][3]: gradient at the pre-sigmoid output
@@ -191,7 +192,9 @@ __global__ __launch_bounds__(256) void rgb_composite_bwd_kernel(RgbBwdArgs a) {
         }
     }
     const float gb = wave_sum(gbeta_acc);
-    if (lane == 0 && gb != 0.f) atomicAdd(a.g_beta, gb * dbeta_dbp);
+    if (lane == 0) a.g_beta[blockIdx.x * 4 + wave] = gb * dbeta_dbp;
+    if (blockIdx.x == 0 && wave == 0)               // the waves of the blocks that were not launched (small renders)
+        for (int e = gridDim.x * 4 + lane; e < 2048; e += 64) a.g_beta[e] = 0.f;
 }
 
 }  // namespace sc

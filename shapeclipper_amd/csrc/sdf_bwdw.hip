@@ -42,8 +42,10 @@ struct SdfBwdwArgs {
     const float* g_feat;   // TBL64 or null
     float* g_points;       // [n_points][3] or null
     float* park;           // [gridDim.x * 4][4][1024] floats of per-wave scratch (L2-resident)
-    float* partial;        // [gridDim.x][SdfPack::TOTAL]: one partial gradient image per workgroup (fully written)
-    float* g_cbias;        // [n_images][5][64], zero-filled by the caller (atomicAdd)
+    float* partial;        // [gridDim.x][partial_stride]: one partial gradient image per workgroup (fully written): SdfPack::TOTAL floats
+                           // of d/d(w_pack), then -- when cb_dense -- [n_images][5][64] of d/d(per-image biases)
+    float* g_cbias;        // !cb_dense only: [n_images][5][64], zero-filled by the caller (float atomicAdd: order depends on timing)
+    int partial_stride, cb_dense;
 #ifdef SC_BWDW_PROFILE
     unsigned long long* prof;   // [8 waves][64] s_memtime stamps of one iteration of one workgroup (tools/prof_bwdw.py)
     int prof_block, prof_iter;
@@ -149,6 +151,12 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     stage_sdf_weights(lds, a.w, tid, 512);
     for (int e = tid; e < BW_LDS_FLOATS - BW_XCH; e += 512) lds[BW_XCH + e] = 0.f;      // slots, point stash, sums
+    // Per-image bias gradients: with cb_dense every workgroup owns a zero-filled [n_images][5][64] block behind its weight-gradient
+    // image and ONE lane (wave w, lane i, kg == 0) is the only writer of an address, so plain read-modify-writes replace the float
+    // atomics; sc_partial_reduce then adds the workgroups' blocks in index order (results independent of timing).
+    float* cbp = a.partial + (size_t)blockIdx.x * a.partial_stride + SdfPack::TOTAL;
+    if (a.cb_dense)
+        for (int e = tid; e < a.n_images * 320; e += 512) cbp[e] = 0.f;
     __syncthreads();
 
     const int ntiles = (a.n_points + TP - 1) / TP;
@@ -472,7 +480,9 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
 #undef BW_PE_DOT2
 #undef BW_D2
         __syncthreads();        // the wgrad waves' sum of Gs is in LDS
-        if (tid == 0) a.partial[(size_t)blockIdx.x * SdfPack::TOTAL + SdfPack::B5] = lds[BW_RED + 64];
+        if (tid == 0)       // db5[0] = sum of Gs: the four wgrad waves' sums, added in wave order
+            a.partial[(size_t)blockIdx.x * a.partial_stride + SdfPack::B5] =
+                (lds[BW_RED + 64] + lds[BW_RED + 65]) + (lds[BW_RED + 66] + lds[BW_RED + 67]);
     } else {
         // =====================================================================================================
         // wgrad role: wave w owns rows 16w..16w+15 of every matrix
@@ -493,7 +503,10 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
                     float v = rs[l];
                     v += __shfl_xor(v, 16);
                     v += __shfl_xor(v, 32);
-                    if (kg == 0) atomicAdd(&a.g_cbias[((size_t)cur_img * 5 + l) * 64 + 16 * w + i], v);
+                    if (kg == 0) {
+                        const size_t o = ((size_t)cur_img * 5 + l) * 64 + 16 * w + i;
+                        if (a.cb_dense) cbp[o] += v; else atomicAdd(&a.g_cbias[o], v);
+                    }
                     rs[l] = 0.f;
                 }
             }
@@ -528,8 +541,10 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
                     t += __shfl_xor(t, 16);                                                  \
                     t += __shfl_xor(t, 32);                                                  \
                     const int img = min((base + c) / tiles_per_image, a.n_images - 1);       \
-                    if (kg == 0 && base + c < t_end)                                         \
-                        atomicAdd(&a.g_cbias[((size_t)img * 5 + ((RS >= 0 && RS < 5) ? RS : 0)) * 64 + 16 * w + i], t); \
+                    if (kg == 0 && base + c < t_end) {                                       \
+                        const size_t o = ((size_t)img * 5 + ((RS >= 0 && RS < 5) ? RS : 0)) * 64 + 16 * w + i; \
+                        if (a.cb_dense) cbp[o] += t; else atomicAdd(&a.g_cbias[o], t);       \
+                    }                                                                        \
                 }                                                                            \
             }                                                                                \
         }
@@ -574,11 +589,11 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
         flush();
         {
             const float gs = row_sum16(gss);
-            if (lane == 0) atomicAdd(&lds[BW_RED + 64], gs);
+            if (lane == 0) lds[BW_RED + 64 + w] = gs;
         }
         __syncthreads();
         // ---- this workgroup's partial image: rows 16w + 4kg + r, columns 16n + i of every matrix ----
-        float* out = a.partial + (size_t)blockIdx.x * SdfPack::TOTAL;
+        float* out = a.partial + (size_t)blockIdx.x * a.partial_stride;
         {
             float v0 = rs0;
             v0 += __shfl_xor(v0, 16);
@@ -623,13 +638,21 @@ int sc_sdf_backward_fused_parts(int n_points) {
     return blocks > 256 ? 256 : (blocks < 1 ? 1 : blocks);
 }
 
+// Floats per partial image of sc_sdf_backward_fused: the packed weight-gradient image, followed -- for up to 256 images -- by the
+// [n_images][5][64] per-image bias gradients (fixed summation order; beyond that they go through float atomics into g_cbias).
+int sc_sdf_backward_fused_partial_floats(int n_images) {
+    return sc::SdfPack::TOTAL + (n_images > 0 && n_images <= 256 ? n_images * 320 : 0);
+}
+
 int sc_sdf_backward_fused(const float* points, const float* w_pack, int n_points, int n_per_image, int n_images, int symmetric,
                           const float* stash_a, const float* stash_p, const float* g_sdf, const float* g_grad,
                           const float* g_feat, float* g_points, float* park, float* partial, float* g_cbias, void* stream_) {
     if (n_points <= 0) return 0;
     if (!g_grad || !stash_p || n_per_image <= 0 || n_per_image % sc::TP != 0 || n_images <= 0) return (int)hipErrorInvalidValue;
+    const int stride = sc_sdf_backward_fused_partial_floats(n_images), dense = stride > sc::SdfPack::TOTAL;
+    if (!dense && !g_cbias) return (int)hipErrorInvalidValue;
     sc::SdfBwdwArgs a{points, w_pack, n_points, n_per_image, n_images, symmetric, stash_a, stash_p, g_sdf, g_grad, g_feat,
-                      g_points, park, partial, g_cbias};
+                      g_points, park, partial, g_cbias, stride, dense};
 #ifdef SC_BWDW_PROFILE
     a.prof = sc_bwdw_prof_buf; a.prof_block = sc_bwdw_prof_block; a.prof_iter = sc_bwdw_prof_iter;
 #endif

@@ -40,7 +40,8 @@ struct WgradArgs {
     int nb0, nb1;          // widths of the two B segments (48 or 64; nb1 may be 0)
     float* partial;        // [gridDim.x][partial_stride]
     int partial_stride, out_offset, out_ld;
-    float* rowsum;         // optional [n_images][64] (zero-filled): per-image sum over points of term 0's A operand
+    float* rowsum;         // optional [nparts * 4][n_images][64]: per wave, per-image sum over points of term 0's A operand (fully
+                           // written here; the caller adds the nparts * 4 partial images in index order: sc_partial_reduce)
     int n_per_image, n_images;   // (= the bias / latent gradient of the layer); needs n_per_image % 16 == 0
 };
 
@@ -248,6 +249,12 @@ __global__ __launch_bounds__(256, WPS) void wgrad_kernel(WgradArgs a) {
     float rsum[NT] = {0.f, 0.f, 0.f, 0.f};
     const int tiles_per_image = want_rs ? a.n_per_image / TP : 1;
     int cur_img = -1;
+    // Row sums leave through a partial image PER WAVE ([n_images][64], zero-filled here): a wave visits the images in ascending
+    // order, so every (image, channel) is stored at most once -- no atomics, and the caller's fixed-order sum over the waves makes the
+    // result independent of timing (it used to be one float atomicAdd per wave, image and channel).
+    float* rs_part = want_rs ? a.rowsum + (size_t)(blockIdx.x * 4 + wave) * a.n_images * 64 : nullptr;
+    if (want_rs)
+        for (int e = lane; e < a.n_images * 64; e += 64) rs_part[e] = 0.f;
     auto flush_rowsum = [&]() {          // wave-uniform: cur_img is the same in every lane
         if (cur_img >= 0) {
 #pragma unroll
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(256, WPS) void wgrad_kernel(WgradArgs a) {
                 float v = rsum[m];
                 v += __shfl_xor(v, 16);
                 v += __shfl_xor(v, 32);
-                if (g == 0) atomicAdd(&a.rowsum[(size_t)cur_img * 64 + 16 * m + i], v);
+                if (g == 0) rs_part[(size_t)cur_img * 64 + 16 * m + i] = v;
                 rsum[m] = 0.f;
             }
         }
@@ -283,33 +290,51 @@ __global__ __launch_bounds__(256, WPS) void wgrad_kernel(WgradArgs a) {
         if constexpr (A1 != OP_NONE) term_compute(c1, P, a.w5row, i, valid, acc, rsum, false);
     }
     if (want_rs) flush_rowsum();
-    // combine the four waves of the workgroup in LDS, then one partial image per workgroup
-    __syncthreads();
+    // combine the four waves of the workgroup in LDS in wave order (a fixed summation order), then one partial image per workgroup
     const int ld = 16 * nnt;
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
 #pragma unroll
-    for (int m = 0; m < NT; ++m)
+            for (int m = 0; m < NT; ++m)
 #pragma unroll
-        for (int n = 0; n < NNT; ++n)
-            {
+                for (int n = 0; n < NNT; ++n)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(&red[(16 * m + 4 * g + r) * ld + 16 * n + i], acc[m][n][r]);
-            }
+                    for (int r = 0; r < 4; ++r) red[(16 * m + 4 * g + r) * ld + 16 * n + i] += acc[m][n][r];
+        }
+    }
     __syncthreads();
     float* out = a.partial + (size_t)blockIdx.x * a.partial_stride + a.out_offset;
     for (int e = tid; e < 64 * ld; e += 256) out[(e / ld) * a.out_ld + (e % ld)] = red[e];
 }
 
-// out[i] = sum_b partial[b][i].  blockIdx.y splits the parts into 16 chunks (each summed in a fixed order) that
-// are combined with one atomicAdd each: out must be zero-filled by the caller.
-__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ partial, int nparts, int stride,
-                                                             int n, float* __restrict__ out) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n) return;
-    const int per = (nparts + gridDim.y - 1) / gridDim.y;
-    const int b0 = blockIdx.y * per, b1 = min(nparts, b0 + per);
-    float s = 0.f;
-    for (int b = b0; b < b1; ++b) s += partial[(size_t)b * stride + idx];
-    if (b1 > b0) atomicAdd(&out[idx], s);
+// out[i] = sum_b partial[b][i] in a FIXED order (no atomics: results do not depend on timing).  A workgroup of 1024 threads handles
+// 32 consecutive elements; its 32 thread rows take the parts b = row, row + 32, ... (four interleaved sequential sums each, so that four
+// loads are in flight) and the 32 row sums are added by a fixed binary tree.  `out` is assigned (it need not be zero-filled).
+__global__ __launch_bounds__(1024) void partial_reduce_kernel(const float* __restrict__ partial, int nparts, int stride,
+                                                              int n, float* __restrict__ out) {
+    __shared__ float rows[32][33];
+    const int e = threadIdx.x & 31, row = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (idx < n) {
+        const float* src = partial + idx;
+        int b = row;
+        for (; b + 96 < nparts; b += 128) {
+            s0 += src[(size_t)b * stride];
+            s1 += src[(size_t)(b + 32) * stride];
+            s2 += src[(size_t)(b + 64) * stride];
+            s3 += src[(size_t)(b + 96) * stride];
+        }
+        for (; b < nparts; b += 32) s0 += src[(size_t)b * stride];
+    }
+    rows[row][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    for (int half = 16; half >= 1; half >>= 1) {
+        if (row < half) rows[row][e] += rows[row + half][e];
+        __syncthreads();
+    }
+    if (row == 0 && idx < n) out[idx] = rows[0][e];
 }
 
 // out[img][k][ch] += sum_{p in img} coef_k(p) * X[ch][p]     (K = 1: coef = 1;  K = 3: coef = cw[p][k])
@@ -317,14 +342,23 @@ struct TblSumArgs {
     const float* xs[8];  // up to 8 TBL64 tensors, one per blockIdx.y
     const float* coef;   // [n_points][3] or null
     int n_points, n_per_image, n_images;
-    float* outs[8];      // each [n_images][K][64], pre-zeroed, atomicAdd
+    float* outs[8];      // each [n_images][K][64]: legacy mode (part == null): pre-zeroed, atomicAdd
+    float* part;         // fixed-order mode: [gridDim.x][n_tensors][n_images][K][64] partial images, one per block, fully written here
 };
 
 template <int K>
 __global__ __launch_bounds__(256) void tbl_sum_kernel(TblSumArgs a) {
     const int tid = threadIdx.x, grp = tid >> 4, pt = tid & 15;
     const float* __restrict__ x = a.xs[blockIdx.y];
-    float* __restrict__ out = a.outs[blockIdx.y];
+    // Fixed-order mode (n_per_image % 16 == 0: a tile never straddles two images): the block owns a partial image, visits the images in
+    // ascending order and stores every (image, k, channel) at most once; the caller adds the blocks' images in block order.
+    const bool fixed = a.part != nullptr;
+    const size_t E = (size_t)a.n_images * K * 64;
+    float* __restrict__ out = fixed ? a.part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * E : a.outs[blockIdx.y];
+    if (fixed) {
+        for (size_t e = tid; e < E; e += 256) out[e] = 0.f;
+        __syncthreads();
+    }
     const int ntiles = (a.n_points + TP - 1) / TP;
     const int tiles_per_block = (ntiles + gridDim.x - 1) / gridDim.x;
     const int t0 = blockIdx.x * tiles_per_block, t1 = min(ntiles, t0 + tiles_per_block);
@@ -345,7 +379,10 @@ __global__ __launch_bounds__(256) void tbl_sum_kernel(TblSumArgs a) {
                 float v = have ? acc[k][r] : 0.f;
                 if (uniform) {
                     v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-                    if (pt == 0 && have) atomicAdd(&out[((size_t)cur * K + k) * 64 + 4 * grp + r], v);
+                    if (pt == 0 && have) {
+                        if (fixed) out[((size_t)cur * K + k) * 64 + 4 * grp + r] += v;       // (this lane is the only writer of the address)
+                        else atomicAdd(&out[((size_t)cur * K + k) * 64 + 4 * grp + r], v);
+                    }
                 } else if (have) {
                     atomicAdd(&out[((size_t)cur * K + k) * 64 + 4 * grp + r], v);
                 }
@@ -421,25 +458,38 @@ int sc_wgrad(int nterms,
 }
 
 int sc_partial_reduce(const float* partial, int nparts, int stride, int n, float* out, void* stream_) {
-    hipLaunchKernelGGL(sc::partial_reduce_kernel, dim3((n + 255) / 256, 16), dim3(256), 0, (hipStream_t)stream_,
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(sc::partial_reduce_kernel, dim3((n + 31) / 32), dim3(1024), 0, (hipStream_t)stream_,
                        partial, nparts, stride, n, out);
     return (int)hipGetLastError();
 }
 
-// xs / outs: HOST arrays of n_tensors (<= 8) device pointers; every out [n_images][K][64] must be zero-filled
-// by the caller; K = 3 when coef != NULL else 1.  One launch for all tensors (blockIdx.y).
-int sc_tbl_sum(const float* const* xs, int n_tensors, const float* coef, int n_points, int n_per_image, int n_images,
-               float* const* outs, void* stream_) {
-    if (n_points <= 0 || n_tensors <= 0) return 0;
-    if (n_tensors > 8) return (int)hipErrorInvalidValue;
-    sc::TblSumArgs a;
-    for (int t = 0; t < 8; ++t) { a.xs[t] = t < n_tensors ? xs[t] : nullptr; a.outs[t] = t < n_tensors ? outs[t] : nullptr; }
-    a.coef = coef; a.n_points = n_points; a.n_per_image = n_per_image; a.n_images = n_images;
+// Number of blocks (= partial images per tensor in fixed-order mode) sc_tbl_sum launches for n_points.
+int sc_tbl_sum_blocks(int n_points) {
     const int ntiles = (n_points + sc::TP - 1) / sc::TP;
     int blocks = (ntiles + 63) / 64;
-    if (blocks > 1024) blocks = 1024;
+    return blocks > 1024 ? 1024 : (blocks < 1 ? 1 : blocks);
+}
+
+// xs / outs: HOST arrays of n_tensors (<= 8) device pointers; K = 3 when coef != NULL else 1.  One launch for all tensors (blockIdx.y).
+// part != NULL (needs n_per_image % 16 == 0): fixed summation order -- `part` is sc_tbl_sum_blocks(n_points) * n_tensors * n_images * K * 64
+// floats of workspace, outs[0] must be ONE buffer holding all tensors back to back ([n_tensors][n_images][K][64], fully written);
+// part == NULL: legacy mode, every out [n_images][K][64] zero-filled by the caller, float atomicAdd (order depends on timing).
+int sc_tbl_sum(const float* const* xs, int n_tensors, const float* coef, int n_points, int n_per_image, int n_images,
+               float* const* outs, float* part, void* stream_) {
+    if (n_points <= 0 || n_tensors <= 0) return 0;
+    if (n_tensors > 8) return (int)hipErrorInvalidValue;
+    if (part && (n_per_image <= 0 || n_per_image % sc::TP != 0)) return (int)hipErrorInvalidValue;
+    sc::TblSumArgs a;
+    for (int t = 0; t < 8; ++t) { a.xs[t] = t < n_tensors ? xs[t] : nullptr; a.outs[t] = t < n_tensors ? outs[t] : nullptr; }
+    a.coef = coef; a.n_points = n_points; a.n_per_image = n_per_image; a.n_images = n_images; a.part = part;
+    const int blocks = sc_tbl_sum_blocks(n_points);
     if (coef) hipLaunchKernelGGL(sc::tbl_sum_kernel<3>, dim3(blocks, n_tensors), dim3(256), 0, (hipStream_t)stream_, a);
     else hipLaunchKernelGGL(sc::tbl_sum_kernel<1>, dim3(blocks, n_tensors), dim3(256), 0, (hipStream_t)stream_, a);
+    if (part) {
+        const int E = n_tensors * n_images * (coef ? 3 : 1) * 64;
+        hipLaunchKernelGGL(sc::partial_reduce_kernel, dim3((E + 31) / 32), dim3(1024), 0, (hipStream_t)stream_, part, blocks, E, E, outs[0]);
+    }
     return (int)hipGetLastError();
 }
 

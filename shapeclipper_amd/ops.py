@@ -81,21 +81,40 @@ def rgb_composite_forward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, db
 # operand transform codes of sc_wgrad (csrc/wgrad.hip)
 OP_NONE, OP_PLAIN, OP_SP, OP_Q, OP_Q4, OP_PE, OP_EPS = range(7)
 WGRAD_PARTS = 512
+RGB_BWD_BETA_PARTS = 2048      # SC_RGB_BWD_BETA_PARTS (include/shapeclipper_hip.h)
+
+
+def _partial_reduce(lib, partial, nparts, stride, n, out):
+    """out[:n] = sum over the parts in a fixed order (csrc/wgrad.hip partial_reduce_kernel: no atomics)."""
+    _lib.check(lib.sc_partial_reduce(_lib.ptr(partial), c_int(nparts), c_int(stride), c_int(n), _lib.ptr(out), _lib.stream()),
+               "sc_partial_reduce")
+    return out
+
+
+def _rowsum_scratch(dev, n_floats):
+    key = ("rowsum", dev.type, dev.index, torch.cuda.current_stream().cuda_stream if dev.type == "cuda" else 0)
+    if key not in _SCRATCH or _SCRATCH[key].numel() < n_floats:
+        _SCRATCH[key] = torch.empty(n_floats, device=dev, dtype=torch.float32)
+    return _SCRATCH[key]
 
 
 def _wgrad(lib, terms, points, g_grad, w5row, n_points, symmetric, nb0, nb1, partial, stride, out_offset, out_ld,
            rowsum=None, n_per_image=0, n_images=0):
-    """terms: list of 1 or 2 tuples (a0, a1, aop, b0, bop0, b1, bop1).  rowsum [n_images,64] (zeroed): per-image sum
-    of term 0's A operand, produced on the way."""
+    """terms: list of 1 or 2 tuples (a0, a1, aop, b0, bop0, b1, bop1).  rowsum [n_images,64] (any content): receives the per-image
+    sum of term 0's A operand, produced on the way -- every wave of the grid writes its own partial image and the partials are
+    added in index order (fixed summation order)."""
     t = list(terms) + [(None, None, OP_NONE, None, OP_NONE, None, OP_NONE)] * (2 - len(terms))
     args = []
     for (a0, a1, aop, b0, bop0, b1, bop1) in t:
         args += [_lib.ptr(a0), _lib.ptr(a1), c_int(aop), _lib.ptr(b0), c_int(bop0), _lib.ptr(b1), c_int(bop1)]
+    rs_part = _rowsum_scratch(points.device, WGRAD_PARTS * 4 * n_images * 64) if rowsum is not None else None
     code = lib.sc_wgrad(c_int(len(terms)), *args, _lib.ptr(points), _lib.ptr(g_grad), _lib.ptr(w5row),
                         c_int(n_points), c_int(1 if symmetric else 0), c_int(nb0), c_int(nb1), _lib.ptr(partial),
-                        c_int(WGRAD_PARTS), c_int(stride), c_int(out_offset), c_int(out_ld), _lib.ptr(rowsum),
+                        c_int(WGRAD_PARTS), c_int(stride), c_int(out_offset), c_int(out_ld), _lib.ptr(rs_part),
                         c_int(n_per_image), c_int(n_images), _lib.stream())
     _lib.check(code, "sc_wgrad")
+    if rowsum is not None:
+        _partial_reduce(lib, rs_part, WGRAD_PARTS * 4, n_images * 64, n_images * 64, rowsum)
 
 
 def tbl_sum_multi(xs, n_points, n_per_image, n_images, coef=None):
@@ -104,11 +123,19 @@ def tbl_sum_multi(xs, n_points, n_per_image, n_images, coef=None):
     lib = _lib.load()
     K = 3 if coef is not None else 1
     n = len(xs)
-    out = torch.zeros(n, n_images, K, 64, device=xs[0].device, dtype=torch.float32)
+    dev = xs[0].device
     PtrArr = ctypes.c_void_p * n
     xp = PtrArr(*[x.data_ptr() for x in xs])
+    blocks = int(lib.sc_tbl_sum_blocks(c_int(n_points)))
+    fixed = n_per_image % 16 == 0 and blocks * n * n_images * K * 64 <= (1 << 26)     # partial images of at most 256 MB
+    if fixed:       # fixed summation order: per-block partial images + an ordered sum
+        out = torch.empty(n, n_images, K, 64, device=dev, dtype=torch.float32)
+        part = _rowsum_scratch(dev, blocks * n * n_images * K * 64)
+    else:           # images that are not whole tiles (per-point latents) or too many of them: float atomics
+        out = torch.zeros(n, n_images, K, 64, device=dev, dtype=torch.float32)
+        part = None
     op = PtrArr(*[out[i].data_ptr() for i in range(n)])
-    code = lib.sc_tbl_sum(xp, c_int(n), _lib.ptr(coef), c_int(n_points), c_int(n_per_image), c_int(n_images), op,
+    code = lib.sc_tbl_sum(xp, c_int(n), _lib.ptr(coef), c_int(n_points), c_int(n_per_image), c_int(n_images), op, _lib.ptr(part),
                           _lib.stream())
     _lib.check(code, "sc_tbl_sum")
     return out
@@ -135,20 +162,21 @@ def sdf_backward_fused(points, w_pack, n_per_image, n_images, symmetric, stash_a
     dev = points.device
     f32 = dict(device=dev, dtype=torch.float32)
     parts = int(lib.sc_sdf_backward_fused_parts(c_int(n)))
+    stride = int(lib.sc_sdf_backward_fused_partial_floats(c_int(n_images)))
+    dense = stride > SDF_PACK_FLOATS                  # per-image bias gradients ride in the partial images (fixed summation order)
     park = _park_scratch(dev, 256 * 4 * 4 * 1024)
-    partial = torch.empty(parts * SDF_PACK_FLOATS, **f32)
-    g_c = torch.zeros(n_images, 5, 64, **f32)
+    partial = torch.empty(parts * stride, **f32)
+    g_c = None if dense else torch.zeros(n_images, 5, 64, **f32)
     g_points = torch.empty(n, 3, **f32) if want_points_grad else None
     code = lib.sc_sdf_backward_fused(_lib.ptr(points), _lib.ptr(w_pack), c_int(n), c_int(n_per_image), c_int(n_images),
                                      c_int(1 if symmetric else 0), _lib.ptr(stash_a), _lib.ptr(stash_p), _lib.ptr(g_sdf),
                                      _lib.ptr(g_grad), _lib.ptr(g_feat), _lib.ptr(g_points), _lib.ptr(park),
                                      _lib.ptr(partial), _lib.ptr(g_c), _lib.stream())
     _lib.check(code, "sc_sdf_backward_fused")
-    g_w = torch.zeros(SDF_PACK_FLOATS, **f32)
-    code = lib.sc_partial_reduce(_lib.ptr(partial), c_int(parts), c_int(SDF_PACK_FLOATS), c_int(SDF_PACK_FLOATS),
-                                 _lib.ptr(g_w), _lib.stream())
-    _lib.check(code, "sc_partial_reduce")
-    return g_points, g_w, g_c
+    g_all = _partial_reduce(lib, partial, parts, stride, stride, torch.empty(stride, **f32))
+    if dense:
+        g_c = g_all[SDF_PACK_FLOATS:].view(n_images, 5, 64)
+    return g_points, g_all[:SDF_PACK_FLOATS], g_c
 
 
 def sdf_backward(points, w_pack, n_per_image, n_images, symmetric, stash_a, stash_p, g_sdf, g_grad, g_feat,
@@ -188,7 +216,7 @@ def sdf_backward(points, w_pack, n_per_image, n_images, symmetric, stash_a, stas
 
     # per-image sums of Ga_l (the gradient of the per-image biases c_l) come out of the launch that streams Ga_l anyway
     fold = n_per_image % 16 == 0
-    g_c5 = torch.zeros(5, n_images, 64, **f32) if fold else None
+    g_c5 = torch.empty(5, n_images, 64, **f32) if fold else None
 
     def launch(terms, nb0, nb1, off, ld, layer=None):
         rs = g_c5[layer] if (fold and layer is not None) else None
@@ -218,10 +246,7 @@ def sdf_backward(points, w_pack, n_per_image, n_images, symmetric, stash_a, stas
     if g_feat is not None:
         launch([(g_feat, None, OP_PLAIN, A(4), OP_SP, None, OP_NONE)], 64, 0, SDF_OFF["W5"] + 64, 64)
 
-    g_w = torch.zeros(stride, **f32)
-    code = lib.sc_partial_reduce(_lib.ptr(partial), c_int(WGRAD_PARTS), c_int(stride), c_int(stride), _lib.ptr(g_w),
-                                 _lib.stream())
-    _lib.check(code, "sc_partial_reduce")
+    g_w = _partial_reduce(lib, partial, WGRAD_PARTS, stride, stride, torch.empty(stride, **f32))
     # W5 row 0 (sdf row):  sum_p (Gs * h4 + Gq4 * sp'(a4))   and the output bias
     tot = tbl_sum_multi([r0] + ([g_feat] if g_feat is not None else []), n, n, 1)
     g_w[SDF_OFF["W5"]:SDF_OFF["W5"] + 64] = tot[0].view(64)
@@ -253,7 +278,7 @@ def rgb_composite_backward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, d
     f32 = dict(device=dev, dtype=torch.float32)
     g = dict(sdf=torch.empty(P, **f32), grad=torch.empty(P, 3, **f32), feat=torch.empty(T, **f32),
              points=torch.empty(P, 3, **f32), z_vals=torch.empty(n_rays, 64, **f32),
-             depth_fac=torch.empty(n_rays, **f32), beta=torch.zeros(1, **f32))
+             depth_fac=torch.empty(n_rays, **f32), beta=torch.empty(RGB_BWD_BETA_PARTS, **f32))
     gy = torch.empty(3 * T, **f32)
     rr = torch.empty(3 * T, **f32)
     gy3 = torch.empty(P, 3, **f32)
@@ -274,16 +299,14 @@ def rgb_composite_backward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, d
     common = (points, None, None, P, symmetric)
     # per-image sums of Gy_l (gradient of the per-image biases d_l) are produced by the launch that streams Gy_l
     npi = rays_per_image * 64
-    g_d3 = torch.zeros(3, n_images, 64, **f32)
+    g_d3 = torch.empty(3, n_images, 64, **f32)
     rs = lambda l: (g_d3[l], npi, n_images)
     # V0 = [PE 48 | sdf feature 64]: one launch (Gy0 is streamed once, 7 N tiles)
     _wgrad(lib, [(GY(0), None, OP_PLAIN, None, OP_PE, feat, OP_PLAIN)], *common, 48, 64, partial, stride, RGB_OFF["V0"], 112, *rs(0))
     _wgrad(lib, [(GY(1), None, OP_PLAIN, RR(0), OP_PLAIN, None, OP_NONE)], *common, 64, 0, partial, stride, RGB_OFF["V1"], 64, *rs(1))
     _wgrad(lib, [(GY(2), None, OP_PLAIN, RR(1), OP_PLAIN, None, OP_NONE)], *common, 64, 0, partial, stride, RGB_OFF["V2"], 64, *rs(2))
-    g_v = torch.zeros(stride, **f32)
-    code = lib.sc_partial_reduce(_lib.ptr(partial), c_int(WGRAD_PARTS), c_int(stride), c_int(stride), _lib.ptr(g_v),
-                                 _lib.stream())
-    _lib.check(code, "sc_partial_reduce")
+    g_v = _partial_reduce(lib, partial, WGRAD_PARTS, stride, stride, torch.empty(stride, **f32))
+    g["beta"] = _partial_reduce(lib, g["beta"], RGB_BWD_BETA_PARTS, 1, 1, torch.empty(1, **f32))     # per-wave partials, index order
     g_v[RGB_OFF["V3"]:RGB_OFF["V3"] + 192] = tbl_sum(RR(2), P, P, 1, coef=gy3).view(192)
     # column sums of a [P,3] tensor: a plain sum(dim=0) runs on 4 workgroups (435 us at P = 1M); split the rows first
     chunks = 1024 if P % 1024 == 0 else 1
@@ -307,18 +330,18 @@ def loss_fused_forward(rgb, rgb_t, mask, mask_t, normal, normal_t, eik, normal_l
     if eik is not None:
         eik = c(eik).view(B, -1)
         E = eik.shape[1]
-    out = torch.zeros(4, **f32)
+    out = torch.zeros(8, **f32)           # 4 losses | arrival counter of the fixed-order reduction (must start at zero) | pad
     g_rgb, g_mask, g_normal = torch.empty(B, R, 3, **f32), torch.empty(B, R, **f32), torch.empty(B, R, 3, **f32)
     g_eik = torch.empty(B, E, **f32) if eik is not None else None
     g_normal_t = torch.empty(B, R, 3, **f32) if want_target_grad else None
-    ws = torch.empty(B * R, **f32)
+    ws = torch.empty(B * R + 4 * B, **f32)
     code = lib.sc_loss_fused_forward(_lib.ptr(rgb), _lib.ptr(rgb_t), _lib.ptr(mask), _lib.ptr(mask_t), _lib.ptr(normal),
                                      _lib.ptr(normal_t), _lib.ptr(eik), c_int(B), c_int(R), c_int(E),
                                      ctypes.c_float(normal_l1), ctypes.c_float(mask_mse), ctypes.c_double(keep_frac),
                                      _lib.ptr(out), _lib.ptr(g_rgb), _lib.ptr(g_mask), _lib.ptr(g_normal),
                                      _lib.ptr(g_eik), _lib.ptr(g_normal_t), _lib.ptr(ws), _lib.stream())
     _lib.check(code, "sc_loss_fused_forward")
-    return out, (g_rgb, g_mask, g_normal, g_eik, g_normal_t)
+    return out[:4], (g_rgb, g_mask, g_normal, g_eik, g_normal_t)
 
 
 def ray_sample_forward(cam_loc, ray_dirs, scale_dist, u, rays_per_image, cam_dist):

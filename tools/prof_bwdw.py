@@ -22,7 +22,7 @@ g_sdf, g_grad, g_feat = torch.randn(n, device=dev), torch.randn(n, 3, device=dev
 lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "micro", "libbwdw_prof.so"))
 parts = lib.sc_sdf_backward_fused_parts(ctypes.c_int(n))
 park = torch.empty(256 * 4 * 4 * 1024, device=dev)
-partial = torch.empty(parts * packing.SDF_PACK_FLOATS, device=dev)
+partial = torch.empty(parts * lib.sc_sdf_backward_fused_partial_floats(ctypes.c_int(B)), device=dev)
 g_c = torch.zeros(B, 5, 64, device=dev)
 g_points = torch.empty(n, 3, device=dev)
 prof = torch.zeros(8 * 64, dtype=torch.int64, device=dev)
