@@ -1,11 +1,11 @@
-"""Single-node data parallelism for MI355X: one process per GPU, ONE flat RCCL all-reduce per step.
+"""Single-node data parallelism for MI355X: one process per GPU, the gradients of a step in ONE flat buffer, exchanged over
+RCCL / xGMI with one all-reduce -- or, overlapped with the backward pass, as its two contiguous halves (see FlatGradAllReduce).
 
 The reference wraps the graph in DistributedDataParallel (25 MB buckets, find_unused_parameters
 graph walk, per-forward buffer broadcast; model/runner.py:121).  On an 8-GPU xGMI node the whole
 gradient is 36.8 M fp32 = 147 MB, small next to the step, so this build keeps every gradient in one
-contiguous buffer (parameters' .grad are views into it -- autograd accumulates in place, nothing is
-copied) and issues a single all_reduce(SUM) over RCCL, then scales by 1/world.  Parameters that
-received no gradient simply contribute zeros (the semantics of find_unused_parameters=True).
+contiguous buffer (parameters' .grad end up as views into it) and all-reduces (SUM) that buffer, then scales by 1/world.
+Parameters that received no gradient simply contribute zeros (the semantics of find_unused_parameters=True).
 """
 from __future__ import annotations
 
@@ -25,25 +25,74 @@ class ModuleHolder(nn.Module):
         return self.module(*args, **kwargs)
 
 
-class FlatGradAllReduce:
-    """Gradients are produced by autograd as usual (`.grad` starts as None each step, so the first accumulation of a
-    parameter is a pointer move, not an add kernel), then packed with one multi-tensor copy into the flat buffer,
-    all-reduced with ONE collective, averaged, and handed back to the optimizer as views of the flat buffer."""
+def _is_late(name: str) -> bool:
+    """Parameters whose gradients are produced LAST by the backward pass: the stems and layer1 / layer2 of the two ResNet trunks
+    (5.5 % of the bytes but about half of the trunks' backward time: the feature maps are largest there; everything else -- layer3 /
+    layer4 with 90 % of the parameters, the heads, the MLPs, the projections -- is ready while those still run)."""
+    parts = name.split(".")
+    for trunk in ("encoder", "feature_extractor"):
+        if trunk in parts:
+            k = parts.index(trunk)
+            return len(parts) > k + 1 and parts[k + 1] in ("conv1", "bn1", "layer1", "layer2")
+    return False
 
-    def __init__(self, module: nn.Module, world_size: int, broadcast_buffers: bool = True, always_communicate: bool = False):
+
+class FlatGradAllReduce:
+    """All gradients of a step in ONE flat buffer, exchanged over RCCL as the reference's DDP would (mean over ranks), without DDP's
+    25 MB buckets, graph walk and per-forward buffer broadcast (model/runner.py:121).
+
+    Gradients are produced by autograd as usual (`.grad` starts as None each step, so the first accumulation of a parameter is a
+    pointer move, not an add kernel), packed with multi-tensor copies into the flat buffer, all-reduced (SUM) and averaged; the
+    optimizer sees `.grad` as views of the flat buffer.
+
+    Exchange schedule.  `overlap=False`: one all_reduce of the whole buffer after backward (the north-star form).  `overlap=True`
+    (default on GPUs): the buffer is laid out [early | late] -- `late` = the trunks' stems, layer1 and layer2, whose gradients the
+    backward pass produces last -- and the all-reduce of the EARLY segment (94.5 % of the 147 MB) is issued from a
+    post-accumulate-grad hook on a side stream as soon as its last gradient exists, so it travels over xGMI while the early trunk
+    layers are still being differentiated; after backward only the 8 MB late segment remains: two collectives per step instead of one,
+    the same bytes, the same result (each element is summed over the ranks exactly once).
+    BatchNorm running statistics follow rank 0 (DDP's broadcast_buffers=True): the floating-point buffers are re-homed once into a
+    persistent flat tensor (they become views of it), so the per-step broadcast is ONE collective on that tensor, no cat / copy-back."""
+
+    def __init__(self, module: nn.Module, world_size: int, broadcast_buffers: bool = True, always_communicate: bool = False,
+                 overlap=None):
         self.module = module
         self.world = world_size
         self.comm = world_size > 1 or always_communicate      # always_communicate: run the collectives on 1 rank too (tests)
-        self.params = [p for p in module.parameters() if p.requires_grad]
-        # shared parameters (renderer.sdf_network is sdf_network) appear once in .parameters()
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]       # shared parameters appear once
+        early = [(n, p) for n, p in named if not _is_late(n)]
+        late = [(n, p) for n, p in named if _is_late(n)]
+        dev = named[0][1].device
+        self.overlap = (dev.type == "cuda" and self.comm) if overlap is None else bool(overlap)
+        if not self.overlap:
+            early, late = named, []                            # module order, one segment
+        self.params = [p for _, p in early + late]
+        self.n_early = len(early)
+        self.early_numel = sum(p.numel() for _, p in early)
         total = sum(p.numel() for p in self.params)
-        dev = self.params[0].device
         self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
         self.views, off = [], 0
         for p in self.params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
-        self.buffers = [b for b in module.buffers() if b.dtype.is_floating_point] if broadcast_buffers else []
+        self.collectives = 0                                   # data-path collectives issued so far (tests, bench)
+        self._early_work, self._early_done, self._seen = None, False, 0
+        self._comm_stream = torch.cuda.Stream(device=dev) if (self.overlap and dev.type == "cuda") else None
+        if self.overlap and late:
+            for p in self.params[:self.n_early]:
+                p.register_post_accumulate_grad_hook(self._on_grad)
+        # persistent flat home of the floating-point buffers
+        self.buffers, self.buf_flat = [], None
+        if broadcast_buffers:
+            bufs = [(m, k, b) for m in module.modules() for k, b in m._buffers.items() if b is not None and b.dtype.is_floating_point]
+            if bufs:
+                self.buf_flat = torch.cat([b.detach().reshape(-1).float() for _, _, b in bufs])
+                off = 0
+                for m, k, b in bufs:
+                    view = self.buf_flat[off:off + b.numel()].view_as(b)
+                    b.data = view                              # same Tensor object (state_dict, BN kernels), storage inside buf_flat
+                    self.buffers.append(b)
+                    off += b.numel()
         if self.comm:
             self.broadcast_parameters()
 
@@ -54,17 +103,53 @@ class FlatGradAllReduce:
     def zero_grad(self):
         for p in self.params:
             p.grad = None
+        self._early_work, self._early_done, self._seen = None, False, 0
 
-    def pack(self):
-        """Copy every produced gradient into its slot of the flat buffer (parameters that received none contribute
-        zeros, the semantics of find_unused_parameters=True) and point `.grad` at the slots."""
-        have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
-        if len(have) != len(self.params):
-            self.flat.zero_()
+    # ---- packing ---------------------------------------------------------------------------------------------------------
+    def _pack_range(self, lo, hi):
+        """Copy the produced gradients of params[lo:hi] into their slots (parameters that received none contribute zeros, the
+        semantics of find_unused_parameters=True) and point `.grad` at the slots."""
+        views, params = self.views[lo:hi], self.params[lo:hi]
+        have = [(v, p.grad) for v, p in zip(views, params) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+        if len(have) != len(params) and hi > lo:
+            a = self.views[lo].data_ptr() - self.flat.data_ptr()
+            self.flat[a // 4: a // 4 + sum(p.numel() for p in params)].zero_()
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
-        for v, p in zip(self.views, self.params):
+        for v, p in zip(views, params):
             p.grad = v
+        return have
+
+    def pack(self):
+        self._pack_range(0, len(self.params))
+
+    # ---- early segment: issued from inside backward ---------------------------------------------------------------------------
+    def _on_grad(self, param):
+        self._seen += 1
+        if self._seen == self.n_early and not self._early_done and self.comm:
+            self._launch_early()
+
+    def _launch_early(self):
+        seg = self.flat[:self.early_numel]
+        self._early_done = True
+        if self._comm_stream is None:                          # CPU / gloo: no streams, same schedule
+            self._pack_range(0, self.n_early)
+            self._early_work = dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True)
+            self.collectives += 1
+            return
+        cur = torch.cuda.current_stream()
+        grads = [p.grad for p in self.params[:self.n_early] if p.grad is not None]
+        ev = torch.cuda.Event()
+        ev.record(cur)                                         # everything enqueued so far on the hook's stream ...
+        self._comm_stream.wait_event(ev)
+        for s in _known_streams(seg.device):                   # ... and on the second trunk's stream
+            self._comm_stream.wait_stream(s)
+        with torch.cuda.stream(self._comm_stream):
+            for g in grads:
+                g.record_stream(self._comm_stream)             # produced on another stream, read here
+            self._pack_range(0, self.n_early)
+            self._early_work = dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True)
+        self.collectives += 1
 
     def broadcast_parameters(self, src=0):
         flat = torch.cat([p.data.reshape(-1) for p in self.params])
@@ -75,23 +160,40 @@ class FlatGradAllReduce:
             off += p.numel()
 
     def broadcast_buffers(self, src=0):
-        """BN running statistics follow rank 0, as DDP's broadcast_buffers=True does each forward."""
-        if not self.comm or not self.buffers:
+        """BN running statistics follow rank 0, as DDP's broadcast_buffers=True does each forward: ONE collective on the persistent
+        flat tensor the buffers live in."""
+        if not self.comm or self.buf_flat is None:
             return
-        flat = torch.cat([b.reshape(-1) for b in self.buffers])
-        dist.broadcast(flat, src)
-        views, off = [], 0
-        for b in self.buffers:
-            views.append(flat[off:off + b.numel()].view_as(b))
-            off += b.numel()
-        torch._foreach_copy_(self.buffers, views)
+        dist.broadcast(self.buf_flat, src)
 
     def all_reduce(self):
-        """Call after backward(): mean of the gradients over all ranks, one collective."""
-        self.pack()
+        """Call after backward(): mean of the gradients over all ranks."""
+        if not self._early_done:                               # no overlap, or an early gradient never arrived: everything now
+            self.pack()
+            if self.comm:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+                self.collectives += 1
+                self.flat.mul_(1.0 / self.world)
+            return
+        self._pack_range(self.n_early, len(self.params))
         if self.comm:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            dist.all_reduce(self.flat[self.early_numel:], op=dist.ReduceOp.SUM)
+            self.collectives += 1
+            if self._early_work is not None:
+                self._early_work.wait()                        # the current stream waits for the side-stream collective
+            if self._comm_stream is not None:
+                torch.cuda.current_stream().wait_stream(self._comm_stream)
             self.flat.mul_(1.0 / self.world)
+
+
+def _known_streams(device):
+    """Streams the backward pass may be running on besides the current one (the estimator trunk's side stream, model/graph.py)."""
+    try:
+        from .model.graph import _SIDE_STREAMS
+        s = _SIDE_STREAMS.get(str(device))
+        return [s] if s is not None else []
+    except Exception:       # noqa: BLE001
+        return []
 
 
 def gather_eval_records(records: torch.Tensor, world_size: int) -> torch.Tensor:

@@ -59,6 +59,87 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _worker_graph(rank, world, port, out):
+    """The product Graph's REAL parameter layout (36.8 M parameters, 147 MB of gradients) through the reducer calls of
+    Runner.train_iteration -- zero_grad, broadcast_buffers, backward, all_reduce, optimizer step -- with a stub forward (the HIP kernels
+    need a GPU): schedule of the exchange (one collective, or the early / late halves with the early one issued from inside backward),
+    its result, and the persistent buffer home."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from shapeclipper_amd.model.graph import Graph
+    from shapeclipper_amd.parallel import FlatGradAllReduce, _is_late
+    from shapeclipper_amd.utils import options
+    opt = options.set(options.parse_arguments(["--yaml=options/pix3d/config.yaml", "--name=pytest_gloo", "--output_root=/tmp/sc_pytest",
+                                               "--tb!", "--arch.enc_pretrained!", "--cpu"]), verbose=False)
+    torch.manual_seed(7 + rank)
+    g = Graph(opt)
+    keys_before = list(g.state_dict().keys())
+    failed = []
+
+    def chk(k, cond):
+        if not bool(cond):
+            failed.append(k)
+    calls = []
+    real_ar, real_bc = dist.all_reduce, dist.broadcast
+    dist.all_reduce = lambda t, *a, **k: (calls.append(("all_reduce", t.numel())), real_ar(t, *a, **k))[1]
+    dist.broadcast = lambda t, *a, **k: (calls.append(("broadcast", t.numel())), real_bc(t, *a, **k))[1]
+    try:
+        results = {}
+        for overlap in (False, True):
+            red = FlatGradAllReduce(g, world, overlap=overlap)
+            chk(1, red.flat.numel() == sum(p.numel() for p in g.parameters()) and red.nbytes > 140e6)
+            chk(2, list(g.state_dict().keys()) == keys_before)                          # buffers were re-homed, not replaced
+            optim = torch.optim.SGD(g.parameters(), lr=0.1)
+            names = {id(p): n for n, p in g.named_parameters()}
+            if overlap:
+                late = [names[id(p)] for p in red.params[red.n_early:]]
+                chk(3, len(late) > 0 and all(_is_late(n) for n in late) and not any(_is_late(names[id(p)]) for p in red.params[:red.n_early]))
+                chk(4, 0.03 < 1 - red.early_numel / red.flat.numel() < 0.2)         # the late segment is a small part of the bytes (5.5 %)
+            calls.clear()
+            # one "training iteration" as Runner.train_iteration issues it
+            red.zero_grad()
+            g.encoder.bn1.running_mean.fill_(float(rank + 1))
+            red.broadcast_buffers()
+            chk(5, calls == [("broadcast", red.buf_flat.numel())])                      # ONE collective for all BN statistics
+            chk(6, float(g.encoder.bn1.running_mean[0]) == 1.0)                          # rank 0's value everywhere
+            chk(7, g.encoder.bn1.running_mean.data_ptr() >= red.buf_flat.data_ptr())     # still a view of the flat home
+            calls.clear()
+            coef = float(rank + 1)
+            # stub forward: parameters in module order, so autograd finishes the trunks' first layers last
+            loss = sum((p * p).sum() * coef for p in g.parameters())
+            loss.backward()
+            in_backward = list(calls)
+            red.all_reduce()
+            optim.step()
+            n_ar = [c for c in calls if c[0] == "all_reduce"]
+            if overlap:
+                chk(8, in_backward == [("all_reduce", red.early_numel)])                 # issued from the hook, inside backward
+                chk(9, n_ar == [("all_reduce", red.early_numel), ("all_reduce", red.flat.numel() - red.early_numel)])
+                chk(10, red.collectives == 2)
+            else:
+                chk(11, in_backward == [] and n_ar == [("all_reduce", red.flat.numel())] and red.collectives == 1)
+            # mean over ranks of d/dp [coef * sum p^2] = 2 p * mean(coef); parameters were broadcast from rank 0 at construction
+            mean_coef = sum(range(1, world + 1)) / world
+            flat_params = torch.cat([(p.detach() + 0.1 * p.grad).reshape(-1) for p in red.params])      # undo the SGD step
+            chk(12, torch.allclose(red.flat, 2 * mean_coef * flat_params, rtol=1e-5, atol=1e-7))
+            chk(13, all(p.grad.data_ptr() >= red.flat.data_ptr() for p in g.parameters()))
+            results[overlap] = torch.cat([p.detach().reshape(-1) for p in g.parameters()]).clone()
+            del red, optim
+        out[rank] = list(failed)
+    finally:
+        dist.all_reduce, dist.broadcast = real_ar, real_bc
+        dist.destroy_process_group()
+
+
+def test_reducer_schedule_on_the_real_parameter_layout():
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_graph, args=(2, port, out), nprocs=2, join=True)
+    assert out[0] == [] and out[1] == [], "failed checks (numbered in source order): rank 0 %s, rank 1 %s" % (out[0], out[1])
+
+
 def test_flat_allreduce_two_ranks():
     port = _free_port()
     mgr = mp.Manager()

@@ -128,6 +128,8 @@ def test_flat_reducer_path_on_rccl_single_rank():
             results.append({n: p.detach().clone() for n, p in g.named_parameters()})
             if use_reducer:
                 assert all(p.grad.data_ptr() >= runner.reducer.flat.data_ptr() for p in g.parameters() if p.grad is not None)
+                # overlapped schedule on the GPU: the early segment from inside backward (side stream) + the late one after it
+                assert runner.reducer.overlap and runner.reducer.collectives == 2 * 2, runner.reducer.collectives
         # Adam moves every weight by ~lr = 1e-4 per step whatever the gradient's size, so run-to-run gradient noise (atomic
         # accumulation order in MIOpen's and this build's weight-gradient kernels) moves noise-dominated weights (most of the
         # encoder) differently even between two identical runs.  Bound for all: 2 steps * 2 lr.  The estimator's gradients
@@ -148,7 +150,8 @@ def test_flat_reducer_path_on_rccl_single_rank():
 
 
 @pytest.mark.parametrize("flag", ["--hip.two_streams!", "--hip.batched_encoders!", "--hip.fused_loss!", "--hip.fused_adam!", "--hip.device_rng",
-                                  "--hip.fused_backward!", "--hip.device_choice!", "--hip.conv3x3!", "--hip.conv3x3_split", "--hip.conv_stem!", "--hip.conv1x1!", "--hip.conv3x3s2!"])
+                                  "--hip.fused_backward!", "--hip.device_choice!", "--hip.conv3x3!", "--hip.conv3x3_split!", "--hip.conv_stem!", "--hip.conv1x1!", "--hip.conv3x3s2!",
+                                  "--hip.overlap_allreduce!"])
 def test_every_hip_option_has_a_working_alternate_path(flag):
     """Each fast path of this build can be switched off (README): the step still runs and gives the same loss
     (device_rng draws different jitter, so only finiteness is compared there)."""
