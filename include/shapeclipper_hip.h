@@ -363,8 +363,22 @@ int sc_conv3x3_tile_channels_split(int hw);
 int sc_conv3x3_forward_split(const float* x, const float* w_pack, float* out, float* workspace, int batch, int cin, int cout, int hw,
                              void* stream);
 
-/* 3x3 / stride 2 / pad 1 (BasicBlock.conv1 of layer2-4), forward only, same kernel family: hw = side of the INPUT map (56, 28 or 14),
- * out [batch][cout][hw/2][hw/2].  Filter image: sc_conv3x3_pack with bit 2 (value 4) of transpose_flip set, sc_conv3x3s2_pack_floats floats. */
+/* 3x3 / stride 2 / pad 1 (BasicBlock.conv1 of layer2-4; torchvision layer{2,3,4}.0.conv1 behind model/graph.py:50-54 and
+ * model/view_estimator.py:40-42), same kernel family: hw = side of the INPUT map (56, 28 or 14), out [batch][cout][hw/2][hw/2].
+ * Forward filter image: sc_conv3x3_pack with bit 2 (value 4) of transpose_flip set, sc_conv3x3s2_pack_floats floats.
+ * Backward-data (sc_conv3x3s2_backward_data: gx [batch][cin][hw][hw] from gy [batch][cout][hw/2][hw/2]): four stride-1 sub-convolutions
+ *   over the gradient map, one per output parity, each with the 1 / 2 / 2 / 4 filter taps that reach it -- every product of the transposed
+ *   convolution once; exact three-piece bf16 operand splits with fp32 accumulation (the arithmetic of sc_conv3x3_forward_split).  Filter
+ *   image: sc_conv3x3s2_bd_pack from the FORWARD filter w [cout][cin][3][3], sc_conv3x3s2_bd_pack_floats floats; workspace
+ *   sc_conv3x3s2_bd_workspace_floats(hw) floats.  cout % 8 == 0.
+ * Backward-weight (sc_conv3x3s2_wgrad: dw [cout][cin][3][3] from gy and x [batch][cin][hw][hw]): csrc/conv3x3_wgrad.hip with stride-2 patch
+ *   addressing, fp32 MFMA, fixed summation order; workspace sc_conv3x3_wgrad_workspace_floats(cin, cout) floats; cin, cout % 64 == 0. */
+long long sc_conv3x3s2_bd_pack_floats(int cin, int cout, int hw);
+long long sc_conv3x3s2_bd_workspace_floats(int hw);
+int sc_conv3x3s2_bd_pack(const float* w, float* w_pack, int cin, int cout, int hw, void* stream);
+int sc_conv3x3s2_backward_data(const float* gy, const float* w_pack, float* gx, float* workspace, int batch, int cin, int cout, int hw,
+                               void* stream);
+int sc_conv3x3s2_wgrad(const float* gy, const float* x, float* dw, float* workspace, int batch, int cin, int cout, int hw, void* stream);
 long long sc_conv3x3s2_pack_floats(int cin, int cout, int hw);
 long long sc_conv3x3s2_workspace_floats(int hw);
 int sc_conv3x3s2_forward(const float* x, const float* w_pack, float* out, float* workspace, int batch, int cin, int cout, int hw,

@@ -43,16 +43,24 @@ __device__ __forceinline__ void conv_glds16(const void* gsrc, unsigned lds_dst) 
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-template <int W_, int CT_, int PT_, int WGM_, int WGN_, bool SPLIT_ = false, int S_ = 1>
+// BD2: backward-data of the 3x3 / stride-2 / pad-1 convolutions (BasicBlock.conv1 of layer2-4) as FOUR stride-1 sub-convolutions over the
+// W x W gradient map, one per parity (py, px) of the 2W x 2W result:  gx[ci][2y + py][2x + px] = sum_co sum_taps w[co][ci][ky][kx]
+// gy[co][y + dy][x + dx]  with the taps whose (2y + py + 1 - ky, 2x + px + 1 - kx) are even -- 1, 2, 2 and 4 of the nine, at (dy, dx) in
+// {0, 1}^2: every product of the transposed convolution is computed exactly once (a zero-stuffed stride-1 convolution would do 4x the
+// work).  A tile is (phase, CT channels, PT pixels of the gradient map); the tap-pair list and the filter image depend on the phase.
+template <int W_, int CT_, int PT_, int WGM_, int WGN_, bool SPLIT_ = false, int S_ = 1, bool BD2_ = false>
 struct ConvCfg {
     static constexpr int W = W_, CT = CT_, PT = PT_, WGM = WGM_, WGN = WGN_, CB = 8;
     static constexpr bool SPLIT = SPLIT_;            // operands as three bf16 pieces on the bf16 matrix pipe (see conv3x3 SPLIT below)
+    static constexpr bool BD2 = BD2_;
+    static constexpr int PSZ = 3 * 2 * CT * 4;       // floats of one tap-pair image (SPLIT): [piece][half][CT][8 bf16]
+    static_assert(!BD2 || (SPLIT && S_ == 1), "the stride-2 backward-data instance exists in the split arithmetic only");
     static constexpr int Wp = W + 2, HW = W * W, Sp = Wp * Wp;             // geometry of the INPUT map (W x W, one pad ring)
     static constexpr int S = S_, WO = W / S, HWO = WO * WO;                  // stride and output map (stride 2: the three conv1 of layer2-4)
     static constexpr int NT = 64 * WGM * WGN;
     static constexpr int WM = CT / (32 * WGM), WN = PT / (32 * WGN);        // 32x32 MFMA tiles per wave
     // floats (4-byte units) of one weight stage: fp32 [tap][half][CT][4]; SPLIT [tap pair (5)][piece (3)][half][CT][8 bf16]
-    static constexpr int WIMG = SPLIT ? 5 * 3 * 2 * CT * 4 : 9 * CB * CT;
+    static constexpr int WIMG = BD2 ? 2 * PSZ : (SPLIT ? 5 * PSZ : 9 * CB * CT);
     // longest padded-flat span of PT consecutive (output) pixels plus the halo.  Stride 1: 2 pad columns per row crossed, 2 pad rows
     // per image crossed.  Stride S: S positions per pixel, S (Wp - WO) extra per row crossed, Sp - S (WO - 1)(Wp + 1) per image crossed.
     static constexpr int LMAX = S == 1 ? PT + 2 * (PT / W + 2) + 2 * Wp * (PT / HW + 1) + 2 * (Wp + 1)
@@ -72,6 +80,25 @@ __device__ __forceinline__ int padded_q(int p) {
     return b * C::Sp + (C::S * y + 1) * C::Wp + (C::S * x + 1);
 }
 
+// ---- BD2 tables: phase = 2 py + px; tap pairs per phase 1, 1, 1, 2; lane half h of pair t multiplies patch position (ky', kx') (offset
+// ky' Wp + kx' from the patch origin, centre = (1, 1)) with forward-filter tap (ky, kx) -- none for the second half of phase 0.
+__host__ __device__ constexpr int bd2_pairs(int phase) { return phase == 3 ? 2 : 1; }
+__host__ __device__ constexpr int bd2_pair_base(int phase) { return phase; }                      // pairs before this phase: 0, 1, 2, 3
+// forward-filter tap ky * 3 + kx of (phase, pair, half), -1 = none
+__host__ __device__ constexpr int bd2_filter_tap(int phase, int pair, int h) {
+    return phase == 0 ? (h == 0 ? 4 : -1)
+         : phase == 1 ? (h == 0 ? 3 : 5)
+         : phase == 2 ? (h == 0 ? 1 : 7)
+         : pair == 0 ? (h == 0 ? 0 : 2) : (h == 0 ? 6 : 8);
+}
+// patch position ky' * 3 + kx' the same lane half reads (the second half of phase 0 re-reads the centre: finite values x zero weights)
+__host__ __device__ constexpr int bd2_patch_tap(int phase, int pair, int h) {
+    return phase == 0 ? 4
+         : phase == 1 ? (h == 0 ? 5 : 4)
+         : phase == 2 ? (h == 0 ? 7 : 4)
+         : pair == 0 ? (h == 0 ? 8 : 7) : (h == 0 ? 5 : 4);
+}
+
 // The tiles of the last, incomplete round of the grid are cut into equal spans of K-steps ("units").
 struct ConvSplit {
     int rounds;          // whole rounds: workgroup g computes tiles r * G + g, r < rounds, completely
@@ -87,23 +114,83 @@ __host__ __device__ inline ConvSplit conv_split(int tiles, int nk, int G) {
 }
 
 // acc[r] of a 32x32 C/D tile is row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31
+// tile -> (phase, pixel tile, channel tile); address of output pixel p (of that phase) in channel 0 of its image, and the channel stride
+template <class C>
+__device__ __forceinline__ void conv_tile_decode(int tile, int nct, int& phase, int& pt, int& ct) {
+    phase = C::BD2 ? tile & 3 : 0;
+    const int t = C::BD2 ? tile >> 2 : tile;
+    pt = t / nct, ct = t - pt * nct;
+}
+template <class C>
+__device__ __forceinline__ float* conv_out_pixel(float* __restrict__ out, int p, int phase, int cout, int& cstride) {
+    const int b = p / C::HWO, rem = p - b * C::HWO;
+    if constexpr (C::BD2) {                         // the result lives on the 2W x 2W map: pixel (2y + py, 2x + px)
+        const int y = rem / C::W, x = rem - y * C::W;
+        cstride = 4 * C::HW;
+        return out + (size_t)b * cout * cstride + (2 * y + (phase >> 1)) * (2 * C::W) + 2 * x + (phase & 1);
+    } else {
+        cstride = C::HWO;
+        return out + (size_t)b * cout * C::HWO + rem;
+    }
+}
+
 template <class C>
 __device__ __forceinline__ void conv_store_tile(float* __restrict__ out, const f32x16 (&acc)[C::WM][C::WN], int tile, int nct, int npix,
                                                 int cout, int wm, int wn, int lane) {
-    const int pt = tile / nct, ct = tile - pt * nct;
+    int phase, pt, ct;
+    conv_tile_decode<C>(tile, nct, phase, pt, ct);
 #pragma unroll
     for (int j = 0; j < C::WN; ++j) {
         const int p = pt * C::PT + (wn * C::WN + j) * 32 + (lane & 31);
         if (p >= npix) continue;
-        const int b = p / C::HWO, rem = p - b * C::HWO;
-        float* ob = out + (size_t)b * cout * C::HWO + rem;
+        int cs;
+        float* ob = conv_out_pixel<C>(out, p, phase, cout, cs);
 #pragma unroll
         for (int i = 0; i < C::WM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = ct * C::CT + (wm * C::WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (co < cout) ob[(size_t)co * C::HWO] = acc[i][j][r];
+                if (co < cout) ob[(size_t)co * cs] = acc[i][j][r];
             }
+    }
+}
+
+// six exact piece products of one tap pair (SPLIT): a_p b_q with p + q <= 2, small terms first
+template <class C>
+__device__ __forceinline__ void conv_split_terms(const float4 (&a)[C::WM][3], const float4 (&b)[C::WN][3], f32x16 (&acc)[C::WM][C::WN]) {
+#pragma unroll
+    for (int term = 0; term < 6; ++term) {
+        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+        for (int i = 0; i < C::WM; ++i)
+#pragma unroll
+            for (int j = 0; j < C::WN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cv_bf16x8, a[i][PA[term]]),
+                                                                    __builtin_bit_cast(cv_bf16x8, b[j][PB[term]]), acc[i][j], 0, 0, 0);
+    }
+}
+// the tap pairs of one K-step of a BD2 tile of phase PHASE
+template <class C, int PHASE>
+__device__ __forceinline__ void conv_bd2_step(const float* Ws, const float* Xs, const int (&aoff)[C::WM], const int (&boff)[C::WN], int half,
+                                              f32x16 (&acc)[C::WM][C::WN]) {
+    constexpr int Wp = C::Wp, LX = C::LX, CT = C::CT;
+#pragma unroll
+    for (int tp = 0; tp < bd2_pairs(PHASE); ++tp) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int t0 = bd2_patch_tap(PHASE, tp, 0), t1 = bd2_patch_tap(PHASE, tp, 1);
+        const int o0 = (t0 / 3) * Wp + t0 % 3, o1 = (t1 / 3) * Wp + t1 % 3;
+        float4 a[C::WM][3], b[C::WN][3];
+#pragma unroll
+        for (int i = 0; i < C::WM; ++i)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) a[i][pc] = *reinterpret_cast<const float4*>(Ws + aoff[i] + (tp * 3 + pc) * 2 * CT * 4);
+#pragma unroll
+        for (int j = 0; j < C::WN; ++j)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+                b[j][pc] = *reinterpret_cast<const float4*>(Xs + boff[j] + (pc * LX + o0) * 4 + half * (o1 - o0) * 4);
+        conv_split_terms<C>(a, b, acc);
     }
 }
 
@@ -117,7 +204,7 @@ __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const flo
     float* S = reinterpret_cast<float*>(conv_smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const int wm = wave / C::WGN, wn = wave % C::WGN;
-    const int npix = batch * C::HWO, nct = (cout + CT - 1) / CT, tiles = ((npix + PT - 1) / PT) * nct;
+    const int npix = batch * C::HWO, nct = (cout + CT - 1) / CT, tiles = ((npix + PT - 1) / PT) * nct * (C::BD2 ? 4 : 1);
     const int nk = cin / CB, G = gridDim.x, g = blockIdx.x;
     const ConvSplit sp = conv_split(tiles, nk, G);
     // workgroup b runs on XCD b % 8: give every XCD a contiguous range of each round's tiles (shared patches / weights stay in its L2)
@@ -142,7 +229,8 @@ __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const flo
             if (unit_lo >= unit_hi || (long long)t * nk >= unit_hi) continue;
             tile = sp.rounds * G + t, kb0 = 0, kb1 = (int)(unit_hi - (long long)t * nk);
         }
-        const int pt = tile / nct, ct = tile - pt * nct;
+        int phase, pt, ct;
+        conv_tile_decode<C>(tile, nct, phase, pt, ct);
         const int p0 = pt * PT;
         const int q0 = padded_q<C>(p0), q_lo = q0 - Wp - 1;
 
@@ -169,10 +257,12 @@ __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const flo
             for (int j = 0; j < WN; ++j) boff[j] -= half * LX * 4;
         }
 
-        const float* wsrc = wpack + (size_t)ct * nk * C::WIMG;              // [ct][kb][tap][half][CT][4]
+        // filter image of one K-step: [ct][kb][tap][half][CT][4]; BD2: [phase][ct][kb][pair][piece][half][CT][8 bf16], 1 or 2 pairs per phase
+        const int wimg = C::BD2 ? bd2_pairs(phase) * C::PSZ : C::WIMG;
+        const float* wsrc = wpack + (C::BD2 ? (size_t)bd2_pair_base(phase) * nct * nk * C::PSZ : 0) + (size_t)ct * nk * wimg;
         auto issue_w = [&](int kb, int stage) {
-            constexpr int CHUNKS = C::WIMG / 4;
-            const char* src = reinterpret_cast<const char*>(wsrc + (size_t)kb * C::WIMG);
+            const int CHUNKS = wimg / 4;
+            const char* src = reinterpret_cast<const char*>(wsrc + (size_t)kb * wimg);
             const unsigned dst = lds0 + (unsigned)stage * (C::STAGE * 4);
 #pragma unroll
             for (int c = 0; c < (CHUNKS + NT - 1) / NT; ++c) {
@@ -234,7 +324,14 @@ __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const flo
             if (kb + 1 < kb1) { issue_w(kb + 1, st ^ 1); load_x(kb + 1); }
             const float* Ws = S + st * C::STAGE;
             const float* Xs = Ws + C::WIMG;
-            if constexpr (C::SPLIT) {
+            if constexpr (C::BD2) {
+                switch (phase) {
+                    case 0: conv_bd2_step<C, 0>(Ws, Xs, aoff, boff, half, acc); break;
+                    case 1: conv_bd2_step<C, 1>(Ws, Xs, aoff, boff, half, acc); break;
+                    case 2: conv_bd2_step<C, 2>(Ws, Xs, aoff, boff, half, acc); break;
+                    default: conv_bd2_step<C, 3>(Ws, Xs, aoff, boff, half, acc); break;
+                }
+            } else if constexpr (C::SPLIT) {
                 // k block of an MFMA (32x32x16): lane half h holds the 8 channels of tap 2 tp + h (tap 9: zero weights).  Per tap pair:
                 // WM + WN operand tiles x 3 pieces, six products a_p b_q with p + q <= 2 (what is dropped is < 2^-23 of |a||b|)
                 float4 a[WM][3], b[WN][3];
@@ -252,16 +349,7 @@ __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const flo
 #pragma unroll
                         for (int pc = 0; pc < 3; ++pc)
                             b[j][pc] = *reinterpret_cast<const float4*>(Xs + boff[j] + (pc * LX + o0) * 4 + half * (o1 - o0) * 4);
-#pragma unroll
-                    for (int term = 0; term < 6; ++term) {
-                        constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};      // small terms first
-#pragma unroll
-                        for (int i = 0; i < WM; ++i)
-#pragma unroll
-                            for (int j = 0; j < WN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cv_bf16x8, a[i][PA[term]]),
-                                                                                    __builtin_bit_cast(cv_bf16x8, b[j][PB[term]]), acc[i][j], 0, 0, 0);
-                    }
+                    conv_split_terms<C>(a, b, acc);
                 }
             } else {
             float4 a[2][WM], b[2][WN];
@@ -311,7 +399,7 @@ __global__ __launch_bounds__(C::NT) void conv3x3_fixup_kernel(const float* __res
                                                               int cin, int cout, int G) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / C::WGN, wn = wave % C::WGN;
-    const int npix = batch * C::HWO, nct = (cout + C::CT - 1) / C::CT, tiles = ((npix + C::PT - 1) / C::PT) * nct;
+    const int npix = batch * C::HWO, nct = (cout + C::CT - 1) / C::CT, tiles = ((npix + C::PT - 1) / C::PT) * nct * (C::BD2 ? 4 : 1);
     const int nk = cin / C::CB;
     const ConvSplit sp = conv_split(tiles, nk, G);
     const int t = blockIdx.x, r0 = 4 * blockIdx.y;
@@ -335,19 +423,21 @@ __global__ __launch_bounds__(C::NT) void conv3x3_fixup_kernel(const float* __res
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] += src[(((wave * C::WM + i) * C::WN + j) * 16 + r0 + r) * 64 + lane];
     }
-    const int tile = sp.rounds * G + t, pt = tile / nct, ct = tile - pt * nct;
+    const int tile = sp.rounds * G + t;
+    int phase, pt, ct;
+    conv_tile_decode<C>(tile, nct, phase, pt, ct);
 #pragma unroll
     for (int j = 0; j < C::WN; ++j) {
         const int p = pt * C::PT + (wn * C::WN + j) * 32 + (lane & 31);
         if (p >= npix) continue;
-        const int b = p / C::HWO, rem = p - b * C::HWO;
-        float* ob = out + (size_t)b * cout * C::HWO + rem;
+        int cs;
+        float* ob = conv_out_pixel<C>(out, p, phase, cout, cs);
 #pragma unroll
         for (int i = 0; i < C::WM; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = ct * C::CT + (wm * C::WM + i) * 32 + r + 2 * r0 + 4 * (lane >> 5);      // row of acc[r0 + r]: r + 8 (r0 / 4)
-                if (co < cout) ob[(size_t)co * C::HWO] = acc[i][j][r];
+                if (co < cout) ob[(size_t)co * cs] = acc[i][j][r];
             }
     }
 }
@@ -404,6 +494,37 @@ __device__ __forceinline__ float conv_pack_word(const float* __restrict__ w, lon
     return __uint_as_float(lo | (hi << 16));
 }
 
+// Filter image of the stride-2 backward-data instance (BD2): [pair region 0..4][ct][kb][...] as read by conv3x3_kernel -- phases 0, 1, 2
+// own one tap pair per K-step, phase 3 two.  w is the FORWARD filter [cfwd_out][cfwd_in][3][3]; this convolution's reduction channels are
+// the forward's output channels (kb), its output channels the forward's input channels (ct, cl).
+template <class C>
+__global__ void conv3x3_pack_bd2_kernel(const float* __restrict__ w, float* __restrict__ wpack, int cfwd_in, int cfwd_out) {
+    const int nk = cfwd_out / C::CB, nct = (cfwd_in + C::CT - 1) / C::CT;
+    const long long region = (long long)nct * nk * C::PSZ, total = 5 * region;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / region), phase = r < 3 ? r : 3;
+        long long u = i - (long long)bd2_pair_base(phase) * region;
+        const int blk = bd2_pairs(phase) * C::PSZ;
+        const int ctkb = (int)(u / blk);
+        u -= (long long)ctkb * blk;
+        const int ct = ctkb / nk, kb = ctkb - ct * nk;
+        const int pair = (int)(u / C::PSZ);
+        int v = (int)(u - (long long)pair * C::PSZ);
+        const int wi = v & 3;
+        v >>= 2;
+        const int cl = v % C::CT;
+        v /= C::CT;
+        const int h = v & 1, pc = v >> 1;
+        const int tap = bd2_filter_tap(phase, pair, h), co_o = ct * C::CT + cl, ck = kb * 8 + 2 * wi;
+        unsigned lo = 0, hi = 0;
+        if (tap >= 0 && co_o < cfwd_in) {
+            lo = conv_bf16_piece(w[((size_t)ck * cfwd_in + co_o) * 9 + tap], pc);
+            hi = conv_bf16_piece(w[((size_t)(ck + 1) * cfwd_in + co_o) * 9 + tap], pc);
+        }
+        wpack[i] = __uint_as_float(lo | (hi << 16));
+    }
+}
+
 template <class C>
 __global__ void conv3x3_pack_kernel(const float* __restrict__ w, float* __restrict__ wpack, int cin, int cout, int transpose_flip) {
     const int nk = cin / C::CB, nct = (cout + C::CT - 1) / C::CT;
@@ -428,6 +549,10 @@ using Conv56S = ConvCfg<56, 64, 512, 1, 8, true>;
 using Conv28S = ConvCfg<28, 64, 512, 1, 8, true>;
 using Conv14S = ConvCfg<14, 64, 512, 1, 8, true>;
 using Conv7S = ConvCfg<7, 64, 256, 1, 8, true>;
+// backward-data of the stride-2 layers (first argument: side of the GRADIENT map = half the side of the result), split arithmetic
+using Conv28BD = ConvCfg<28, 64, 512, 1, 8, true, 1, true>;
+using Conv14BD = ConvCfg<14, 64, 512, 1, 8, true, 1, true>;
+using Conv7BD = ConvCfg<7, 64, 256, 1, 8, true, 1, true>;
 
 template <class C>
 static long long pack_floats(int cin, int cout) { return cin % C::CB ? -1 : (long long)((cout + C::CT - 1) / C::CT) * (cin / C::CB) * C::WIMG; }
@@ -472,7 +597,7 @@ static int launch_pack(const float* w, float* wpack, int cin, int cout, int tf, 
 template <class C>
 static int launch_conv(const float* x, const float* wpack, float* out, float* workspace, int batch, int cin, int cout, hipStream_t st) {
     if (cin % C::CB || batch <= 0) return (int)hipErrorInvalidValue;
-    const int tiles = ((batch * C::HWO + C::PT - 1) / C::PT) * ((cout + C::CT - 1) / C::CT), nk = cin / C::CB;
+    const int tiles = ((batch * C::HWO + C::PT - 1) / C::PT) * ((cout + C::CT - 1) / C::CT) * (C::BD2 ? 4 : 1), nk = cin / C::CB;
     const int G = conv_grid() * C::WGS_PER_CU;
     (void)hipFuncSetAttribute((const void*)conv3x3_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     hipLaunchKernelGGL((conv3x3_kernel<C>), dim3(G), dim3(C::NT), C::LDS_BYTES, st, x, wpack, out, workspace, batch, cin, cout);
@@ -509,6 +634,49 @@ static int launch_conv(const float* x, const float* wpack, float* out, float* wo
         case 14: return CALL(sc::Conv14S2);          \
         default: return -1;                          \
     }
+
+// ---- backward-data of the stride-2 convolutions (hw = side of the forward INPUT map = side of the result: 56 / 28 / 14) ----
+#define SC_CONV_DISPATCH_BD(hw, CALL)                 \
+    switch (hw) {                                    \
+        case 56: return CALL(sc::Conv28BD);          \
+        case 28: return CALL(sc::Conv14BD);          \
+        case 14: return CALL(sc::Conv7BD);           \
+        default: return -1;                          \
+    }
+// floats of the filter image sc_conv3x3s2_bd_pack writes for a forward filter [cout][cin][3][3]
+extern "C" long long sc_conv3x3s2_bd_pack_floats(int cin, int cout, int hw) {
+#define CALL(C) (cout % C::CB ? -1 : 5LL * ((cin + C::CT - 1) / C::CT) * (cout / C::CB) * C::PSZ)
+    SC_CONV_DISPATCH_BD(hw, CALL)
+#undef CALL
+}
+extern "C" long long sc_conv3x3s2_bd_workspace_floats(int hw) {
+#define CALL(C) sc::workspace_floats<C>()
+    SC_CONV_DISPATCH_BD(hw, CALL)
+#undef CALL
+}
+namespace sc {
+template <class C>
+static int launch_pack_bd2(const float* w, float* wpack, int cin, int cout, hipStream_t st) {
+    if (cout % C::CB) return (int)hipErrorInvalidValue;
+    const long long total = 5LL * ((cin + C::CT - 1) / C::CT) * (cout / C::CB) * C::PSZ;
+    hipLaunchKernelGGL((conv3x3_pack_bd2_kernel<C>), dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), dim3(256), 0, st,
+                       w, wpack, cin, cout);
+    return (int)hipGetLastError();
+}
+}  // namespace sc
+// w: the forward filter [cout][cin][3][3]
+extern "C" int sc_conv3x3s2_bd_pack(const float* w, float* w_pack, int cin, int cout, int hw, void* stream) {
+#define CALL(C) sc::launch_pack_bd2<C>(w, w_pack, cin, cout, (hipStream_t)stream)
+    SC_CONV_DISPATCH_BD(hw, CALL)
+#undef CALL
+}
+// gx [batch][cin][hw][hw] = dL/dx of F.conv2d(x, w, None, 2, 1) from gy [batch][cout][hw/2][hw/2] (cin / cout: the FORWARD convolution's)
+extern "C" int sc_conv3x3s2_backward_data(const float* gy, const float* w_pack, float* gx, float* workspace, int batch, int cin, int cout,
+                                          int hw, void* stream) {
+#define CALL(C) sc::launch_conv<C>(gy, w_pack, gx, workspace, batch, cout, cin, (hipStream_t)stream)
+    SC_CONV_DISPATCH_BD(hw, CALL)
+#undef CALL
+}
 
 extern "C" long long sc_conv3x3s2_pack_floats(int cin, int cout, int hw) {
 #define CALL(C) sc::pack_floats<C>(cin, cout)

@@ -26,36 +26,45 @@ namespace sc {
 
 typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
 
-template <int W_, int NR_, int NIMG_, int GS_>
+// S = 2: the weight gradient of the three 3x3 / stride-2 / pad-1 convolutions per trunk (BasicBlock.conv1 of layer2-4): gy lives on the
+// W x W OUTPUT map, x on the 2W x 2W input map; output pixel (y, x) meets input (2y + ky - 1, 2x + kx - 1), so the patch of NR output
+// rows holds 2 NR + 1 input rows (only a top halo) of 2W + 1 positions (only a left pad), and the 3 kx of GS consecutive output pixels
+// are 2 GS + 1 consecutive patch values.
+template <int W_, int NR_, int NIMG_, int GS_, int S_ = 1>
 struct WgCfg {
-    static constexpr int W = W_, H = W_, NR = NR_, NIMG = NIMG_, GS = GS_;
-    static constexpr int HW = W * W, Wp = W + 2;
+    static constexpr int W = W_, H = W_, NR = NR_, NIMG = NIMG_, GS = GS_, S = S_;
+    static constexpr int HW = W * W;
+    static constexpr int XW = S * W, XH = S * H, XHW = XW * XH;             // the input map
+    static constexpr int Wp = S == 1 ? W + 2 : XW + 1;                       // patch row: left pad (+ right pad for stride 1)
     static constexpr bool WHOLE = NR == H;                                   // K-step = whole image(s): the halo rows are always zero
     static constexpr int SLOTW = (W + 2 * GS - 1) / (2 * GS) * (2 * GS);     // k slots per row (7 -> 8: one zero slot)
     static constexpr int ROWS = NIMG * NR;                                   // rows per K-step
     static constexpr int NSLOT = ROWS * SLOTW;
     static constexpr int GST = NSLOT + (((NSLOT / GS) & 1) ? 0 : GS);        // gy row stride: GST / GS odd -> conflict-free operand reads
-    static constexpr int PR = NR + 2;                                        // patch rows per image
+    static constexpr int PR = S == 1 ? NR + 2 : 2 * NR + 1;                  // patch rows per image
     static constexpr int PATCH = NIMG * PR * Wp;
-    static constexpr int LQ = PATCH | 1;                                     // odd channel stride; position PATCH may be read (x 0), kept zero
-    static constexpr int LDS_FLOATS = 64 * GST + 64 * LQ;
+    static constexpr int LQ = (S == 1 ? PATCH : PATCH + 2 * GS + 2) | 1;     // odd channel stride; a few positions past PATCH may be read (x 0), kept zero
+    static constexpr int LDS_FLOATS = 64 * GST + 64 * LQ > 4 * 48 * 64 ? 64 * GST + 64 * LQ : 4 * 48 * 64;   // (>= the final reduction's scratch)
     static constexpr int CHUNK = W == 7 ? 49 : 56;                           // floats per staging load: whole rows, contiguous in memory
     static constexpr int RPC = CHUNK / W;                                    // rows per chunk
-    // x: rows y0 - 1 .. y0 + NR (halo rows may be real) unless the K-step is a whole image; gy: the K-step's rows
-    static constexpr int XROWS = WHOLE ? NR : PR;
-    static constexpr int XCH = (XROWS + RPC - 1) / RPC, GCH = (NR + RPC - 1) / RPC;          // chunks per channel and image
+    static constexpr int XCHUNK = XW == 7 ? 49 : 56, XRPC = XCHUNK / XW;     // the same for the input map's rows
+    // x: rows S y0 - 1 .. (halo rows may be real) unless the K-step is a whole image; gy: the K-step's rows
+    static constexpr int XROWS = WHOLE ? XH : PR;
+    static constexpr int XCH = (XROWS + XRPC - 1) / XRPC, GCH = (NR + RPC - 1) / RPC;        // chunks per channel and image
     static constexpr int HR = ROWS / 2;                                      // rows per K-step half
     static constexpr int GPR = SLOTW / (2 * GS);                             // MFMA groups per row
     static constexpr int KH_A = HR * SLOTW;                                  // second half: offset in the gy tile ...
-    static constexpr int KH_B = NIMG == 2 ? PR * Wp : HR * Wp;               // ... and in the patch
-    static_assert(ROWS % 2 == 0 && H % NR == 0 && SLOTW % (2 * GS) == 0 && CHUNK % W == 0, "K-step shape");
+    static constexpr int KH_B = NIMG == 2 ? PR * Wp : S * HR * Wp;           // ... and in the patch
+    static constexpr int NBV = S == 1 ? GS + 2 : 2 * GS + 1;                 // patch values per filter row that serve GS pixels x 3 kx
+    static_assert(ROWS % 2 == 0 && H % NR == 0 && SLOTW % (2 * GS) == 0 && CHUNK % W == 0 && XCHUNK % XW == 0 && (S == 1 || S == 2), "K-step shape");
     static_assert(LDS_FLOATS * 4 <= 160 * 1024 && 4 * 48 * 64 <= LDS_FLOATS, "LDS");
 };
 
 template <class C>
 __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_kernel(const float* __restrict__ gy, const float* __restrict__ x,
                                                                float* __restrict__ partial, int batch, int cin, int cout, int S) {
-    constexpr int W = C::W, H = C::H, HW = C::HW, Wp = C::Wp, GS = C::GS, NIMG = C::NIMG, NR = C::NR;
+    constexpr int W = C::W, H = C::H, HW = C::HW, Wp = C::Wp, GS = C::GS, NIMG = C::NIMG, NR = C::NR, ST = C::S;
+    constexpr int XW = C::XW, XH = C::XH, XHW = C::XHW;
     extern __shared__ float4 wg_smem[];
     float* As = reinterpret_cast<float*>(wg_smem);                           // gy tile  [64][GST]
     float* Xs = As + 64 * C::GST;                                            // x patch  [64][LQ]
@@ -71,8 +80,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_kernel(const float* __re
     for (int i = tid; i < C::LDS_FLOATS; i += 512) As[i] = 0.f;
 
     // staging: wave w copies channels 8 w .. 8 w + 7 of both operands; lane = position inside a CHUNK of whole rows
-    const bool lane_on = lane < C::CHUNK;
+    const bool lane_on = lane < C::CHUNK, xlane_on = lane < C::XCHUNK;
     const int lrow = lane / W, lx = lane - lrow * W;
+    const int xlrow = lane / XW, xlx = lane - xlrow * XW;
     float xv[8][C::XCH * NIMG], gv[8][C::GCH * NIMG];
     auto load = [&](int kstep) {
         int b, y0;
@@ -80,15 +90,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_kernel(const float* __re
 #pragma unroll
         for (int im = 0; im < NIMG; ++im) {
             const bool img_ok = b + im < batch;
-            const float* xb = x + ((size_t)(b + im) * cin + ci0 + 8 * wave) * HW;
+            const float* xb = x + ((size_t)(b + im) * cin + ci0 + 8 * wave) * XHW;
             const float* gb = gy + ((size_t)(b + im) * cout + co0 + 8 * wave) * HW;
 #pragma unroll
             for (int c = 0; c < C::XCH; ++c) {
-                const int yr = (C::WHOLE ? 0 : y0 - 1) + c * C::RPC + lrow;          // image row of this lane's element
-                const bool ok = lane_on && img_ok && (unsigned)yr < (unsigned)H && c * C::RPC + lrow < C::XROWS;
-                const int off = yr * W + lx;
+                const int yr = (C::WHOLE ? 0 : ST * y0 - 1) + c * C::XRPC + xlrow;    // input-map row of this lane's element
+                const bool ok = xlane_on && img_ok && (unsigned)yr < (unsigned)XH && c * C::XRPC + xlrow < C::XROWS;
+                const int off = yr * XW + xlx;
 #pragma unroll
-                for (int ch = 0; ch < 8; ++ch) xv[ch][im * C::XCH + c] = ok ? xb[ch * HW + off] : 0.f;
+                for (int ch = 0; ch < 8; ++ch) xv[ch][im * C::XCH + c] = ok ? xb[ch * XHW + off] : 0.f;
             }
 #pragma unroll
             for (int c = 0; c < C::GCH; ++c) {
@@ -105,10 +115,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_kernel(const float* __re
         for (int im = 0; im < NIMG; ++im) {
 #pragma unroll
             for (int c = 0; c < C::XCH; ++c) {
-                const int pr = (C::WHOLE ? 1 : 0) + c * C::RPC + lrow;               // patch row
-                if (lane_on && c * C::RPC + lrow < C::XROWS) {
+                const int pr = (C::WHOLE ? 1 : 0) + c * C::XRPC + xlrow;             // patch row
+                if (xlane_on && c * C::XRPC + xlrow < C::XROWS) {
 #pragma unroll
-                    for (int ch = 0; ch < 8; ++ch) Xs[(8 * wave + ch) * C::LQ + (im * C::PR + pr) * Wp + 1 + lx] = xv[ch][im * C::XCH + c];
+                    for (int ch = 0; ch < 8; ++ch) Xs[(8 * wave + ch) * C::LQ + (im * C::PR + pr) * Wp + 1 + xlx] = xv[ch][im * C::XCH + c];
                 }
             }
 #pragma unroll
@@ -129,7 +139,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_kernel(const float* __re
 
     // operand bases: lane = (row of the 32 x 32 tile, k half): the k pair of an MFMA is (pixel, pixel + GS)
     const float* Ab = As + ((wt >> 1) * 32 + (lane & 31)) * C::GST + half * GS + kh * C::KH_A;
-    const float* Bb = Xs + ((wt & 1) * 32 + (lane & 31)) * C::LQ + half * GS + kh * C::KH_B;
+    const float* Bb = Xs + ((wt & 1) * 32 + (lane & 31)) * C::LQ + half * ST * GS + kh * C::KH_B;
 
     if (k_lo < k_hi) load(k_lo);
     __syncthreads();                                                          // zero fill done
@@ -154,14 +164,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_kernel(const float* __re
                 }
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
-                    float bv[GS + 2];
+                    float bv[C::NBV];
 #pragma unroll
-                    for (int t = 0; t < GS + 2; ++t) bv[t] = Bb[(yr + ky) * Wp + gx * 2 * GS + t];
+                    for (int t = 0; t < C::NBV; ++t) bv[t] = Bb[(ST * yr + ky) * Wp + ST * gx * 2 * GS + t];
 #pragma unroll
                     for (int ss = 0; ss < GS; ++ss)
 #pragma unroll
                         for (int kx = 0; kx < 3; ++kx)
-                            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ss], bv[kx + ss], acc[ky * 3 + kx], 0, 0, 0);
+                            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ss], bv[ST * ss + kx], acc[ky * 3 + kx], 0, 0, 0);
                 }
             }
         }
@@ -227,6 +237,10 @@ using Wg56 = WgCfg<56, 2, 1, 4>;
 using Wg28 = WgCfg<28, 4, 1, 2>;
 using Wg14 = WgCfg<14, 14, 1, 1>;
 using Wg7 = WgCfg<7, 7, 2, 1>;
+// stride 2 (template arguments: side of the OUTPUT map = side of gy): 56 -> 28, 28 -> 14, 14 -> 7
+using Wg28S2 = WgCfg<28, 2, 1, 2, 2>;
+using Wg14S2 = WgCfg<14, 2, 1, 1, 2>;
+using Wg7S2 = WgCfg<7, 7, 2, 1, 2>;
 
 static int wg_cus() {
     int dev = 0, cus = 256;
@@ -253,6 +267,17 @@ static int launch_wgrad(const float* gy, const float* x, float* dw, float* works
 extern "C" long long sc_conv3x3_wgrad_workspace_floats(int cin, int cout) {
     if (cin <= 0 || cout <= 0 || cin % 64 || cout % 64) return -1;
     return (long long)(cin / 64) * (cout / 64) * sc::wg_splits(cin, cout) * 36864;
+}
+
+// dL/dw [cout][cin][3][3] of F.conv2d(x, w, None, 2, 1): gy [batch][cout][hw/2][hw/2], x [batch][cin][hw][hw], hw = 56 / 28 / 14 (side of the
+// INPUT map); workspace: sc_conv3x3_wgrad_workspace_floats(cin, cout) floats.  Same kernel, stride-2 patch addressing.
+extern "C" int sc_conv3x3s2_wgrad(const float* gy, const float* x, float* dw, float* workspace, int batch, int cin, int cout, int hw, void* stream) {
+    switch (hw) {
+        case 56: return sc::launch_wgrad<sc::Wg28S2>(gy, x, dw, workspace, batch, cin, cout, (hipStream_t)stream);
+        case 28: return sc::launch_wgrad<sc::Wg14S2>(gy, x, dw, workspace, batch, cin, cout, (hipStream_t)stream);
+        case 14: return sc::launch_wgrad<sc::Wg7S2>(gy, x, dw, workspace, batch, cin, cout, (hipStream_t)stream);
+        default: return -1;
+    }
 }
 
 extern "C" int sc_conv3x3_wgrad(const float* gy, const float* x, float* dw, float* workspace, int batch, int cin, int cout, int hw, void* stream) {

@@ -302,7 +302,10 @@ def conv1x1s2(conv, x):
 
 
 class Conv3x3S2Function(torch.autograd.Function):
-    """BasicBlock.conv1 of layer2-4 (3x3 / stride 2): forward on csrc/conv3x3.hip (stride-2 instance), both gradients on MIOpen."""
+    """BasicBlock.conv1 of layer2-4 (3x3 / stride 2): forward on csrc/conv3x3.hip (stride-2 instance); backward-data as four parity
+    sub-convolutions on the same kernel family (exact bf16x3 split, the default arithmetic), backward-weight on csrc/conv3x3_wgrad.hip with
+    stride-2 patch addressing.  With `--hip.conv3x3_split!` (fp32 MFMA everywhere) or channel counts that are not multiples of 64 the
+    two gradients go to MIOpen."""
 
     @staticmethod
     def forward(ctx, x, w):
@@ -313,7 +316,19 @@ class Conv3x3S2Function(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        gx, gw, _ = torch.ops.aten.convolution_backward(ops._aligned(gy), x, w, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
+        gy = ops._aligned(gy)
+        from .model import resnet
+        if resnet.HIP_CONV3X3_S2_GRADS and ops.conv3x3s2_grads_supported(x.shape, w.shape):
+            gx = gw = None
+            if ctx.needs_input_grad[0]:
+                if resnet.HIP_CONV3X3_SPLIT:
+                    gx = ops.conv3x3s2_backward_data(gy, w, x.shape[2])
+                else:
+                    gx = torch.ops.aten.convolution_backward(gy, x, w, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+            if ctx.needs_input_grad[1]:
+                gw = ops.conv3x3s2_backward_weight(gy, x)
+            return gx, gw
+        gx, gw, _ = torch.ops.aten.convolution_backward(gy, x, w, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
                                                         [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
         return gx, gw
 

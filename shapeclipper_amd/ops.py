@@ -161,6 +161,11 @@ def sdf_backward_fused(points, w_pack, n_per_image, n_images, symmetric, stash_a
     n = points.shape[0]
     dev = points.device
     f32 = dict(device=dev, dtype=torch.float32)
+    if n == 0:          # nothing is launched for an empty point set: the gradients are zeros, not uninitialised partial images
+        return (torch.zeros(0, 3, **f32) if want_points_grad else None), torch.zeros(SDF_PACK_FLOATS, **f32), torch.zeros(n_images, 5, 64, **f32)
+    for t in (g_sdf, g_grad, g_feat):
+        if t is not None and not (t.is_contiguous() and t.dtype == torch.float32):
+            raise RuntimeError("shapeclipper_amd: sc_sdf_backward_fused needs contiguous fp32 upstream gradients")
     parts = int(lib.sc_sdf_backward_fused_parts(c_int(n)))
     stride = int(lib.sc_sdf_backward_fused_partial_floats(c_int(n_images)))
     dense = stride > SDF_PACK_FLOATS                  # per-image bias gradients ride in the partial images (fixed summation order)
@@ -767,6 +772,50 @@ def conv3x3s2_forward(x, w):
     _lib.check(lib.sc_conv3x3s2_forward(_lib.ptr(x), _lib.ptr(w_pack), _lib.ptr(out), _lib.ptr(ws), B, cin, cout, H, _lib.stream()),
                "sc_conv3x3s2_forward")
     return out
+
+
+def conv3x3s2_grads_supported(x_shape, w_shape) -> bool:
+    """Shapes sc_conv3x3s2_backward_data / sc_conv3x3s2_wgrad take: what conv3x3s2_supported takes, with channel counts that are multiples of 64."""
+    return conv3x3s2_supported(x_shape, w_shape) and w_shape[0] % 64 == 0 and w_shape[1] % 64 == 0
+
+
+def conv3x3s2_backward_data(gy, w, hw):
+    """dL/dx [B, Cin, hw, hw] of F.conv2d(x, w, None, 2, 1) from gy [B, Cout, hw/2, hw/2] and the forward filter w [Cout, Cin, 3, 3]."""
+    lib = _lib.load()
+    gy, w = _aligned(gy), _aligned(w)
+    B, cout = gy.shape[0], gy.shape[1]
+    cin = w.shape[1]
+    n = lib.sc_conv3x3s2_bd_pack_floats(cin, cout, hw)
+    if n < 0 or tuple(gy.shape[2:]) != (hw // 2, hw // 2) or w.shape[0] != cout:
+        raise RuntimeError("shapeclipper_amd: sc_conv3x3s2_backward_data does not take gy %s with w %s" % (tuple(gy.shape), tuple(w.shape)))
+    w_pack = torch.empty(n, device=gy.device, dtype=torch.float32)
+    _lib.check(lib.sc_conv3x3s2_bd_pack(_lib.ptr(w), _lib.ptr(w_pack), cin, cout, hw, _lib.stream()), "sc_conv3x3s2_bd_pack")
+    key = (gy.device.index, torch.cuda.current_stream().cuda_stream, hw, "s2bd")
+    ws = _conv_ws.get(key)
+    if ws is None:
+        ws = _conv_ws[key] = torch.empty(lib.sc_conv3x3s2_bd_workspace_floats(hw), device=gy.device, dtype=torch.float32)
+    gx = torch.empty(B, cin, hw, hw, device=gy.device, dtype=torch.float32)
+    _lib.check(lib.sc_conv3x3s2_backward_data(_lib.ptr(gy), _lib.ptr(w_pack), _lib.ptr(gx), _lib.ptr(ws), B, cin, cout, hw, _lib.stream()),
+               "sc_conv3x3s2_backward_data")
+    return gx
+
+
+def conv3x3s2_backward_weight(gy, x):
+    """dL/dw [Cout, Cin, 3, 3] of F.conv2d(x, w, None, 2, 1) from gy [B, Cout, hw/2, hw/2] and x [B, Cin, hw, hw]."""
+    lib = _lib.load()
+    gy, x = _aligned(gy), _aligned(x)
+    B, cin, hw, _ = x.shape
+    cout = gy.shape[1]
+    n = lib.sc_conv3x3_wgrad_workspace_floats(cin, cout)
+    if n < 0 or hw not in (56, 28, 14) or tuple(gy.shape) != (B, cout, hw // 2, hw // 2):
+        raise RuntimeError("shapeclipper_amd: sc_conv3x3s2_wgrad does not take gy %s with x %s" % (tuple(gy.shape), tuple(x.shape)))
+    key = (x.device.index, torch.cuda.current_stream().cuda_stream, "wgrad")
+    ws = _conv_ws.get(key)
+    if ws is None or ws.numel() < n:
+        ws = _conv_ws[key] = torch.empty(n, device=x.device, dtype=torch.float32)
+    dw = torch.empty(cout, cin, 3, 3, device=x.device, dtype=torch.float32)
+    _lib.check(lib.sc_conv3x3s2_wgrad(_lib.ptr(gy), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(ws), B, cin, cout, hw, _lib.stream()), "sc_conv3x3s2_wgrad")
+    return dw
 
 
 class Conv3x3PackSet:

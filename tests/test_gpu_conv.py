@@ -273,6 +273,36 @@ def test_conv3x3_stride2_forward(hin, cin, cout, batch):
     assert y.shape == y64.shape and e < 2e-5
 
 
+@pytest.mark.parametrize("hin,cin,cout,batch", [(56, 64, 128, 3), (28, 128, 256, 5), (14, 256, 512, 7), (14, 256, 512, 1), (56, 64, 128, 33), (28, 64, 64, 2),
+                                                (14, 256, 512, 64), (56, 64, 128, 96)])
+def test_conv3x3_stride2_gradients(hin, cin, cout, batch):
+    """The two gradients of BasicBlock.conv1 of layer2-4 (3x3 / stride 2 / pad 1; torchvision layer{2,3,4}.0.conv1): backward-data as four
+    parity sub-convolutions in the exact bf16x3 split arithmetic (csrc/conv3x3.hip, BD2), backward-weight with stride-2 patch addressing
+    (csrc/conv3x3_wgrad.hip), both against float64 with torch / MIOpen beside them.  Bar: 2e-5 of the output scale, as for every
+    convolution kernel; the weight gradient has a fixed summation order (two runs bit-identical)."""
+    from shapeclipper_amd import ops
+    torch.manual_seed(hin + cin + batch)
+    dev = torch.device("cuda:0")
+    x = torch.randn(batch, cin, hin, hin, device=dev)
+    w = torch.randn(cout, cin, 3, 3, device=dev) * (2.0 / (9 * cin)) ** 0.5
+    gy = torch.randn(batch, cout, hin // 2, hin // 2, device=dev)
+    assert ops.conv3x3s2_grads_supported(x.shape, w.shape)
+    nref = min(batch, 8)
+    gx = ops.conv3x3s2_backward_data(gy, w, hin)
+    gx64 = torch.nn.grad.conv2d_input((nref, cin, hin, hin), w.double(), gy[:nref].double(), 2, 1)
+    dw = ops.conv3x3s2_backward_weight(gy, x)
+    dw64 = torch.nn.grad.conv2d_weight(x.double(), w.shape, gy.double(), 2, 1)
+    gx_t, dw_t, _ = torch.ops.aten.convolution_backward(gy, x, w, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [True, True, False])
+    e = (_rel(gx[:nref].double(), gx64), _rel(dw.double(), dw64), _rel(gx_t[:nref].double(), gx64), _rel(dw_t.double(), dw64))
+    print("conv3x3/2 gradients %dx%d %d>%d B=%d: backward-data %.2e, backward-weight %.2e of max (torch/MIOpen %.2e, %.2e)"
+          % ((hin, hin, cin, cout, batch) + e))
+    assert gx.shape == x.shape and dw.shape == w.shape
+    assert e[0] < 2e-5 and e[1] < 2e-5
+    if batch > nref:        # the images beyond the float64 sample against torch's fp32 operator
+        assert _rel(gx.double(), gx_t.double()) < 2e-5
+    assert torch.equal(dw, ops.conv3x3s2_backward_weight(gy, x)) and torch.equal(gx, ops.conv3x3s2_backward_data(gy, w, hin))
+
+
 @pytest.mark.parametrize("kind,cin,cout,side,k,stride,pad", [("conv3x3", 64, 64, 56, 3, 1, 1), ("conv3x3", 256, 256, 14, 3, 1, 1),
                                                                ("conv3x3s2", 64, 128, 56, 3, 2, 1), ("conv3x3s2", 256, 512, 14, 3, 2, 1),
                                                                ("conv1x1s2", 128, 256, 28, 1, 2, 0), ("conv_stem", 3, 64, 224, 7, 2, 3)])
