@@ -254,11 +254,13 @@ def main():
         big = sorted([s.elapsed_time(e) for s, e, _ in timing[dom]], reverse=True)[:2 * a.steps]
         mean_big = sum(big) / len(big)
         achieved = FLOPS_PER_POINT[dom] * n_pts_main / (mean_big * 1e-3) / 1e12
-        traffic = None
-        for prof in ("r02_traffic.json", "r01_traffic.json"):
+        traffic, traffic_source = None, None
+        for prof in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             try:   # HBM-side bytes per launch measured with rocprofv3 --pmc on this workload (profiles/, see its _comment)
                 with open(os.path.join(ROOT, "profiles", prof)) as f:
                     traffic = json.load(f)["kernels"][dom]["traffic_bytes"] if a.batch == 32 else None
+                traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, corrected per MI355X_MICROARCH.md; a " \
+                                 "committed constant, NOT measured in this run)" % prof
                 break
             except Exception:
                 pass
@@ -266,9 +268,14 @@ def main():
         # its roof is the fp32 matrix pipe; but when the bytes it actually moves run at >= 75 % of the achievable HBM rate
         # (6.3 TB/s measured float4 copy, MI355X_MICROARCH.md) the HBM traffic it creates is what sets its time: say so.
         hbm_rate = traffic / (mean_big * 1e-3) / 1e9 if traffic else None
+        # "mfma" = the fp32 matrix pipe is the roof this kernel is scored against (its algorithmic bytes are ~0); what holds it below
+        # that roof today is instruction issue -- fp32 MFMA and vector instructions of a SIMD add up on this chip --
+        # see `limiter`.
         bound = "hbm" if (hbm_rate and hbm_rate >= 0.75 * 6300.0) else "mfma"
         roofline = dict(kernel=dom, bound=bound, achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS,
-                        unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
+                        unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic, traffic_source=traffic_source,
+                        limiter="issue: 60 k MFMA + 27 k vector-instruction cycles per 4 tiles and SIMD against 107 k measured (profiles/"
+                                "r03_bwdw_phase_profile_after.txt); wave-cycles parked at waits 30 % (profiles/r03_pmc_sq_stalls.txt)",
                         launch_ms=round(mean_big, 4), points_per_launch=n_pts_main,
                         flops_per_point=FLOPS_PER_POINT[dom],
                         hbm_GBps_of_measured_traffic=round(hbm_rate, 1) if hbm_rate else None)
