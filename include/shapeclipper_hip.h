@@ -328,6 +328,51 @@ int sc_pose_from_trig_backward(const float* azim, const float* elev, const float
                                int image_height, const float* g_pose, const float* g_intr, float* g_azim,
                                float* g_elev, float* g_theta, float* g_scale_focal, float* g_scale_dist, void* stream);
 
+/* ---- the [n_images]-sized arithmetic around the view estimator (csrc/camera_prior.hip): one launch each way where the
+ * reference spends dozens of [B]-shaped torch operators.
+ * sc_estimator_head_*: model/view_estimator.py:62-75.  trig [n_rows][6] (extr_fc output), size_lin / persp_lin [n_rows]
+ *   (size_fc / perspect_fc outputs) -> azim, elev, theta [n_rows][2] = F.normalize of the three pairs (eps 1e-12),
+ *   scale_focal = 1 + tanh(persp_lin) * persp_range, scale_dist = (1 + tanh(size_lin) * size_range) * scale_focal.
+ *   Backward: the rows are n_groups stacked image sets of n_rows / n_groups rows (<= 8 groups); grads is a HOST array of
+ *   5 * n_groups device pointers (group-major: azim, elev, theta, scale_focal, scale_dist of that group, each
+ *   [rows][2] or [rows]; NULL = that output was not differentiated).  Returns -1 for a bad group count.            */
+int sc_estimator_head_forward(const float* trig, const float* size_lin, const float* persp_lin, int n_rows,
+                              float size_range, float persp_range, float* azim, float* elev, float* theta,
+                              float* scale_focal, float* scale_dist, void* stream);
+int sc_estimator_head_backward(const float* trig, const float* size_lin, const float* persp_lin, int n_rows,
+                               float size_range, float persp_range, const float* const* grads, int n_groups,
+                               float* g_trig, float* g_size_lin, float* g_persp_lin, void* stream);
+
+/* sc_camera_prior_*: model/loss.py:99-167 -- cam_margin_loss (elevation and roll ranges in degrees, eps = margin_eps),
+ *   cam_uniform_loss (sorted (cos, sin, cos*sin) of the azimuth against the sorted uniform grid; emd_p 1 or 2) and
+ *   cam_sym_loss against the estimator's outputs on the mirrored images (flip_*), all [n_images][2].
+ *   out [3] = (cam_margin, cam_uniform, cam_sym); grads [6][n_images][2] = d margin/d elev, d margin/d theta,
+ *   d uniform/d azim, d sym/d azim, d sym/d elev, d sym/d theta.  One workgroup; n_images <= sc_camera_prior_max_images()
+ *   (1024), otherwise -1.  The backward scales by the upstream gradients of the three values (device scalars, NULL = 0)
+ *   and also returns d sym/d flip_*.                                                                               */
+int sc_camera_prior_max_images(void);
+int sc_camera_prior_forward(const float* azim, const float* elev, const float* theta, const float* flip_azim,
+                            const float* flip_elev, const float* flip_theta, int n_images, float elev_lo, float elev_hi,
+                            float theta_lo, float theta_hi, float margin_eps, int emd_p, float* out, float* grads,
+                            void* stream);
+int sc_camera_prior_backward(const float* grads, int n_images, const float* G_margin, const float* G_uniform,
+                             const float* G_sym, float* g_azim, float* g_elev, float* g_theta, float* g_flip_azim,
+                             float* g_flip_elev, float* g_flip_theta, void* stream);
+
+/* sc_transform_normal_*: utils/camera.py:98-103 -- out[b][r][:] = normals[b][r][:] @ R_b with R_b the rotation block of
+ *   pose [n_images][3][4].  Backward: g_pose [n_images][3][4] (translation column zero); the normals are data.      */
+int sc_transform_normal_forward(const float* normals, const float* pose, int n_images, int n_per_image, float* out,
+                                void* stream);
+int sc_transform_normal_backward(const float* normals, const float* g_out, int n_images, int n_per_image, float* g_pose,
+                                 void* stream);
+
+/* sc_loss_total_*: model/runner.py:294-305 -- total = sum_k weights[k] * *values[k] added in index order (<= 16 terms;
+ *   values is a HOST array of device scalars, weights a HOST array), bad = 1 if any term is NaN/Inf.  Backward:
+ *   g_values[k] = weights[k] * *G.                                                                                 */
+int sc_loss_total_forward(const float* const* values, const float* weights, int n_terms, float* total, unsigned char* bad,
+                          void* stream);
+int sc_loss_total_backward(const float* weights, int n_terms, const float* G, float* g_values, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * 3x3 / stride 1 / pad 1 convolution of the ResNet-18/34 trunks (torchvision BasicBlock conv1/conv2 behind
  * model/graph.py:50-54 and model/view_estimator.py:40-42), NCHW fp32, on the fp32 matrix pipe (csrc/conv3x3.hip).

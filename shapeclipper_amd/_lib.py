@@ -24,6 +24,9 @@ SYMBOLS = (
     "sc_bn_splits", "sc_bn_act_forward", "sc_bn_act_backward", "sc_bn_relu_pool_forward", "sc_bn_relu_pool_backward",
     "sc_isosurface_count", "sc_isosurface_emit",
     "sc_camera_rays_forward", "sc_camera_rays_backward", "sc_pose_from_trig_forward", "sc_pose_from_trig_backward",
+    "sc_estimator_head_forward", "sc_estimator_head_backward", "sc_camera_prior_forward", "sc_camera_prior_backward",
+    "sc_camera_prior_max_images", "sc_transform_normal_forward", "sc_transform_normal_backward", "sc_loss_total_forward",
+    "sc_loss_total_backward",
     "sc_render_backward", "sc_sdf_backward_fused", "sc_sdf_backward_fused_parts", "sc_sdf_backward_fused_partial_floats", "sc_tbl_sum_blocks", "sc_conv3x3_pack", "sc_conv3x3_forward", "sc_conv3x3_pack_multi", "sc_conv3x3_tile_channels", "sc_conv3x3_wgrad", "sc_conv3x3_forward_split", "sc_conv3x3_tile_channels_split", "sc_conv_stem_forward", "sc_conv_stem_wgrad", "sc_conv1x1s2_forward", "sc_conv1x1s2_backward_data", "sc_conv1x1s2_wgrad", "sc_conv3x3s2_forward", "sc_conv3x3s2_bd_pack", "sc_conv3x3s2_backward_data", "sc_conv3x3s2_wgrad",
 )
 # entry points that do not return an int status

@@ -15,6 +15,7 @@ class SdfFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, points, w_pack, cbias, n_per_image, symmetric, want_grad, want_feat, fused_backward=True):
+        ctx.set_materialize_grads(False)       # the kernels take null for an output nobody differentiated: no zero fills
         points = points.contiguous()
         need = any(ctx.needs_input_grad[:3])
         res = ops.sdf_forward(points, w_pack, cbias, n_per_image, symmetric=symmetric, want_grad=want_grad,
@@ -55,6 +56,7 @@ class RgbCompositeFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta, rays_per_image, symmetric,
                 beta_min, bgcolor, normal_pow, keep_samples):
+        ctx.set_materialize_grads(False)
         need = any(ctx.needs_input_grad[:9])
         beta1 = beta.reshape(1).contiguous()
         out = ops.rgb_composite_forward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta1,
@@ -84,28 +86,31 @@ class RgbCompositeFunction(torch.autograd.Function):
 
 class FusedRenderLoss(torch.autograd.Function):
     """render MSE, mask (IoU + mask_mse*MSE), robust masked normal loss and eikonal MSE of one render in a
-    single HIP launch (csrc/loss.hip).  Returns a [4] tensor (render, mask, normal, eikonal)."""
+    single HIP launch (csrc/loss.hip).  Returns four scalars (render, mask, normal, eikonal): separate outputs rather
+    than one [4] tensor, whose indexing would cost a select node (fill + copy + add in the backward) per loss term."""
 
     @staticmethod
     def forward(ctx, rgb, rgb_t, mask, mask_t, normal, normal_t, eik, normal_l1, mask_mse, keep_frac):
         # The normal target is transform_normal(input normal, predicted pose): the reference's normal_loss
         # back-propagates through it into the view estimator (model/loss.py:52-67, model/graph.py:85,260).
+        ctx.set_materialize_grads(False)
         want_t = ctx.needs_input_grad[5]
         out, grads = ops.loss_fused_forward(rgb, rgb_t, mask, mask_t, normal, normal_t, eik, normal_l1, mask_mse, keep_frac,
                                             want_target_grad=want_t)
         ctx.shapes = (rgb.shape, mask.shape, normal.shape, eik.shape if eik is not None else None)
         ctx.save_for_backward(*[g for g in grads if g is not None])
         ctx.has_eik, ctx.has_t = eik is not None, want_t
-        return out
+        return out[0], out[1], out[2], out[3]
 
     @staticmethod
-    def backward(ctx, G):
+    def backward(ctx, G_render, G_mask, G_normal, G_eik):
         saved = list(ctx.saved_tensors)
         g_rgb, g_mask, g_normal = saved[0], saved[1], saved[2]
         s_rgb, s_mask, s_normal, s_eik = ctx.shapes
-        g_eik = (saved[3] * G[3]).view(s_eik) if ctx.has_eik else None
-        g_t = (saved[-1] * G[2]).view(s_normal) if ctx.has_t else None
-        return ((g_rgb * G[0]).view(s_rgb), None, (g_mask * G[1]).view(s_mask), None, (g_normal * G[2]).view(s_normal),
+        scale = lambda g, G, shape: (g * G).view(shape) if G is not None else None
+        g_eik = scale(saved[3], G_eik, s_eik) if ctx.has_eik else None
+        g_t = scale(saved[-1], G_normal, s_normal) if ctx.has_t else None
+        return (scale(g_rgb, G_render, s_rgb), None, scale(g_mask, G_mask, s_mask), None, scale(g_normal, G_normal, s_normal),
                 g_t, g_eik, None, None, None)
 
 
@@ -115,6 +120,7 @@ class RaySampleFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cam_loc, ray_dirs, scale_dist, u, rays_per_image, cam_dist):
+        ctx.set_materialize_grads(False)
         cam_loc, ray_dirs, scale_dist = cam_loc.contiguous(), ray_dirs.contiguous(), scale_dist.contiguous()
         z, pts = ops.ray_sample_forward(cam_loc, ray_dirs, scale_dist, u, rays_per_image, cam_dist)
         ctx.save_for_backward(ray_dirs, z)
@@ -362,6 +368,7 @@ class CameraRaysFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pose, intr, ray_idx, n_rays, width):
+        ctx.set_materialize_grads(False)
         pose, intr = pose.contiguous().float(), intr.contiguous().float()
         if ray_idx is not None:
             ray_idx = ray_idx.contiguous().long()
@@ -384,6 +391,7 @@ class PoseFromTrigFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, azim, elev, theta, scale_focal, scale_dist, cam_dist, focal, width, height):
+        ctx.set_materialize_grads(False)
         args = [t.contiguous().float() for t in (azim, elev, theta, scale_focal, scale_dist)]
         ctx.save_for_backward(*args)
         ctx.meta = (cam_dist, focal, width, height)
@@ -399,3 +407,88 @@ class PoseFromTrigFunction(torch.autograd.Function):
             g_intr = torch.zeros(B, 3, 3, device=args[0].device)
         ga, ge, gt, gsf, gsd = ops.pose_from_trig_backward(*args, *ctx.meta, g_pose.contiguous(), g_intr.contiguous())
         return ga, ge, gt, gsf, gsd, None, None, None, None
+
+
+class EstimatorHeadFunction(torch.autograd.Function):
+    """extr_fc / size_fc / perspect_fc outputs -> the estimator's five results (reference model/view_estimator.py:62-75), one launch
+    each way.  The rows are `groups` stacked image sets: the results come back PER SET, 5 * groups tensors (azim, elev, theta
+    [B,2], scale_focal, scale_dist [B] of set 0, then of set 1, ...), so that no slice node (fill + copy + add in its backward)
+    sits between the estimator and its consumers."""
+
+    @staticmethod
+    def forward(ctx, trig, size_lin, persp_lin, size_range, persp_range, groups):
+        ctx.set_materialize_grads(False)
+        trig, size_lin, persp_lin = ops._f32c(trig), ops._f32c(size_lin.reshape(-1)), ops._f32c(persp_lin.reshape(-1))
+        N = trig.shape[0]
+        assert N % groups == 0
+        B = N // groups
+        o = ops.estimator_head_forward(trig, size_lin, persp_lin, size_range, persp_range)
+        ctx.save_for_backward(trig, size_lin, persp_lin)
+        ctx.meta = (size_range, persp_range, groups)
+        outs = []
+        for g in range(groups):
+            for k in range(3):
+                outs.append(o[2 * N * k + 2 * B * g:2 * N * k + 2 * B * (g + 1)].view(B, 2))
+            outs.append(o[6 * N + B * g:6 * N + B * (g + 1)])
+            outs.append(o[7 * N + B * g:7 * N + B * (g + 1)])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        trig, size_lin, persp_lin = ctx.saved_tensors
+        size_range, persp_range, groups = ctx.meta
+        g_trig, g_size, g_persp = ops.estimator_head_backward(trig, size_lin, persp_lin, size_range, persp_range, list(grads), groups)
+        return g_trig, g_size.view(-1, 1), g_persp.view(-1, 1), None, None, None
+
+
+class CameraPriorLossFunction(torch.autograd.Function):
+    """cam_margin_loss, cam_uniform_loss and cam_sym_loss (reference model/loss.py:99-167) as three scalars from one launch; the
+    gradients w.r.t. the six [B,2] estimator outputs are produced alongside and scaled in the backward (one launch)."""
+
+    @staticmethod
+    def forward(ctx, azim, elev, theta, f_azim, f_elev, f_theta, elev_range, theta_range, margin_eps, emd_p):
+        ctx.set_materialize_grads(False)
+        args = [ops._f32c(t) for t in (azim, elev, theta, f_azim, f_elev, f_theta)]
+        out, grads = ops.camera_prior_forward(*args, elev_range, theta_range, margin_eps, emd_p)
+        ctx.save_for_backward(grads)
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, G_margin, G_uniform, G_sym):
+        grads, = ctx.saved_tensors
+        g = ops.camera_prior_backward(grads, G_margin, G_uniform, G_sym)
+        return g[0], g[1], g[2], g[3], g[4], g[5], None, None, None, None
+
+
+class TransformNormalFunction(torch.autograd.Function):
+    """camera.transform_normal (reference utils/camera.py:98-103): [B,R,3] camera-frame normals (data) rotated by the predicted
+    pose; the backward is the per-image 3x3 sum that reaches the view estimator through the normal loss."""
+
+    @staticmethod
+    def forward(ctx, normals, pose):
+        normals, pose = ops._f32c(normals), ops._f32c(pose)
+        ctx.save_for_backward(normals)
+        return ops.transform_normal_forward(normals, pose)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        normals, = ctx.saved_tensors
+        return None, ops.transform_normal_backward(normals, ops._f32c(g_out))
+
+
+class LossTotalFunction(torch.autograd.Function):
+    """loss.all = sum_k float(w_k) * loss_k in key order (reference model/runner.py:294-305) and the NaN/Inf flag of all terms: one
+    launch instead of ~8 per key.  apply(weights tuple, *scalars) -> (total, bad)."""
+
+    @staticmethod
+    def forward(ctx, weights, *values):
+        values = [ops._f32c(v) for v in values]
+        total, bad = ops.loss_total_forward(values, weights)
+        ctx.weights = weights
+        ctx.mark_non_differentiable(bad)
+        return total, bad
+
+    @staticmethod
+    def backward(ctx, G, _):
+        g = ops.loss_total_backward(ctx.weights, G)
+        return (None,) + tuple(g[k] for k in range(len(ctx.weights)))

@@ -117,7 +117,7 @@ class Graph(nn.Module):
         var.proj_latent_rgb = self.latent_proj_rgb(var.latent_rgb)
 
         var.pose, var.intr, var.scale_dist = self.pred_pose(opt, var)
-        var.normal_transformed = camera.transform_normal(var.normal_gt if "normal_gt" in var else var.normal_input, var.pose)
+        var.normal_transformed = self.transform_normal(var.normal_gt if "normal_gt" in var else var.normal_input, var.pose)
 
         out = self.renderer(opt, var.pose, var.intr, var.scale_dist, var.proj_latent_sdf, var.proj_latent_rgb,
                             ray_idx=ray_idx, training=training, visualize=visualize)
@@ -222,24 +222,26 @@ class Graph(nn.Module):
             main = torch.cuda.current_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                est = self.estimator(est_in, groups=len(images) + len(mirrored))
+                est = self.estimator(est_in, groups=len(images) + len(mirrored), split=True)
         latent = self.encoder(torch.cat(images, 0), groups=len(images))
         if side is not None:
             main.wait_stream(side)
-            for t in est:
-                t.record_stream(main)
+            for st in est:
+                for t in st:
+                    t.record_stream(main)
             est_in.record_stream(side)
         else:
-            est = self.estimator(est_in, groups=len(images) + len(mirrored))
-        var._latent_batched = latent[:B]
+            est = self.estimator(est_in, groups=len(images) + len(mirrored), split=True)
+        # one unbind node (a stack in the backward) instead of a slice node per image set (fill + copy + add each)
+        latents = latent.reshape(len(images), B, latent.shape[1]).unbind(0)
+        var._latent_batched = latents[0]
         for v, nn_in in enumerate(views):
-            nn_in.latent_raw = latent[(v + 1) * B:(v + 2) * B]
-        part = lambda k: tuple(t[k * B:(k + 1) * B] for t in est)
-        var._estim_input = part(0)
+            nn_in.latent_raw = latents[v + 1]
+        var._estim_input = est[0]
         for v, nn_in in enumerate(views):
-            nn_in.estim = part(v + 1)
+            nn_in.estim = est[v + 1]
         if mirrored:
-            var._estim_flip = part(len(images))
+            var._estim_flip = est[len(images)]
 
     @staticmethod
     def _side_stream(device):
@@ -336,21 +338,19 @@ class Graph(nn.Module):
         if training:
             if eik is not None:
                 out.eikonal = main[3]
-            if lw.cam_margin is not None:
-                out.cam_margin = fns.cam_margin_loss(opt, var)
-            if lw.cam_uniform is not None:
-                out.cam_uniform = fns.cam_uniform_loss(opt, var.trig_azim)
-            if lw.cam_sym is not None:
-                out.cam_sym = fns.cam_sym_loss(opt, var, self.estimator)
+            priors = fns.camera_prior_losses(opt, var, self.estimator)      # the three of them in one launch where possible
+            for key in ("cam_margin", "cam_uniform", "cam_sym"):
+                if lw[key] is not None:
+                    out[key] = priors[key]()
             if lw.nearest_img is not None or lw.nearest_mask is not None or lw.nearest_normal is not None:
                 tot = None
                 for v in range(opt.reg.n_views):
                     nn_in = var["input_NN_{}".format(v)]
-                    target = camera.transform_normal(nn_in.normal_input, var["pose_NN_{}".format(v)])
+                    target = self.transform_normal(nn_in.normal_input, var["pose_NN_{}".format(v)])
                     r = FusedRenderLoss.apply(var["rgb_recon_NN_{}".format(v)], nn_in.rgb_input, var["mask_recon_NN_{}".format(v)],
                                               nn_in.mask_input, var["normal_recon_NN_{}".format(v)], target, None,
                                               float(opt.reg.normal_l1), float(opt.reg.mask_mse), keep)
-                    tot = r if tot is None else tot + r
+                    tot = r if tot is None else tuple(a + b for a, b in zip(tot, r))
                 if lw.nearest_img is not None:
                     out.nearest_img = tot[0]
                 if lw.nearest_mask is not None:
@@ -358,6 +358,14 @@ class Graph(nn.Module):
                 if lw.nearest_normal is not None:
                     out.nearest_normal = tot[2]
         return out
+
+    @staticmethod
+    def transform_normal(normals, pose):
+        """camera.transform_normal; [B,R,3] device normals take one HIP launch each way (csrc/camera_prior.hip)."""
+        if normals.is_cuda and normals.dim() == 3 and normals.shape[-1] == 3 and tuple(pose.shape[1:]) == (3, 4) and not normals.requires_grad:
+            from ..functional import TransformNormalFunction
+            return TransformNormalFunction.apply(normals, pose)
+        return camera.transform_normal(normals, pose)
 
     # ------------------------------------------------------------------------------------------------
     def pred_pose(self, opt, var, pred_NN=False, given_input=None, estim=None):

@@ -101,6 +101,26 @@ class Loss(nn.Module):
             return (trig[:, 0] - flipped[:, 0]) ** 2 + (sign * trig[:, 1] - flipped[:, 1]) ** 2
         return sq(var.trig_azim, fa, -1).mean() + sq(var.trig_elev, fe, 1).mean() + sq(var.trig_theta, ft, -1).mean()
 
+    def camera_prior_losses(self, opt, var, estimator):
+        """{"cam_margin" | "cam_uniform" | "cam_sym": thunk}.  On the device with all three enabled they are one launch
+        (csrc/camera_prior.hip, ~90 [B]-sized torch operators forward + as many backward otherwise)."""
+        lw = opt.loss_weight
+        trig = var.trig_azim
+        if (trig.is_cuda and lw.cam_margin is not None and lw.cam_uniform is not None and lw.cam_sym is not None
+                and "_estim_flip" in var and opt.get("hip", {}).get("fused_loss", True)):
+            from .. import ops
+            if ops.camera_prior_supported(trig.shape[0], opt.reg.emd_p):
+                from ..functional import CameraPriorLossFunction
+                r = opt.data[opt.data.dataset]
+                assert r.elev_range[0] > -180 and r.elev_range[1] < 180 and r.theta_range[0] > -180 and r.theta_range[1] < 180
+                fa, fe, ft = var._estim_flip[:3]
+                m, u, s = CameraPriorLossFunction.apply(trig, var.trig_elev, var.trig_theta, fa, fe, ft,
+                                                        (float(r.elev_range[0]), float(r.elev_range[1])),
+                                                        (float(r.theta_range[0]), float(r.theta_range[1])), 5.0, int(opt.reg.emd_p))
+                return dict(cam_margin=lambda: m, cam_uniform=lambda: u, cam_sym=lambda: s)
+        return dict(cam_margin=lambda: self.cam_margin_loss(opt, var), cam_uniform=lambda: self.cam_uniform_loss(opt, trig),
+                    cam_sym=lambda: self.cam_sym_loss(opt, var, estimator))
+
     def cam_uniform_loss(self, opt, trig):
         B = trig.shape[0]
         grid = torch.arange(1., 2 * B, 2., device=trig.device).float() * np.pi / B

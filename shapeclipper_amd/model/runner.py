@@ -209,14 +209,23 @@ class Runner:
         (train_iteration calls it after the backward pass is queued and before the optimizer step)."""
         assert "all" not in loss
         total, bad = 0., None
+        keys = []
         for key in loss:
             assert key in opt.loss_weight
-            if opt.loss_weight[key] is None:
-                continue
-            value = loss[key].mean()
-            flag = ~torch.isfinite(value)
-            bad = flag if bad is None else (bad | flag)
-            total = total + (0.0 if key in non_act_loss_key else float(opt.loss_weight[key])) * value
+            if opt.loss_weight[key] is not None:
+                keys.append(key)
+        weights = tuple(0.0 if key in non_act_loss_key else float(opt.loss_weight[key]) for key in keys)
+        values = [loss[key] if loss[key].dim() == 0 else loss[key].mean() for key in keys]
+        from .. import ops
+        if values and all(v.is_cuda for v in values) and len(values) <= ops.LOSS_TOTAL_MAX_TERMS:
+            # the weighted sum (same order of additions) and the NaN/Inf flag of every term in one launch (csrc/camera_prior.hip)
+            from ..functional import LossTotalFunction
+            total, bad = LossTotalFunction.apply(weights, *values)
+        else:
+            for w, value in zip(weights, values):
+                flag = ~torch.isfinite(value)
+                bad = flag if bad is None else (bad | flag)
+                total = total + w * value
         if "_bad_choice" in var and bad is not None:          # NaN neighbour probabilities (np.random.choice would have raised)
             bad = bad | var.pop("_bad_choice").to(bad.device)
         self._pending_check = None

@@ -25,17 +25,19 @@ class Bottleneck_Linear(nn.Module):
             nn.init.constant_(self.bn2.weight, 0)
 
     @staticmethod
-    def _conv1x1(conv, v):
+    def _linear(conv, x):
         """A 1x1 convolution on a 1x1 map IS a matrix product: one GEMM [N, C] x [C, C] instead of MIOpen's N strided-batched
-        512 x 1 x 512 products and their layout transposes (6 forward + 12 backward calls per step, 28 us each)."""
-        if conv.bias is None and v.shape[2:] == (1, 1):
-            return torch_F.linear(v[:, :, 0, 0], conv.weight[:, :, 0, 0])[..., None, None]
-        return conv(v)
+        512 x 1 x 512 products and their layout transposes.  The weight is taken as a VIEW [C_out, C_in] of the conv
+        parameter (same state_dict layout as the reference): indexing it with [:, :, 0, 0] costs two select nodes whose
+        backward is a fill + a copy each (~20 launches per block and step)."""
+        assert conv.bias is None and conv.kernel_size == (1, 1)
+        return torch_F.linear(x, conv.weight.view(conv.out_channels, conv.in_channels))
 
     def forward(self, x, groups=1):
         v = x[..., None, None]
-        out = bn_act(self.bn1, self._conv1x1(self.linear1, v), groups=groups)       # conv1x1 -> BN -> ReLU
-        return bn_act(self.bn2, self._conv1x1(self.linear2, out), residual=v, groups=groups)[..., 0, 0]
+        out = bn_act(self.bn1, self._linear(self.linear1, x)[..., None, None], groups=groups)        # conv1x1 -> BN -> ReLU
+        out = self._linear(self.linear2, out.flatten(1))[..., None, None]
+        return bn_act(self.bn2, out, residual=v, groups=groups).flatten(1)
 
 
 def _random_trunk_ok(opt):
@@ -71,14 +73,29 @@ class Estimator(nn.Module):
             nn.init.constant_(fc.weight, 0.0)
             nn.init.constant_(fc.bias, 0.0)
 
-    def forward(self, inputs, groups=1):
+    def forward(self, inputs, groups=1, split=False):
         """groups > 1: `inputs` stacks several image sets that the reference sends through the estimator in separate
-        calls (input view, CLIP neighbour, mirrored input); BatchNorm keeps them separate, see resnet.ResNet.forward."""
+        calls (input view, CLIP neighbour, mirrored input); BatchNorm keeps them separate, see resnet.ResNet.forward.
+        split: return one 5-tuple per image set instead of 5 stacked tensors."""
         feat = self.feature_extractor(inputs, groups=groups)
         trig = self.extr_fc(self.extr_head[0](feat, groups=groups))
+        size_lin = self.size_fc(self.size_head[0](feat, groups=groups))
+        persp_lin = self.perspect_fc(self.perspect_head[0](feat, groups=groups))
+        if trig.is_cuda:        # normalisation / tanh / range scaling of all outputs: one launch each way (csrc/camera_prior.hip)
+            from ..functional import EstimatorHeadFunction
+            outs = EstimatorHeadFunction.apply(trig, size_lin, persp_lin, float(self.opt.camera.size_range),
+                                               float(self.opt.camera.perspect_range), groups)
+            sets = [tuple(outs[5 * g:5 * g + 5]) for g in range(groups)]
+            if split:
+                return sets
+            return sets[0] if groups == 1 else tuple(torch.cat([st[k] for st in sets], 0) for k in range(5))
         azim, elev, theta = (torch_F.normalize(trig[:, 2 * k:2 * k + 2], dim=1, p=2) for k in range(3))
-        size_raw = torch.tanh(self.size_fc(self.size_head[0](feat, groups=groups))).squeeze(-1)
-        persp_raw = torch.tanh(self.perspect_fc(self.perspect_head[0](feat, groups=groups))).squeeze(-1)
+        size_raw = torch.tanh(size_lin).squeeze(-1)
+        persp_raw = torch.tanh(persp_lin).squeeze(-1)
         scale_size = 1 + size_raw * self.opt.camera.size_range
         scale_perspect = 1 + persp_raw * self.opt.camera.perspect_range
-        return azim, elev, theta, scale_perspect, scale_size * scale_perspect
+        out = (azim, elev, theta, scale_perspect, scale_size * scale_perspect)
+        if split:
+            B = inputs.shape[0] // groups
+            return [tuple(t[g * B:(g + 1) * B] for t in out) for g in range(groups)]
+        return out

@@ -593,6 +593,120 @@ def pose_from_trig_backward(azim, elev, theta, scale_focal, scale_dist, cam_dist
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
+# the [B]-sized arithmetic around the view estimator (csrc/camera_prior.hip)
+c_float = ctypes.c_float
+
+
+def _ptr_array(tensors):
+    """HOST array of device pointers (NULL for None) for the entry points that take `const float* const*`."""
+    return (ctypes.c_void_p * max(len(tensors), 1))(*[_lib.ptr(t).value for t in tensors])
+
+
+def _f32c(t):
+    if t is not None and not (t.is_contiguous() and t.dtype == torch.float32):
+        t = t.contiguous().float()
+    return t
+
+
+def estimator_head_forward(trig, size_lin, persp_lin, size_range, persp_range):
+    """trig [N,6], size_lin, persp_lin [N] -> one [8, N] buffer holding azim [N,2] | elev [N,2] | theta [N,2] | scale_focal [N] | scale_dist [N]."""
+    lib = _lib.load()
+    N = trig.shape[0]
+    o = torch.empty(8 * N, device=trig.device, dtype=torch.float32)
+    _lib.check(lib.sc_estimator_head_forward(_lib.ptr(trig), _lib.ptr(size_lin), _lib.ptr(persp_lin), c_int(N), c_float(size_range),
+                                             c_float(persp_range), _lib.ptr(o[0:2 * N]), _lib.ptr(o[2 * N:4 * N]), _lib.ptr(o[4 * N:6 * N]),
+                                             _lib.ptr(o[6 * N:7 * N]), _lib.ptr(o[7 * N:8 * N]), _lib.stream()), "sc_estimator_head_forward")
+    return o
+
+
+def estimator_head_backward(trig, size_lin, persp_lin, size_range, persp_range, grads, n_groups):
+    """grads: 5 * n_groups upstream gradients (None = not differentiated), group-major."""
+    lib = _lib.load()
+    N = trig.shape[0]
+    g = torch.empty(8 * N, device=trig.device, dtype=torch.float32)
+    grads = [_f32c(t) for t in grads]
+    _lib.check(lib.sc_estimator_head_backward(_lib.ptr(trig), _lib.ptr(size_lin), _lib.ptr(persp_lin), c_int(N), c_float(size_range),
+                                              c_float(persp_range), _ptr_array(grads), c_int(n_groups), _lib.ptr(g[:6 * N]),
+                                              _lib.ptr(g[6 * N:7 * N]), _lib.ptr(g[7 * N:]), _lib.stream()), "sc_estimator_head_backward")
+    return g[:6 * N].view(N, 6), g[6 * N:7 * N], g[7 * N:]
+
+
+_PRIOR_MAX = None
+
+
+def camera_prior_supported(n_images, emd_p) -> bool:
+    global _PRIOR_MAX
+    if _PRIOR_MAX is None:
+        _PRIOR_MAX = int(_lib.load().sc_camera_prior_max_images())
+    return 0 < n_images <= _PRIOR_MAX and emd_p in (1, 2)
+
+
+def camera_prior_forward(azim, elev, theta, f_azim, f_elev, f_theta, elev_range, theta_range, margin_eps, emd_p):
+    """-> out [3] (cam_margin, cam_uniform, cam_sym), grads [6, B, 2] (see include/shapeclipper_hip.h)."""
+    lib = _lib.load()
+    B = azim.shape[0]
+    out = torch.empty(3, device=azim.device, dtype=torch.float32)
+    grads = torch.empty(6, B, 2, device=azim.device, dtype=torch.float32)
+    _lib.check(lib.sc_camera_prior_forward(_lib.ptr(azim), _lib.ptr(elev), _lib.ptr(theta), _lib.ptr(f_azim), _lib.ptr(f_elev),
+                                           _lib.ptr(f_theta), c_int(B), c_float(elev_range[0]), c_float(elev_range[1]),
+                                           c_float(theta_range[0]), c_float(theta_range[1]), c_float(margin_eps), c_int(emd_p),
+                                           _lib.ptr(out), _lib.ptr(grads), _lib.stream()), "sc_camera_prior_forward")
+    return out, grads
+
+
+def camera_prior_backward(grads, G_margin, G_uniform, G_sym):
+    """-> g [6, B, 2]: azim, elev, theta, flipped azim, flipped elev, flipped theta."""
+    lib = _lib.load()
+    B = grads.shape[1]
+    g = torch.empty(6, B, 2, device=grads.device, dtype=torch.float32)
+    _lib.check(lib.sc_camera_prior_backward(_lib.ptr(grads), c_int(B), _lib.ptr(_f32c(G_margin)), _lib.ptr(_f32c(G_uniform)),
+                                            _lib.ptr(_f32c(G_sym)), *[_lib.ptr(g[k]) for k in range(6)], _lib.stream()),
+               "sc_camera_prior_backward")
+    return g
+
+
+def transform_normal_forward(normals, pose):
+    lib = _lib.load()
+    B, R = normals.shape[0], normals.shape[1]
+    out = torch.empty(B, R, 3, device=normals.device, dtype=torch.float32)
+    _lib.check(lib.sc_transform_normal_forward(_lib.ptr(normals), _lib.ptr(pose), c_int(B), c_int(R), _lib.ptr(out), _lib.stream()),
+               "sc_transform_normal_forward")
+    return out
+
+
+def transform_normal_backward(normals, g_out):
+    lib = _lib.load()
+    B, R = normals.shape[0], normals.shape[1]
+    g_pose = torch.empty(B, 3, 4, device=normals.device, dtype=torch.float32)
+    _lib.check(lib.sc_transform_normal_backward(_lib.ptr(normals), _lib.ptr(g_out), c_int(B), c_int(R), _lib.ptr(g_pose), _lib.stream()),
+               "sc_transform_normal_backward")
+    return g_pose
+
+
+LOSS_TOTAL_MAX_TERMS = 16
+
+
+def loss_total_forward(values, weights):
+    """values: device scalars, weights: python floats -> (total [], bad [] bool)."""
+    lib = _lib.load()
+    dev = values[0].device
+    total = torch.empty((), device=dev, dtype=torch.float32)
+    bad = torch.empty((), device=dev, dtype=torch.bool)
+    w = (c_float * len(weights))(*weights)
+    _lib.check(lib.sc_loss_total_forward(_ptr_array(values), w, c_int(len(values)), _lib.ptr(total), _lib.ptr(bad), _lib.stream()),
+               "sc_loss_total_forward")
+    return total, bad
+
+
+def loss_total_backward(weights, G):
+    lib = _lib.load()
+    g = torch.empty(len(weights), device=G.device, dtype=torch.float32)
+    w = (c_float * len(weights))(*weights)
+    _lib.check(lib.sc_loss_total_backward(w, c_int(len(weights)), _lib.ptr(_f32c(G)), _lib.ptr(g), _lib.stream()), "sc_loss_total_backward")
+    return g
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
 # 3x3 stride-1 convolutions of the ResNet trunks on the fp32 matrix pipe (csrc/conv3x3.hip)
 CONV3X3_SIDES = (56, 28, 14, 7)
 

@@ -15,7 +15,7 @@ def test_fused_losses_golden(golden):
     rgb, pm, npred, eik = (t(k).requires_grad_(True) for k in ("pred3", "pm", "npred", "eik"))
     ngt = t("ngt").requires_grad_(True)      # transform_normal(input normal, predicted pose): differentiable target
     out = FusedRenderLoss.apply(rgb, t("tgt3"), pm, t("tm"), npred, ngt, eik, 5.0, 0.0, 1 - 0.2)
-    vals = out.detach().cpu().numpy()
+    vals = torch.stack([o.detach() for o in out]).cpu().numpy()
     assert abs(vals[0] - g["val.mse"]) < 1e-6 and abs(vals[1] - g["val.mask"]) < 1e-6
     assert abs(vals[2] - g["val.normal"]) < 1e-5 and abs(vals[3] - g["val.mse_eik"]) < 1e-6
     (out[0] + 0.5 * out[1] + 0.01 * out[2] + 0.03 * out[3]).backward()

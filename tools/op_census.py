@@ -63,3 +63,41 @@ bw = collections.Counter(e.name.split(":")[-1].strip() for e in ev if e.name.sta
 print("backward nodes:", sum(bw.values()))
 for k, v in bw.most_common(25):
     print("%6d  %s" % (v, k))
+
+# which autograd node / optimizer range does each backward-side launch belong to, and what are the aten kernels it launches?
+nodes = [(e.name.split("evaluate_function:")[-1].strip(), e.time_range.start, e.time_range.end) for e in ev
+         if e.name.startswith("autograd::engine::evaluate_function")]
+nodes += [(e.name, e.time_range.start, e.time_range.end) for e in ev if e.name.startswith("Optimizer.step")]
+nodes.sort(key=lambda r: r[1])
+import bisect
+starts = [r[1] for r in nodes]
+aten = [e for e in ev if e.name.startswith("aten::") and e.cpu_parent is not None]
+per_node = collections.Counter(); per_node_ops = collections.defaultdict(collections.Counter)
+mem = [e for e in ev if e.name in ("hipMemcpyAsync", "hipMemsetAsync", "hipMemcpyWithStream")]
+for e in launch + mem:
+    t = e.time_range.start
+    if any(r[1] <= t <= r[2] for r in regions):
+        continue
+    i = bisect.bisect_right(starts, t) - 1
+    name = nodes[i][0] if i >= 0 and nodes[i][2] >= t else "(no node)"
+    per_node[name] += 1
+    p = e.cpu_parent
+    while p is not None and not p.name.startswith("aten::"):
+        p = p.cpu_parent
+    per_node_ops[name][p.name if p is not None else e.name] += 1
+print("\nbackward / optimizer launches by autograd node (aten parents listed):")
+for k, v in per_node.most_common(40):
+    print("%6d  %-45s %s" % (v, k, ", ".join("%s x%d" % kv for kv in per_node_ops[k].most_common(6))))
+
+# where in the forward were the select / slice views made (their backward is fill + copy + add_ each)?
+fw = collections.defaultdict(collections.Counter)
+for e in ev:
+    if e.name in ("aten::select", "aten::slice", "aten::unsqueeze", "aten::index_select", "aten::gather") and e.sequence_nr >= 0 and e.cpu_parent is not None:
+        t = e.time_range.start
+        inside = [r for r in regions if r[1] <= t <= r[2]]
+        if inside:
+            fw[e.name][min(inside, key=lambda r: r[2] - r[1])[0]] += 1
+        elif not (nodes and nodes[0][1] <= t):
+            fw[e.name]["(forward, outside regions)"] += 1
+for k, c in fw.items():
+    print(k, dict(c))
