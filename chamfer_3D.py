@@ -9,14 +9,21 @@ The caller allocates every output (zero-filled; the backward *accumulates* into 
 tensors are fp32 / int32, contiguous, on one ROCm device.  Returns 1 on success like the
 reference (chamfer3D.cu:151,193); unlike the reference a failed launch raises instead of
 printf-and-return-0, and kernels go to torch's current stream rather than the legacy default one.
-The work is done by the hand-written gfx950 kernels in shapeclipper_amd/csrc/chamfer.hip through the
-C ABI (include/shapeclipper_hip.h); there is no CPU fallback.
+The work is done by the hand-written gfx950 kernels in shapeclipper_amd/csrc/chamfer.hip (all pairs) and
+chamfer_grid.hip (exact uniform-grid search, same results bit for bit, used for clouds of GRID_MIN_POINTS points or more)
+through the C ABI (include/shapeclipper_hip.h); there is no CPU fallback.  SEARCH = "brute" (or the environment
+variable SHAPECLIPPER_CHAMFER_SEARCH=brute) keeps every call on the all-pairs kernels.
 """
 import ctypes
+import os
 
 import torch
 
 from shapeclipper_amd import _lib
+
+
+SEARCH = os.environ.get("SHAPECLIPPER_CHAMFER_SEARCH", "grid")
+GRID_MIN_POINTS = 2048
 
 
 def _dims(xyz1, xyz2):
@@ -50,6 +57,16 @@ def forward(xyz1, xyz2, dist1, dist2, idx1, idx2):
 
 
 def _forward(lib, b, n, m, xyz1, xyz2, dist1, dist2, idx1, idx2):
+    if SEARCH not in ("grid", "brute"):
+        raise ValueError("chamfer_3D.SEARCH must be 'grid' or 'brute', got %r" % (SEARCH,))
+    if SEARCH == "grid" and min(n, m) >= GRID_MIN_POINTS:
+        ws = torch.empty(int(lib.sc_chamfer3d_grid_workspace_bytes(ctypes.c_int(b), ctypes.c_int(n), ctypes.c_int(m))),
+                         dtype=torch.uint8, device=xyz1.device)
+        code = lib.sc_chamfer3d_forward_grid(_lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(dist1), _lib.ptr(dist2), _lib.ptr(idx1),
+                                             _lib.ptr(idx2), ctypes.c_int(b), ctypes.c_int(n), ctypes.c_int(m), _lib.ptr(ws),
+                                             _lib.stream())
+        _lib.check(code, "sc_chamfer3d_forward_grid")
+        return 1
     blocks = b * ((min(n, m) + 1023) // 1024)
     if 0 < blocks < 1024 and max(n, m) >= 4096:
         # too few workgroups to fill 256 CUs (evaluation: b = 1): split the target cloud over workgroup slices

@@ -38,6 +38,16 @@ int sc_chamfer3d_forward_split(const float* xyz1, const float* xyz2, float* dist
                                int32_t* idx1, int32_t* idx2, int b, int n, int m, int nsplit,
                                void* workspace, void* stream);
 
+/* Same results (bit for bit) from an exact accelerated search (csrc/chamfer_grid.hip): each cloud is binned into a uniform
+ * grid and every query walks rings of cells around its own, evaluating candidates with the same expression and accepting on
+ * d < best || (d == best && index < best_index); the walk stops only when no unseen target can tie or beat the best (rounding
+ * of the binning and of d included).  Queries that do not terminate within a few rings (far outside the other cloud, one huge
+ * cell, non-finite coordinates) are answered by the brute-force scan, so the worst case is sc_chamfer3d_forward's cost.
+ * workspace: sc_chamfer3d_grid_workspace_bytes(b, n, m) bytes of device scratch (contents irrelevant on entry).       */
+long long sc_chamfer3d_grid_workspace_bytes(int b, int n, int m);
+int sc_chamfer3d_forward_grid(const float* xyz1, const float* xyz2, float* dist1, float* dist2,
+                              int32_t* idx1, int32_t* idx2, int b, int n, int m, void* workspace, void* stream);
+
 /* gradxyz1 [b,n,3], gradxyz2 [b,m,3] must be ZERO-FILLED by the caller (atomicAdd accumulation,
  * chamfer3D.cu:166-171,177-178).                                                                */
 int sc_chamfer3d_backward(const float* xyz1, const float* xyz2, float* gradxyz1, float* gradxyz2,

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SHAPECLIPPER_HIP_LIB") or os.path.join(_HERE, "lib", "libshapeclipper_hip.so")
 
 SYMBOLS = (
-    "sc_chamfer3d_forward", "sc_chamfer3d_forward_split", "sc_chamfer3d_backward", "sc_sdf_forward", "sc_rgb_composite_forward",
+    "sc_chamfer3d_forward", "sc_chamfer3d_forward_split", "sc_chamfer3d_forward_grid", "sc_chamfer3d_backward", "sc_sdf_forward", "sc_rgb_composite_forward",
     "sc_rgb_composite_backward", "sc_sdf_backward", "sc_wgrad", "sc_partial_reduce", "sc_tbl_sum", "sc_loss_fused_forward",
     "sc_clip_vit_forward", "sc_gemm_bf16", "sc_f32_to_bf16", "sc_clip_vit_forward_f16", "sc_gemm_f16", "sc_f32_to_f16",
     "sc_ray_sample_forward", "sc_ray_sample_backward", "sc_render_forward", "sc_sdf_grid_forward", "sc_loss_fused_backward",
@@ -30,7 +30,7 @@ SYMBOLS = (
     "sc_render_backward", "sc_sdf_backward_fused", "sc_sdf_backward_fused_parts", "sc_sdf_backward_fused_partial_floats", "sc_tbl_sum_blocks", "sc_conv3x3_pack", "sc_conv3x3_forward", "sc_conv3x3_pack_multi", "sc_conv3x3_tile_channels", "sc_conv3x3_wgrad", "sc_conv3x3_forward_split", "sc_conv3x3_tile_channels_split", "sc_conv_stem_forward", "sc_conv_stem_wgrad", "sc_conv1x1s2_forward", "sc_conv1x1s2_backward_data", "sc_conv1x1s2_wgrad", "sc_conv3x3s2_forward", "sc_conv3x3s2_bd_pack", "sc_conv3x3s2_backward_data", "sc_conv3x3s2_wgrad",
 )
 # entry points that do not return an int status
-SYMBOLS_OTHER = ("sc_render_backward_workspace_bytes", "sc_clip_vit_workspace_bytes", "sc_conv3x3_pack_floats", "sc_conv3x3_workspace_floats", "sc_conv3x3_wgrad_workspace_floats", "sc_conv3x3_pack_floats_split", "sc_conv3x3_workspace_floats_split", "sc_conv_stem_wgrad_workspace_floats", "sc_conv1x1s2_wgrad_workspace_floats", "sc_conv3x3s2_pack_floats", "sc_conv3x3s2_workspace_floats", "sc_conv3x3s2_bd_pack_floats", "sc_conv3x3s2_bd_workspace_floats")
+SYMBOLS_OTHER = ("sc_render_backward_workspace_bytes", "sc_chamfer3d_grid_workspace_bytes", "sc_clip_vit_workspace_bytes", "sc_conv3x3_pack_floats", "sc_conv3x3_workspace_floats", "sc_conv3x3_wgrad_workspace_floats", "sc_conv3x3_pack_floats_split", "sc_conv3x3_workspace_floats_split", "sc_conv_stem_wgrad_workspace_floats", "sc_conv1x1s2_wgrad_workspace_floats", "sc_conv3x3s2_pack_floats", "sc_conv3x3s2_workspace_floats", "sc_conv3x3s2_bd_pack_floats", "sc_conv3x3s2_bd_workspace_floats")
 
 _lib: Optional[ctypes.CDLL] = None
 

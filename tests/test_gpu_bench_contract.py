@@ -50,4 +50,5 @@ def test_workloads_line():
         assert k in out, k
     assert out["algorithmic_flop"] == 80640 * 101 ** 3 and 0 < out["frac"] < 1.0
     c = w.chamfer(1, N=20000, with_cpu=False)
-    assert c["algorithmic_flop"] == 16.0 * 20000 * 20000 and 0 < c["frac"] < 1.0
+    assert c["all_pairs"]["algorithmic_flop"] == 16.0 * 20000 * 20000 and 0 < c["all_pairs"]["frac"] < 1.0
+    assert c["same_results_as_all_pairs"] is True and c["speedup_vs_all_pairs"] > 0 and c["ms"] > 0

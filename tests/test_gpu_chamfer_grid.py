@@ -1,0 +1,136 @@
+"""The exact grid search (csrc/chamfer_grid.hip) against the all-pairs kernels (csrc/chamfer.hip, themselves pinned bit for bit to
+the reference build and the oracle in test_gpu_chamfer*.py): squared distances AND indices identical on every kind of cloud --
+uniform, clustered, lattices full of exact ties, flat and line-like clouds, disjoint clouds (every query falls back to the scan),
+duplicated points, one-point extents, non-finite coordinates -- at sizes up to the evaluation's 100,000 x 100,000."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(a, b, search):
+    from shapeclipper_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    x1, x2 = torch.as_tensor(a, device=dev).contiguous(), torch.as_tensor(b, device=dev).contiguous()
+    B, N, M = x1.shape[0], x1.shape[1], x2.shape[1]
+    d1, d2 = torch.full((B, N), -1.0, device=dev), torch.full((B, M), -1.0, device=dev)
+    i1, i2 = torch.full((B, N), -1, dtype=torch.int32, device=dev), torch.full((B, M), -1, dtype=torch.int32, device=dev)
+    args = (_lib.ptr(x1), _lib.ptr(x2), _lib.ptr(d1), _lib.ptr(d2), _lib.ptr(i1), _lib.ptr(i2), ctypes.c_int(B), ctypes.c_int(N), ctypes.c_int(M))
+    if search == "grid":
+        nbytes = int(lib.sc_chamfer3d_grid_workspace_bytes(ctypes.c_int(B), ctypes.c_int(N), ctypes.c_int(M)))
+        ws = torch.randint(0, 255, (nbytes,), dtype=torch.uint8, device=dev)        # "contents irrelevant on entry"
+        rc = lib.sc_chamfer3d_forward_grid(*args, _lib.ptr(ws), _lib.stream())
+    else:
+        rc = lib.sc_chamfer3d_forward(*args, _lib.stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    return d1, d2, i1, i2
+
+
+def _clouds(kind, B, N, M, seed):
+    rng = np.random.RandomState(seed)
+    u = lambda n: rng.uniform(-0.5, 0.5, (B, n, 3)).astype(np.float32)
+    if kind == "uniform":
+        a, b = u(N), u(M)
+    elif kind == "clustered":      # a few tight blobs + background: cells with hundreds of points next to empty ones
+        def blobs(n):
+            c = rng.uniform(-0.5, 0.5, (B, 6, 3))
+            pick = rng.randint(0, 6, (B, n))
+            p = np.take_along_axis(c, pick[..., None].repeat(3, -1), 1) + rng.normal(0, 0.004, (B, n, 3))
+            bg = rng.rand(B, n, 1) < 0.2
+            return np.where(bg, rng.uniform(-0.5, 0.5, (B, n, 3)), p).astype(np.float32)
+        a, b = blobs(N), blobs(M)
+    elif kind == "lattice":        # exact ties by the thousand and exact zero distances
+        a = rng.randint(-8, 9, (B, N, 3)).astype(np.float32) * 0.0625
+        b = rng.randint(-8, 9, (B, M, 3)).astype(np.float32) * 0.0625
+    elif kind == "flat":           # a plane and a line: zero extent along axes
+        a, b = u(N), u(M)
+        b[..., 2] = 0.25
+        a[..., 0] = -0.125; a[..., 1] = 0.375
+    elif kind == "disjoint":       # far apart: the ring walk cannot terminate, every query is answered by the scan
+        a, b = u(N), u(M) + np.float32(40.0)
+    elif kind == "surface":        # points on a sphere (what the evaluation compares), large offset from the origin
+        def sph(n):
+            v = rng.normal(size=(B, n, 3)); v /= np.linalg.norm(v, axis=-1, keepdims=True)
+            return (0.4 * v + 100.0).astype(np.float32)
+        a, b = sph(N), sph(M)
+    elif kind == "onepoint":       # every target identical: the grid is declared invalid
+        a, b = u(N), np.zeros((B, M, 3), np.float32) + np.float32(0.125)
+    else:
+        raise ValueError(kind)
+    if M > 40:
+        b[:, 33] = b[:, 3]; b[:, M - 1] = b[:, 3]       # duplicates: the lower index has to win
+    return a, b
+
+
+CASES = [("uniform", 2, 5000, 7001), ("uniform", 1, 100000, 100000), ("clustered", 2, 30000, 20000), ("clustered", 1, 100000, 100000),
+         ("lattice", 2, 20000, 30000), ("lattice", 1, 100000, 100000), ("flat", 2, 9000, 8000), ("disjoint", 1, 6000, 5000),
+         ("surface", 2, 40000, 40000), ("onepoint", 1, 3000, 2500), ("uniform", 3, 2049, 64), ("uniform", 1, 1, 5000), ("uniform", 1, 5000, 1)]
+
+
+@pytest.mark.parametrize("kind,B,N,M", CASES)
+def test_grid_search_is_bit_identical_to_all_pairs(kind, B, N, M):
+    a, b = _clouds(kind, B, N, M, N + 7 * M)
+    g, r = _run(a, b, "grid"), _run(a, b, "brute")
+    for name, x, y in zip(("dist1", "dist2", "idx1", "idx2"), g, r):
+        assert torch.equal(x, y), "%s: %d of %d entries differ (%s)" % (name, int((x != y).sum()), x.numel(), kind)
+    assert int(g[2].min()) >= 0 and int(g[3].min()) >= 0 and float(g[0].min()) >= 0
+
+
+def test_non_finite_coordinates_take_the_scan():
+    a, b = _clouds("uniform", 1, 4000, 3000, 5)
+    for poison in (np.nan, np.inf, -np.inf, 3e20):
+        for which in (0, 1):
+            a2, b2 = a.copy(), b.copy()
+            (a2 if which == 0 else b2)[0, 17, 1] = poison
+            g, r = _run(a2, b2, "grid"), _run(a2, b2, "brute")
+            for x, y in zip(g, r):
+                assert torch.equal(x, y) or (x.dtype == torch.float32 and torch.equal(torch.isnan(x), torch.isnan(y))
+                                             and torch.equal(x[~torch.isnan(x)], y[~torch.isnan(y)]))
+
+
+def test_module_dispatch_and_switch():
+    """chamfer_3D.forward takes the grid search from GRID_MIN_POINTS points up, SEARCH = 'brute' keeps the all-pairs kernels."""
+    import chamfer_3D
+    a, b = _clouds("clustered", 2, 4096, 3000, 11)
+    dev = torch.device("cuda:0")
+    outs = []
+    for mode in ("grid", "brute"):
+        old, chamfer_3D.SEARCH = chamfer_3D.SEARCH, mode
+        try:
+            x1, x2 = torch.tensor(a, device=dev), torch.tensor(b, device=dev)
+            d1, d2 = torch.zeros(2, 4096, device=dev), torch.zeros(2, 3000, device=dev)
+            i1, i2 = torch.zeros(2, 4096, dtype=torch.int32, device=dev), torch.zeros(2, 3000, dtype=torch.int32, device=dev)
+            assert chamfer_3D.forward(x1, x2, d1, d2, i1, i2) == 1
+            outs.append((d1, d2, i1, i2))
+        finally:
+            chamfer_3D.SEARCH = old
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    chamfer_3D.SEARCH = "fast"
+    try:
+        with pytest.raises(ValueError):
+            chamfer_3D.forward(x1, x2, d1, d2, i1, i2)
+    finally:
+        chamfer_3D.SEARCH = "grid"
+
+
+def test_config2_size_speedup_is_real():
+    """B=4 x 100k x 100k (an eighth of BASELINE config[2]): same bits, and the grid search is at least 5x faster than all pairs."""
+    a, b = (torch.tensor(c, device="cuda:0") for c in _clouds("uniform", 4, 100000, 100000, 3))
+    t = {}
+    for mode in ("grid", "brute"):
+        _run(a, b, mode)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = _run(a, b, mode)
+        e.record(); torch.cuda.synchronize()
+        t[mode] = (s.elapsed_time(e), out)
+    for x, y in zip(t["grid"][1], t["brute"][1]):
+        assert torch.equal(x, y)
+    print("grid %.2f ms, all pairs %.2f ms (output allocation included)" % (t["grid"][0], t["brute"][0]))
+    assert t["grid"][0] * 5 < t["brute"][0]
