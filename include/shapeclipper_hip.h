@@ -314,6 +314,15 @@ int sc_isosurface_count(const float* level, int n_images, int n_axis, float iso,
 int sc_isosurface_emit(const float* level, int n_images, int n_axis, float iso, const int* counts,
                        const long long* offsets, float* tris, void* stream);
 
+/* sc_marching_cubes_*: the same contract with marching CUBES (the algorithm of the reference's PyMCubes call, utils/eval_3D.py:
+ * 123-153): up to 5 triangles per cube from the 256-case table of csrc/mc_table.hpp (generated by tools/gen_mc_table.py).  The
+ * vertex set is the one every marching-cubes implementation produces -- one vertex per grid edge whose end values lie on
+ * different sides of iso (inside = value < iso), at the linear interpolation point -- the triangulation of ambiguous faces
+ * (diagonal corners inside) cuts off the inside corners, identically on both sides of the face.                          */
+int sc_marching_cubes_count(const float* level, int n_images, int n_axis, float iso, int* counts, void* stream);
+int sc_marching_cubes_emit(const float* level, int n_images, int n_axis, float iso, const int* counts,
+                           const long long* offsets, float* tris, void* stream);
+
 /* ---- camera algebra of a render -------------------------------------------------------------------
  * sc_camera_rays_*: utils/camera.py:157-196 (get_center_and_ray on the rendered pixels only) + the normalisation of
  * model/renderer.py:69-76.  pose [n_images][3][4] = [R|t] world->camera, intr [n_images][3][3], ray_idx

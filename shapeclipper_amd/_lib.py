@@ -22,7 +22,7 @@ SYMBOLS = (
     "sc_clip_vit_forward", "sc_gemm_bf16", "sc_f32_to_bf16", "sc_clip_vit_forward_f16", "sc_gemm_f16", "sc_f32_to_f16",
     "sc_ray_sample_forward", "sc_ray_sample_backward", "sc_render_forward", "sc_sdf_grid_forward", "sc_loss_fused_backward",
     "sc_bn_splits", "sc_bn_act_forward", "sc_bn_act_backward", "sc_bn_relu_pool_forward", "sc_bn_relu_pool_backward",
-    "sc_isosurface_count", "sc_isosurface_emit",
+    "sc_isosurface_count", "sc_isosurface_emit", "sc_marching_cubes_count", "sc_marching_cubes_emit",
     "sc_camera_rays_forward", "sc_camera_rays_backward", "sc_pose_from_trig_forward", "sc_pose_from_trig_backward",
     "sc_estimator_head_forward", "sc_estimator_head_backward", "sc_camera_prior_forward", "sc_camera_prior_backward",
     "sc_camera_prior_max_images", "sc_transform_normal_forward", "sc_transform_normal_backward", "sc_loss_total_forward",

@@ -3,10 +3,12 @@ Call surface of the reference's utils/eval_3D.py.
 
   * compute_level_grid: the whole (N+1)^3 grid of every image goes through the HIP SDF kernel in ONE
     launch (the reference loops over N+1 slabs of small launches, eval_3D.py:27-35).
-  * chamfer_distance: chamfer_3D.forward (HIP, csrc/chamfer.hip), then sqrt as the reference.
+  * chamfer_distance: chamfer_3D.forward (HIP; csrc/chamfer_grid.hip exact grid search, csrc/chamfer.hip all pairs), then sqrt
+    as the reference.
   * marching cubes / mesh sampling are third-party in the reference (PyMCubes, trimesh; CPU threads).
-    They are used when importable; otherwise surface points come from the sign changes along grid
-    edges (linear interpolation), sub-sampled to eval.num_points -- see DESIGN.md, SURVEY 8f-2.
+    They are used when importable; otherwise the mesh comes from the device marching-cubes kernels (csrc/isosurface.hip: the
+    same vertex set, one vertex per sign-changing grid edge) and is sampled area-uniformly like trimesh does -- see DESIGN.md,
+    SURVEY 8f-2.
 """
 from __future__ import annotations
 
@@ -77,18 +79,19 @@ def _edge_crossing_points(level, lo, hi, num_points, rng):
 
 
 @torch.no_grad()
-def surface_points_device(level, lo, hi, num_points, seed=0, iso=0.0):
+def surface_points_device(level, lo, hi, num_points, seed=0, iso=0.0, method="cubes"):
     """level [B,S,S,S] on the GPU -> (points [B,num_points,3], tris list) sampled area-uniformly on the iso-surface.
 
     Device-side replacement of `mcubes.marching_cubes` + `trimesh.Trimesh.sample` (reference utils/eval_3D.py:123-153)
-    when those packages are absent: triangles from the HIP marching-tetrahedra kernels (csrc/isosurface.hip), a
+    when those packages are absent: triangles from the HIP marching-cubes kernels (csrc/isosurface.hip; the vertex set is the one
+    PyMCubes produces, `method="tetrahedra"` selects the table-free variant of rounds 1-2), a
     triangle per sample drawn with probability proportional to its area, a uniform point inside it (the same scheme
     trimesh uses).  Vertices get the reference's 1/S rescale.  No D2H of the (N+1)^3 grid, no Python threads; seeded per
     call so that sharded evaluation is independent of which rank handles a sample."""
     from .. import ops
     B, S = level.shape[0], level.shape[1]
     dev = level.device
-    tris, per_image = ops.isosurface_triangles(level, iso)
+    tris, per_image = ops.isosurface_triangles(level, iso, method=method)
     out = torch.zeros(B, num_points, 3, device=dev)
     meshes = []
     gen = torch.Generator(device=dev)
@@ -177,7 +180,7 @@ def eval_metrics(opt, var, sdf_network, vis_only=False):
         meshes, pointclouds = convert_to_explicit(opt, level_grids, isoval=0., to_pointcloud=True)
         var.mesh_pred = meshes
         var.dpc_pred = torch.tensor(pointclouds, dtype=torch.float32, device=dev)
-    else:   # stay on the device: marching-tetrahedra triangles + area-uniform samples (csrc/isosurface.hip)
+    else:   # stay on the device: marching-cubes triangles + area-uniform samples (csrc/isosurface.hip)
         lo, hi = opt.eval.range
         var.dpc_pred, var.mesh_pred = surface_points_device(level_vox, lo, hi, opt.eval.num_points,
                                                             seed=int(var.idx[0]) if len(var.idx) else 0)

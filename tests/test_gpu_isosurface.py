@@ -1,7 +1,8 @@
-"""Iso-surface extraction on the GPU (csrc/isosurface.hip) against its CPU restatement (oracle/isosurface_ref.py) and
-analytic properties.  The reference's PyMCubes/trimesh step (utils/eval_3D.py:123-153) is third-party and absent:
-the triangulation is parity-unpinned; what is checked is kernel == restatement triangle by triangle (bit-exact, same
-fp32 interpolation and emission order), the area of a sphere, and area-uniform sampling."""
+"""Iso-surface extraction on the GPU (csrc/isosurface.hip: marching cubes, the evaluation's default, and marching tetrahedra) against
+the CPU restatements (oracle/isosurface_ref.py) and analytic properties.  The reference's PyMCubes/trimesh step (utils/eval_3D.py:
+123-153) is third-party and absent: the triangulation is parity-unpinned; what is checked is kernel == restatement triangle by
+triangle (bit-exact, same fp32 interpolation and emission order), the marching-cubes VERTEX SET (one vertex per sign-changing grid
+edge -- what PyMCubes produces too) at the evaluation's vox_res = 100, the area of a sphere, and area-uniform sampling."""
 import math
 
 import numpy as np
@@ -18,7 +19,7 @@ def _sphere(S, r, centre=(0.0, 0.0, 0.0)):
 
 
 def test_triangles_equal_cpu_restatement_bit_exact():
-    from oracle.isosurface_ref import marching_tets
+    from oracle.isosurface_ref import marching_cubes, marching_tets
     from shapeclipper_amd import ops
     rng = np.random.RandomState(0)
     grids = [rng.randn(7, 7, 7).astype(np.float32),                       # noise: every case of every tetrahedron
@@ -27,20 +28,47 @@ def test_triangles_equal_cpu_restatement_bit_exact():
              _sphere(13, 0.5)]                                            # exact zeros on grid vertices (ties)
     grids[3][6, 6, 1] = 0.0
     for g in grids:
-        tris, per = ops.isosurface_triangles(torch.tensor(g[None]).cuda(), 0.0)
-        ref = marching_tets(g, 0.0)
-        assert int(per[0]) == ref.shape[0] == tris.shape[0]
-        assert np.array_equal(tris.cpu().numpy(), ref)
+        for method, restated in (("tetrahedra", marching_tets), ("cubes", marching_cubes)):
+            tris, per = ops.isosurface_triangles(torch.tensor(g[None]).cuda(), 0.0, method=method)
+            ref = restated(g, 0.0)
+            assert int(per[0]) == ref.shape[0] == tris.shape[0], method
+            assert np.array_equal(tris.cpu().numpy(), ref), method
+    with pytest.raises(ValueError):
+        ops.isosurface_triangles(torch.tensor(grids[0][None]).cuda(), 0.0, method="dual contouring")
 
 
 def test_batched_grid_and_offsets():
     from oracle.isosurface_ref import marching_tets
     from shapeclipper_amd import ops
     a, b, c = _sphere(9, 0.5), np.full((9, 9, 9), -1.0, np.float32), _sphere(9, 0.7, (0.1, 0.1, 0.0))
-    tris, per = ops.isosurface_triangles(torch.tensor(np.stack([a, b, c])).cuda(), 0.0)
-    ra, rc = marching_tets(a), marching_tets(c)
-    assert per.tolist() == [ra.shape[0], 0, rc.shape[0]]
-    assert np.array_equal(tris.cpu().numpy(), np.concatenate([ra, rc]))
+    from oracle.isosurface_ref import marching_cubes
+    for method, restated in (("tetrahedra", marching_tets), ("cubes", marching_cubes)):
+        tris, per = ops.isosurface_triangles(torch.tensor(np.stack([a, b, c])).cuda(), 0.0, method=method)
+        ra, rc = restated(a), restated(c)
+        assert per.tolist() == [ra.shape[0], 0, rc.shape[0]]
+        assert np.array_equal(tris.cpu().numpy(), np.concatenate([ra, rc]))
+
+
+def test_marching_cubes_vertex_set_at_evaluation_resolution():
+    """vox_res = 100 (BASELINE config[4]): the vertices of the device mesh are exactly the sign-changing grid edges' interpolation
+    points -- the vertex set of `mcubes.marching_cubes(level, 0)` up to its float64 interpolation -- on a sphere-with-dent field
+    and on noise; every triangle has three distinct vertices; isovalue != 0 works the same."""
+    from oracle.isosurface_ref import crossing_edge_vertices
+    from shapeclipper_amd import ops
+    S = 101
+    ax = np.linspace(-0.6, 0.6, S)
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
+    shape = (np.sqrt(X * X + Y * Y + 1.4 * Z * Z) - 0.41 + 0.05 * np.sin(9 * X) * np.cos(7 * Y)).astype(np.float32)
+    noise = np.random.RandomState(5).randn(33, 33, 33).astype(np.float32)
+    for level, iso in ((shape, 0.0), (shape, 0.03), (noise, 0.0)):
+        tris, per = ops.isosurface_triangles(torch.tensor(level[None]).cuda(), iso, method="cubes")
+        assert int(per[0]) == tris.shape[0] > 1000
+        got = torch.unique(tris.reshape(-1, 3), dim=0).cpu().numpy()
+        want = np.unique(crossing_edge_vertices(level, iso), axis=0)
+        assert got.shape == want.shape and np.array_equal(got[np.lexsort(got.T[::-1])], want[np.lexsort(want.T[::-1])])
+        t = tris
+        degenerate = ((t[:, 0] == t[:, 1]).all(1) | (t[:, 1] == t[:, 2]).all(1) | (t[:, 0] == t[:, 2]).all(1))
+        assert int(degenerate.sum()) == 0
 
 
 def test_sphere_area_and_uniform_samples():
