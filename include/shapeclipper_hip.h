@@ -454,6 +454,9 @@ int sc_conv3x3s2_forward(const float* x, const float* w_pack, float* out, float*
  * workspace: sc_conv3x3_wgrad_workspace_floats(cin, cout) floats (one partial 64 x 64 x 9 block per workgroup).                       */
 long long sc_conv3x3_wgrad_workspace_floats(int cin, int cout);
 int sc_conv3x3_wgrad(const float* gy, const float* x, float* dw, float* workspace, int batch, int cin, int cout, int hw, void* stream);
+/* The same gradient with fp32-accurate products on the bf16 matrix pipe (the arithmetic of sc_conv3x3_forward_split: exact three-way
+ * bf16 split of BOTH operands, the six piece products with p + q <= 2, smallest first, fp32 accumulate); same arguments and workspace. */
+int sc_conv3x3_wgrad_split(const float* gy, const float* x, float* dw, float* workspace, int batch, int cin, int cout, int hw, void* stream);
 
 /* The stem of the trunks (torchvision ResNet.conv1: 7x7 / stride 2 / pad 3, 3 -> 64 channels, 224 x 224 inputs only; csrc/conv_stem.hip):
  *   sc_conv_stem_forward   out [batch][64][112][112] = conv(x [batch][3][224][224], w [64][3][7][7]), fully overwritten

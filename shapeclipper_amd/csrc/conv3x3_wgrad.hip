@@ -242,6 +242,184 @@ using Wg28S2 = WgCfg<28, 2, 1, 2, 2>;
 using Wg14S2 = WgCfg<14, 2, 1, 1, 2>;
 using Wg7S2 = WgCfg<7, 7, 2, 1, 2>;
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same weight gradient with fp32-accurate products on the bf16 matrix pipe (the arithmetic of sc_conv3x3_forward_split): every
+// operand is staged as its exact three-way bf16 split v = p0 + p1 + p2 (round to nearest even, residuals exact), the six piece
+// products a_p b_q with p + q <= 2 go through v_mfma_f32_32x32x16_bf16, smallest terms first, fp32 accumulate.
+//
+// The reduction index of an MFMA is 16 consecutive pixel SLOTS of one row (rows are padded to a multiple of 16 slots with zeros of
+// gy; a 7-wide map packs two rows of 7 + 1 slots): lane half h owns slots 8h .. 8h + 7, so the gy operand is one ds_read_b128 per piece
+// and the three kx taps of the patch are the 8-element windows at +0, +1, +2 of ten consecutive bf16 patch values (5 dwords): kx = 0
+// and kx = 2 are register renames, kx = 1 is four v_alignbit_b32 -- no per-tap copies of the patch.  A workgroup owns a 64 x 64
+// (co, ci) block as 2 x 2 tiles x 3 filter ROWS: its 12 waves hold the three kx accumulators of one (tile, ky), every wave sees the
+// whole K-step, and no cross-wave sum is needed at the end.  Per 16 slots and wave: 3 + 15 LDS reads, 12 v_alignbit, 18 MFMAs of 32
+// cycles (the fp32 kernel: 21 MFMAs of 64 cycles per 14 pixels and tap row).  K-steps are sized by LDS (6 bytes per element instead
+// of 4): 2 rows of a 56-wide map, 4 of 28, 7 of 14, two 7 x 7 images.  Partial blocks and the fixed-order reduction are those above.
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int W_, int NR_, int NIMG_>
+struct WsCfg {
+    static constexpr int W = W_, H = W_, NR = NR_, NIMG = NIMG_, HW = W * W;
+    static constexpr int SLOTS = W == 7 ? 8 : (W + 15) / 16 * 16;             // slots per map row in the gy tile
+    static constexpr int ROWS = NIMG * NR, NSLOT = ROWS * SLOTS, G = NSLOT / 16;
+    static constexpr int ASTR = NSLOT + 8;                                    // bf16 per channel; ASTR / 8 odd: conflict-free b128 reads
+    static constexpr int Wp = SLOTS + 2, PR = NR + 2, PATCH = NIMG * PR * Wp;
+    static constexpr int BSTR = (PATCH + 3) / 4 * 4 + 2;                      // bf16 per channel; an odd number of dwords
+    static constexpr bool WHOLE = NR == H;
+    static constexpr int LDS_BYTES = 3 * 64 * (ASTR + BSTR) * 2;
+    static constexpr int CHUNK = W == 7 ? 49 : 56, RPC = CHUNK / W;           // floats per staging load: whole rows, contiguous in memory
+    static constexpr int XROWS = WHOLE ? H : PR;
+    static constexpr int XCH = (XROWS + RPC - 1) / RPC, GCH = (NR + RPC - 1) / RPC;
+    static_assert(NSLOT % 16 == 0 && H % NR == 0 && LDS_BYTES <= 160 * 1024 && (W >= 14 || (NIMG == 2 && NR == 7)), "K-step shape");
+    // patch offset (bf16 units, ky = kx = 0) of slot 0 of lane half h in group g
+    static constexpr int boff(int g, int h) {
+        if (W == 7) { const int r = 2 * g + h; return ((r / 7) * PR + r % 7) * Wp; }
+        const int r = g / (SLOTS / 16), gx = g % (SLOTS / 16);
+        return ((r / NR) * PR + r % NR) * Wp + 16 * gx + 8 * h;
+    }
+};
+
+template <class C>
+__global__ __launch_bounds__(768, 1) void conv3x3_wgrad_split_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                                     float* __restrict__ partial, int batch, int cin, int cout, int S) {
+    constexpr int W = C::W, H = C::H, HW = C::HW, Wp = C::Wp, NIMG = C::NIMG, NR = C::NR;
+    extern __shared__ float4 wg_smem[];
+    __bf16* As = reinterpret_cast<__bf16*>(wg_smem);                          // gy pieces [3][64][ASTR]
+    __bf16* Xs = As + 3 * 64 * C::ASTR;                                       // patch pieces [3][64][BSTR]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = lane >> 5;
+    const int wt = wave & 3, ky = wave >> 2;                                  // MFMA tile (co half, ci half) and filter row
+    const int nti = cin / 64;
+    const int blk = blockIdx.x / S, s = blockIdx.x - blk * S;
+    const int co0 = (blk / nti) * 64, ci0 = (blk % nti) * 64;
+    const int nimg_steps = NIMG == 2 ? (batch + 1) / 2 : batch * (H / NR);
+    const int k_lo = (int)((long long)s * nimg_steps / S), k_hi = (int)((long long)(s + 1) * nimg_steps / S);
+
+    for (int i = tid; i < C::LDS_BYTES / 16; i += 768) wg_smem[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // pads, zero slots, absent halo rows
+
+    // staging: waves 0-7 copy 8 patch channels each, waves 8-11 copy 16 gy channels each (every SIMD hosts two of the former and one of
+    // the latter); lane = position inside a chunk of whole rows; prefetched into registers during the MFMAs of the previous K-step
+    const bool lane_on = lane < C::CHUNK, xrole = wave < 8;
+    const int lrow = lane / W, lx = lane - lrow * W;
+    constexpr int NSV = 8 * C::XCH * NIMG > 16 * C::GCH * NIMG ? 8 * C::XCH * NIMG : 16 * C::GCH * NIMG;
+    float sv[NSV];
+    auto load = [&](int kstep) {
+        int b, y0;
+        if (NIMG == 2) { b = 2 * kstep; y0 = 0; } else { b = kstep / (H / NR); y0 = (kstep - b * (H / NR)) * NR; }
+        if (xrole) {
+#pragma unroll
+            for (int im = 0; im < NIMG; ++im) {
+                const float* xb = x + ((size_t)(b + im) * cin + ci0 + 8 * wave) * HW;
+#pragma unroll
+                for (int c = 0; c < C::XCH; ++c) {
+                    const int rr = c * C::RPC + lrow, yr = (C::WHOLE ? 0 : y0 - 1) + rr;
+                    const bool ok = lane_on && b + im < batch && (unsigned)yr < (unsigned)H && rr < C::XROWS;
+                    const int off = yr * W + lx;
+#pragma unroll
+                    for (int ch = 0; ch < 8; ++ch) sv[(im * C::XCH + c) * 8 + ch] = ok ? xb[ch * HW + off] : 0.f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int im = 0; im < NIMG; ++im) {
+                const float* gb = gy + ((size_t)(b + im) * cout + co0 + 16 * (wave - 8)) * HW;
+#pragma unroll
+                for (int c = 0; c < C::GCH; ++c) {
+                    const int rr = c * C::RPC + lrow;
+                    const bool ok = lane_on && b + im < batch && rr < NR;
+                    const int off = (y0 + rr) * W + lx;
+#pragma unroll
+                    for (int ch = 0; ch < 16; ++ch) sv[(im * C::GCH + c) * 16 + ch] = ok ? gb[ch * HW + off] : 0.f;
+                }
+            }
+        }
+    };
+    auto put = [&](__bf16* d, int stride, float v) {      // v = p0 + p1 + p2 exactly, each piece a bf16 (round to nearest even, residuals exact)
+        const __bf16 h0 = (__bf16)v;
+        const float r1 = v - (float)h0;
+        const __bf16 h1 = (__bf16)r1;
+        d[0] = h0; d[stride] = h1; d[2 * stride] = (__bf16)(r1 - (float)h1);
+    };
+    auto store = [&]() {
+        if (xrole) {
+#pragma unroll
+            for (int im = 0; im < NIMG; ++im)
+#pragma unroll
+                for (int c = 0; c < C::XCH; ++c) {
+                    const int rr = c * C::RPC + lrow;
+                    if (lane_on && rr < C::XROWS) {
+                        __bf16* d = Xs + 8 * wave * C::BSTR + (im * C::PR + (C::WHOLE ? 1 : 0) + rr) * Wp + 1 + lx;
+#pragma unroll
+                        for (int ch = 0; ch < 8; ++ch) put(d + ch * C::BSTR, 64 * C::BSTR, sv[(im * C::XCH + c) * 8 + ch]);
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int im = 0; im < NIMG; ++im)
+#pragma unroll
+                for (int c = 0; c < C::GCH; ++c) {
+                    const int rr = c * C::RPC + lrow;
+                    if (lane_on && rr < NR) {
+                        __bf16* d = As + 16 * (wave - 8) * C::ASTR + (im * NR + rr) * C::SLOTS + lx;
+#pragma unroll
+                        for (int ch = 0; ch < 16; ++ch) put(d + ch * C::ASTR, 64 * C::ASTR, sv[(im * C::GCH + c) * 16 + ch]);
+                    }
+                }
+        }
+    };
+
+    wg_f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const __bf16* Ab = As + ((wt >> 1) * 32 + (lane & 31)) * C::ASTR + 8 * half;
+    const unsigned* Bb = reinterpret_cast<const unsigned*>(Xs + ((wt & 1) * 32 + (lane & 31)) * C::BSTR + ky * Wp);
+
+    if (k_lo < k_hi) load(k_lo);
+    __syncthreads();                                                          // zero fill done
+    for (int kstep = k_lo; kstep < k_hi; ++kstep) {
+        store();
+        __syncthreads();
+        if (kstep + 1 < k_hi) load(kstep + 1);
+#pragma unroll
+        for (int g = 0; g < C::G; ++g) {
+            float4 a[3];
+            unsigned d[3][5];
+            const int bo = (half ? C::boff(g, 1) : C::boff(g, 0)) >> 1;       // dword offset: every term of boff is even
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                a[pc] = *reinterpret_cast<const float4*>(Ab + pc * 64 * C::ASTR + 16 * g);
+#pragma unroll
+                for (int q = 0; q < 5; ++q) d[pc][q] = Bb[pc * 32 * C::BSTR + bo + q];
+            }
+#pragma unroll
+            for (int term = 0; term < 6; ++term) {
+                constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+                const unsigned* q = d[PB[term]];
+                const wg_bf16x8 av = __builtin_bit_cast(wg_bf16x8, a[PA[term]]);
+                uint4 b0 = {q[0], q[1], q[2], q[3]}, b2 = {q[1], q[2], q[3], q[4]};
+                uint4 b1 = {__builtin_amdgcn_alignbit(q[1], q[0], 16), __builtin_amdgcn_alignbit(q[2], q[1], 16),
+                            __builtin_amdgcn_alignbit(q[3], q[2], 16), __builtin_amdgcn_alignbit(q[4], q[3], 16)};
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(wg_bf16x8, b0), acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(wg_bf16x8, b1), acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(wg_bf16x8, b2), acc[2], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                                      // every wave is done reading this K-step's tiles
+    }
+    float* dst = partial + (size_t)blockIdx.x * (64 * 64 * 9);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[((wt * 9 + ky * 3 + t) * 16 + r) * 64 + lane] = acc[t][r];
+}
+
+using Ws56 = WsCfg<56, 2, 1>;
+using Ws28 = WsCfg<28, 4, 1>;
+using Ws14 = WsCfg<14, 7, 1>;
+using Ws7 = WsCfg<7, 7, 2>;
+
 static int wg_cus() {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -262,7 +440,29 @@ static int launch_wgrad(const float* gy, const float* x, float* dw, float* works
     return (int)hipGetLastError();
 }
 
+template <class C>
+static int launch_wgrad_split(const float* gy, const float* x, float* dw, float* workspace, int batch, int cin, int cout, hipStream_t st) {
+    if (cin % 64 || cout % 64 || batch <= 0) return (int)hipErrorInvalidValue;
+    const int nblk = (cin / 64) * (cout / 64), S = wg_splits(cin, cout);
+    (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_split_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    hipLaunchKernelGGL((conv3x3_wgrad_split_kernel<C>), dim3(nblk * S), dim3(768), C::LDS_BYTES, st, gy, x, workspace, batch, cin, cout, S);
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(nblk * 576), dim3(256), 0, st, workspace, dw, cin, cout, S);
+    return (int)hipGetLastError();
+}
+
 }  // namespace sc
+
+// sc_conv3x3_wgrad with fp32-accurate products on the bf16 matrix pipe (exact three-way bf16 split of both operands, six piece
+// products, fp32 accumulate): same arguments, workspace and summation order over the pixel ranges.
+extern "C" int sc_conv3x3_wgrad_split(const float* gy, const float* x, float* dw, float* workspace, int batch, int cin, int cout, int hw, void* stream) {
+    switch (hw) {
+        case 56: return sc::launch_wgrad_split<sc::Ws56>(gy, x, dw, workspace, batch, cin, cout, (hipStream_t)stream);
+        case 28: return sc::launch_wgrad_split<sc::Ws28>(gy, x, dw, workspace, batch, cin, cout, (hipStream_t)stream);
+        case 14: return sc::launch_wgrad_split<sc::Ws14>(gy, x, dw, workspace, batch, cin, cout, (hipStream_t)stream);
+        case 7: return sc::launch_wgrad_split<sc::Ws7>(gy, x, dw, workspace, batch, cin, cout, (hipStream_t)stream);
+        default: return -1;
+    }
+}
 
 extern "C" long long sc_conv3x3_wgrad_workspace_floats(int cin, int cout) {
     if (cin <= 0 || cout <= 0 || cin % 64 || cout % 64) return -1;

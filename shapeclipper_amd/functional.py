@@ -246,7 +246,7 @@ class Conv3x3Function(torch.autograd.Function):
         gw = None
         if ctx.needs_input_grad[1]:
             if ops.conv3x3_wgrad_supported(x.shape, w.shape):
-                gw = ops.conv3x3_backward_weight(gy, x)
+                gw = ops.conv3x3_backward_weight(gy, x, split=ctx.split)
             else:           # channel counts that are not multiples of 64: MIOpen
                 gw = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
         return gx, gw, None, None, None

@@ -786,8 +786,9 @@ def conv3x3_wgrad_supported(x_shape, w_shape, stride=1, padding=1) -> bool:
     return conv3x3_supported(x_shape, w_shape, stride, padding) and w_shape[0] % 64 == 0 and w_shape[1] % 64 == 0
 
 
-def conv3x3_backward_weight(gy, x):
-    """dL/dw [Cout, Cin, 3, 3] of F.conv2d(x, w, None, 1, 1) from gy [B, Cout, H, H] and x [B, Cin, H, H] (sc_conv3x3_wgrad)."""
+def conv3x3_backward_weight(gy, x, split=False):
+    """dL/dw [Cout, Cin, 3, 3] of F.conv2d(x, w, None, 1, 1) from gy [B, Cout, H, H] and x [B, Cin, H, H] (sc_conv3x3_wgrad).
+    split: fp32-accurate products on the bf16 matrix pipe (sc_conv3x3_wgrad_split), the arithmetic of the split forward pass."""
     lib = _lib.load()
     gy, x = _aligned(gy), _aligned(x)
     B, cout, H, _ = gy.shape
@@ -800,7 +801,8 @@ def conv3x3_backward_weight(gy, x):
     if ws is None or ws.numel() < n:
         ws = _conv_ws[key] = torch.empty(n, device=x.device, dtype=torch.float32)
     dw = torch.empty(cout, cin, 3, 3, device=x.device, dtype=torch.float32)
-    _lib.check(lib.sc_conv3x3_wgrad(_lib.ptr(gy), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(ws), B, cin, cout, H, _lib.stream()), "sc_conv3x3_wgrad")
+    fn = lib.sc_conv3x3_wgrad_split if split else lib.sc_conv3x3_wgrad
+    _lib.check(fn(_lib.ptr(gy), _lib.ptr(x), _lib.ptr(dw), _lib.ptr(ws), B, cin, cout, H, _lib.stream()), "sc_conv3x3_wgrad")
     return dw
 
 

@@ -109,6 +109,38 @@ def test_conv3x3_backward_weight(side, cin, cout, batch):
 
 
 @pytest.mark.parametrize("side,cin,cout,batch", [(56, 64, 64, 3), (28, 128, 128, 5), (14, 256, 256, 7), (7, 512, 512, 13), (7, 512, 512, 1),
+                                                  (14, 64, 128, 2), (28, 128, 64, 1), (56, 64, 64, 1), (7, 64, 64, 2), (14, 128, 64, 96), (7, 64, 64, 3)])
+def test_conv3x3_backward_weight_split_is_fp32_accurate(side, cin, cout, batch):
+    """sc_conv3x3_wgrad_split (both operands as exact three-piece bf16 splits, six products, fp32 accumulate): the fp32 kernel's bar
+    (2e-5 of the output scale against float64) on operands of mixed magnitudes, no worse than 2x the fp32-MFMA kernel on the same
+    tensors, bit-identical run to run, and a single hot pixel lands in exactly the nine taps it belongs to."""
+    from shapeclipper_amd import ops
+    torch.manual_seed(side + cin + batch)
+    dev = torch.device("cuda:0")
+    x = torch.randn(batch, cin, side, side, device=dev) * torch.rand(batch, cin, 1, 1, device=dev) * 4
+    gy = torch.randn(batch, cout, side, side, device=dev) * torch.rand(batch, cout, 1, 1, device=dev) * 1e-2
+    dw = ops.conv3x3_backward_weight(gy, x, split=True)
+    dw64 = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, 3, 3), gy.double(), 1, 1)
+    e_split, e_fp32 = _rel(dw.double(), dw64), _rel(ops.conv3x3_backward_weight(gy, x).double(), dw64)
+    print("conv3x3 wgrad split %dx%d %d>%d B=%d: %.2e of max (fp32 MFMA kernel: %.2e)" % (side, side, cin, cout, batch, e_split, e_fp32))
+    assert e_split < 2e-5 and e_split < 2 * e_fp32 + 1e-7
+    assert torch.equal(dw, ops.conv3x3_backward_weight(gy, x, split=True))
+    # one non-zero pixel in each operand: exact products, every (ky, kx) addressed on its own, borders and corners included
+    for (yy, xx) in ((0, 0), (side - 1, side - 1), (side // 2, side - 1), (side - 1, 0), (3, 2)):
+        x1, g1 = torch.zeros_like(x), torch.zeros_like(gy)
+        b = batch - 1
+        x1[b, 5, yy, xx] = 1.5
+        for ky in range(3):
+            for kx in range(3):
+                oy, ox = yy - ky + 1, xx - kx + 1          # output pixel that meets input (yy, xx) through tap (ky, kx)
+                if 0 <= oy < side and 0 <= ox < side:
+                    g1[b, 7, oy, ox] = float(1 + ky * 3 + kx)
+        d1 = ops.conv3x3_backward_weight(g1, x1, split=True)
+        ref = torch.nn.grad.conv2d_weight(x1.double(), (cout, cin, 3, 3), g1.double(), 1, 1).float()
+        assert torch.equal(d1, ref), (yy, xx)
+
+
+@pytest.mark.parametrize("side,cin,cout,batch", [(56, 64, 64, 3), (28, 128, 128, 5), (14, 256, 256, 7), (7, 512, 512, 13), (7, 512, 512, 1),
                                                   (14, 64, 128, 2), (28, 64, 72, 1), (56, 8, 64, 1)])
 def test_conv3x3_split_bf16_is_fp32_accurate(side, cin, cout, batch):
     """--hip.conv3x3_split: three-piece bf16 operands, six products, fp32 accumulate.  The bar is the fp32 kernels' own: 2e-5 of the
