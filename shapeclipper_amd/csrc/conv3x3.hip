@@ -459,7 +459,9 @@ __device__ __forceinline__ unsigned conv_bf16_piece(float v, int pc) {
 }
 // one 4-byte word of a packed filter image.  fp32: [tap][half][CT][4]: element (co = ct CT + cl, ci = 8 kb + 4 half + s).
 // split: [tap pair][piece][half][CT][8 bf16]: lane half h of tap pair tp holds tap 2 tp + h (tap 9 = zeros), channels 8 kb .. 8 kb + 7.
-__device__ __forceinline__ float conv_pack_word(const float* __restrict__ w, long long t, int CT, int nk, int cin, int cout, int flip,
+// (t is a 32-bit offset inside ONE filter's image: at most 512 x 512 x 10 x 3 / 2 words -- 64-bit divisions by the run-time CT / nk
+// made the all-filters pack kernel compute-bound: 284 us per network)
+__device__ __forceinline__ float conv_pack_word(const float* __restrict__ w, unsigned t, int CT, int nk, int cin, int cout, int flip,
                                                 bool split) {
     if (!split) {
         const int s4 = (int)(t & 3);
@@ -530,7 +532,7 @@ __global__ void conv3x3_pack_kernel(const float* __restrict__ w, float* __restri
     const int nk = cin / C::CB, nct = (cout + C::CT - 1) / C::CT;
     const long long total = (long long)nct * nk * C::WIMG;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
-        wpack[i] = conv_pack_word(w, i, C::CT, nk, cin, cout, transpose_flip, C::SPLIT);
+        wpack[i] = conv_pack_word(w, (unsigned)i, C::CT, nk, cin, cout, transpose_flip, C::SPLIT);
 }
 
 // Tile shapes (measured, tools/perf_conv.py): 8 waves of 64 x 64 each.  Four-wave workgroups, two per CU (NT = 256: 64 x 256 tiles) reach
@@ -572,7 +574,57 @@ __global__ void conv3x3_pack_multi_kernel(const long long* __restrict__ table_g,
         const long long* row = table + lo * 6;
         const float* w = reinterpret_cast<const float*>(row[0]);
         const int cin = (int)row[2], cout = (int)row[3], CT = (int)row[4], flags = (int)row[5];     // flags: 1 transpose_flip, 2 split
-        dst[i] = conv_pack_word(w, i - row[1], CT, cin / 8, cin, cout, flags & 1, (flags & 2) != 0);
+        dst[i] = conv_pack_word(w, (unsigned)(i - row[1]), CT, cin / 8, cin, cout, flags & 1, (flags & 2) != 0);
+    }
+}
+
+// The same for tables whose rows are all SPLIT images with 64-channel tiles (the default arithmetic): one workgroup per (filter, ct, kb)
+// unit = 64 output channels x 8 reduction channels x 9 taps.  The 4608 weights of a unit arrive in LDS through contiguous segments (72
+// floats per output channel; 576 per reduction channel in the transposed orientation) and leave as the unit's 7680 contiguous words
+// [tap pair][piece][half][64][4]: the word-driven kernel above gathers two weights per word from 64 different cache lines per wave.
+__global__ __launch_bounds__(256) void conv3x3_pack_multi_split_kernel(const long long* __restrict__ table_g, int n, float* __restrict__ dst) {
+    constexpr int CT = 64, UNIT = 5 * 3 * 2 * CT * 4, LST = 73;
+    __shared__ float wl[CT * LST];
+    __shared__ long long row_s[6];
+    const int tid = threadIdx.x;
+    const long long i0 = (long long)blockIdx.x * UNIT;
+    if (tid == 0) {
+        int lo = 0, hi = n - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (table_g[mid * 6 + 1] <= i0) lo = mid; else hi = mid - 1;
+        }
+        for (int k = 0; k < 6; ++k) row_s[k] = table_g[lo * 6 + k];
+    }
+    __syncthreads();
+    const float* w = reinterpret_cast<const float*>(row_s[0]);
+    const int cin = (int)row_s[2], cout = (int)row_s[3], flip = (int)row_s[5] & 1, nk = cin / 8;
+    const int unit = (int)((i0 - row_s[1]) / UNIT), ct = unit / nk, kb = unit - ct * nk;
+    for (int e = tid; e < 8 * CT * 9; e += 256) {
+        int cl, sc, tap;
+        float v = 0.f;
+        if (flip) {      // w[ci][co][8 - tap]: per reduction channel 64 x 9 contiguous floats
+            sc = e / (CT * 9);
+            const int r = e - sc * (CT * 9);
+            cl = r / 9; tap = 8 - (r - cl * 9);
+            if (ct * CT + cl < cout) v = w[((size_t)(kb * 8 + sc) * cout + ct * CT) * 9 + r];
+        } else {         // w[co][ci][tap]: per output channel 8 x 9 contiguous floats
+            cl = e / 72;
+            const int r = e - cl * 72;
+            sc = r / 9; tap = r - sc * 9;
+            if (ct * CT + cl < cout) v = w[((size_t)(ct * CT + cl) * cin + kb * 8) * 9 + r];
+        }
+        wl[cl * LST + sc * 9 + tap] = v;
+    }
+    __syncthreads();
+    for (int v = tid; v < UNIT; v += 256) {
+        const int wi = v & 3, cl = (v >> 2) & 63, h = (v >> 8) & 1, q = v >> 9, pc = q % 3, tp = q / 3, tap = 2 * tp + h;
+        unsigned lo = 0, hi = 0;
+        if (tap < 9) {
+            lo = conv_bf16_piece(wl[cl * LST + (2 * wi) * 9 + tap], pc);
+            hi = conv_bf16_piece(wl[cl * LST + (2 * wi + 1) * 9 + tap], pc);
+        }
+        dst[i0 + v] = __uint_as_float(lo | (hi << 16));
     }
 }
 
@@ -733,6 +785,14 @@ extern "C" int sc_conv3x3_tile_channels(int hw) {
 #define CALL(C) C::CT
     SC_CONV_DISPATCH(hw, CALL)
 #undef CALL
+}
+
+// `unit_form` != 0: the caller guarantees that every row is a split image with 64-channel tiles (flags & 2, CT = 64): the unit kernel.
+extern "C" int sc_conv3x3_pack_multi_units(const long long* table, int n, float* dst, long long total, void* stream) {
+    if (n <= 0 || total <= 0) return 0;
+    if (n > 128 || total % 7680) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(sc::conv3x3_pack_multi_split_kernel, dim3((unsigned)(total / 7680)), dim3(256), 0, (hipStream_t)stream, table, n, dst);
+    return (int)hipGetLastError();
 }
 
 extern "C" int sc_conv3x3_pack_multi(const long long* table, int n, float* dst, long long total, void* stream) {

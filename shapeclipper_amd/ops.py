@@ -969,6 +969,8 @@ class Conv3x3PackSet:
             raise RuntimeError("shapeclipper_amd: Conv3x3PackSet holds at most 64 filters (sc_conv3x3_pack_multi table limit)")
         dev = self.weights[0].device
         self.total = off
+        # all rows split images with 64-channel tiles: the unit-per-workgroup pack kernel (coalesced reads, contiguous writes)
+        self.units = bool(split) and all(r[4] == 64 for r in rows) and off % 7680 == 0
         self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
         self.buf = torch.empty(off, device=dev, dtype=torch.float32)
         self.index = {id(w): k for k, w in enumerate(self.weights)}
@@ -978,8 +980,9 @@ class Conv3x3PackSet:
         return any(w.data_ptr() != p for w, p in zip(self.weights, self.ptrs))
 
     def refresh(self):
-        _lib.check(_lib.load().sc_conv3x3_pack_multi(_lib.ptr(self.table), len(self.where), _lib.ptr(self.buf), self.total, _lib.stream()),
-                   "sc_conv3x3_pack_multi")
+        lib = _lib.load()
+        fn = lib.sc_conv3x3_pack_multi_units if self.units else lib.sc_conv3x3_pack_multi
+        _lib.check(fn(_lib.ptr(self.table), len(self.where), _lib.ptr(self.buf), self.total, _lib.stream()), "sc_conv3x3_pack_multi")
 
     def get(self, w, flip):
         off, n = self.where[(self.index[id(w)], int(flip))]

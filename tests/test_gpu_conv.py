@@ -81,12 +81,28 @@ def test_pack_set_equals_single_packs():
     dev = torch.device("cuda:0")
     items = [(torch.randn(64, 64, 3, 3, device=dev), 56), (torch.randn(128, 128, 3, 3, device=dev), 28), (torch.randn(72, 64, 3, 3, device=dev), 28),
              (torch.randn(256, 256, 3, 3, device=dev), 14), (torch.randn(512, 512, 3, 3, device=dev), 7)]
-    packs = ops.Conv3x3PackSet(items)
-    packs.refresh()
-    for w, side in items:
-        for flip in (False, True):
-            assert torch.equal(packs.get(w, flip), ops.conv3x3_pack(w, side, flip)), (tuple(w.shape), side, flip)
-    assert not packs.stale()
+    for split in (False, True):         # split: the unit-per-workgroup kernel (sc_conv3x3_pack_multi_units), also on a 72-channel filter
+        packs = ops.Conv3x3PackSet(items, split=split)
+        assert packs.units == split
+        packs.buf.fill_(float("nan"))
+        packs.refresh()
+        for w, side in items:
+            for flip in (False, True):
+                a, b = packs.get(w, flip), ops.conv3x3_pack(w, side, flip, split)
+                assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (tuple(w.shape), side, flip, split)
+        assert not packs.stale()
+    import time
+    big = [(torch.randn(c, c, 3, 3, device=dev), s) for c, s, k in ((64, 56, 6), (128, 28, 7), (256, 14, 11), (512, 7, 5)) for _ in range(k)]
+    packs = ops.Conv3x3PackSet(big, split=True)
+    for fn in ("units", "words"):
+        packs.units = fn == "units"
+        packs.refresh(); torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(5):
+            packs.refresh()
+        e.record(); torch.cuda.synchronize()
+        print("ResNet-34 filter pack (%s kernel): %.1f us" % (fn, s.elapsed_time(e) / 5 * 1e3))
 
 
 @pytest.mark.parametrize("side,cin,cout,batch", [(56, 64, 64, 3), (28, 128, 128, 5), (14, 256, 256, 7), (7, 512, 512, 13), (7, 512, 512, 1),
