@@ -203,7 +203,7 @@ def main():
         sustained = dict(steps=a.sustained, ms_per_step=round(sdt / a.sustained * 1e3, 3),
                          value=round(a.batch * world / (sdt / a.sustained), 2))
     # `value` above is measured in the default arithmetic (round 3, VERDICT r02 ruling): every product of the step is an fp32 product
-    # with fp32 accumulation; the forward / backward-data products of the 3x3 stride-1 convolutions are evaluated on the bf16 matrix
+    # with fp32 accumulation; the forward / backward-data / backward-weight products of the 3x3 stride-1 convolutions are evaluated on the bf16 matrix
     # pipe from exact three-piece operand splits (x = p0 + p1 + p2, six exact piece products summed in fp32: error against float64 no
     # larger than the fp32-MFMA kernels', tests/test_gpu_conv.py), everything else on the fp32 matrix pipe.  Second measurement: the
     # same step with `--hip.conv3x3_split!`, i.e. fp32 MFMA instructions throughout.
@@ -222,7 +222,7 @@ def main():
             torch.cuda.synchronize()
             adt = (time.time() - t1) / a.alt_steps
             alt = dict(steps=a.alt_steps, ms_per_step=round(adt * 1e3, 3), value=round(a.batch / adt, 2), dtype="f32 (fp32 MFMA throughout)",
-                       note="same step with --hip.conv3x3_split!: the 3x3 convolution forward/backward-data products on v_mfma_f32_32x32x2_f32 "
+                       note="same step with --hip.conv3x3_split!: the 3x3 convolution forward / backward-data / backward-weight products on v_mfma_f32_32x32x2_f32 "
                             "instead of the exact bf16x3 split; not the headline")
         finally:
             resnet.HIP_CONV3X3_SPLIT = True
@@ -301,7 +301,7 @@ def main():
                    dtype="f32 (bf16x3-split MFMA, fp32 accumulate)" if split_default else "f32", data="synthetic",
                    config=dict(workload="Pix3D train step: bs32/GPU, 224x224 inputs, 512 rays x 64 samples, 2 renders "
                                         "(input + CLIP-NN view) + eikonal, ResNet-34 encoder + ResNet-18 estimator, Adam; fp32 arithmetic "
-                                        "throughout" + ("; the 3x3 stride-1 convolution forward/backward-data products run on the bf16 matrix pipe "
+                                        "throughout" + ("; the 3x3 stride-1 convolution products (forward, backward-data, backward-weight) run on the bf16 matrix pipe "
                                                         "from exact 3-piece operand splits with fp32 accumulation (fp32-accurate), all other "
                                                         "products on fp32 MFMA" if split_default else " (fp32 MFMA)"),
                                global_batch=a.batch * world, rays_per_image=opt.render.rand_sample, samples_per_ray=64,

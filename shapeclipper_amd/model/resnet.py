@@ -18,7 +18,7 @@ HIP_CONV_STEM = True      # the 7x7 / 2 stem on csrc/conv_stem.hip (`--hip.conv_
 HIP_CONV3X3_S2 = True    # forward of the 3x3 / stride-2 conv1 of layer2-4 on the stride-2 instance of conv3x3.hip (`--hip.conv3x3s2!`)
 HIP_CONV3X3_S2_GRADS = True  # ... and their two gradients on conv3x3.hip (four parity sub-convolutions) / conv3x3_wgrad.hip (`--hip.conv3x3s2_grads!`: MIOpen)
 HIP_CONV_1X1 = True       # the 1x1 / stride-2 shortcuts on csrc/conv1x1s2.hip (`--hip.conv1x1!`)
-HIP_CONV3X3_SPLIT = True  # their forward / backward-data products on the bf16 matrix pipe from exact three-piece operand splits, fp32 accumulate
+HIP_CONV3X3_SPLIT = True  # their forward / backward-data / backward-weight products on the bf16 matrix pipe from exact three-piece operand splits, fp32 accumulate
                           # (default since round 3, VERDICT r02 ruling; `--hip.conv3x3_split!` selects the fp32-MFMA kernels)
 
 

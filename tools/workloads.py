@@ -268,7 +268,7 @@ def resnet_conv3x3(with_cpu=True):
     for layers, batch in (([2, 2, 2, 2], 96), ([3, 4, 6, 3], 64)):       # view estimator: 3 x 32 images, encoder: 2 x 32
         for li, (c, side) in enumerate(((64, 56), (128, 28), (256, 14), (512, 7))):
             shapes.append((c, side, batch, 2 * layers[li] - (1 if li else 0)))
-    ms_split = ms_f32 = ms_wg = ms_lib = flop1 = 0.0
+    ms_split = ms_f32 = ms_wg = ms_wgs = ms_lib = flop1 = 0.0
     rows = []
     for c, side, batch, count in shapes:
         x = torch.randn(batch, c, side, side, device=dev)
@@ -278,7 +278,8 @@ def resnet_conv3x3(with_cpu=True):
         ws_f, ws_b = ops.conv3x3_pack(w, side, False, True), ops.conv3x3_pack(w, side, True, True)
         t = [_gpu_ms(f, iters=10)[0] for f in (lambda: ops.conv3x3_apply(x, wp_f, c), lambda: ops.conv3x3_apply(gy, wp_b, c),
                                                lambda: ops.conv3x3_backward_weight(gy, x))]
-        ts = [_gpu_ms(f, iters=10)[0] for f in (lambda: ops.conv3x3_apply(x, ws_f, c, True), lambda: ops.conv3x3_apply(gy, ws_b, c, True))]
+        ts = [_gpu_ms(f, iters=10)[0] for f in (lambda: ops.conv3x3_apply(x, ws_f, c, True), lambda: ops.conv3x3_apply(gy, ws_b, c, True),
+                                                lambda: ops.conv3x3_backward_weight(gy, x, split=True))]
         bw = lambda m: torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, m)
         tl = [_gpu_ms(f, iters=10)[0] for f in (lambda: torch.nn.functional.conv2d(x, w, None, 1, 1), lambda: bw([True, False, False]),
                                                 lambda: bw([False, True, False]))]
@@ -286,27 +287,27 @@ def resnet_conv3x3(with_cpu=True):
         ms_split += count * sum(ts)
         ms_f32 += count * (t[0] + t[1])
         ms_wg += count * t[2]
+        ms_wgs += count * ts[2]
         ms_lib += count * sum(tl)
         flop1 += count * f1
         rows.append(dict(channels=c, side=side, batch=batch, layers=count, split_ms=[round(v, 3) for v in ts], fp32_mfma_ms=[round(v, 3) for v in t],
                          miopen_ms=[round(v, 3) for v in tl], split_tflops=[round(f1 / v / 1e9, 1) for v in ts],
                          fp32_mfma_tflops=[round(f1 / v / 1e9, 1) for v in t]))
         del x, w, gy
-    ms_hip = ms_split + ms_wg
-    tf_s, tf_w, tf_f = 2 * flop1 / (ms_split * 1e-3) / 1e12, flop1 / (ms_wg * 1e-3) / 1e12, 2 * flop1 / (ms_f32 * 1e-3) / 1e12
+    ms_hip = ms_split                      # the product path: all three products in split arithmetic
+    tf_s, tf_ws = 3 * flop1 / (ms_split * 1e-3) / 1e12, flop1 / (ms_wgs * 1e-3) / 1e12
+    tf_w, tf_f = flop1 / (ms_wg * 1e-3) / 1e12, 2 * flop1 / (ms_f32 * 1e-3) / 1e12
     out = dict(workload="3x3 stride-1 convolutions of one bs32 step (ResNet-34 encoder x 64 images, ResNet-18 estimator x 96): fwd + bwd-data + bwd-weight of 42 layers",
-               ms=round(ms_hip, 3), ms_miopen=round(ms_lib, 3), algorithmic_flop=3 * flop1, achieved=round(3 * flop1 / (ms_hip * 1e-3) / 1e12, 2),
-               unit="TFLOP/s", dtype="f32 (forward / backward-data: bf16x3-split MFMA, fp32 accumulate; backward-weight: fp32 MFMA)",
-               forward_backward_data=dict(ms=round(ms_split, 3), achieved=round(tf_s, 2), peak=round(PEAK_SPLIT, 1), unit="TFLOP/s",
-                                          bound="bf16 MFMA / 6 (exact 3-piece split: six bf16 products per fp32 product)",
-                                          frac=round(tf_s / PEAK_SPLIT, 4)),
-               backward_weight=dict(ms=round(ms_wg, 3), achieved=round(tf_w, 2), peak=PEAK_FP32, unit="TFLOP/s", bound="fp32 MFMA",
-                                    frac=round(tf_w / PEAK_FP32, 4)),
+               ms=round(ms_hip, 3), ms_miopen=round(ms_lib, 3), algorithmic_flop=3 * flop1, achieved=round(tf_s, 2), peak=round(PEAK_SPLIT, 1),
+               unit="TFLOP/s", dtype="f32 (bf16x3-split MFMA, fp32 accumulate, all three products)",
+               bound="bf16 MFMA / 6 (exact 3-piece split: six bf16 products per fp32 product)", frac=round(tf_s / PEAK_SPLIT, 4),
+               backward_weight=dict(ms=round(ms_wgs, 3), achieved=round(tf_ws, 2), peak=round(PEAK_SPLIT, 1), unit="TFLOP/s",
+                                    bound="bf16 MFMA / 6", frac=round(tf_ws / PEAK_SPLIT, 4)),
+               fp32_mfma_backward_weight=dict(ms=round(ms_wg, 3), achieved=round(tf_w, 2), peak=PEAK_FP32, unit="TFLOP/s", bound="fp32 MFMA",
+                                              frac=round(tf_w / PEAK_FP32, 4), note="--hip.conv3x3_split!"),
                fp32_mfma_forward_backward_data=dict(ms=round(ms_f32, 3), achieved=round(tf_f, 2), peak=PEAK_FP32, unit="TFLOP/s", bound="fp32 MFMA",
                                                     frac=round(tf_f / PEAK_FP32, 4), note="--hip.conv3x3_split!"),
-               # one number for the table: time-weighted fraction of the two roofs
-               frac=round((ms_split * (tf_s / PEAK_SPLIT) + ms_wg * (tf_w / PEAK_FP32)) / ms_hip, 4), peak=None,
-               bound="bf16 MFMA / 6 (fwd, bwd-data) + fp32 MFMA (bwd-weight), time-weighted", layers=rows)
+               layers=rows)
     if with_cpu:
         torch.set_num_threads(cpu_threads())
         c, side, batch = 128, 28, 8
