@@ -148,7 +148,8 @@ __device__ __forceinline__ void bn_forward_stats(const BnStatArgs& a, int c, con
         float s1, s2;
         combine_partials(a.partial, c, g, sh.S, a.G, s1, s2);
         const float dm = s1 / n;
-        var = fmaxf(s2 / n - dm * dm, 0.f);
+        const float v0 = s2 / n - dm * dm;
+        var = v0 < 0.f ? 0.f : v0;                 // (not fmaxf: a NaN variance stays NaN, as in torch)
         m = a.x[((size_t)g * sh.Ng * a.C + c) * a.HW] + dm;
     };
     if (a.training) {
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(BN_T) void bn_apply_fwd_kernel(BnFwdArgs a) {
         }
         if (a.relu) {
 #pragma unroll
-            for (int k = 0; k < W; ++k) v.v[k] = fmaxf(v.v[k], 0.f);
+            for (int k = 0; k < W; ++k) v.v[k] = v.v[k] < 0.f ? 0.f : v.v[k];      // relu(NaN) = NaN, as torch (fmaxf would return 0)
         }
         v.st(a.y + off);
     });
@@ -225,10 +226,10 @@ __device__ __forceinline__ Vec<W> bn_masked_grad(const BnBwdArgs& a, size_t off,
         if (a.has_res) {
             const auto yv = Vec<W>::ld(a.y + off);
 #pragma unroll
-            for (int k = 0; k < W; ++k) g.v[k] = yv.v[k] > 0.f ? g.v[k] : 0.f;
+            for (int k = 0; k < W; ++k) g.v[k] = yv.v[k] <= 0.f ? 0.f : g.v[k];        // threshold_backward: a NaN output passes its gradient
         } else {
 #pragma unroll
-            for (int k = 0; k < W; ++k) g.v[k] = fmaf(xv.v[k], scale, shift) > 0.f ? g.v[k] : 0.f;
+            for (int k = 0; k < W; ++k) g.v[k] = fmaf(xv.v[k], scale, shift) <= 0.f ? 0.f : g.v[k];
         }
     }
     return g;
@@ -323,8 +324,8 @@ __global__ __launch_bounds__(BN_T) void bn_relu_pool_fwd_kernel(PoolFwdArgs a) {
             for (int dw = 0; dw < 3; ++dw) {
                 const int w = 2 * wo - 1 + dw;
                 if (w < 0 || w >= a.W) continue;
-                const float v = fmaxf(fmaf(xp[h * a.W + w], scale, shift), 0.f);
-                if (v > best || bi < 0) {          // strict >: first maximum in scan order
+                const float u = fmaf(xp[h * a.W + w], scale, shift), v = u < 0.f ? 0.f : u;       // relu(NaN) = NaN
+                if (v > best || bi < 0 || v != v) {          // strict >: first maximum in scan order; a NaN wins like in torch's max_pool2d
                     best = v;
                     bi = h * a.W + w;
                 }

@@ -180,12 +180,15 @@ class Runner:
             self.reducer.broadcast_buffers()
         else:
             optim.zero_grad()
-        self.check_finite()                   # the PREVIOUS step's flag (copied to pinned memory asynchronously): long there
         var, loss = self.graph.forward(opt, var, training=True, get_loss=True)
         loss = self.summarize_loss(opt, var, loss, non_act_loss_key=frozen_keys, defer_check=True)
         loss.all.backward()
         if self.reducer is not None:
             self.reducer.all_reduce()
+        # The reference asserts on NaN / Inf losses before it back-propagates (runner.py:296-302).  Here the flag left for pinned memory
+        # right after the forward pass; reading it now -- the whole backward pass is queued behind it, so the GPU has ~20 ms of work while
+        # the host waits for an event that is usually long complete -- keeps the weights and the Adam state of a poisoned step untouched.
+        self.check_finite()
         optim.step()
 
         if _rank0(opt):
@@ -251,9 +254,9 @@ class Runner:
             assert not torch.isnan(v), "loss {} is NaN".format(key)
 
     def check_finite(self, loss=None):
-        """Raise the reference's NaN/Inf assertions (runner.py:296-302) for the step whose flag is pending.  The training
-        loop calls this at the start of the NEXT iteration (and before a checkpoint / at the end of an epoch), when the
-        flag has long arrived in pinned memory: the host never waits for the stream inside a step."""
+        """Raise the reference's NaN/Inf assertions (runner.py:296-302) for the step whose flag is pending.  train_iteration
+        calls this between the (queued) backward pass and the optimizer step: the flag was copied to pinned memory right after
+        the forward pass, so the wait is for an event that has usually completed, and never for the backward pass."""
         pending, self._pending_check = getattr(self, "_pending_check", None), None
         if pending is not None:
             host, done, pending_loss = pending

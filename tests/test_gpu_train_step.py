@@ -46,6 +46,44 @@ def test_two_training_iterations():
     pickle.dumps(runner.graph.state_dict())
 
 
+def test_non_finite_loss_raises_before_the_optimizer_step():
+    """The reference asserts on NaN / Inf losses in summarize_loss, before backward (runner.py:296-302).  Here the flag is read between the
+    queued backward pass and optim.step(): the assertion names the loss, and neither the weights nor the Adam state of the poisoned step
+    change; the next (clean) step trains normally."""
+    from shapeclipper_amd import synthetic
+    from shapeclipper_amd.model.runner import Runner
+    from shapeclipper_amd.utils import options, util
+    from shapeclipper_amd.utils.util import EasyDict as edict
+    opt = options.set(options.parse_arguments(["--yaml=options/pix3d/config.yaml", "--name=pytest_nan", "--output_root=/tmp/sc_pytest",
+                                               "--batch_size=2", "--tb!", "--arch.enc_pretrained!"]), verbose=False)
+    opt.device, opt.world_size, opt.port = 0, 1, 0
+    opt.freq.scalar, opt.freq.ckpt_latest = 0, 10 ** 9
+    torch.manual_seed(0)
+    runner = Runner(opt)
+    runner.build_networks(opt)
+    runner.setup_optimizer(opt)
+    runner.graph.train()
+    runner.it, runner.ep, runner.best_val = 1, 0, 0.0
+    runner.timer = edict(start=time.time(), it_mean=None)
+    batch = util.move_to_device(synthetic.make_batch(opt, 2, seed=0), "cuda:0")
+    opt.H, opt.W = opt.image_size
+    runner.train_iteration(opt, edict(batch), None)                    # one clean step: the Adam state exists
+    g = runner.graph.module
+    state = lambda: ({n: p.detach().clone() for n, p in g.named_parameters()},
+                     [v["exp_avg"].clone() for v in runner.optim_full.state.values() if "exp_avg" in v])
+    poisoned = edict(batch)
+    poisoned.rgb_input_map = batch["rgb_input_map"].clone()
+    poisoned.rgb_input_map[0, 0, 5, 5] = float("nan")                 # through the encoders into every loss
+    before_p, before_m = state()
+    with pytest.raises(AssertionError, match="is NaN|is Inf"):
+        runner.train_iteration(opt, poisoned, None)
+    after_p, after_m = state()
+    assert all(torch.equal(after_p[n], before_p[n]) for n in before_p), "weights were updated by a non-finite step"
+    assert all(torch.equal(a, b) for a, b in zip(after_m, before_m)), "Adam moments were updated by a non-finite step"
+    loss = runner.train_iteration(opt, edict(batch), None)             # BatchNorm running statistics are poisoned like in the reference;
+    assert set(loss.keys()) >= {"render", "all"}                       # the step itself runs (training-mode BN uses batch statistics)
+
+
 def test_batched_encoder_passes_equal_sequential_passes():
     """hip.batched_encoders (one grouped encoder pass + one grouped estimator pass per step) gives the losses,
     gradients and BatchNorm running statistics of the reference's five separate passes."""
