@@ -626,6 +626,99 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
     }
 }
 
+// T <= 64 (ViT-B/32: 50 tokens): the whole key range is two 32-key chunks, so nothing has to be walked twice.  Two waves per (image, head)
+// -- one per 32-query block; the four-wave kernel above left two of them idle here -- request Q and ALL K fragments in one round
+// trip, keep both score tiles in registers, take the softmax statistics from them and feed P straight into P V: one pass, 8 + 8 MFMAs per
+// wave.  (The general kernel recomputes S in its second pass and re-reads K from global memory: 45 us per layer at batch 256.)
+template <bool H16>
+__global__ __launch_bounds__(128) void attention_small_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int T, int D,
+                                                              int heads, float scale) {
+    constexpr int Tp = 64, ldv = Tp + 4;
+    __shared__ bf16_t Vt[64 * ldv];                   // V transposed: [head dim][key]
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
+    const size_t rs = (size_t)3 * D;
+    const bf16_t* base = qkv + (size_t)b * T * rs + (size_t)hd * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 31, h = lane >> 5;
+    auto frag = [&](int row, int col_off) -> bf16x8 {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < T) v = *reinterpret_cast<const uint4*>(base + (size_t)row * rs + col_off + 8 * h);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    const int q = wave * 32 + n;
+    bf16x8 qf[4], kf[2][4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        qf[s4] = frag(q, 16 * s4);
+        kf[0][s4] = frag(n, D + 16 * s4);
+        kf[1][s4] = frag(32 + n, D + 16 * s4);
+    }
+    for (int e = threadIdx.x; e < Tp * 8; e += 128) {
+        const int key = e >> 3, dc = (e & 7) * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (key < T) v = *reinterpret_cast<const uint4*>(base + (size_t)key * rs + 2 * D + dc);
+        const bf16_t* pv = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Vt[(dc + j) * ldv + key] = pv[j];
+    }
+    const float NEG = -3.0e38f;
+    float v[2][16];
+    float m = NEG;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) S = mfma16<H16>(kf[c][s4], qf[s4], S);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * h;
+            v[c][r] = key < T ? S[r] * scale : NEG;
+            m = fmaxf(m, v[c][r]);
+        }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            v[c][r] = v[c][r] > NEG ? __expf(v[c][r] - m) : 0.f;
+            l += v[c][r];
+        }
+    l += __shfl_xor(l, 32);
+    const float inv = 1.f / l;
+    __syncthreads();                                   // Vt is complete
+    f32x16 O[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[t][r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bf16_t tmp[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tmp[e] = cvt16<H16>(v[c][8 * j + e] * inv);
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, tmp);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const bf16_t* vp = Vt + (32 * t + n) * ldv + 32 * c + 16 * j + 4 * h;
+                const uint2 lo = *reinterpret_cast<const uint2*>(vp), hi = *reinterpret_cast<const uint2*>(vp + 8);
+                const uint4 pk = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                O[t] = mfma16<H16>(pf, __builtin_bit_cast(bf16x8, pk), O[t]);
+            }
+        }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qq = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (qq < T) out[((size_t)b * T + qq) * D + hd * 64 + 32 * t + n] = cvt16<H16>(O[t][r]);
+        }
+}
+
 template <bool H16>
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = cvt16<H16>(x[i]);
@@ -719,7 +812,8 @@ static int clip_vit_forward(const float* image, int B, int C, int H, int W, int 
         const float* b_fc2 = wf; wf += D;
         hipLaunchKernelGGL((layernorm_kernel<true, H16>), dim3((M + 3) / 4), dim3(256), 0, st, x, D, ln1_g, ln1_b, (void*)xn, M, D, ln_eps);
         if ((rc = launch_gemm<H16>(EPI_BF16, xn, w_qkv, b_qkv, qkv, M, 3 * D, D, st))) return rc;
-        hipLaunchKernelGGL(attention_kernel<H16>, dim3(B * heads), dim3(256), att_lds, st, qkv, att, T, D, heads, 0.125f);
+        if (T <= 64 && T > 32) hipLaunchKernelGGL(attention_small_kernel<H16>, dim3(B * heads), dim3(128), 0, st, qkv, att, T, D, heads, 0.125f);
+        else hipLaunchKernelGGL(attention_kernel<H16>, dim3(B * heads), dim3(256), att_lds, st, qkv, att, T, D, heads, 0.125f);
         if ((rc = launch_gemm<H16>(EPI_RESID, att, w_o, b_o, x, M, D, D, st))) return rc;
         hipLaunchKernelGGL((layernorm_kernel<true, H16>), dim3((M + 3) / 4), dim3(256), 0, st, x, D, ln2_g, ln2_b, (void*)xn, M, D, ln_eps);
         if ((rc = launch_gemm<H16>(EPI_GELU_BF16, xn, w_fc1, b_fc1, hbuf, M, mlp, D, st))) return rc;
