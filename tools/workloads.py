@@ -29,6 +29,7 @@ if ROOT not in sys.path:
 
 PEAK_FP32 = 157.3       # TFLOP/s, fp32 vector = fp32 MFMA dense peak
 PEAK_BF16 = 2500.0      # TFLOP/s, bf16 MFMA dense peak
+PEAK_HBM_GBPS = 8000.0  # GB/s, HBM3E (MI355X_MICROARCH.md)
 PEAK_SPLIT = PEAK_BF16 / 6   # fp32-equivalent roof of the exact bf16x3 split: six bf16 MFMA products per fp32 product (416.7 TFLOP/s)
 CHAMFER_FLOP_PER_PAIR = 8
 VIT_B32_GFLOP = 8.725
@@ -256,6 +257,28 @@ def level_grid_100(with_cpu=True):
     return out
 
 
+def marching_cubes_100(B=32):
+    """Evaluation meshing on the device (utils/eval_3D.py:123-153 in the reference: PyMCubes + trimesh on CPU threads): marching cubes of
+    B level grids at vox_res = 100 (count, prefix sum, emit) and 100,000 area-uniform surface samples per image."""
+    from shapeclipper_amd import ops
+    from shapeclipper_amd.utils import eval_3D
+    S = 101
+    ax = torch.linspace(-0.6, 0.6, S, device="cuda")
+    X, Y, Z = torch.meshgrid(ax, ax, ax, indexing="ij")
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    r = 0.25 + 0.2 * torch.rand(B, 1, 1, 1, device="cuda", generator=gen)
+    level = (torch.sqrt(X * X + Y * Y + 1.3 * Z * Z)[None] - r + 0.04 * torch.sin(9 * X)[None] * torch.cos(7 * Y)[None]).contiguous()
+    tris, per = ops.isosurface_triangles(level, 0.0)
+    ms, best = _gpu_ms(lambda: ops.isosurface_triangles(level, 0.0), iters=10)
+    ms_s, _ = _gpu_ms(lambda: eval_3D.surface_points_device(level, -0.6, 0.6, 100000, seed=1), iters=3, warm=1)
+    nbytes = 4.0 * B * S ** 3 + 36.0 * tris.shape[0] + 12.0 * B * (S - 1) ** 3     # grid read, triangles written, counts + offsets
+    return dict(workload="marching cubes of %d level grids at vox_res=100 (%d triangles) + 100,000 surface samples per image" % (B, tris.shape[0]),
+                ms=round(ms, 3), ms_best=round(best, 3), algorithmic_bytes=nbytes, achieved=round(nbytes / (ms * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBPS,
+                unit="GB/s", bound="hbm / latency (count + cumsum + emit; one host read of the per-image triangle counts)",
+                frac=round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), mcubes_per_s=round(B * (S - 1) ** 3 / (ms * 1e-3) / 1e6, 1),
+                with_sampling_ms=round(ms_s, 3), triangles_per_image=int(tris.shape[0] // B))
+
+
 def resnet_conv3x3(with_cpu=True):
     """csrc/conv3x3.hip + conv3x3_wgrad.hip on every 3x3 / stride-1 layer shape of the two trunks, weighted by how often a step runs
     it, with MIOpen (torch's operators) on the same tensors beside it.  Default arithmetic: forward / backward-data from exact
@@ -323,7 +346,7 @@ def run_all(with_cpu=True):
     for name, fn in (("chamfer_b1", lambda: chamfer(1, with_cpu=with_cpu)), ("chamfer_b32", lambda: chamfer(32, with_cpu=False)),
                      ("clip_vit_b32", lambda: clip_vit(32, with_cpu=with_cpu)), ("clip_vit_b32_batch256", lambda: clip_vit(256, with_cpu=False)),
                      ("clip_vit_l14_b32", lambda: clip_vit(32, with_cpu=False, model="ViT-L/14")), ("render_eval_128", lambda: render_eval_128(32, with_cpu=with_cpu)),
-                     ("level_grid_100", lambda: level_grid_100(with_cpu=with_cpu)),
+                     ("level_grid_100", lambda: level_grid_100(with_cpu=with_cpu)), ("marching_cubes_100", lambda: marching_cubes_100(32)),
                      ("resnet_conv3x3", lambda: resnet_conv3x3(with_cpu=with_cpu))):
         out[name] = fn()
         torch.cuda.empty_cache()
