@@ -291,6 +291,167 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 4) void gemm_bf16_kernel(const
         }
 }
 
+// 256 x 256 x 64 tiles for the large shapes (M >= 2048 tokens, N a multiple of 256).  Why: the 128 x 128 kernels run at 600-700 TFLOP/s whatever
+// the problem size (M = 51,200 included) with the matrix pipe ~30 % busy, the LDS read port 15 % busy and no bank conflicts (PMC) -- what
+// they saturate is the L2 -> LDS path: a 128 x 128 tile pulls 32 KB per 512 MFMA cycles and SIMD, i.e. ~10 TB/s chip-wide at that rate.  A
+// 256 x 256 tile needs half the operand bytes per FLOP.  Eight waves as 4 (M) x 2 (N), each 64 x 128 = 2 x 4 MFMA tiles (128 accumulator
+// registers); per K sub-step a wave reads 2 + 4 fragments for 8 MFMAs.  128 KB of LDS stages, one workgroup per CU, the same LDS-DMA
+// addressing and single barrier per K-step as above.  Measured on the way (M = 51,200, fp16): this kernel 700-820 TFLOP/s against 620-720 of
+// the 128 x 128 persistent kernel; four 32 KB stages (K-step 32, three batches in flight) 5 % SLOWER than two 64 KB stages; the same kernel
+// without its LDS-DMA instructions 890-1,150, without its MFMAs 860-970: operand delivery and matrix work cost about the same and overlap
+// only partly -- an LDS-DMA piece occupies its wave for 60-185 issue cycles (MI355X_MICROARCH.md), 8 pieces per wave and K-step against 32
+// MFMAs.  Operands through registers (global_load_dwordx4 + ds_write_b128) ended up in scratch memory under hipcc (2.6x slower) and was dropped.  The epilogue stages the tile through the free LDS: 16-bit outputs at
+// once, fp32 outputs in two 128-row halves.
+#ifndef SC_GEMM256_BK
+#define SC_GEMM256_BK 64
+#endif
+
+template <int EPI, bool H16>
+__global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt, const float* __restrict__ bias,
+                                                         void* __restrict__ out, int M, int N, int K) {
+    // K-step BK = 64: two 64 KB stages (one batch in flight); BK = 32: four 32 KB stages (three batches in flight -- what hides the DMA
+    // round trip when there is ONE workgroup per CU).  Rows of BK / 8 sixteen-byte chunks; the XOR swizzle of the chunk slot is
+    // (row >> 1) & 7 for 8-chunk rows (as above) and (row >> 2) & 3 for 4-chunk rows (same service groups, same argument).
+    constexpr int BT = 256, BK = SC_GEMM256_BK, CPR = BK / 8, CH = BT * CPR, QN = CH / 512, NS = 128 * 1024 / (2 * CH * 16), PD = NS - 1, KK = BK / 16;
+    static_assert(BK == 64 || BK == 32, "K-step");
+    extern __shared__ uint4 Sbuf[];            // [NS stages][A: 256 rows x CPR chunks | B: 256 rows x CPR chunks]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int ntn = gridDim.x, tiles = gridDim.x * gridDim.y;
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, idx = lin >> 3;
+    const int tq = tiles >> 3, trem = tiles & 7;
+    const int tile = (xcd < trem ? xcd * (tq + 1) : trem * (tq + 1) + (xcd - trem) * tq) + idx;
+    const int bm = (tile / ntn) * BT, bn = (tile % ntn) * BT;
+    const int kt1 = K / BK;
+    auto swz = [](int row) { return BK == 64 ? (row >> 1) & 7 : (row >> 2) & 3; };
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const bf16_t* pa[QN];
+    const bf16_t* pb[QN];
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+        const int c = q * 512 + tid, row = c / CPR, kc = (c % CPR) ^ swz(row);
+        pa[q] = A + (size_t)min(bm + row, M - 1) * K + kc * 8;
+        pb[q] = Wt + (size_t)min(bn + row, N - 1) * K + kc * 8;
+    }
+    const unsigned wave_off = (unsigned)__builtin_amdgcn_readfirstlane(wave * 64 * 16);
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr(Sbuf)) + wave_off;
+    auto issue = [&](int kt, int stage) {
+        const unsigned base = lds0 + (unsigned)stage * (2u * CH) * 16u;
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+            glds16(pa[q] + (size_t)kt * BK, base + q * 512 * 16);
+            glds16(pb[q] + (size_t)kt * BK, base + (CH + q * 512) * 16);
+        }
+    };
+    auto compute = [&](int stage) {
+        const uint4* As = Sbuf + stage * (2 * CH);
+        const uint4* Bs = As + CH;
+        const int ra = 64 * wr + (lane & 31), rb = 128 * wc + (lane & 31);
+        const int sa = swz(ra), sb = swz(rb);                      // rows + 32 keep the swizzle term
+        bf16x8 af[2][2], bf[2][4];
+        auto frags = [&](int kk, bf16x8 (&a2)[2], bf16x8 (&b2)[4]) {
+            const int kc = 2 * kk + (lane >> 5);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a2[i] = __builtin_bit_cast(bf16x8, As[(ra + 32 * i) * CPR + (kc ^ sa)]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b2[j] = __builtin_bit_cast(bf16x8, Bs[(rb + 32 * j) * CPR + (kc ^ sb)]);
+        };
+        frags(0, af[0], bf[0]);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            if (kk + 1 < KK) frags(kk + 1, af[(kk + 1) & 1], bf[(kk + 1) & 1]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<H16>(af[kk & 1][i], bf[kk & 1][j], acc[i][j]);
+        }
+    };
+#define SC_GEMM_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#pragma unroll
+    for (int d = 0; d < PD; ++d)
+        if (d < kt1) issue(d, d);
+    for (int kt = 0; kt < kt1; ++kt) {
+        // step kt has landed once at most min(PD - 1, steps issued after it) DMA groups (2 QN instructions each) are outstanding
+        const int later = min(PD - 1, kt1 - 1 - kt);
+        if (later <= 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 * QN) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(4 * QN) : "memory");
+        if (kt + PD < kt1) issue(kt + PD, (kt + PD) % NS);       // into the stage read at step kt - 1: everybody is past it
+        compute(kt % NS);
+    }
+    SC_GEMM_SYNC();                                             // every wave is done with the stages
+    constexpr bool OUT_BF16 = EPI == EPI_GELU_BF16 || EPI == EPI_BF16;
+    if (OUT_BF16) {
+        bf16_t* Ch = reinterpret_cast<bf16_t*>(Sbuf);           // [256][256] 16-bit: 128 KB
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cl = 128 * wc + 32 * j + (lane & 31);
+                const float bv = bias ? bias[bn + cl] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const float v = acc[i][j][r] + bv;
+                    Ch[rl * BT + cl] = cvt16<H16>(EPI == EPI_GELU_BF16 ? v / (1.f + __expf(-1.702f * v)) : v);
+                }
+            }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < BT * 32 / 512; ++q) {
+            const int chunk = q * 512 + tid, rl = chunk >> 5, c8 = (chunk & 31) * 8;
+            if (bm + rl < M)
+                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(out) + (size_t)(bm + rl) * N + bn + c8) =
+                    *reinterpret_cast<const uint4*>(Ch + rl * BT + c8);
+        }
+    } else {
+        float* Cf = reinterpret_cast<float*>(Sbuf);             // [128][256] fp32: 128 KB, one half of the tile at a time
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            if ((wr >> 1) == hh) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int cl = 128 * wc + 32 * j + (lane & 31);
+                        const float bv = bias ? bias[bn + cl] : 0.f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int rl = 64 * (wr & 1) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                            Cf[rl * BT + cl] = acc[i][j][r] + bv;
+                        }
+                    }
+            }
+            __syncthreads();
+            constexpr int NQ = 128 * 64 / 512;
+            float4 res[NQ];
+            if (EPI == EPI_RESID) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int chunk = q * 512 + tid, rl = chunk >> 6, c4 = (chunk & 63) * 4, row = bm + 128 * hh + rl;
+                    res[q] = row < M ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(out) + (size_t)row * N + bn + c4)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int chunk = q * 512 + tid, rl = chunk >> 6, c4 = (chunk & 63) * 4, row = bm + 128 * hh + rl;
+                float4 v = *reinterpret_cast<const float4*>(Cf + rl * BT + c4);
+                if (EPI == EPI_RESID) { v.x += res[q].x; v.y += res[q].y; v.z += res[q].z; v.w += res[q].w; }
+                if (row < M) *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)row * N + bn + c4) = v;
+            }
+            __syncthreads();
+        }
+    }
+#undef SC_GEMM_SYNC
+}
+
 // Persistent form of the 128x128 kernel for large grids: 2 workgroups per CU stay resident and walk the tile list of their XCD.
 // What it buys over one workgroup per tile: the first K-step of the NEXT tile is requested during the last K-step of the current
 // one, so its DMA round trip (~1.3 us under load) and the pointer set-up run under the epilogue instead of in front of an idle
@@ -732,8 +893,18 @@ static int launch_gemm(int epi, const bf16_t* A, const bf16_t* Wt, const float* 
     const long long t128 = (long long)((N + 127) / 128) * ((M + 127) / 128);
     static const long long t128_min = [] { const char* e = getenv("SC_GEMM_T128_MIN"); return e ? atoll(e) : 384LL; }();   // tuning override
     const bool small = t128 < t128_min;
+    // 256 x 256 tiles (half the L2 -> LDS bytes per FLOP) when there are enough of them to give most CUs one
+    const long long t256 = (long long)(N / 256) * ((M + 255) / 256);
+    static const long long t256_min = [] { const char* e = getenv("SC_GEMM_T256_MIN"); return e ? atoll(e) : 128LL; }();          // tuning override
+    // ... and when the last round of the one-workgroup-per-CU grid is not mostly empty (qkv at 12,800 tokens: 450 tiles = 88 % of two rounds:
+    // 66 -> 60 us; fc1: 600 tiles = 78 % of three rounds: slower than the persistent 128-wide kernel, which balances its tail)
+    const long long rounds256 = (t256 + 255) / 256;
+    const bool big = (N % 256) == 0 && M >= 2048 && t256 >= t256_min && t256 * 100 >= rounds256 * 256 * 85;
 #define SC_LAUNCH(E)                                                                                                          \
-    if (small) {                                                                                                              \
+    if (big) {                                                                                                                \
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<E, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);        \
+        hipLaunchKernelGGL((gemm256_kernel<E, H16>), dim3(N / 256, (M + 255) / 256), dim3(512), 131072, st, A, Wt, bias, out, M, N, K); \
+    } else if (small) {                                                                                                       \
         (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<E, 64, H16>, hipFuncAttributeMaxDynamicSharedMemorySize,           \
                                    SC_GEMM64_STAGES * 2 * 64 * 8 * 16);                                                       \
         hipLaunchKernelGGL((gemm_bf16_kernel<E, 64, H16>), dim3((N + 63) / 64, (M + 63) / 64), dim3(256),                          \

@@ -144,6 +144,45 @@ def test_gemm_16bit_transpose_detecting(M, N, K, dtype):
     assert (out - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("M,N,K", [(12800, 768, 3072), (8224, 1024, 1024), (2049, 256, 64), (12800, 3072, 768)])
+def test_gemm_256_tiles_all_epilogues(M, N, K, dtype):
+    """The 256 x 256 tile kernel (M >= 2048, N % 256 == 0): every epilogue (fp32, residual accumulate, QuickGELU -> 16 bit, 16 bit)
+    against float64, ragged last row tile included; the residual epilogue must read its rows before it writes them."""
+    import ctypes
+    from shapeclipper_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(M + N)
+    td = torch.bfloat16 if dtype == "bf16" else torch.float16
+    A = (torch.randn(M, K, device=dev) * 0.5).to(td)
+    W = ((torch.randn(N, K, device=dev) + torch.arange(N, device=dev)[:, None] * 0.002) * 0.1).to(td)
+    bias = torch.randn(N, device=dev)
+    fn = lib.sc_gemm_bf16 if dtype == "bf16" else lib.sc_gemm_f16
+    ref = A.double() @ W.double().t() + bias.double()
+    scale = ref.abs().max().item()
+    resid = torch.randn(M, N, device=dev)
+    for epi in (0, 1, 2, 3):
+        if epi == 1:
+            out = resid.clone()
+            want = ref + resid.double()
+        elif epi == 2:
+            out = torch.zeros(M, N, device=dev, dtype=td)
+            want = ref * torch.sigmoid(1.702 * ref)
+        else:
+            out = torch.zeros(M, N, device=dev, dtype=torch.float32 if epi == 0 else td)
+            want = ref
+        pad = torch.full((4096,), 7.0, device=dev, dtype=out.dtype)          # a canary behind the output: the ragged tile must not write past row M
+        buf = torch.cat([out.view(-1), pad]); out = buf[:M * N].view(M, N)
+        rc = fn(ctypes.c_int(epi), _lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), _lib.ptr(out), ctypes.c_int(M), ctypes.c_int(N), ctypes.c_int(K), _lib.stream())
+        assert rc == 0
+        torch.cuda.synchronize()
+        tol = 1e-5 if epi in (0, 1) else (8e-3 if dtype == "bf16" else 1e-3)
+        err = (out.double() - want).abs().max().item()
+        assert err < tol * max(scale, 1.0), (epi, err, scale)
+        assert (buf[M * N:] == 7.0).all()
+
+
 def test_clip_tower_golden_fixture():
     """G11 (tests/golden/make_golden_clip.py): committed weights / input / embedding of a shrunken tower."""
     import os

@@ -1,46 +1,46 @@
-// Micro-benchmark: sustained rate of v_mfma_f32_16x16x4_f32 (the instruction of the MLP chain kernels) with NACC independent
-// accumulators per wave and W waves per SIMD, operands in registers (no LDS, no memory).
-//   hipcc --offload-arch=gfx950 -O3 tools/micro/mfma_peak.hip -o /tmp/mfma_peak && /tmp/mfma_peak
+// Chip-wide sustained rate of v_mfma_f32_32x32x16_bf16 / f16 from registers (no memory traffic): what the matrix pipe delivers at the clock
+// the chip holds under that load.  hipcc --offload-arch=gfx950 -O3 mfma_peak.hip -o mfma_peak && ./mfma_peak
 #include <hip/hip_runtime.h>
-#include <cstdio>
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-template <int NACC>
-__global__ void mfma_loop(float* out, int iters, float a0, float b0) {
-    f32x4 acc[NACC];
-    for (int i = 0; i < NACC; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float a = a0 + threadIdx.x * 1e-6f, b = b0;
-    for (int it = 0; it < iters; ++it) {
+#include <stdio.h>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+template <bool H, int NACC>
+__global__ __launch_bounds__(256) void k(float* out, int iters) {
+    f32x16 acc[NACC];
+    for (int a = 0; a < NACC; ++a) for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    bf16x8 x, y;
+    for (int e = 0; e < 8; ++e) { x[e] = (__bf16)(float)(threadIdx.x & 7); y[e] = (__bf16)1.0f; }
+    for (int i = 0; i < iters; ++i) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
-#pragma unroll
-            for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+        for (int a = 0; a < NACC; ++a)
+            acc[a] = H ? __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), acc[a], 0, 0, 0)
+                       : __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc[a], 0, 0, 0);
     }
     float s = 0.f;
-    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    for (int a = 0; a < NACC; ++a) s += acc[a][0];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
 }
-
-template <int NACC>
-void run(int waves_per_simd) {
-    const int cus = 256, threads = 64 * 4 * waves_per_simd, iters = 2000;
-    float* out;
-    hipMalloc(&out, (size_t)cus * threads * 4);
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(mfma_loop<NACC>, dim3(cus), dim3(threads), 0, 0, out, 10, 1.0f, 0.5f);
-    hipEventRecord(e0);
-    hipLaunchKernelGGL(mfma_loop<NACC>, dim3(cus), dim3(threads), 0, 0, out, iters, 1.0f, 0.5f);
-    hipEventRecord(e1);
-    hipEventSynchronize(e1);
-    float ms;
-    hipEventElapsedTime(&ms, e0, e1);
-    const double flops = (double)cus * (threads / 64) * iters * 16 * NACC * 2048.0;
-    printf("NACC=%d waves/SIMD=%d: %.1f TFLOP/s\n", NACC, waves_per_simd, flops / (ms * 1e-3) / 1e12);
+template <bool H, int NACC>
+static void run(const char* name, int wgs_per_cu) {
+    float* out; hipMalloc(&out, 256 * 8 * 256 * 4);
+    const int iters = 20000, blocks = 256 * wgs_per_cu;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(a);
+        hipLaunchKernelGGL((k<H, NACC>), dim3(blocks), dim3(256), 0, 0, out, iters);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        const double flop = 2.0 * 32 * 32 * 16 * (double)NACC * iters * 4.0 * blocks;
+        printf("%s, %d accumulators, %d waves/SIMD, run %d: %.2f ms  %.0f TFLOP/s  (%.1f cycles per MFMA at 2.4 GHz)\n", name, NACC, wgs_per_cu, rep, ms,
+               flop / ms / 1e9, ms * 1e-3 * 2.4e9 / ((double)NACC * iters * wgs_per_cu));
+    }
     hipFree(out);
 }
-
 int main() {
-    run<1>(1); run<2>(1); run<4>(1); run<4>(2); run<8>(1); run<8>(2);
+    run<false, 8>("bf16 32x32x16", 1);
+    run<false, 8>("bf16 32x32x16", 2);
+    run<true, 8>("f16  32x32x16", 2);
+    run<false, 4>("bf16 32x32x16", 2);
     return 0;
 }
