@@ -300,7 +300,11 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 4) void gemm_bf16_kernel(const
 // the 128 x 128 persistent kernel; four 32 KB stages (K-step 32, three batches in flight) 5 % SLOWER than two 64 KB stages; the same kernel
 // without its LDS-DMA instructions 890-1,150, without its MFMAs 860-970: operand delivery and matrix work cost about the same and overlap
 // only partly -- an LDS-DMA piece occupies its wave for 60-185 issue cycles (MI355X_MICROARCH.md), 8 pieces per wave and K-step against 32
-// MFMAs.  Operands through registers (global_load_dwordx4 + ds_write_b128) ended up in scratch memory under hipcc (2.6x slower) and was dropped.  The epilogue stages the tile through the free LDS: 16-bit outputs at
+// MFMAs.  Operands through registers (global_load_dwordx4 + ds_write_b128) ended up in scratch memory under hipcc (2.6x slower) and was dropped.
+// A producer / consumer form (8 computing waves that never issue a DMA, 4 loader waves three K-steps ahead through four 32 KB stages, one
+// s_barrier per K-step) passed the same tests and ran 660-750: the computing waves were not what was short -- the DMA-only rate above is
+// ~6.5 TB/s of L2 -> LDS traffic chip-wide in 16-byte-per-lane pieces that use 64-128 bytes of each cache line's row.  The next lever is the
+// operand LAYOUT (tile-major weights and activations so that a piece is one contiguous KB), not the schedule.  The epilogue stages the tile through the free LDS: 16-bit outputs at
 // once, fp32 outputs in two 128-row halves.
 #ifndef SC_GEMM256_BK
 #define SC_GEMM256_BK 64
@@ -901,7 +905,7 @@ static int launch_gemm(int epi, const bf16_t* A, const bf16_t* Wt, const float* 
     const long long rounds256 = (t256 + 255) / 256;
     const bool big = (N % 256) == 0 && M >= 2048 && t256 >= t256_min && t256 * 100 >= rounds256 * 256 * 85;
 #define SC_LAUNCH(E)                                                                                                          \
-    if (big) {                                                                                                                \
+    if (big) {                                                                                                         \
         (void)hipFuncSetAttribute((const void*)gemm256_kernel<E, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);        \
         hipLaunchKernelGGL((gemm256_kernel<E, H16>), dim3(N / 256, (M + 255) / 256), dim3(512), 131072, st, A, Wt, bias, out, M, N, K); \
     } else if (small) {                                                                                                       \
