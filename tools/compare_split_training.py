@@ -16,16 +16,15 @@ from shapeclipper_amd.utils.util import EasyDict as edict
 
 
 def run(split):
-    resnet.HIP_CONV3X3_SPLIT = split
     torch.manual_seed(0)
     np.random.seed(0)
-    runner, opt, batch = bench.build_runner(32, 0, 0, 1, [])
+    runner, opt, batch = bench.build_runner(32, 0, 0, 1, [] if split else ["--hip.conv3x3_split!"])     # (options.set applies the switch)
+    assert bool(resnet.HIP_CONV3X3_SPLIT) == bool(split)
     losses = []
     for _ in range(steps):
         opt.H, opt.W = opt.image_size
         loss = runner.train_iteration(opt, edict(batch), None)
         losses.append(float(loss.all))
-    resnet.HIP_CONV3X3_SPLIT = False
     return np.array(losses)
 
 
