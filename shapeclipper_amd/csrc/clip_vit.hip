@@ -300,7 +300,8 @@ __global__ __launch_bounds__(256, BT == 128 ? 2 : 4) void gemm_bf16_kernel(const
 // the 128 x 128 persistent kernel; four 32 KB stages (K-step 32, three batches in flight) 5 % SLOWER than two 64 KB stages; the same kernel
 // without its LDS-DMA instructions 890-1,150, without its MFMAs 860-970: operand delivery and matrix work cost about the same and overlap
 // only partly -- an LDS-DMA piece occupies its wave for 60-185 issue cycles (MI355X_MICROARCH.md), 8 pieces per wave and K-step against 32
-// MFMAs.  Operands through registers (global_load_dwordx4 + ds_write_b128) ended up in scratch memory under hipcc (2.6x slower) and was dropped.
+// MFMAs.  Operands through registers (global_load_dwordx4 into eight named uint4 + ds_write_b128, no LDS-DMA at all): 610-750, the same; with
+// tile-major, pre-swizzled operands (every piece one contiguous KB): the same.  Neither the transport nor the layout is the limit.
 // A producer / consumer form (8 computing waves that never issue a DMA, 4 loader waves three K-steps ahead through four 32 KB stages, one
 // s_barrier per K-step) passed the same tests and ran 660-750: the computing waves were not what was short -- the DMA-only rate above is
 // ~6.5 TB/s of L2 -> LDS traffic chip-wide in 16-byte-per-lane pieces that use 64-128 bytes of each cache line's row.  The next lever is the
