@@ -1,0 +1,70 @@
+// MFMA loop fed from LDS (no global traffic): what does the ds_read_b128 -> v_mfma_f32_32x32x16 pattern of the GEMM / convolution kernels
+// deliver chip-wide?  8 waves per CU (2 per SIMD), per sub-step NA + NB fragment reads and NA * NB MFMAs.
+//   hipcc --offload-arch=gfx950 -O3 mfma_lds.hip -o mfma_lds && ./mfma_lds
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+template <int NA, int NB, bool DATA, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k(float* out, int iters, unsigned seed) {
+    extern __shared__ uint4 S[];            // 64 KB: A 2048 chunks, B 2048 chunks
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 4096; i += 64 * WAVES) {
+        unsigned h = (i * 2654435761u) ^ seed;
+        S[i] = DATA ? make_uint4(0x3c003c00u ^ (h & 0x03ff03ffu), 0x3c003c00u ^ ((h >> 3) & 0x03ff03ffu), 0x3c003c00u ^ ((h >> 5) & 0x03ff03ffu), 0x3c003c00u ^ ((h >> 7) & 0x03ff03ffu))
+                    : make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    f32x16 acc[NA][NB];
+    for (int a = 0; a < NA; ++a) for (int b = 0; b < NB; ++b) for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int ra = 64 * (wave & 3) + (lane & 31), rb = 128 * (wave >> 2 & 1) + (lane & 31);
+    const int sa = (ra >> 1) & 7, sb = (rb >> 1) & 7;
+    const uint4* As = S;
+    const uint4* Bs = S + 2048;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int kc = 2 * kk + (lane >> 5);
+            bf16x8 af[NA], bf[NB];
+#pragma unroll
+            for (int i = 0; i < NA; ++i) af[i] = __builtin_bit_cast(bf16x8, As[((ra + 32 * i) & 255) * 8 + (kc ^ sa)]);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) bf[j] = __builtin_bit_cast(bf16x8, Bs[((rb + 32 * j) & 255) * 8 + (kc ^ sb)]);
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+    for (int a = 0; a < NA; ++a) for (int b = 0; b < NB; ++b) s += acc[a][b][0];
+    out[blockIdx.x * 64 * WAVES + tid] = s;
+}
+template <int NA, int NB, bool DATA, int WAVES>
+static void run(const char* name) {
+    float* out; hipMalloc(&out, 256 * 64 * WAVES * 4);
+    const int iters = 4000;
+    hipFuncSetAttribute((const void*)k<NA, NB, DATA, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    float best = 1e9f;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(a);
+        hipLaunchKernelGGL((k<NA, NB, DATA, WAVES>), dim3(256), dim3(64 * WAVES), 65536, 0, out, iters, 12345u);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        best = ms < best ? ms : best;
+    }
+    const double mfmas = (double)NA * NB * 4 * iters;
+    printf("%-44s %d waves/CU: %.2f ms  %.0f TFLOP/s  (%.1f cycles per MFMA and SIMD at 2.4 GHz, %d reads per %d MFMAs)\n", name, WAVES, best,
+           2.0 * 32 * 32 * 16 * mfmas * WAVES * 256 / best / 1e9, best * 1e-3 * 2.4e9 / (mfmas * WAVES / 4), NA + NB, NA * NB);
+    hipFree(out);
+}
+int main() {
+    run<2, 4, true, 8>("2 + 4 fragments, random data");
+    run<2, 4, false, 8>("2 + 4 fragments, zero data");
+    run<2, 2, true, 8>("2 + 2 fragments (128-tile pattern), random");
+    run<2, 2, false, 8>("2 + 2 fragments, zero data");
+    run<2, 4, true, 4>("2 + 4 fragments, random, 1 wave per SIMD");
+    run<1, 4, true, 8>("1 + 4 fragments, random");
+    return 0;
+}
