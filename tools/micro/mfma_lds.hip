@@ -5,7 +5,7 @@
 #include <stdio.h>
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-template <int NA, int NB, bool DATA, int WAVES>
+template <int NA, int NB, bool DATA, int WAVES, bool BAR = false>
 __global__ __launch_bounds__(64 * WAVES) void k(float* out, int iters, unsigned seed) {
     extern __shared__ uint4 S[];            // 64 KB: A 2048 chunks, B 2048 chunks
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -22,6 +22,7 @@ __global__ __launch_bounds__(64 * WAVES) void k(float* out, int iters, unsigned 
     const uint4* As = S;
     const uint4* Bs = S + 2048;
     for (int it = 0; it < iters; ++it) {
+        if (BAR) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // one K-step of 64 = 4 sub-steps per barrier, as in the GEMM
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int kc = 2 * kk + (lane >> 5);
@@ -40,16 +41,16 @@ __global__ __launch_bounds__(64 * WAVES) void k(float* out, int iters, unsigned 
     for (int a = 0; a < NA; ++a) for (int b = 0; b < NB; ++b) s += acc[a][b][0];
     out[blockIdx.x * 64 * WAVES + tid] = s;
 }
-template <int NA, int NB, bool DATA, int WAVES>
+template <int NA, int NB, bool DATA, int WAVES, bool BAR = false>
 static void run(const char* name) {
     float* out; hipMalloc(&out, 256 * 64 * WAVES * 4);
     const int iters = 4000;
-    hipFuncSetAttribute((const void*)k<NA, NB, DATA, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipFuncSetAttribute((const void*)k<NA, NB, DATA, WAVES, BAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     float best = 1e9f;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(a);
-        hipLaunchKernelGGL((k<NA, NB, DATA, WAVES>), dim3(256), dim3(64 * WAVES), 65536, 0, out, iters, 12345u);
+        hipLaunchKernelGGL((k<NA, NB, DATA, WAVES, BAR>), dim3(256), dim3(64 * WAVES), 65536, 0, out, iters, 12345u);
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         best = ms < best ? ms : best;
@@ -66,5 +67,7 @@ int main() {
     run<2, 2, false, 8>("2 + 2 fragments, zero data");
     run<2, 4, true, 4>("2 + 4 fragments, random, 1 wave per SIMD");
     run<1, 4, true, 8>("1 + 4 fragments, random");
+    run<2, 4, true, 8, true>("2 + 4 fragments, random, barrier per 4 sub-steps");
+    run<2, 2, true, 8, true>("2 + 2 fragments, random, barrier per 4 sub-steps");
     return 0;
 }
