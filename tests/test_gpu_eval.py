@@ -62,6 +62,45 @@ def test_graph_eval_forward_and_metrics():
     assert sdf.abs().max().item() < 0.02
 
 
+def test_eval_metrics_at_config4_size():
+    """BASELINE config[4] shapes for one evaluation sample set: vox_res = 100 level grid, marching cubes, 100,000 surface samples per image
+    against 100,000 ground-truth points (eval.num_points of the shipped yaml), Chamfer through the exact grid search: finite metrics, the
+    grid search equals the all-pairs search on exactly these clouds, and the sampled points sit on the network's zero level set."""
+    import chamfer_3D
+    from shapeclipper_amd import synthetic
+    from shapeclipper_amd.model.graph import Graph
+    from shapeclipper_amd.utils import eval_3D, util
+    o = _opt(["--eval.vox_res=100"])                 # config[4]: evaluate.py --eval.vox_res=100 (the yaml's default is 64)
+    assert o.eval.vox_res == 100 and o.eval.num_points == 100000
+    torch.manual_seed(1)
+    graph = Graph(o).cuda().eval()
+    batch = synthetic.make_batch(o, 2, seed=5, training=False, n_gt_points=100000)
+    var = util.move_to_device(batch, "cuda:0")
+    o.H, o.W = o.eval.image_size
+    with torch.no_grad():
+        var = graph(o, var, training=False, get_loss=False)
+    acc, comp = eval_3D.eval_metrics(o, var, graph.sdf_network)
+    assert var.dpc_pred.shape == (2, 100000, 3) and var.f_score.shape == (2, 6)
+    assert torch.isfinite(acc) and torch.isfinite(comp) and float(acc) > 0 and float(comp) > 0
+    assert 0 <= float(var.f_score.min()) <= float(var.f_score.max()) <= 1
+    # the two searches on the evaluation's own clouds (rotated to the canonical frame and normalised by eval_metrics)
+    a, b = var.dpc_pred.contiguous().float(), var.dpc.points.contiguous().float()
+    assert b.shape == (2, 100000, 3)
+    outs = []
+    for mode in ("grid", "brute"):
+        old, chamfer_3D.SEARCH = chamfer_3D.SEARCH, mode
+        try:
+            d1, d2 = torch.zeros(2, 100000, device="cuda"), torch.zeros(2, 100000, device="cuda")
+            i1, i2 = torch.zeros(2, 100000, dtype=torch.int32, device="cuda"), torch.zeros(2, 100000, dtype=torch.int32, device="cuda")
+            chamfer_3D.forward(a, b, d1, d2, i1, i2)
+            outs.append((d1, d2, i1, i2))
+        finally:
+            chamfer_3D.SEARCH = old
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    assert abs(float(outs[0][0].sqrt().mean()) - float(acc)) < 1e-6 * max(1.0, float(acc))       # eval_metrics' accuracy is that mean
+
+
 def test_pretrain_step_reduces_sphere_loss():
     from shapeclipper_amd.model.pretrainer import Graph
     from shapeclipper_amd.utils.util import EasyDict as edict
