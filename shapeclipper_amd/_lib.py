@@ -101,8 +101,14 @@ def ptr(t: Optional[torch.Tensor]):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def raw_stream() -> int:
+    """hipStream_t of torch's current stream on the current device as an integer.  (torch.cuda.current_stream() builds a Python Stream
+    object per call, ~8 us: at ~280 entry-point calls per training step that was 2.4 ms of host time per step.)"""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
 def stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(raw_stream())
 
 
 def check(code: int, what: str):
