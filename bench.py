@@ -226,6 +226,31 @@ def main():
                             "instead of the exact bf16x3 split; not the headline")
         finally:
             resnet.HIP_CONV3X3_SPLIT = True
+    # BASELINE config[1] ("Pix3D train.py bs16, 1 x MI355X") beside the headline: the same step at 16 images per GPU on its own runner.  At this
+    # size the step is paced by the host (enqueue work per step does not shrink with the batch), which is what the object says.
+    config1 = None
+    if world == 1 and not a.no_alt and a.batch == 32:
+        import gc
+        r16, o16, b16 = build_runner(16, rank, local, world, a.opt)
+        from shapeclipper_amd.utils.util import EasyDict as _ed
+
+        def step16():
+            o16.H, o16.W = o16.image_size
+            return r16.train_iteration(o16, _ed(b16), None)
+        for _ in range(5):
+            step16()
+        torch.cuda.synchronize()
+        t1 = time.time()
+        for _ in range(a.alt_steps):
+            step16()
+        torch.cuda.synchronize()
+        cdt = (time.time() - t1) / a.alt_steps
+        config1 = dict(workload="BASELINE config[1]: the same training step at bs16 on one GPU", steps=a.alt_steps, ms_per_step=round(cdt * 1e3, 3),
+                       value=round(16 / cdt, 2), unit="images/s", note="host-paced at this batch size: ~17 ms of enqueue work per step whatever the batch "
+                       "(tools/host_profile.py); not the headline")
+        del r16, o16, b16, step16
+        gc.collect()
+        torch.cuda.empty_cache()
     allreduce = None
     if world > 1 and runner.reducer is not None:      # the step's only exchange: one flat all-reduce
         flat = runner.reducer.flat
@@ -313,6 +338,8 @@ def main():
             out["allreduce"] = allreduce
         if alt is not None:
             out["fp32_mfma_convolutions"] = alt
+        if config1 is not None:
+            out["config1_bs16"] = config1
         if not a.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks must not wait for rank 0)
             out["cpu_baseline"] = cpu_baseline(a.cpu_batch or a.batch)
         if not a.no_workloads and world == 1:

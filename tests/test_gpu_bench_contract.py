@@ -40,6 +40,19 @@ def test_bench_line_contract():
     assert "sc_sdf_forward" in d["hip_ms_per_step"] and "sc_rgb_composite_backward" in d["hip_ms_per_step"]
 
 
+def test_bench_default_batch_reports_config1_beside_the_headline():
+    """At the headline batch (bs32) the line also carries BASELINE config[1] (bs16 on one GPU) as a secondary object; contract keys unchanged."""
+    env = dict(os.environ, MIOPEN_LOG_LEVEL="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--sustained", "0", "--alt-steps", "3",
+                        "--no-cpu-baseline", "--no-workloads"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["config"]["global_batch"] == 32 and d["metric"].endswith("bs32/GPU)") and abs(d["value"] - 32 / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]
+    c1 = d["config1_bs16"]
+    assert c1["steps"] == 3 and c1["ms_per_step"] > 0 and abs(c1["value"] - 16 / (c1["ms_per_step"] * 1e-3)) < 0.01 * c1["value"]
+    assert len([l for l in r.stdout.splitlines() if l.startswith("{")]) == 1
+
+
 def test_workloads_line():
     import importlib.util
     spec = importlib.util.spec_from_file_location("sc_workloads_test", os.path.join(ROOT, "tools", "workloads.py"))
