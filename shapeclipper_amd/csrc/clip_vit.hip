@@ -686,89 +686,96 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ pa
 // One workgroup (4 waves) per (image, head); a wave owns blocks of 32 queries and walks the keys 32 at a time.
 //   S^T[key][query] = K Q^T      A = K rows, B = Q rows, both read straight from global memory: the contraction index
 //                                (head dim) is contiguous in the qkv row, which is exactly the 32x32x16 operand layout
-//   softmax over keys            two passes over the key chunks (statistics, then probabilities): S is recomputed (4 MFMAs
-//                                per chunk) instead of rescaling the output accumulators
+//   softmax over keys            two passes over the key chunks (maximum, then p = exp(s - max) with its sum): S is recomputed (4 MFMAs
+//                                per chunk) instead of rescaling the output accumulators; O is divided by the sum at the end
 //   O[query][d] += P V           A = P: the C/D registers of S^T ARE a legal A operand (lane = query, the 8 values of a
 //                                K-step are 8 keys); B = V with keys contiguous per lane -> V is staged once per
 //                                workgroup TRANSPOSED in LDS (Vt[d][key]), the K-step's key order follows the C/D layout
 // fp32 scores / statistics / accumulation, bf16 probabilities (openai/CLIP on GPU keeps them in fp16).
+// K of the (image, head) is staged in LDS as well when it fits next to V^T (k_lds: rows of 72 elements = 144 bytes, so that the 32 rows of
+// a fragment read spread over the banks): both passes walk the keys with ds_read_b128 instead of one dependent global round trip per
+// chunk and pass -- at T = 257 (ViT-L/14) that was 54 round trips in a row for the wave with three query blocks, 87 us per layer.  Eight
+// waves: the nine query blocks of T = 257 are two deep instead of three.
+constexpr int ATT_NW = 8, ATT_KLD = 72;
 template <bool H16>
-__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int T, int D,
-                                                        int heads, float scale) {
-    extern __shared__ bf16_t Vt[];                   // [64][ldv], ldv = Tp + 4 (row stride = odd multiple of 2 words)
+__global__ __launch_bounds__(64 * ATT_NW) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int T, int D,
+                                                                int heads, float scale, int k_lds) {
+    extern __shared__ bf16_t Vt[];                   // [64][ldv], ldv = Tp + 4 (row stride = odd multiple of 2 words); then K [Tp][72]
     const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
     const int Tp = (T + 31) & ~31, ldv = Tp + 4;
+    bf16_t* Ks = Vt + 64 * ldv;                      // 64 ldv elements = 128 (Tp + 4) bytes: 16-byte aligned
     const size_t rs = (size_t)3 * D;
     const bf16_t* base = qkv + (size_t)b * T * rs + (size_t)hd * 64;
-    for (int e = threadIdx.x; e < Tp * 8; e += 256) {
+    for (int e = threadIdx.x; e < Tp * 8; e += 64 * ATT_NW) {
         const int key = e >> 3, dc = (e & 7) * 8;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (key < T) v = *reinterpret_cast<const uint4*>(base + (size_t)key * rs + 2 * D + dc);
+        uint4 v = make_uint4(0, 0, 0, 0), k = make_uint4(0, 0, 0, 0);
+        if (key < T) {
+            v = *reinterpret_cast<const uint4*>(base + (size_t)key * rs + 2 * D + dc);
+            if (k_lds) k = *reinterpret_cast<const uint4*>(base + (size_t)key * rs + D + dc);
+        }
         const bf16_t* pv = reinterpret_cast<const bf16_t*>(&v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) Vt[(dc + j) * ldv + key] = pv[j];
+        if (k_lds) *reinterpret_cast<uint4*>(Ks + key * ATT_KLD + dc) = k;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 31, h = lane >> 5;
-    const float NEG = -3.0e38f;
     auto frag = [&](int row, int col_off) -> bf16x8 {       // 8 consecutive head-dim values of a qkv row (zero past T)
         uint4 v = make_uint4(0, 0, 0, 0);
         if (row < T) v = *reinterpret_cast<const uint4*>(base + (size_t)row * rs + col_off + 8 * h);
         return __builtin_bit_cast(bf16x8, v);
     };
-    for (int qb = wave; qb * 32 < T; qb += 4) {
+    const float c2 = scale * 1.44269504088896341f;            // exp(scale s - m) = exp2(c2 s - c2 max s): one fma + v_exp_f32 per score
+    const int Tfull = T & ~31;                                // keys below Tfull need no mask
+    for (int qb = wave; qb * 32 < T; qb += ATT_NW) {
         const int q = qb * 32 + n;
         bf16x8 qf[4];
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) qf[s4] = frag(q, 16 * s4);
-        auto scores = [&](int kc, float (&v)[16]) {           // v[r] = scaled score of key kc + (r&3) + 8(r>>2) + 4h, query q
+        auto scores = [&](int kc) -> f32x16 {                 // S[r] = raw score of key kc + (r&3) + 8(r>>2) + 4h, query q
             f32x16 S;
 #pragma unroll
             for (int r = 0; r < 16; ++r) S[r] = 0.f;
+            if (k_lds) {                                      // rows past T were staged as zeros, like frag() returns them
+                const bf16_t* kp = Ks + (kc + n) * ATT_KLD + 8 * h;
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) S = mfma16<H16>(frag(kc + n, D + 16 * s4), qf[s4], S);
+                for (int s4 = 0; s4 < 4; ++s4)
+                    S = mfma16<H16>(__builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(kp + 16 * s4)), qf[s4], S);
+            } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kc + (r & 3) + 8 * (r >> 2) + 4 * h;
-                v[r] = key < T ? S[r] * scale : NEG;
+                for (int s4 = 0; s4 < 4; ++s4) S = mfma16<H16>(frag(kc + n, D + 16 * s4), qf[s4], S);
             }
+            return S;
         };
-        // pass 1: running maximum and normaliser of this lane's query (the two halves of the wave hold 16 keys each)
-        float m = NEG, l = 0.f;
-        for (int kc = 0; kc < Tp; kc += 32) {
-            float v[16];
-            scores(kc, v);
-            float cm = NEG;
+        // pass 1: the maximum raw score of this lane's query (the two halves of the wave hold 16 keys of a chunk each); scale > 0
+        float smax = -3.0e38f;
+        for (int kc = 0; kc < Tfull; kc += 32) {
+            const f32x16 S = scores(kc);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) cm = fmaxf(cm, v[r]);
-            cm = fmaxf(cm, __shfl_xor(cm, 32));
-            const float nm = fmaxf(m, cm);
-            float cs = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) cs += v[r] > NEG ? __expf(v[r] - nm) : 0.f;
-            cs += __shfl_xor(cs, 32);
-            l = l * __expf(m - nm) + cs;
-            m = nm;
+            for (int r = 0; r < 16; ++r) smax = fmaxf(smax, S[r]);
         }
-        const float inv = 1.f / l;
-        // pass 2: probabilities and P V
+        if (Tfull < T) {
+            const f32x16 S = scores(Tfull);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (Tfull + (r & 3) + 8 * (r >> 2) + 4 * h < T) smax = fmaxf(smax, S[r]);
+        }
+        smax = fmaxf(smax, __shfl_xor(smax, 32));
+        const float mc = smax * c2;
+        // pass 2: p = exp(scale (s - max)) in (0, 1], O += p V, l += p; O is divided by l at the end (fp32)
         f32x16 O[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) O[t][r] = 0.f;
-        for (int kc = 0; kc < Tp; kc += 32) {
-            float v[16];
-            scores(kc, v);
+        float l = 0.f;
+        auto accumulate = [&](int kc, const float (&pr)[16]) {
             bf16x8 pf[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 bf16_t tmp[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float x = v[8 * j + e];
-                    tmp[e] = cvt16<H16>(x > NEG ? __expf(x - m) * inv : 0.f);
-                }
+                for (int e = 0; e < 8; ++e) tmp[e] = cvt16<H16>(pr[8 * j + e]);
                 pf[j] = __builtin_bit_cast(bf16x8, tmp);
             }
 #pragma unroll
@@ -781,14 +788,37 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
                     const uint4 pk = make_uint4(lo.x, lo.y, hi.x, hi.y);
                     O[t] = mfma16<H16>(pf[j], __builtin_bit_cast(bf16x8, pk), O[t]);
                 }
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
+        };
+        for (int kc = 0; kc < Tfull; kc += 32) {
+            const f32x16 S = scores(kc);
+            float pr[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int qq = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (qq < T) out[((size_t)b * T + qq) * D + hd * 64 + 32 * t + n] = cvt16<H16>(O[t][r]);
+                pr[r] = __builtin_amdgcn_exp2f(fmaf(S[r], c2, -mc));
+                l += pr[r];
             }
+            accumulate(kc, pr);
+        }
+        if (Tfull < T) {
+            const f32x16 S = scores(Tfull);
+            float pr[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                pr[r] = Tfull + (r & 3) + 8 * (r >> 2) + 4 * h < T ? __builtin_amdgcn_exp2f(fmaf(S[r], c2, -mc)) : 0.f;
+                l += pr[r];
+            }
+            accumulate(Tfull, pr);
+        }
+        l += __shfl_xor(l, 32);
+        const float inv = 1.f / l;                            // of query n (this lane's column of S^T); O's rows are queries (r, h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ql = (r & 3) + 8 * (r >> 2) + 4 * h, qq = qb * 32 + ql;
+            const float iq = __shfl(inv, ql);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                if (qq < T) out[((size_t)b * T + qq) * D + hd * 64 + 32 * t + n] = cvt16<H16>(O[t][r] * iq);
+        }
     }
 }
 
@@ -890,6 +920,56 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = cvt16<H16>(x[i]);
 }
 
+// The last rows of a GEMM whose row count is not a multiple of the 128-row tile (ViT-L/14: 257 tokens x 32 images = 64 tiles + 32 rows).  Left
+// to the tiled kernels they cost a full extra tile per 128 columns -- and with 8 / 24 / 32 such tiles on top of exactly 1 / 3 / 4 rounds of
+// the 512 resident workgroups (proj + fc2 / qkv / fc1 of ViT-L/14 at batch 32) an almost empty extra ROUND: 520 tile slots of work on 512.
+// Here: one workgroup per 32 x 32 block of the result, its sixteen waves split K, operands straight from global memory into the MFMA
+// (no LDS staging: nothing is reused inside a wave), the sixteen partial blocks added in wave order through LDS (fixed order).
+constexpr int THIN_NW = 16;
+template <int EPI, bool H16>
+__global__ __launch_bounds__(64 * THIN_NW) void gemm_thin_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ Wt, const float* __restrict__ bias,
+                                                                 void* __restrict__ out, int M, int N, int K) {
+    __shared__ float red[THIN_NW][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 31, h = lane >> 5;
+    const int bm = blockIdx.y * 32, bn = blockIdx.x * 32;
+    const int kw = K / THIN_NW;                                      // K % 256 == 0: a multiple of 16 per wave
+    const bf16_t* ap = A + (size_t)min(bm + n, M - 1) * K + wave * kw + 8 * h;
+    const bf16_t* wp = Wt + (size_t)(bn + n) * K + wave * kw + 8 * h;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k = 0; k < kw; k += 128) {                              // eight K-steps per trip while they last: 16 loads in flight per lane
+        uint4 a[8], w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k + 16 * u < kw) {
+                a[u] = *reinterpret_cast<const uint4*>(ap + k + 16 * u);
+                w[u] = *reinterpret_cast<const uint4*>(wp + k + 16 * u);
+            }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k + 16 * u < kw) acc = mfma16<H16>(__builtin_bit_cast(bf16x8, a[u]), __builtin_bit_cast(bf16x8, w[u]), acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    {
+        const int rr = wave;                                         // one accumulator row set per wave
+        float v = 0.f;
+#pragma unroll
+        for (int s = 0; s < THIN_NW; ++s) v += red[s][rr][lane];
+        const int row = bm + (rr & 3) + 8 * (rr >> 2) + 4 * h, col = bn + n;
+        if (row < M) {
+            v += bias ? bias[col] : 0.f;
+            const size_t o = (size_t)row * N + col;
+            if (EPI == EPI_F32) reinterpret_cast<float*>(out)[o] = v;
+            else if (EPI == EPI_RESID) reinterpret_cast<float*>(out)[o] += v;
+            else if (EPI == EPI_GELU_BF16) reinterpret_cast<bf16_t*>(out)[o] = cvt16<H16>(v / (1.f + __expf(-1.702f * v)));
+            else reinterpret_cast<bf16_t*>(out)[o] = cvt16<H16>(v);
+        }
+    }
+}
+
 template <bool H16>
 static int launch_gemm(int epi, const bf16_t* A, const bf16_t* Wt, const float* bias, void* out, int M, int N, int K,
                        hipStream_t st) {
@@ -905,6 +985,11 @@ static int launch_gemm(int epi, const bf16_t* A, const bf16_t* Wt, const float* 
     // 66 -> 60 us; fc1: 600 tiles = 78 % of three rounds: slower than the persistent 128-wide kernel, which balances its tail)
     const long long rounds256 = (t256 + 255) / 256;
     const bool big = (N % 256) == 0 && M >= 2048 && t256 >= t256_min && t256 * 100 >= rounds256 * 256 * 85;
+    // persistent kernel: a ragged last row tile that would open another round of the 512 resident workgroups goes to gemm_thin_kernel
+    const int rem = M % 128;
+    const long long t_full = (long long)((N + 127) / 128) * (M / 128);
+    static const int peel_on = [] { const char* e = getenv("SC_GEMM_PEEL"); return e ? atoi(e) : 1; }();                          // tuning override
+    const bool peel = peel_on && rem != 0 && t_full > 0 && (N % 32) == 0 && (K % 256) == 0 && (t128 + 511) / 512 > (t_full + 511) / 512;
 #define SC_LAUNCH(E)                                                                                                          \
     if (big) {                                                                                                         \
         (void)hipFuncSetAttribute((const void*)gemm256_kernel<E, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);        \
@@ -916,8 +1001,11 @@ static int launch_gemm(int epi, const bf16_t* A, const bf16_t* Wt, const float* 
                            SC_GEMM64_STAGES * 2 * 64 * 8 * 16, st, A, Wt, bias, out, M, N, K);                                \
     } else if ((N % 8) == 0) {          /* persistent: 2 resident workgroups per CU walk the tile list */                     \
         (void)hipFuncSetAttribute((const void*)gemm_bf16_persist_kernel<E, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); \
-        hipLaunchKernelGGL((gemm_bf16_persist_kernel<E, H16>), dim3(512), dim3(256), 65536, st, A, Wt, bias, out, M, N, K,         \
-                           (N + 127) / 128, (int)t128);                                                                       \
+        hipLaunchKernelGGL((gemm_bf16_persist_kernel<E, H16>), dim3(512), dim3(256), 65536, st, A, Wt, bias, out, peel ? M - rem : M, N, K, \
+                           (N + 127) / 128, (int)(peel ? t_full : t128));                                                     \
+        if (peel)                                                                                                             \
+            hipLaunchKernelGGL((gemm_thin_kernel<E, H16>), dim3(N / 32, (rem + 31) / 32), dim3(64 * THIN_NW), 0, st, A + (size_t)(M - rem) * K, Wt, bias, \
+                               (char*)out + (size_t)(M - rem) * N * ((E) == EPI_F32 || (E) == EPI_RESID ? 4 : 2), rem, N, K);  \
     } else {                                                                                                                  \
         (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<E, 128, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);  \
         hipLaunchKernelGGL((gemm_bf16_kernel<E, 128, H16>), dim3((N + 127) / 128, (M + 127) / 128), dim3(256), 65536, st,          \
@@ -965,8 +1053,10 @@ static int clip_vit_forward(const float* image, int B, int C, int H, int W, int 
     const float* lnpre_b = wf; wf += D;
 
     hipLaunchKernelGGL(patchify_kernel<H16>, dim3(2048), dim3(256), 0, st, image, a_patch, B, C, H, W, patch, Kp);
-    const int att_lds = 64 * (((T + 31) & ~31) + 4) * (int)sizeof(bf16_t);
-    if (att_lds > 160 * 1024) return (int)hipErrorInvalidValue;
+    const int Tp32 = (T + 31) & ~31, att_v = 64 * (Tp32 + 4) * (int)sizeof(bf16_t), att_k = Tp32 * ATT_KLD * (int)sizeof(bf16_t);
+    if (att_v > 160 * 1024) return (int)hipErrorInvalidValue;
+    const int k_lds = att_v + att_k <= 160 * 1024 ? 1 : 0;          // T = 257 (ViT-L/14 at 224 x 224): 77 KB, two workgroups per CU
+    const int att_lds = att_v + (k_lds ? att_k : 0);
     if (att_lds > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<H16>), hipFuncAttributeMaxDynamicSharedMemorySize, att_lds);
     int rc = launch_gemm<H16>(EPI_F32, a_patch, w_patch, nullptr, patch_out, B * np, D, Kp, st);
@@ -989,7 +1079,7 @@ static int clip_vit_forward(const float* image, int B, int C, int H, int W, int 
         hipLaunchKernelGGL((layernorm_kernel<true, H16>), dim3((M + 3) / 4), dim3(256), 0, st, x, D, ln1_g, ln1_b, (void*)xn, M, D, ln_eps);
         if ((rc = launch_gemm<H16>(EPI_BF16, xn, w_qkv, b_qkv, qkv, M, 3 * D, D, st))) return rc;
         if (T <= 64 && T > 32) hipLaunchKernelGGL(attention_small_kernel<H16>, dim3(B * heads), dim3(128), 0, st, qkv, att, T, D, heads, 0.125f);
-        else hipLaunchKernelGGL(attention_kernel<H16>, dim3(B * heads), dim3(256), att_lds, st, qkv, att, T, D, heads, 0.125f);
+        else hipLaunchKernelGGL(attention_kernel<H16>, dim3(B * heads), dim3(64 * ATT_NW), att_lds, st, qkv, att, T, D, heads, 0.125f, k_lds);
         if ((rc = launch_gemm<H16>(EPI_RESID, att, w_o, b_o, x, M, D, D, st))) return rc;
         hipLaunchKernelGGL((layernorm_kernel<true, H16>), dim3((M + 3) / 4), dim3(256), 0, st, x, D, ln2_g, ln2_b, (void*)xn, M, D, ln_eps);
         if ((rc = launch_gemm<H16>(EPI_GELU_BF16, xn, w_fc1, b_fc1, hbuf, M, mlp, D, st))) return rc;
