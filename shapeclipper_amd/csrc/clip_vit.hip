@@ -55,19 +55,34 @@ __device__ __forceinline__ f32x16 mfma16(const bf16x8& a, const bf16x8& b, const
 
 // ---------------------------------------------------------------------------------------------------
 // out [B*np][Kpad]: columns >= C*P*P are zero (the GEMM wants K % 64 == 0; ViT-L/14 has 3*14*14 = 588 -> 640)
+// One thread per 8 consecutive columns (one 16-byte store): the index arithmetic (divisions by run-time sizes) is paid once per chunk and
+// the 8 values are a run along kx that wraps into the next patch row / channel at most a few times (P = 32: never, two float4 loads).
 template <bool H16>
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, bf16_t* __restrict__ out,
                                                        int B, int C, int H, int W, int P, int Kpad) {
-    const int gw = W / P, gh = H / P, np = gw * gh, K = C * P * P;
-    const size_t total = (size_t)B * np * Kpad;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int k = (int)(idx % Kpad);
-        const size_t row = idx / Kpad;
-        if (k >= K) { out[idx] = 0; continue; }
+    const int gw = W / P, gh = H / P, np = gw * gh, K = C * P * P, kc8 = Kpad >> 3;          // Kpad % 64 == 0
+    const unsigned total = (unsigned)B * np * kc8;                                           // chunks (host: < 2^31)
+    const bool wide = (P & 7) == 0 && (W & 3) == 0;
+    for (unsigned ch = blockIdx.x * 256u + threadIdx.x; ch < total; ch += gridDim.x * 256u) {
+        const unsigned row = ch / kc8;
+        const int k0 = (int)(ch - row * kc8) * 8;
         const int pidx = (int)(row % np), b = (int)(row / np);
-        const int c = k / (P * P), ky = (k / P) % P, kx = k % P;
-        const int py = pidx / gw, px = pidx % gw;
-        out[idx] = cvt16<H16>(img[(((size_t)b * C + c) * H + py * P + ky) * W + px * P + kx]);
+        const int py = pidx / gw, px = pidx - py * gw;
+        int c = k0 / (P * P), r = k0 - c * P * P, ky = r / P, kx = r - ky * P;
+        alignas(16) bf16_t v[8];
+        if (wide && k0 + 8 <= K) {
+            const float* src = img + (((size_t)b * C + c) * H + py * P + ky) * W + px * P + kx;
+            const float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+            v[0] = cvt16<H16>(lo.x); v[1] = cvt16<H16>(lo.y); v[2] = cvt16<H16>(lo.z); v[3] = cvt16<H16>(lo.w);
+            v[4] = cvt16<H16>(hi.x); v[5] = cvt16<H16>(hi.y); v[6] = cvt16<H16>(hi.z); v[7] = cvt16<H16>(hi.w);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] = k0 + e < K ? cvt16<H16>(img[(((size_t)b * C + c) * H + py * P + ky) * W + px * P + kx]) : (bf16_t)0;
+                if (++kx == P) { kx = 0; if (++ky == P) { ky = 0; ++c; } }
+            }
+        }
+        *reinterpret_cast<uint4*>(out + (size_t)ch * 8) = *reinterpret_cast<const uint4*>(v);
     }
 }
 
@@ -983,13 +998,23 @@ static int launch_gemm(int epi, const bf16_t* A, const bf16_t* Wt, const float* 
     static const long long t256_min = [] { const char* e = getenv("SC_GEMM_T256_MIN"); return e ? atoll(e) : 128LL; }();          // tuning override
     // ... and when the last round of the one-workgroup-per-CU grid is not mostly empty (qkv at 12,800 tokens: 450 tiles = 88 % of two rounds:
     // 66 -> 60 us; fc1: 600 tiles = 78 % of three rounds: slower than the persistent 128-wide kernel, which balances its tail)
+    // (also tried: cutting whole rounds of 256 x 256 tiles off the top of fc1 -- 504 tiles = two rounds at 98 % -- and leaving 2,048 rows to the
+    // persistent kernel: 4.17 instead of 4.09 ms per tower; and the 256 x 256 kernel for fc1 of ViT-L/14 with its 32 ragged rows peeled: no change)
     const long long rounds256 = (t256 + 255) / 256;
-    const bool big = (N % 256) == 0 && M >= 2048 && t256 >= t256_min && t256 * 100 >= rounds256 * 256 * 85;
+    static const long long fill_pct = [] { const char* e = getenv("SC_GEMM_FILL_PCT"); return e ? atoll(e) : 85LL; }();           // tuning override
+    const bool big = (N % 256) == 0 && M >= 2048 && t256 >= t256_min && t256 * 100 >= rounds256 * 256 * fill_pct;
     // persistent kernel: a ragged last row tile that would open another round of the 512 resident workgroups goes to gemm_thin_kernel
     const int rem = M % 128;
     const long long t_full = (long long)((N + 127) / 128) * (M / 128);
     static const int peel_on = [] { const char* e = getenv("SC_GEMM_PEEL"); return e ? atoi(e) : 1; }();                          // tuning override
     const bool peel = peel_on && rem != 0 && t_full > 0 && (N % 32) == 0 && (K % 256) == 0 && (t128 + 511) / 512 > (t_full + 511) / 512;
+    // ... and a last round that would be less than a quarter full (proj / fc2 at 12,800 tokens: 600 tiles = 512 + 88) is not opened either: the
+    // row tiles it consists of go to the 64 x 64 kernel, whose 4 workgroups per CU spread them over the whole chip
+    static const int tail_pct = [] { const char* e = getenv("SC_GEMM_TAIL_PCT"); return e ? atoi(e) : 25; }();                    // tuning override
+    const int ntn128 = (N + 127) / 128;
+    const long long main_mt = (t128 / 512) * 512 / ntn128;            // whole row tiles inside the full rounds
+    const bool tail64 = !peel && rem == 0 && t128 > 512 && (t128 % 512) != 0 && (t128 % 512) * 100 < 512 * tail_pct && main_mt > 0;
+    const int M0t = (int)main_mt * 128;
 #define SC_LAUNCH(E)                                                                                                          \
     if (big) {                                                                                                         \
         (void)hipFuncSetAttribute((const void*)gemm256_kernel<E, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);        \
@@ -1001,8 +1026,15 @@ static int launch_gemm(int epi, const bf16_t* A, const bf16_t* Wt, const float* 
                            SC_GEMM64_STAGES * 2 * 64 * 8 * 16, st, A, Wt, bias, out, M, N, K);                                \
     } else if ((N % 8) == 0) {          /* persistent: 2 resident workgroups per CU walk the tile list */                     \
         (void)hipFuncSetAttribute((const void*)gemm_bf16_persist_kernel<E, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); \
-        hipLaunchKernelGGL((gemm_bf16_persist_kernel<E, H16>), dim3(512), dim3(256), 65536, st, A, Wt, bias, out, peel ? M - rem : M, N, K, \
-                           (N + 127) / 128, (int)(peel ? t_full : t128));                                                     \
+        hipLaunchKernelGGL((gemm_bf16_persist_kernel<E, H16>), dim3(512), dim3(256), 65536, st, A, Wt, bias, out,                  \
+                           peel ? M - rem : tail64 ? M0t : M, N, K, (N + 127) / 128, (int)(peel ? t_full : tail64 ? main_mt * ntn128 : t128)); \
+        if (tail64) {                                                                                                         \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<E, 64, H16>, hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                       SC_GEMM64_STAGES * 2 * 64 * 8 * 16);                                                   \
+            hipLaunchKernelGGL((gemm_bf16_kernel<E, 64, H16>), dim3((N + 63) / 64, (M - M0t + 63) / 64), dim3(256),                \
+                               SC_GEMM64_STAGES * 2 * 64 * 8 * 16, st, A + (size_t)M0t * K, Wt, bias,                         \
+                               (char*)out + (size_t)M0t * N * ((E) == EPI_F32 || (E) == EPI_RESID ? 4 : 2), M - M0t, N, K);    \
+        }                                                                                                                     \
         if (peel)                                                                                                             \
             hipLaunchKernelGGL((gemm_thin_kernel<E, H16>), dim3(N / 32, (rem + 31) / 32), dim3(64 * THIN_NW), 0, st, A + (size_t)(M - rem) * K, Wt, bias, \
                                (char*)out + (size_t)(M - rem) * N * ((E) == EPI_F32 || (E) == EPI_RESID ? 4 : 2), rem, N, K);  \
@@ -1052,7 +1084,8 @@ static int clip_vit_forward(const float* image, int B, int C, int H, int W, int 
     const float* lnpre_g = wf; wf += D;
     const float* lnpre_b = wf; wf += D;
 
-    hipLaunchKernelGGL(patchify_kernel<H16>, dim3(2048), dim3(256), 0, st, image, a_patch, B, C, H, W, patch, Kp);
+    if ((long long)B * np * (Kp / 8) >= (1LL << 31)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(patchify_kernel<H16>, dim3(4096), dim3(256), 0, st, image, a_patch, B, C, H, W, patch, Kp);
     const int Tp32 = (T + 31) & ~31, att_v = 64 * (Tp32 + 4) * (int)sizeof(bf16_t), att_k = Tp32 * ATT_KLD * (int)sizeof(bf16_t);
     if (att_v > 160 * 1024) return (int)hipErrorInvalidValue;
     const int k_lds = att_v + att_k <= 160 * 1024 ? 1 : 0;          // T = 257 (ViT-L/14 at 224 x 224): 77 KB, two workgroups per CU
