@@ -323,6 +323,20 @@ int sc_marching_cubes_count(const float* level, int n_images, int n_axis, float 
 int sc_marching_cubes_emit(const float* level, int n_images, int n_axis, float iso, const int* counts,
                            const long long* offsets, float* tris, void* stream);
 
+/* Block form of both (what the Python side uses): a workgroup owns 1,024 consecutive cubes of one image.
+ *   sc_isosurface_blocks_per_image(n_axis)   blocks per image = ceil((n_axis-1)^3 / 1024)  (-1: n_axis outside 2..1024)
+ *   *_block_count    block_counts [n_images * blocks_per_image] int: triangles of each block
+ *   *_block_emit     block_offsets: exclusive int64 prefix sum of block_counts; the kernel recomputes the per-cube counts and takes
+ *                    their prefix inside the workgroup -- no per-cube count / offset arrays (12 bytes per cube), and the prefix sum
+ *                    between the launches runs over 1/1024 of the values.  Same triangles in the same order as the per-cube form. */
+int sc_isosurface_blocks_per_image(int n_axis);
+int sc_isosurface_block_count(const float* level, int n_images, int n_axis, float iso, int* block_counts, void* stream);
+int sc_isosurface_block_emit(const float* level, int n_images, int n_axis, float iso, const long long* block_offsets, float* tris,
+                             void* stream);
+int sc_marching_cubes_block_count(const float* level, int n_images, int n_axis, float iso, int* block_counts, void* stream);
+int sc_marching_cubes_block_emit(const float* level, int n_images, int n_axis, float iso, const long long* block_offsets, float* tris,
+                                 void* stream);
+
 /* ---- camera algebra of a render -------------------------------------------------------------------
  * sc_camera_rays_*: utils/camera.py:157-196 (get_center_and_ray on the rendered pixels only) + the normalisation of
  * model/renderer.py:69-76.  pose [n_images][3][4] = [R|t] world->camera, intr [n_images][3][3], ray_idx

@@ -23,6 +23,8 @@ SYMBOLS = (
     "sc_ray_sample_forward", "sc_ray_sample_backward", "sc_render_forward", "sc_sdf_grid_forward", "sc_loss_fused_backward",
     "sc_bn_splits", "sc_bn_act_forward", "sc_bn_act_backward", "sc_bn_relu_pool_forward", "sc_bn_relu_pool_backward",
     "sc_isosurface_count", "sc_isosurface_emit", "sc_marching_cubes_count", "sc_marching_cubes_emit",
+    "sc_isosurface_blocks_per_image", "sc_isosurface_block_count", "sc_isosurface_block_emit", "sc_marching_cubes_block_count",
+    "sc_marching_cubes_block_emit",
     "sc_camera_rays_forward", "sc_camera_rays_backward", "sc_pose_from_trig_forward", "sc_pose_from_trig_backward",
     "sc_estimator_head_forward", "sc_estimator_head_backward", "sc_camera_prior_forward", "sc_camera_prior_backward",
     "sc_camera_prior_max_images", "sc_transform_normal_forward", "sc_transform_normal_backward", "sc_loss_total_forward",
@@ -37,7 +39,7 @@ _lib: Optional[ctypes.CDLL] = None
 # Optional per-entry-point GPU timing (bench.py): when TIMING is a dict every C-ABI call is bracketed by
 # two events on torch's current stream (the stream the kernels are enqueued on).
 TIMING = None
-TIMING_SKIP = ("sc_bn_splits", "sc_bn_act_forward", "sc_bn_act_backward", "sc_bn_relu_pool_forward", "sc_bn_relu_pool_backward",
+TIMING_SKIP = ("sc_bn_splits", "sc_isosurface_blocks_per_image", "sc_bn_act_forward", "sc_bn_act_backward", "sc_bn_relu_pool_forward", "sc_bn_relu_pool_backward",
                # the trunks' convolutions: ~250 calls per step -- two events each cost the step ~1 ms (rocprofv3 covers them: profiles/)
                "sc_conv3x3_forward", "sc_conv3x3_forward_split", "sc_conv3x3_wgrad", "sc_conv3x3_wgrad_split", "sc_conv3x3_pack", "sc_conv3x3_pack_multi", "sc_conv3x3_pack_multi_units",
                "sc_conv_stem_forward", "sc_conv_stem_wgrad", "sc_conv1x1s2_forward", "sc_conv1x1s2_backward_data", "sc_conv1x1s2_wgrad",

@@ -527,27 +527,30 @@ ISOSURFACE_METHODS = ("cubes", "tetrahedra")
 def isosurface_triangles(level: torch.Tensor, iso: float = 0.0, method: str = "cubes"):
     """level [B,S,S,S] (device) -> (tris [T,3,3] in grid-index units, tri_count [B] int64 on the host).
     method "cubes": marching cubes, the algorithm of the reference's PyMCubes call (same vertex set); "tetrahedra": the
-    table-free marching tetrahedra of rounds 1-2.  Two launches around one prefix sum either way (csrc/isosurface.hip)."""
+    table-free marching tetrahedra of rounds 1-2.  Two launches around one prefix sum over per-workgroup counts either way
+    (csrc/isosurface.hip, block form)."""
     if method not in ISOSURFACE_METHODS:
         raise ValueError("isosurface_triangles: method must be one of %s, got %r" % (ISOSURFACE_METHODS, method))
     lib = _lib.load()
-    count_fn, emit_fn = (lib.sc_marching_cubes_count, lib.sc_marching_cubes_emit) if method == "cubes" else \
-        (lib.sc_isosurface_count, lib.sc_isosurface_emit)
+    count_fn, emit_fn = (lib.sc_marching_cubes_block_count, lib.sc_marching_cubes_block_emit) if method == "cubes" else \
+        (lib.sc_isosurface_block_count, lib.sc_isosurface_block_emit)
     level = level.contiguous().float()
     B, S = level.shape[0], level.shape[1]
     assert level.shape[1:] == (S, S, S)
-    n_cubes = B * (S - 1) ** 3
-    counts = torch.empty(n_cubes, device=level.device, dtype=torch.int32)
+    bpi = int(lib.sc_isosurface_blocks_per_image(c_int(S)))
+    if bpi <= 0:
+        raise RuntimeError("shapeclipper_amd: isosurface_triangles needs 2 <= grid side <= 1024, got %d" % S)
+    counts = torch.empty(B * bpi, device=level.device, dtype=torch.int32)           # triangles per workgroup of 1,024 cubes
     _lib.check(count_fn(_lib.ptr(level), c_int(B), c_int(S), ctypes.c_float(iso), _lib.ptr(counts), _lib.stream()),
-               "sc_isosurface_count / sc_marching_cubes_count")
+               "sc_isosurface_block_count / sc_marching_cubes_block_count")
     ends = torch.cumsum(counts, 0, dtype=torch.int64)
     offsets = (ends - counts).contiguous()
-    per_image = counts.view(B, -1).sum(dim=1, dtype=torch.int64).cpu()
+    per_image = counts.view(B, bpi).sum(dim=1, dtype=torch.int64).cpu()
     total = int(per_image.sum())
     tris = torch.empty(total, 3, 3, device=level.device, dtype=torch.float32)
     if total > 0:
-        _lib.check(emit_fn(_lib.ptr(level), c_int(B), c_int(S), ctypes.c_float(iso), _lib.ptr(counts),
-                           _lib.ptr(offsets), _lib.ptr(tris), _lib.stream()), "sc_isosurface_emit / sc_marching_cubes_emit")
+        _lib.check(emit_fn(_lib.ptr(level), c_int(B), c_int(S), ctypes.c_float(iso), _lib.ptr(offsets), _lib.ptr(tris), _lib.stream()),
+                   "sc_isosurface_block_emit / sc_marching_cubes_block_emit")
     return tris, per_image
 
 

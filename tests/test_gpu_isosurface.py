@@ -94,3 +94,31 @@ def test_empty_surface_gives_zero_points():
     from shapeclipper_amd.utils import eval_3D
     pts, meshes = eval_3D.surface_points_device(torch.ones(2, 9, 9, 9).cuda(), -0.6, 0.6, 100)
     assert meshes[0].shape[0] == 0 and float(pts.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("method", ["cubes", "tetrahedra"])
+def test_block_form_equals_per_cube_form(method):
+    """ops.isosurface_triangles (one count per workgroup of 1,024 cubes, prefix inside the workgroup) against the per-cube entry points of
+    the C ABI (a count and a 64-bit offset per cube): the same triangles in the same order, on a batch whose images differ, whose cube count
+    is not a multiple of the block size, and whose first / last blocks of an image are empty."""
+    import ctypes
+    from shapeclipper_amd import _lib, ops
+    lib = _lib.load()
+    rng = np.random.RandomState(4)
+    S = 37                                                               # 36^3 = 46,656 cubes = 45.6 blocks per image
+    level = np.stack([_sphere(S, 0.5, (0.1, 0.0, -0.2)), rng.randn(S, S, S).astype(np.float32), np.full((S, S, S), 2.0, np.float32),
+                      _sphere(S, 0.8)]).astype(np.float32)
+    lv = torch.tensor(level).cuda()
+    tris, per = ops.isosurface_triangles(lv, 0.0, method=method)
+    B, n_cubes = lv.shape[0], lv.shape[0] * (S - 1) ** 3
+    cnt_fn, emit_fn = (lib.sc_marching_cubes_count, lib.sc_marching_cubes_emit) if method == "cubes" else (lib.sc_isosurface_count, lib.sc_isosurface_emit)
+    counts = torch.empty(n_cubes, device="cuda", dtype=torch.int32)
+    assert cnt_fn(_lib.ptr(lv), ctypes.c_int(B), ctypes.c_int(S), ctypes.c_float(0.0), _lib.ptr(counts), _lib.stream()) == 0
+    ends = torch.cumsum(counts, 0, dtype=torch.int64)
+    offsets = (ends - counts).contiguous()
+    ref = torch.full((int(ends[-1]), 3, 3), float("nan"), device="cuda")
+    assert emit_fn(_lib.ptr(lv), ctypes.c_int(B), ctypes.c_int(S), ctypes.c_float(0.0), _lib.ptr(counts), _lib.ptr(offsets), _lib.ptr(ref), _lib.stream()) == 0
+    torch.cuda.synchronize()
+    assert tris.shape == ref.shape and torch.equal(tris, ref)
+    assert per.tolist() == counts.view(B, -1).sum(1).tolist() and per[2] == 0 and per[1] > per[0] > 0
+    assert int(lib.sc_isosurface_blocks_per_image(ctypes.c_int(S))) == 46 and int(lib.sc_isosurface_blocks_per_image(ctypes.c_int(1))) == -1
