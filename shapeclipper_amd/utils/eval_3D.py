@@ -87,33 +87,36 @@ def surface_points_device(level, lo, hi, num_points, seed=0, iso=0.0, method="cu
     PyMCubes produces, `method="tetrahedra"` selects the table-free variant of rounds 1-2), a
     triangle per sample drawn with probability proportional to its area, a uniform point inside it (the same scheme
     trimesh uses).  Vertices get the reference's 1/S rescale.  No D2H of the (N+1)^3 grid, no Python threads; seeded per
-    call so that sharded evaluation is independent of which rank handles a sample."""
+    call (the draws of image b depend on `seed` and b only)."""
     from .. import ops
     B, S = level.shape[0], level.shape[1]
     dev = level.device
     tris, per_image = ops.isosurface_triangles(level, iso, method=method)
+    t_all = tris / S * (hi - lo) + lo
+    ends = torch.cumsum(per_image, 0)                                   # host: triangles up to and including image b
+    starts = ends - per_image
+    meshes = [t_all[int(starts[b]):int(ends[b])] for b in range(B)]
     out = torch.zeros(B, num_points, 3, device=dev)
-    meshes = []
+    if t_all.shape[0] == 0:
+        return out, meshes                                              # the reference returns zeros for an empty mesh
+    # all images at once: inverse-CDF draw over the concatenated triangle list -- image b's samples search its own segment of the
+    # (float64) cumulative area, so no per-image loop, launch sequence or host synchronisation is left
+    e1, e2 = t_all[:, 1] - t_all[:, 0], t_all[:, 2] - t_all[:, 0]
+    cdf = torch.cumsum(torch.linalg.cross(e1, e2).norm(dim=1).double(), 0)
+    cdf0 = torch.cat([cdf.new_zeros(1), cdf])                           # cdf0[k] = area of the first k triangles
+    st, en = starts.to(dev), ends.to(dev)
+    base, total = cdf0[st], cdf0[en] - cdf0[st]                         # [B]
     gen = torch.Generator(device=dev)
-    start = 0
-    for b in range(B):
-        n = int(per_image[b])
-        t = tris[start:start + n] / S * (hi - lo) + lo
-        start += n
-        meshes.append(t)
-        if n == 0:
-            continue                                               # the reference returns zeros for an empty mesh
-        gen.manual_seed(seed + b)
-        e1, e2 = t[:, 1] - t[:, 0], t[:, 2] - t[:, 0]
-        area = torch.linalg.cross(e1, e2).norm(dim=1)
-        if float(area.sum()) <= 0:
-            continue
-        pick = torch.multinomial(area, num_points, replacement=True, generator=gen)
-        uv = torch.rand(num_points, 2, device=dev, generator=gen)
-        flip = uv.sum(dim=1, keepdim=True) > 1
-        uv = torch.where(flip, 1 - uv, uv)
-        out[b] = t[pick, 0] + uv[:, :1] * e1[pick] + uv[:, 1:] * e2[pick]
-    return out, meshes
+    gen.manual_seed(seed)
+    u = torch.rand(B, num_points, 3, device=dev, generator=gen)
+    target = base[:, None] + u[..., 0].double() * total[:, None]
+    pick = torch.searchsorted(cdf, target.reshape(-1), right=True).view(B, num_points)
+    pick = torch.minimum(torch.maximum(pick, st[:, None]), (en - 1).clamp_min(0)[:, None])      # stays inside the image's segment
+    uv = u[..., 1:]
+    uv = torch.where(uv.sum(dim=-1, keepdim=True) > 1, 1 - uv, uv)
+    pts = t_all[pick, 0] + uv[..., :1] * e1[pick] + uv[..., 1:] * e2[pick]
+    ok = (total > 0) & (en > st)                                        # empty or zero-area meshes keep their zeros
+    return torch.where(ok[:, None, None], pts, out), meshes
 
 
 def convert_to_explicit_worker(opt, i, level_vox_i, isoval, meshes, pointclouds=None):
