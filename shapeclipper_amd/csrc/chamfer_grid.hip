@@ -18,6 +18,7 @@
 // Bound: latency / L2 gathers (54 candidates per query instead of 100,000); the brute-force line stays in bench.py's workloads.
 #include "chamfer_common.hpp"
 #include <limits.h>
+#include <stdlib.h>
 
 namespace sc {
 
@@ -25,50 +26,73 @@ constexpr int CG_TPC = 2;          // aimed-at targets per cell
 constexpr int CG_GMAX = 128;       // cells per axis
 constexpr int CG_RMAX = 5;         // rings before a query is handed to the brute-force scan
 constexpr int CG_BUDGET = 3072;    // candidates before a query is handed to the brute-force scan
+constexpr int CG_REMPTY = 2;       // rings without any candidate before a query is handed to the scan
+constexpr int CG_DENSE = 8;         // targets per occupied cell from which a cloud counts as surface-like
+constexpr int CG_WAVE_RMAX = 8;     // rings of the wave walk (its candidates cost ~1/50 of the thread walk's per query)
+constexpr int CG_WAVE_REMPTY = 4;   // rings without any candidate before the wave gives up
+constexpr int CG_WAVE_BUDGET = 16384;   // candidates per WAVE (64 queries of one cell) before its open queries are handed to the scan
 
 struct GridMeta {                  // one per batch element
     float lo[3], h[3], inv_h[3];
     int g[3];
     float slack;
     int valid;
+    int dense;                     // >= CG_DENSE targets per OCCUPIED cell (a surface, not a volume): the queries walk in waves (5b)
 };
 
 __host__ __device__ inline int cg_cells_capacity(int m) { return m / CG_TPC * 2 + 64; }
 
-// ---- 1. bounding box of the target cloud -> grid geometry (one workgroup per batch element) -------------------------------
-__global__ __launch_bounds__(1024) void cg_meta_kernel(int m, const float* __restrict__ tgt, GridMeta* __restrict__ meta) {
-    __shared__ float red[6][16];
-    __shared__ int bad_s;
-    const int b = blockIdx.x, tid = threadIdx.x;
+// ---- 1. bounding box of the target cloud -> grid geometry ---------------------------------------------------------------------
+// Many workgroups per image: per-wave minima / maxima go into six order-preserving integer keys with atomicMax (the minima as the
+// complement of their key, so that the all-zero state the workspace memset leaves means "nothing yet" for all six); box[6] collects
+// the "not a plain finite coordinate" flag.  One thread per image turns the box into the grid geometry.  (One 1024-thread workgroup
+// per image took 40 us for 100,000 points -- a tenth of a whole batch-1 search.)
+__device__ __forceinline__ unsigned cg_key(float f) {
+    const unsigned u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float cg_unkey(unsigned k) {
+    return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+__global__ __launch_bounds__(256) void cg_bbox_kernel(int m, const float* __restrict__ tgt, unsigned* __restrict__ box_all) {
+    const int b = blockIdx.y, tid = threadIdx.x;
     const float* t = tgt + (size_t)b * m * 3;
     float mn[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, mx[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-    int bad = 0;
-    if (tid == 0) bad_s = 0;
-    for (int k = tid; k < m; k += blockDim.x)
+    int bad = 0, any = 0;
+    for (int k = blockIdx.x * 256 + tid; k < m; k += gridDim.x * 256) {
+        any = 1;
         for (int a = 0; a < 3; ++a) {
             const float v = t[(size_t)k * 3 + a];
             bad |= !(fabsf(v) < 1.0e15f);          // NaN, Inf and magnitudes the padding / slack arithmetic is not made for
             mn[a] = fminf(mn[a], v); mx[a] = fmaxf(mx[a], v);
         }
+    }
     for (int a = 0; a < 3; ++a)
         for (int d = 32; d >= 1; d >>= 1) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], d)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], d)); }
-    __syncthreads();
-    if ((tid & 63) == 0)
-        for (int a = 0; a < 3; ++a) { red[a][tid >> 6] = mn[a]; red[3 + a][tid >> 6] = mx[a]; }
-    if (bad) bad_s = 1;
-    __syncthreads();
-    if (tid == 0) {
+    any = __any(any);
+    bad = __any(bad);
+    unsigned* box = box_all + (size_t)b * 8;
+    if ((tid & 63) == 0 && any) {
+        for (int a = 0; a < 3; ++a) { atomicMax(&box[a], ~cg_key(mn[a])); atomicMax(&box[3 + a], cg_key(mx[a])); }
+        if (bad) atomicOr(&box[6], 1u);
+    }
+}
+
+__global__ void cg_meta_kernel(int m, int n_images, const unsigned* __restrict__ box_all, GridMeta* __restrict__ meta) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_images) return;
+    const unsigned* box = box_all + (size_t)b * 8;
+    {
         GridMeta g;
         float ext[3], scale = 0.f, emax = 0.f;
         for (int a = 0; a < 3; ++a) {
-            float lo = red[a][0], hi = red[3 + a][0];
-            for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { lo = fminf(lo, red[a][w]); hi = fmaxf(hi, red[3 + a][w]); }
+            const float lo = cg_unkey(~box[a]), hi = cg_unkey(box[3 + a]);
             g.lo[a] = lo;
             ext[a] = hi - lo;
             emax = fmaxf(emax, ext[a]);
             scale = fmaxf(scale, fmaxf(fabsf(lo), fabsf(hi)));
         }
-        g.valid = (!bad_s && m > 0 && emax > 0.f) ? 1 : 0;
+        g.valid = (!box[6] && m > 0 && emax > 0.f) ? 1 : 0;
         // a flat or thin cloud still gets cells of a sensible size along its thin axes
         float vol = 1.f;
         for (int a = 0; a < 3; ++a) { ext[a] = fmaxf(ext[a], emax * 1.0e-3f); vol *= ext[a]; }
@@ -92,6 +116,7 @@ __global__ __launch_bounds__(1024) void cg_meta_kernel(int m, const float* __res
         }
         g.slack = 16.f * 1.1920929e-7f * (scale + emax);
         if (!g.valid) { g.g[0] = g.g[1] = g.g[2] = 1; }
+        g.dense = 0;                                   // set by the scan of the target histogram
         meta[b] = g;
     }
 }
@@ -103,10 +128,11 @@ __device__ __forceinline__ int cg_axis_cell(float v, float lo, float inv_h, int 
 
 // ---- 2. cell of every target + histogram -----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cg_count_kernel(int m, const float* __restrict__ tgt, const GridMeta* __restrict__ meta, int cap,
-                                                       int* __restrict__ cell_of, int* __restrict__ counts) {
+                                                       int* __restrict__ cell_of, int* __restrict__ counts, int only_dense) {
     const int b = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= m) return;
     const GridMeta& g = meta[b];
+    if (only_dense && !g.dense) return;            // the query-side binning is for the wave walk only
     const float* t = tgt + ((size_t)b * m + k) * 3;
     int c = 0;
     if (g.valid) {
@@ -118,35 +144,76 @@ __global__ __launch_bounds__(256) void cg_count_kernel(int m, const float* __res
     atomicAdd(&counts[(size_t)b * (cap + 1) + c], 1);
 }
 
-// ---- 3. exclusive scan of the histogram, in place (one workgroup per batch element); start[cells] = m ----------------------
-__global__ __launch_bounds__(1024) void cg_scan_kernel(const GridMeta* __restrict__ meta, int cap, int* __restrict__ counts) {
-    __shared__ int part[1024];
-    const int b = blockIdx.x, tid = threadIdx.x;
+// ---- 3. exclusive scan of the histogram, in place; start[cells] = total -----------------------------------------------------
+// Two launches over 1,024-cell blocks (one 1024-thread workgroup per image took 77 us for 50,000 cells, and the search runs it four
+// times): a local exclusive scan per block + the block totals, then every block adds the totals in front of it.  The range scanned is
+// [0, cells] INCLUSIVE: the entry behind the last cell is zero on entry and ends up holding the grand total.
+// targets != 0 (the target histogram): also counts the occupied cells and (second launch) sets meta.dense; targets == 0 (the query
+// histogram): runs for dense images only.
+__global__ __launch_bounds__(1024) void cg_scan_local_kernel(const GridMeta* __restrict__ meta, int cap, int* __restrict__ counts,
+                                                             int* __restrict__ block_tot, int nblk, int* __restrict__ occupied, int targets) {
+    __shared__ int wtot[16];
+    const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const GridMeta& g = meta[b];
+    if (!targets && !g.dense) return;
     const int cells = g.g[0] * g.g[1] * g.g[2];
+    if (blk * 1024 > cells) return;
     int* c = counts + (size_t)b * (cap + 1);
-    const int per = (cells + 1023) / 1024, lo = tid * per, hi = min(cells, lo + per);
-    int s = 0;
-    for (int i = lo; i < hi; ++i) s += c[i];
-    part[tid] = s;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const int v = tid >= d ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    const int i = blk * 1024 + tid;
+    const int v = i <= cells ? c[i] : 0;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
     }
-    int run = part[tid] - s;
-    for (int i = lo; i < hi; ++i) { const int v = c[i]; c[i] = run; run += v; }
-    if (tid == 1023) c[cells] = part[1023];
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int t = wtot[w];
+        if (w < wave) before += t;
+        total += t;
+    }
+    if (i <= cells) c[i] = before + incl - v;
+    if (tid == 0) block_tot[(size_t)b * nblk + blk] = total;
+    if (targets) {
+        const unsigned long long nz = __ballot(v > 0);
+        if (lane == 0 && nz) atomicAdd(&occupied[b], __builtin_popcountll(nz));
+    }
+}
+
+__global__ __launch_bounds__(1024) void cg_scan_add_kernel(GridMeta* __restrict__ meta, int cap, int* __restrict__ counts,
+                                                           const int* __restrict__ block_tot, int nblk, const int* __restrict__ occupied,
+                                                           int targets) {
+    const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+    const GridMeta& g = meta[b];
+    if (!targets && !g.dense) return;
+    const int cells = g.g[0] * g.g[1] * g.g[2];
+    if (blk * 1024 > cells) return;
+    __shared__ int off_s;
+    if (tid < 64) {                                                                // <= 100 values in front of this block
+        int part = 0;
+        for (int k = tid; k < blk; k += 64) part += block_tot[(size_t)b * nblk + k];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d);
+        if (tid == 0) off_s = part;
+    }
+    __syncthreads();
+    const int off = off_s;
+    const int i = blk * 1024 + tid;
+    if (i <= cells && off) counts[(size_t)b * (cap + 1) + i] += off;
+    if (targets && blk == 0 && tid == 0) meta[b].dense = (g.valid && (long long)targets >= (long long)occupied[b] * CG_DENSE) ? 1 : 0;
 }
 
 // ---- 4. targets into cell order as {x, y, z, original index}; order inside a cell is arbitrary (see the acceptance rule) ----
 __global__ __launch_bounds__(256) void cg_scatter_kernel(int m, const float* __restrict__ tgt, int cap, const int* __restrict__ cell_of,
                                                          const int* __restrict__ start, int* __restrict__ cursor,
-                                                         float4* __restrict__ sorted) {
+                                                         float4* __restrict__ sorted, const GridMeta* __restrict__ only_dense) {
     const int b = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= m) return;
+    if (only_dense && !only_dense[b].dense) return;
     const int c = cell_of[(size_t)b * m + k];
     const int pos = start[(size_t)b * (cap + 1) + c] + atomicAdd(&cursor[(size_t)b * cap + c], 1);
     const float* t = tgt + ((size_t)b * m + k) * 3;
@@ -157,10 +224,12 @@ __global__ __launch_bounds__(256) void cg_scatter_kernel(int m, const float* __r
 __global__ __launch_bounds__(256) void cg_query_kernel(int n, const float* __restrict__ qry, int m, const GridMeta* __restrict__ meta, int cap,
                                                        const int* __restrict__ start_all, const float4* __restrict__ sorted_all,
                                                        float* __restrict__ dist, int* __restrict__ idx, int* __restrict__ todo,
-                                                       int* __restrict__ todo_count) {
+                                                       int* __restrict__ todo_count, unsigned long long* __restrict__ keys,
+                                                       int wave_walk) {
     const int b = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const GridMeta g = meta[b];
+    if (wave_walk && g.dense) return;              // surface-like targets: the queries of this image walk in waves (cg_query_wave_kernel)
     const float* qp = qry + ((size_t)b * n + j) * 3;
     const float q[3] = {qp[0], qp[1], qp[2]};
     const int* start = start_all + (size_t)b * (cap + 1);
@@ -170,9 +239,14 @@ __global__ __launch_bounds__(256) void cg_query_kernel(int n, const float* __res
     int bidx = INT_MAX;
     if (g.valid && fabsf(q[0]) < 1.0e15f && fabsf(q[1]) < 1.0e15f && fabsf(q[2]) < 1.0e15f) {
         int c[3];
-        for (int a = 0; a < 3; ++a) c[a] = cg_axis_cell(q[a], g.lo[a], g.inv_h[a], g.g[a]);
+        bool outside = false;          // more than CG_REMPTY cells off the targets' bounding box: the walk could only confirm a candidate
+        for (int a = 0; a < 3; ++a) {  // after many rings (its bound grows by one cell per ring, the lateral offsets do not shrink)
+            c[a] = cg_axis_cell(q[a], g.lo[a], g.inv_h[a], g.g[a]);
+            const float off = fmaxf(g.lo[a] - q[a], q[a] - (g.lo[a] + (float)g.g[a] * g.h[a]));
+            outside |= off > (float)CG_REMPTY * g.h[a];
+        }
         int seen = 0;
-        for (int r = 1; r <= CG_RMAX && !done && seen <= CG_BUDGET; ++r) {
+        for (int r = 1; r <= CG_RMAX && !done && !outside && seen <= CG_BUDGET; ++r) {
             const int z0 = max(c[2] - r, 0), z1 = min(c[2] + r, g.g[2] - 1), y0 = max(c[1] - r, 0), y1 = min(c[1] + r, g.g[1] - 1);
             const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, g.g[0] - 1);
             for (int z = z0; z <= z1; ++z)
@@ -205,40 +279,180 @@ __global__ __launch_bounds__(256) void cg_query_kernel(int n, const float* __res
             }
             const float safe = lb - g.slack;
             done = lb == __builtin_inff() ? bidx != INT_MAX : (safe > 0.f && best < safe * safe * 0.9999f);
+            // two rings (125 cells) without a single target: the query is far from the other cloud.  Rings 3-5 are 374 more row look-ups,
+            // each a dependent load -- as much chip time as the scan this query is most likely headed for anyway (mismatched clouds at
+            // evaluation: a 100k x 100k pair took 2.3 ms per direction in this kernel).  Exactness is the scan's.
+            if (r >= CG_REMPTY && bidx == INT_MAX) break;
         }
     }
     if (done) {
         dist[(size_t)b * n + j] = best;
         idx[(size_t)b * n + j] = bidx;
     } else {
-        todo[(size_t)b * n + atomicAdd(&todo_count[b], 1)] = j;
+        const int pos = atomicAdd(&todo_count[b], 1);
+        todo[(size_t)b * n + pos] = j;
+        keys[(size_t)b * n + pos] = ~0ull;           // the scan below publishes (distance bits, index) with atomicMin
+    }
+}
+
+// ---- 5b. the ring walk, one WAVE per (cell, 64 queries of that cell) --------------------------------------------------------
+// The queries are binned into the TARGET grid as well (steps 2-4 on the query cloud) and a wave takes up to 64 queries of one cell: the
+// walk around that cell -- rows, candidate ranges, candidates -- is the same for all of them, so the control flow is wave-uniform and a
+// candidate is fetched ONCE per wave (uniform address: scalar load) and tested against 64 queries.  The thread-per-query kernel above
+// fetches every candidate once per query through divergent 16-byte gathers: ~70 G pairs/s against 7.7 T pairs/s of the all-pairs
+// kernels, so that on SURFACE clouds a few cells apart (1,500-3,000 candidates per query: the evaluation's predicted surface against the
+// ground truth, mean distance 0.05-0.1) the grid search took 6-9 ms where all pairs take 2.9.  Same acceptance rule, same stopping
+// rule per lane; the wave stops when all its lanes have.
+__global__ __launch_bounds__(256) void cg_items_kernel(const GridMeta* __restrict__ meta, int cap, const int* __restrict__ qstart_all,
+                                                       int* __restrict__ items_all, int* __restrict__ item_count, int max_items) {
+    const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    const GridMeta& g = meta[b];
+    if (!g.dense || c >= g.g[0] * g.g[1] * g.g[2]) return;
+    const int* qs = qstart_all + (size_t)b * (cap + 1);
+    const int cnt = qs[c + 1] - qs[c];
+    if (cnt <= 0) return;
+    const int chunks = (cnt + 63) >> 6;
+    const int at = atomicAdd(&item_count[b], chunks);
+    int* items = items_all + (size_t)b * max_items * 2;
+    for (int k = 0; k < chunks; ++k) { items[2 * (at + k)] = c; items[2 * (at + k) + 1] = k; }
+}
+
+__global__ __launch_bounds__(256) void cg_query_wave_kernel(int n, int m, const GridMeta* __restrict__ meta, int cap,
+                                                            const int* __restrict__ start_all, const float4* __restrict__ sorted_all,
+                                                            const int* __restrict__ qstart_all, const float4* __restrict__ qsorted_all,
+                                                            const int* __restrict__ items_all, const int* __restrict__ item_count,
+                                                            int max_items, float* __restrict__ dist, int* __restrict__ idx,
+                                                            int* __restrict__ todo, int* __restrict__ todo_count,
+                                                            unsigned long long* __restrict__ keys) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int n_items = item_count[b];
+    const GridMeta g = meta[b];
+    for (int item = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))); item < n_items; item += (int)gridDim.x * 4) {
+    const int* start = start_all + (size_t)b * (cap + 1);
+    const float4* sorted = sorted_all + (size_t)b * m;
+    const int* qstart = qstart_all + (size_t)b * (cap + 1);
+    const int cell = __builtin_amdgcn_readfirstlane(items_all[((size_t)b * max_items + item) * 2]);
+    const int chunk = __builtin_amdgcn_readfirstlane(items_all[((size_t)b * max_items + item) * 2 + 1]);
+    const int q0 = qstart[cell] + chunk * 64, q1 = qstart[cell + 1];
+    const bool live = q0 + lane < q1;
+    const float4 qv = qsorted_all[(size_t)b * n + (live ? q0 + lane : q0)];
+    const float q[3] = {qv.x, qv.y, qv.z};
+    const int j = __float_as_int(qv.w);
+    int c[3];
+    c[0] = cell % g.g[0];
+    c[1] = (cell / g.g[0]) % g.g[1];
+    c[2] = cell / (g.g[0] * g.g[1]);
+    // (no "outside the bounding box" shortcut here: a wave's candidates are cheap, and a cloud that encloses the other one -- every query
+    // of one direction outside the other's box -- is the common case at evaluation)
+    const bool skip = !(g.valid && fabsf(q[0]) < 1.0e15f && fabsf(q[1]) < 1.0e15f && fabsf(q[2]) < 1.0e15f);
+    bool done = false, hopeless = false;
+    float best = __builtin_inff();
+    int bidx = INT_MAX, seen = 0;
+    const float hinv = fmaxf(g.inv_h[0], fmaxf(g.inv_h[1], g.inv_h[2]));       // 1 / smallest cell side
+    for (int r = 1; r <= CG_WAVE_RMAX && seen <= CG_WAVE_BUDGET; ++r) {
+        if (__builtin_amdgcn_readfirstlane((int)__all((int)(done || skip || hopeless || !live)))) break;
+        const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, g.g[0] - 1);
+        // The shell of ring r as a list of candidate RANGES: (2r+1)^2 rows (z, y), each one run of cells along x (rows on the shell's
+        // z / y faces; ring 1 takes the whole block) or its two end cells (inner rows).  64 ranges at a time: every lane looks up the two
+        // `start` entries of ITS range (one round trip for 64 ranges instead of one per row), then the wave goes through the non-empty ones.
+        const int side_len = 2 * r + 1, nranges = 2 * side_len * side_len;
+        for (int p0 = 0; p0 < nranges; p0 += 64) {
+            const int p = p0 + lane;
+            int rs = 0, re = 0;
+            if (p < nranges) {
+                const int pair = p >> 1, sd = p & 1;
+                const int zc = c[2] - r + pair / side_len, yc = c[1] - r + pair % side_len;
+                if (zc >= 0 && zc < g.g[2] && yc >= 0 && yc < g.g[1]) {
+                    const int row = (zc * g.g[1] + yc) * g.g[0];
+                    const bool full = r == 1 || zc == c[2] - r || zc == c[2] + r || yc == c[1] - r || yc == c[1] + r;
+                    int xa = -1, xb = -1;
+                    if (full) { if (sd == 0) { xa = x0; xb = x1; } }
+                    else {
+                        const int x = sd == 0 ? c[0] - r : c[0] + r;
+                        if (x >= 0 && x < g.g[0]) xa = xb = x;
+                    }
+                    if (xa >= 0) { rs = start[row + xa]; re = start[row + xb + 1]; }
+                }
+            }
+            unsigned long long nonempty = __ballot(re > rs);
+            while (nonempty) {
+                const int i = __builtin_ctzll(nonempty);
+                nonempty &= nonempty - 1;
+                const int s = __builtin_amdgcn_readlane(rs, i), e = __builtin_amdgcn_readlane(re, i);
+                seen += e - s;
+                // 64 candidates per trip: one coalesced 1 KB fetch (a lane each), then every candidate is broadcast from its lane
+                // (v_readlane) and tested against the 64 queries -- no dependent load per candidate
+                for (int base = s; base < e; base += 64) {
+                    const int cnt = min(64, e - base);
+                    const float4 mine = sorted[base + min(lane, cnt - 1)];
+                    for (int k = 0; k < cnt; ++k) {
+                        const float tx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.x), k));
+                        const float ty = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.y), k));
+                        const float tz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.z), k));
+                        const int ti = __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.w), k);
+                        const float d = dist2(tx, ty, tz, q[0], q[1], q[2]);
+                        if (d < best || (d == best && ti < bidx)) { best = d; bidx = ti; }
+                    }
+                }
+            }
+        }
+        float lb = __builtin_inff();
+        for (int a = 0; a < 3; ++a) {
+            if (c[a] - r > 0) lb = fminf(lb, q[a] - (g.lo[a] + (float)(c[a] - r) * g.h[a]));
+            if (c[a] + r < g.g[a] - 1) lb = fminf(lb, (g.lo[a] + (float)(c[a] + r + 1) * g.h[a]) - q[a]);
+        }
+        const float safe = lb - g.slack;
+        // a lane that is done stays done: what it meets later is strictly farther (that is what the test established)
+        done = done || (lb == __builtin_inff() ? bidx != INT_MAX : (safe > 0.f && best < safe * safe * 0.9999f));
+        // the bound grows by one cell per ring: a lane whose best candidate is more rings away than the walk goes stops holding the
+        // wave (the scan answers it; best can still shrink, so this is a cost heuristic, not a correctness condition)
+        if (!done && bidx != INT_MAX && lb != __builtin_inff())
+            hopeless |= (float)r + (sqrtf(best) - safe) * hinv > (float)CG_WAVE_RMAX;
+        if (r >= CG_WAVE_REMPTY && seen == 0) break;                    // empty rings: the scan is the cheaper way (uniform)
+    }
+    if (!live) continue;
+    if (done && !skip) {
+        dist[(size_t)b * n + j] = best;
+        idx[(size_t)b * n + j] = bidx;
+    } else {
+        const int pos = atomicAdd(&todo_count[b], 1);
+        todo[(size_t)b * n + pos] = j;
+        keys[(size_t)b * n + pos] = ~0ull;
+    }
     }
 }
 
 // ---- 6. brute-force scan of the queries on the list (chamfer.hip's inner loop; exact index inside the winning sub-block) -----
+// blockIdx.z walks a slice of the targets (as chamfer_nn_split_kernel does): a list of a few thousand queries -- surface samples far from
+// every target, e.g. an untrained network's prediction against the ground truth at evaluation batch size 1 -- used to be scanned by a
+// handful of workgroups that each walked ALL targets (3 ms per direction whatever the list length).  Every (query, slice) publishes
+// key = (float bits of d) << 32 | index with a 64-bit atomicMin: d >= 0, so the unsigned order of the bits is the numeric order and equal
+// distances resolve to the lowest index -- the all-pairs kernels' rule; cg_fallback_unpack_kernel writes the winners out.
 __global__ __launch_bounds__(CH_THREADS) void cg_fallback_kernel(int n, const float* __restrict__ qry, int m, const float* __restrict__ tgt_all,
                                                                  const int* __restrict__ todo, const int* __restrict__ todo_count,
-                                                                 float* __restrict__ dist, int* __restrict__ idx) {
+                                                                 int slice_len, unsigned long long* __restrict__ keys) {
     __shared__ float4 tgt[CH_TCHUNK];
     const int b = blockIdx.y, tid = threadIdx.x;
     const int cnt_q = todo_count[b];
     const int qbase = blockIdx.x * (CH_THREADS * CH_Q);
     if (qbase >= cnt_q) return;
+    const int t_begin = blockIdx.z * slice_len, t_end = min(m, t_begin + slice_len);
+    if (t_begin >= t_end) return;
     const float* q_ptr = qry + (size_t)b * n * 3;
     const float* t_ptr = tgt_all + (size_t)b * m * 3;
     float qx[CH_Q], qy[CH_Q], qz[CH_Q], best[CH_Q];
-    int bblk[CH_Q], jq[CH_Q];
+    int bblk[CH_Q];
 #pragma unroll
     for (int q = 0; q < CH_Q; ++q) {
         int e = qbase + q * CH_THREADS + tid;
         e = e < cnt_q ? e : cnt_q - 1;
-        jq[q] = todo[(size_t)b * n + e];
-        qx[q] = q_ptr[jq[q] * 3 + 0]; qy[q] = q_ptr[jq[q] * 3 + 1]; qz[q] = q_ptr[jq[q] * 3 + 2];
+        const int jq = todo[(size_t)b * n + e];
+        qx[q] = q_ptr[jq * 3 + 0]; qy[q] = q_ptr[jq * 3 + 1]; qz[q] = q_ptr[jq * 3 + 2];
         best[q] = __builtin_inff();
-        bblk[q] = 0;
+        bblk[q] = t_begin / CH_SUB;
     }
-    for (int k0 = 0; k0 < m; k0 += CH_TCHUNK) {
-        const int cnt = min(CH_TCHUNK, m - k0);
+    for (int k0 = t_begin; k0 < t_end; k0 += CH_TCHUNK) {
+        const int cnt = min(CH_TCHUNK, t_end - k0);
         const int cnt_pad = (cnt + CH_SUB - 1) & ~(CH_SUB - 1);
         __syncthreads();
         stage_targets(tgt, t_ptr, k0, cnt, cnt_pad, tid);
@@ -248,7 +462,7 @@ __global__ __launch_bounds__(CH_THREADS) void cg_fallback_kernel(int n, const fl
 #pragma unroll
             for (int q = 0; q < CH_Q; ++q) mn[q] = __builtin_inff();
             CH_MIN_SUBBLOCK(mn)
-            const int blk = (k0 + sb) / CH_SUB;
+            const int blk = (k0 + sb) / CH_SUB;          // slices start at multiples of CH_SUB
 #pragma unroll
             for (int q = 0; q < CH_Q; ++q) {
                 const bool better = mn[q] < best[q];
@@ -259,34 +473,58 @@ __global__ __launch_bounds__(CH_THREADS) void cg_fallback_kernel(int n, const fl
     }
 #pragma unroll
     for (int q = 0; q < CH_Q; ++q) {
-        if (qbase + q * CH_THREADS + tid >= cnt_q) continue;
+        const int e = qbase + q * CH_THREADS + tid;
+        if (e >= cnt_q) continue;
         const int kb = bblk[q] * CH_SUB;
         int id = kb;          // NaN inputs: nothing compares equal; keep the sub-block start, as chamfer_nn_index_kernel does
         for (int t = CH_SUB - 1; t >= 0; --t) {
             const int k = kb + t;
-            if (k < m && dist2(t_ptr[k * 3 + 0], t_ptr[k * 3 + 1], t_ptr[k * 3 + 2], qx[q], qy[q], qz[q]) == best[q]) id = k;
+            if (k < t_end && dist2(t_ptr[k * 3 + 0], t_ptr[k * 3 + 1], t_ptr[k * 3 + 2], qx[q], qy[q], qz[q]) == best[q]) id = k;
         }
-        dist[(size_t)b * n + jq[q]] = best[q];
-        idx[(size_t)b * n + jq[q]] = id;
+        atomicMin(&keys[(size_t)b * n + e], ((unsigned long long)__float_as_uint(best[q]) << 32) | (unsigned int)id);
+    }
+}
+
+__global__ __launch_bounds__(256) void cg_fallback_unpack_kernel(int n, const int* __restrict__ todo, const int* __restrict__ todo_count,
+                                                                 const unsigned long long* __restrict__ keys, float* __restrict__ dist,
+                                                                 int* __restrict__ idx) {
+    const int b = blockIdx.y, cnt_q = todo_count[b];
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < cnt_q; e += gridDim.x * 256) {
+        const unsigned long long k = keys[(size_t)b * n + e];
+        const int j = todo[(size_t)b * n + e];
+        dist[(size_t)b * n + j] = __uint_as_float((unsigned int)(k >> 32));
+        idx[(size_t)b * n + j] = (int)(unsigned int)(k & 0xFFFFFFFFull);
     }
 }
 
 // workspace of one direction (queries [b][n], targets [b][m]), in 4-byte words
 struct CgCarve {
-    size_t meta, counts, cursor, cell_of, todo, todo_count, sorted, total;
+    size_t meta, counts, cursor, cell_of, todo, todo_count, sorted, keys, qcounts, qcursor, item_count, qcell_of, qsorted, items, max_items, occupied, box, block_tot, nblk, total;
 };
 inline CgCarve cg_carve(int b, int n, int m) {
     CgCarve c;
     const size_t cap = (size_t)cg_cells_capacity(m);
     size_t o = 0;
     auto take = [&](size_t words) { const size_t at = o; o += (words + 3) & ~(size_t)3; return at; };
-    c.counts = take((size_t)b * (cap + 1));      // counts, cursor and todo_count are cleared by ONE memset: keep them first and adjacent
+    c.counts = take((size_t)b * (cap + 1));      // counts, cursors and the two list counters are cleared by ONE memset: first and adjacent
     c.cursor = take((size_t)b * cap);
     c.todo_count = take((size_t)b);
+    c.qcounts = take((size_t)b * (cap + 1));     // the query cloud binned into the same grid (histogram -> starts)
+    c.qcursor = take((size_t)b * cap);
+    c.item_count = take((size_t)b);
+    c.occupied = take((size_t)b);
+    c.box = take((size_t)b * 8);                 // bounding-box keys (zero = nothing yet)
     c.meta = take((size_t)b * (sizeof(GridMeta) / 4));
     c.cell_of = take((size_t)b * m);
     c.todo = take((size_t)b * n);
     c.sorted = take((size_t)b * m * 4);
+    c.keys = take((size_t)b * n * 2);            // 64-bit (distance bits, index) of the listed queries (offsets are multiples of 4 words)
+    c.qcell_of = take((size_t)b * n);
+    c.qsorted = take((size_t)b * n * 4);
+    c.max_items = (size_t)n / 64 + 1 + ((size_t)n < cap ? (size_t)n : cap);      // sum over cells of ceil(count / 64)
+    c.items = take((size_t)b * c.max_items * 2);
+    c.nblk = cap / 1024 + 1;
+    c.block_tot = take((size_t)b * c.nblk);
     c.total = o;
     return c;
 }
@@ -296,15 +534,46 @@ int cg_one_direction(const float* qry, int n, const float* tgt, int m, int b, fl
     const int cap = cg_cells_capacity(m);
     GridMeta* meta = reinterpret_cast<GridMeta*>(ws + c.meta);
     (void)hipMemsetAsync(ws, 0, c.meta * sizeof(int), stream);
-    hipLaunchKernelGGL(cg_meta_kernel, dim3(b), dim3(1024), 0, stream, m, tgt, meta);
-    hipLaunchKernelGGL(cg_count_kernel, dim3((m + 255) / 256, b), dim3(256), 0, stream, m, tgt, meta, cap, ws + c.cell_of, ws + c.counts);
-    hipLaunchKernelGGL(cg_scan_kernel, dim3(b), dim3(1024), 0, stream, meta, cap, ws + c.counts);
+    const int bbox_blocks = (m + 256 * 8 - 1) / (256 * 8);
+    hipLaunchKernelGGL(cg_bbox_kernel, dim3(bbox_blocks < 64 ? bbox_blocks : 64, b), dim3(256), 0, stream, m, tgt, reinterpret_cast<unsigned*>(ws + c.box));
+    hipLaunchKernelGGL(cg_meta_kernel, dim3((b + 63) / 64), dim3(64), 0, stream, m, b, reinterpret_cast<const unsigned*>(ws + c.box), meta);
+    hipLaunchKernelGGL(cg_count_kernel, dim3((m + 255) / 256, b), dim3(256), 0, stream, m, tgt, meta, cap, ws + c.cell_of, ws + c.counts, 0);
+    hipLaunchKernelGGL(cg_scan_local_kernel, dim3((unsigned)c.nblk, b), dim3(1024), 0, stream, meta, cap, ws + c.counts, ws + c.block_tot, (int)c.nblk,
+                       ws + c.occupied, m);
+    hipLaunchKernelGGL(cg_scan_add_kernel, dim3((unsigned)c.nblk, b), dim3(1024), 0, stream, meta, cap, ws + c.counts, ws + c.block_tot, (int)c.nblk,
+                       ws + c.occupied, m);
     hipLaunchKernelGGL(cg_scatter_kernel, dim3((m + 255) / 256, b), dim3(256), 0, stream, m, tgt, cap, ws + c.cell_of, ws + c.counts,
-                       ws + c.cursor, reinterpret_cast<float4*>(ws + c.sorted));
+                       ws + c.cursor, reinterpret_cast<float4*>(ws + c.sorted), nullptr);
+    static const int wave_walk = [] { const char* e = getenv("SC_CHAMFER_GRID_WAVE"); return e ? atoi(e) : 1; }();      // A/B: 0 = thread per query
+    if (wave_walk) {       // images whose targets are surface-like (meta.dense): queries binned into the same grid, one wave per (cell, 64 queries)
+        hipLaunchKernelGGL(cg_count_kernel, dim3((n + 255) / 256, b), dim3(256), 0, stream, n, qry, meta, cap, ws + c.qcell_of, ws + c.qcounts, 1);
+        hipLaunchKernelGGL(cg_scan_local_kernel, dim3((unsigned)c.nblk, b), dim3(1024), 0, stream, meta, cap, ws + c.qcounts, ws + c.block_tot,
+                           (int)c.nblk, ws + c.occupied, 0);
+        hipLaunchKernelGGL(cg_scan_add_kernel, dim3((unsigned)c.nblk, b), dim3(1024), 0, stream, meta, cap, ws + c.qcounts, ws + c.block_tot,
+                           (int)c.nblk, ws + c.occupied, 0);
+        hipLaunchKernelGGL(cg_scatter_kernel, dim3((n + 255) / 256, b), dim3(256), 0, stream, n, qry, cap, ws + c.qcell_of, ws + c.qcounts,
+                           ws + c.qcursor, reinterpret_cast<float4*>(ws + c.qsorted), meta);
+        hipLaunchKernelGGL(cg_items_kernel, dim3((cap + 255) / 256, b), dim3(256), 0, stream, meta, cap, ws + c.qcounts, ws + c.items,
+                           ws + c.item_count, (int)c.max_items);
+        hipLaunchKernelGGL(cg_query_wave_kernel, dim3((unsigned)((c.max_items + 3) / 4 < 4096 ? (c.max_items + 3) / 4 : 4096), b), dim3(256), 0, stream, n, m, meta, cap, ws + c.counts,
+                           reinterpret_cast<const float4*>(ws + c.sorted), ws + c.qcounts, reinterpret_cast<const float4*>(ws + c.qsorted),
+                           ws + c.items, ws + c.item_count, (int)c.max_items, dist, idx, ws + c.todo, ws + c.todo_count,
+                           reinterpret_cast<unsigned long long*>(ws + c.keys));
+    }
     hipLaunchKernelGGL(cg_query_kernel, dim3((n + 255) / 256, b), dim3(256), 0, stream, n, qry, m, meta, cap, ws + c.counts,
-                       reinterpret_cast<const float4*>(ws + c.sorted), dist, idx, ws + c.todo, ws + c.todo_count);
-    hipLaunchKernelGGL(cg_fallback_kernel, dim3((n + CH_THREADS * CH_Q - 1) / (CH_THREADS * CH_Q), b), dim3(CH_THREADS), 0, stream, n, qry, m,
-                       tgt, ws + c.todo, ws + c.todo_count, dist, idx);
+                       reinterpret_cast<const float4*>(ws + c.sorted), dist, idx, ws + c.todo, ws + c.todo_count,
+                       reinterpret_cast<unsigned long long*>(ws + c.keys), wave_walk);
+    // target slices: enough workgroups to fill the chip even when only one group of queries is listed (~2,048 at most in all), each
+    // slice a whole number of LDS chunks
+    const int groups = (n + CH_THREADS * CH_Q - 1) / (CH_THREADS * CH_Q);
+    int nsplit = 2048 / (groups * b);
+    nsplit = nsplit < 1 ? 1 : nsplit > 32 ? 32 : nsplit;
+    int slice = (m + nsplit - 1) / nsplit;
+    slice = (slice + CH_TCHUNK - 1) / CH_TCHUNK * CH_TCHUNK;
+    hipLaunchKernelGGL(cg_fallback_kernel, dim3(groups, b, (m + slice - 1) / slice), dim3(CH_THREADS), 0, stream, n, qry, m, tgt, ws + c.todo,
+                       ws + c.todo_count, slice, reinterpret_cast<unsigned long long*>(ws + c.keys));
+    hipLaunchKernelGGL(cg_fallback_unpack_kernel, dim3(groups < 64 ? groups : 64, b), dim3(256), 0, stream, n, ws + c.todo, ws + c.todo_count,
+                       reinterpret_cast<const unsigned long long*>(ws + c.keys), dist, idx);
     return (int)hipGetLastError();
 }
 

@@ -36,6 +36,25 @@ def sample():
 
 for _ in range(2):
     sample()
+# the stages inside eval_metrics, timed through wrappers (each wrapper synchronises: the sum exceeds the un-instrumented total a little)
+if os.environ.get("PARTS"):
+    parts = {}
+    def wrap(mod, name):
+        fn = getattr(mod, name)
+        def w(*a, **k):
+            r, ms = timed(lambda: fn(*a, **k))
+            parts[name] = parts.get(name, 0.0) + ms
+            return r
+        setattr(mod, name, w)
+    for name in ("get_dense_3D_grid", "compute_level_grid", "surface_points_device", "normalize_pc", "chamfer_distance", "compute_fscore"):
+        wrap(eval_3D, name)
+    for _ in range(3):
+        parts.clear()
+        with torch.no_grad():
+            var = graph(opt, edict(batch), training=False, get_loss=False)
+            _, tot = timed(lambda: eval_3D.eval_metrics(opt, var, graph.sdf_network))
+    print("eval_metrics %.2f ms:" % tot, ", ".join("%s %.2f" % kv for kv in parts.items()))
+    sys.exit(0)
 acc = {}
 N = 5
 t0 = time.time()
