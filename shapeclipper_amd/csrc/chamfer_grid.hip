@@ -12,10 +12,21 @@
 //     faces on the grid boundary bound nothing: there are no targets beyond).  The walk stops when best < (lb - slack)^2 * (1 - 1e-4):
 //     slack (16 ulp of the cloud's coordinate scale) covers the rounding of the binning and of the face coordinates, the factor
 //     covers the rounding of d itself, so a target that could tie or beat `best` is never skipped;
-//   * queries that do not terminate within CG_RMAX rings or CG_BUDGET candidates (far outside the other cloud, one huge cell,
-//     non-finite input) go on a list and are answered by the brute-force scan (the chamfer.hip inner loop with an index list),
-//     so the worst case is the old cost and the answer is the same.
-// Bound: latency / L2 gathers (54 candidates per query instead of 100,000); the brute-force line stays in bench.py's workloads.
+//   * queries that do not terminate within the ring / candidate limits (far from the other cloud, one huge cell, non-finite input)
+//     go on a list and are answered by the brute-force scan (the chamfer.hip inner loop with an index list, split over target
+//     slices and merged with 64-bit atomicMin keys so that a short list still fills the chip), so the worst case is about the old
+//     cost and the answer is the same.
+// Two walks, chosen per image from the targets' occupancy (meta.dense, set while the histogram is scanned):
+//   * volume-like targets (about CG_TPC per cell everywhere): one THREAD per query (cg_query_kernel), ~54 candidates each;
+//   * surface-like targets (>= CG_DENSE per OCCUPIED cell -- what the evaluation compares): hundreds to thousands of candidates per
+//     query as soon as the two surfaces are a few cells apart, which the thread walk fetches through divergent gathers at ~1 % of the
+//     all-pairs kernels' pair rate (it was 2-3x SLOWER than all pairs at a mean distance of 0.05-0.1).  There the queries are binned
+//     into the same grid and one WAVE walks for up to 64 queries of a cell (cg_query_wave_kernel): uniform control flow, 64 candidate
+//     ranges looked up per round trip, 64 candidates per coalesced fetch, each broadcast to the 64 queries.
+// Measured at batch 1, 100,000 x 100,000 (tools/perf_chamfer_surface.py): uniform volumes 0.27 ms, coinciding surfaces 0.34 ms, surfaces
+// a mean 0.02 / 0.05 / 0.09 apart 0.47 / 1.1 / 2.3 ms, all pairs 2.7-2.9 ms; beyond that the walk is wasted effort in front of the scan
+// (4.3-4.6 ms at 0.15-0.25; at batch 8 the same cases cost what all pairs cost).
+// Bound: latency / L2 gathers; the brute-force line stays in bench.py's workloads.
 #include "chamfer_common.hpp"
 #include <limits.h>
 #include <stdlib.h>

@@ -65,3 +65,5 @@ def test_workloads_line():
     c = w.chamfer(1, N=20000, with_cpu=False)
     assert c["all_pairs"]["algorithmic_flop"] == 16.0 * 20000 * 20000 and 0 < c["all_pairs"]["frac"] < 1.0
     assert c["same_results_as_all_pairs"] is True and c["speedup_vs_all_pairs"] > 0 and c["ms"] > 0
+    sc = c["surface_clouds"]                       # the evaluation's kind of cloud: surfaces a few cells apart
+    assert sc["same_results_as_all_pairs"] is True and sc["ms"] > 0 and sc["all_pairs_ms"] > 0
