@@ -21,11 +21,11 @@
 //   * surface-like targets (>= CG_DENSE per OCCUPIED cell -- what the evaluation compares): hundreds to thousands of candidates per
 //     query as soon as the two surfaces are a few cells apart, which the thread walk fetches through divergent gathers at ~1 % of the
 //     all-pairs kernels' pair rate (it was 2-3x SLOWER than all pairs at a mean distance of 0.05-0.1).  There the queries are binned
-//     into the same grid and one WAVE walks for up to 64 queries of a cell (cg_query_wave_kernel): uniform control flow, 64 candidate
-//     ranges looked up per round trip, 64 candidates per coalesced fetch, each broadcast to the 64 queries.
-// Measured at batch 1, 100,000 x 100,000 (tools/perf_chamfer_surface.py): uniform volumes 0.27 ms, coinciding surfaces 0.34 ms, surfaces
-// a mean 0.02 / 0.05 / 0.09 apart 0.47 / 1.1 / 2.3 ms, all pairs 2.7-2.9 ms; beyond that the walk is wasted effort in front of the scan
-// (4.3-4.6 ms at 0.15-0.25; at batch 8 the same cases cost what all pairs cost).
+//     into the same grid by 2 x 2 x 2 tile of cells and one WAVE walks for up to 64 queries of a tile (cg_query_wave_kernel): uniform
+//     control flow, 64 candidate ranges looked up per round trip, 64 candidates per coalesced fetch, each broadcast to the 64 queries.
+// Measured at batch 1, 100,000 x 100,000 (tools/perf_chamfer_surface.py): uniform volumes 0.27 ms, coinciding surfaces 0.30 ms, surfaces
+// a mean 0.02 / 0.05 / 0.09 apart 0.38 / 0.76 / 1.6 ms, all pairs 2.7-2.9 ms; beyond that the walk is wasted effort in front of the scan
+// (3.4-3.9 ms at 0.15-0.25; at batch 8 the same cases cost what all pairs cost).
 // Bound: latency / L2 gathers; the brute-force line stays in bench.py's workloads.
 #include "chamfer_common.hpp"
 #include <limits.h>
@@ -150,6 +150,8 @@ __global__ __launch_bounds__(256) void cg_count_kernel(int m, const float* __res
         const int cx = cg_axis_cell(t[0], g.lo[0], g.inv_h[0], g.g[0]), cy = cg_axis_cell(t[1], g.lo[1], g.inv_h[1], g.g[1]);
         const int cz = cg_axis_cell(t[2], g.lo[2], g.inv_h[2], g.g[2]);
         c = (cz * g.g[1] + cy) * g.g[0] + cx;       // x fastest: a run of cells along x is one contiguous run of sorted targets
+        if (only_dense)                             // the QUERY side is binned by 2 x 2 x 2 TILE of cells (cg_query_wave_kernel)
+            c = ((cz >> 1) * ((g.g[1] + 1) >> 1) + (cy >> 1)) * ((g.g[0] + 1) >> 1) + (cx >> 1);
     }
     cell_of[(size_t)b * m + k] = c;
     atomicAdd(&counts[(size_t)b * (cap + 1) + c], 1);
@@ -306,9 +308,9 @@ __global__ __launch_bounds__(256) void cg_query_kernel(int n, const float* __res
     }
 }
 
-// ---- 5b. the ring walk, one WAVE per (cell, 64 queries of that cell) --------------------------------------------------------
-// The queries are binned into the TARGET grid as well (steps 2-4 on the query cloud) and a wave takes up to 64 queries of one cell: the
-// walk around that cell -- rows, candidate ranges, candidates -- is the same for all of them, so the control flow is wave-uniform and a
+// ---- 5b. the ring walk, one WAVE per (2 x 2 x 2 tile of cells, 64 queries of that tile) --------------------------------------------------------
+// The queries are binned into the TARGET grid as well (steps 2-4 on the query cloud, by tile of 2 x 2 x 2 cells) and a wave takes up to 64
+// queries of one tile: the walk around that tile -- rows, candidate ranges, candidates -- is the same for all of them, so the control flow is wave-uniform and a
 // candidate is fetched ONCE per wave (uniform address: scalar load) and tested against 64 queries.  The thread-per-query kernel above
 // fetches every candidate once per query through divergent 16-byte gathers: ~70 G pairs/s against 7.7 T pairs/s of the all-pairs
 // kernels, so that on SURFACE clouds a few cells apart (1,500-3,000 candidates per query: the evaluation's predicted surface against the
@@ -335,24 +337,34 @@ __global__ __launch_bounds__(256) void cg_query_wave_kernel(int n, int m, const 
                                                             int max_items, float* __restrict__ dist, int* __restrict__ idx,
                                                             int* __restrict__ todo, int* __restrict__ todo_count,
                                                             unsigned long long* __restrict__ keys) {
+#define CG_TEST(t)                                                                              \
+    {                                                                                           \
+        const float d = dist2((t).x, (t).y, (t).z, q[0], q[1], q[2]);                           \
+        const int ti = __float_as_int((t).w);                                                   \
+        if (d < best || (d == best && ti < bidx)) { best = d; bidx = ti; }                      \
+    }
+    __shared__ float4 cand_all[4][64];
     const int b = blockIdx.y, lane = threadIdx.x & 63;
+    float4* cand = cand_all[threadIdx.x >> 6];
     const int n_items = item_count[b];
     const GridMeta g = meta[b];
     for (int item = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6))); item < n_items; item += (int)gridDim.x * 4) {
     const int* start = start_all + (size_t)b * (cap + 1);
     const float4* sorted = sorted_all + (size_t)b * m;
     const int* qstart = qstart_all + (size_t)b * (cap + 1);
-    const int cell = __builtin_amdgcn_readfirstlane(items_all[((size_t)b * max_items + item) * 2]);
+    const int cell = __builtin_amdgcn_readfirstlane(items_all[((size_t)b * max_items + item) * 2]);      // a 2 x 2 x 2 TILE of cells
     const int chunk = __builtin_amdgcn_readfirstlane(items_all[((size_t)b * max_items + item) * 2 + 1]);
     const int q0 = qstart[cell] + chunk * 64, q1 = qstart[cell + 1];
     const bool live = q0 + lane < q1;
     const float4 qv = qsorted_all[(size_t)b * n + (live ? q0 + lane : q0)];
     const float q[3] = {qv.x, qv.y, qv.z};
     const int j = __float_as_int(qv.w);
-    int c[3];
-    c[0] = cell % g.g[0];
-    c[1] = (cell / g.g[0]) % g.g[1];
-    c[2] = cell / (g.g[0] * g.g[1]);
+    const int tgx = (g.g[0] + 1) >> 1, tgy = (g.g[1] + 1) >> 1;
+    int lo[3], hi[3];                  // the tile's cells along every axis (one cell where the grid side is odd and this is its last tile)
+    lo[0] = 2 * (cell % tgx);
+    lo[1] = 2 * ((cell / tgx) % tgy);
+    lo[2] = 2 * (cell / (tgx * tgy));
+    for (int a = 0; a < 3; ++a) hi[a] = min(lo[a] + 1, g.g[a] - 1);
     // (no "outside the bounding box" shortcut here: a wave's candidates are cheap, and a cloud that encloses the other one -- every query
     // of one direction outside the other's box -- is the common case at evaluation)
     const bool skip = !(g.valid && fabsf(q[0]) < 1.0e15f && fabsf(q[1]) < 1.0e15f && fabsf(q[2]) < 1.0e15f);
@@ -362,24 +374,25 @@ __global__ __launch_bounds__(256) void cg_query_wave_kernel(int n, int m, const 
     const float hinv = fmaxf(g.inv_h[0], fmaxf(g.inv_h[1], g.inv_h[2]));       // 1 / smallest cell side
     for (int r = 1; r <= CG_WAVE_RMAX && seen <= CG_WAVE_BUDGET; ++r) {
         if (__builtin_amdgcn_readfirstlane((int)__all((int)(done || skip || hopeless || !live)))) break;
-        const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, g.g[0] - 1);
-        // The shell of ring r as a list of candidate RANGES: (2r+1)^2 rows (z, y), each one run of cells along x (rows on the shell's
-        // z / y faces; ring 1 takes the whole block) or its two end cells (inner rows).  64 ranges at a time: every lane looks up the two
-        // `start` entries of ITS range (one round trip for 64 ranges instead of one per row), then the wave goes through the non-empty ones.
-        const int side_len = 2 * r + 1, nranges = 2 * side_len * side_len;
+        const int x0 = max(lo[0] - r, 0), x1 = min(hi[0] + r, g.g[0] - 1);
+        // The shell of ring r around the tile as a list of candidate RANGES: rows (z, y) of the block tile +- r, each one run of cells
+        // along x (rows on the shell's z / y faces; ring 1 takes the whole block) or its two end cells (inner rows).  64 ranges at a
+        // time: every lane looks up the two `start` entries of ITS range (one round trip for 64 ranges instead of one per row), then
+        // the wave goes through the non-empty ones.
+        const int sy = hi[1] - lo[1] + 1 + 2 * r, sz = hi[2] - lo[2] + 1 + 2 * r, nranges = 2 * sy * sz;
         for (int p0 = 0; p0 < nranges; p0 += 64) {
             const int p = p0 + lane;
             int rs = 0, re = 0;
             if (p < nranges) {
                 const int pair = p >> 1, sd = p & 1;
-                const int zc = c[2] - r + pair / side_len, yc = c[1] - r + pair % side_len;
+                const int zc = lo[2] - r + pair / sy, yc = lo[1] - r + pair % sy;
                 if (zc >= 0 && zc < g.g[2] && yc >= 0 && yc < g.g[1]) {
                     const int row = (zc * g.g[1] + yc) * g.g[0];
-                    const bool full = r == 1 || zc == c[2] - r || zc == c[2] + r || yc == c[1] - r || yc == c[1] + r;
+                    const bool full = r == 1 || zc == lo[2] - r || zc == hi[2] + r || yc == lo[1] - r || yc == hi[1] + r;
                     int xa = -1, xb = -1;
                     if (full) { if (sd == 0) { xa = x0; xb = x1; } }
                     else {
-                        const int x = sd == 0 ? c[0] - r : c[0] + r;
+                        const int x = sd == 0 ? lo[0] - r : hi[0] + r;
                         if (x >= 0 && x < g.g[0]) xa = xb = x;
                     }
                     if (xa >= 0) { rs = start[row + xa]; re = start[row + xb + 1]; }
@@ -391,26 +404,28 @@ __global__ __launch_bounds__(256) void cg_query_wave_kernel(int n, int m, const 
                 nonempty &= nonempty - 1;
                 const int s = __builtin_amdgcn_readlane(rs, i), e = __builtin_amdgcn_readlane(re, i);
                 seen += e - s;
-                // 64 candidates per trip: one coalesced 1 KB fetch (a lane each), then every candidate is broadcast from its lane
-                // (v_readlane) and tested against the 64 queries -- no dependent load per candidate
+                // 64 candidates per trip: one coalesced 1 KB fetch (a lane each) into the wave's LDS slot, then every candidate is read
+                // back at a wave-uniform address (a broadcast ds_read_b128) and tested against the 64 queries -- no dependent global load per
+                // candidate (v_readlane broadcasts were tried first: the SGPR hazards behind them cost more than the LDS round trip)
                 for (int base = s; base < e; base += 64) {
                     const int cnt = min(64, e - base);
-                    const float4 mine = sorted[base + min(lane, cnt - 1)];
-                    for (int k = 0; k < cnt; ++k) {
-                        const float tx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.x), k));
-                        const float ty = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.y), k));
-                        const float tz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.z), k));
-                        const int ti = __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine.w), k);
-                        const float d = dist2(tx, ty, tz, q[0], q[1], q[2]);
-                        if (d < best || (d == best && ti < bidx)) { best = d; bidx = ti; }
+                    cand[lane] = sorted[base + min(lane, cnt - 1)];                                   // this wave's 1 KB slot
+                    int k = 0;
+                    for (; k + 4 <= cnt; k += 4) {                                                    // four broadcast reads in flight
+                        const float4 t0 = cand[k], t1 = cand[k + 1], t2 = cand[k + 2], t3 = cand[k + 3];
+                        CG_TEST(t0) CG_TEST(t1) CG_TEST(t2) CG_TEST(t3)
+                    }
+                    for (; k < cnt; ++k) {
+                        const float4 t0 = cand[k];
+                        CG_TEST(t0)
                     }
                 }
             }
         }
         float lb = __builtin_inff();
         for (int a = 0; a < 3; ++a) {
-            if (c[a] - r > 0) lb = fminf(lb, q[a] - (g.lo[a] + (float)(c[a] - r) * g.h[a]));
-            if (c[a] + r < g.g[a] - 1) lb = fminf(lb, (g.lo[a] + (float)(c[a] + r + 1) * g.h[a]) - q[a]);
+            if (lo[a] - r > 0) lb = fminf(lb, q[a] - (g.lo[a] + (float)(lo[a] - r) * g.h[a]));
+            if (hi[a] + r < g.g[a] - 1) lb = fminf(lb, (g.lo[a] + (float)(hi[a] + r + 1) * g.h[a]) - q[a]);
         }
         const float safe = lb - g.slack;
         // a lane that is done stays done: what it meets later is strictly farther (that is what the test established)
@@ -431,6 +446,7 @@ __global__ __launch_bounds__(256) void cg_query_wave_kernel(int n, int m, const 
         keys[(size_t)b * n + pos] = ~0ull;
     }
     }
+#undef CG_TEST
 }
 
 // ---- 6. brute-force scan of the queries on the list (chamfer.hip's inner loop; exact index inside the winning sub-block) -----
