@@ -199,7 +199,7 @@ __global__ __launch_bounds__(1024) void cg_scan_local_kernel(const GridMeta* __r
 
 __global__ __launch_bounds__(1024) void cg_scan_add_kernel(GridMeta* __restrict__ meta, int cap, int* __restrict__ counts,
                                                            const int* __restrict__ block_tot, int nblk, const int* __restrict__ occupied,
-                                                           int targets) {
+                                                           int targets, int dense_min) {
     const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
     const GridMeta& g = meta[b];
     if (!targets && !g.dense) return;
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(1024) void cg_scan_add_kernel(GridMeta* __restrict_
     const int off = off_s;
     const int i = blk * 1024 + tid;
     if (i <= cells && off) counts[(size_t)b * (cap + 1) + i] += off;
-    if (targets && blk == 0 && tid == 0) meta[b].dense = (g.valid && (long long)targets >= (long long)occupied[b] * CG_DENSE) ? 1 : 0;
+    if (targets && blk == 0 && tid == 0) meta[b].dense = (g.valid && (long long)targets >= (long long)occupied[b] * dense_min) ? 1 : 0;
 }
 
 // ---- 4. targets into cell order as {x, y, z, original index}; order inside a cell is arbitrary (see the acceptance rule) ----
@@ -567,8 +567,9 @@ int cg_one_direction(const float* qry, int n, const float* tgt, int m, int b, fl
     hipLaunchKernelGGL(cg_count_kernel, dim3((m + 255) / 256, b), dim3(256), 0, stream, m, tgt, meta, cap, ws + c.cell_of, ws + c.counts, 0);
     hipLaunchKernelGGL(cg_scan_local_kernel, dim3((unsigned)c.nblk, b), dim3(1024), 0, stream, meta, cap, ws + c.counts, ws + c.block_tot, (int)c.nblk,
                        ws + c.occupied, m);
+    static const int dense_min = [] { const char* e = getenv("SC_CHAMFER_GRID_DENSE"); return e ? atoi(e) : CG_DENSE; }();      // tuning override
     hipLaunchKernelGGL(cg_scan_add_kernel, dim3((unsigned)c.nblk, b), dim3(1024), 0, stream, meta, cap, ws + c.counts, ws + c.block_tot, (int)c.nblk,
-                       ws + c.occupied, m);
+                       ws + c.occupied, m, dense_min);
     hipLaunchKernelGGL(cg_scatter_kernel, dim3((m + 255) / 256, b), dim3(256), 0, stream, m, tgt, cap, ws + c.cell_of, ws + c.counts,
                        ws + c.cursor, reinterpret_cast<float4*>(ws + c.sorted), nullptr);
     static const int wave_walk = [] { const char* e = getenv("SC_CHAMFER_GRID_WAVE"); return e ? atoi(e) : 1; }();      // A/B: 0 = thread per query
@@ -577,7 +578,7 @@ int cg_one_direction(const float* qry, int n, const float* tgt, int m, int b, fl
         hipLaunchKernelGGL(cg_scan_local_kernel, dim3((unsigned)c.nblk, b), dim3(1024), 0, stream, meta, cap, ws + c.qcounts, ws + c.block_tot,
                            (int)c.nblk, ws + c.occupied, 0);
         hipLaunchKernelGGL(cg_scan_add_kernel, dim3((unsigned)c.nblk, b), dim3(1024), 0, stream, meta, cap, ws + c.qcounts, ws + c.block_tot,
-                           (int)c.nblk, ws + c.occupied, 0);
+                           (int)c.nblk, ws + c.occupied, 0, 0);
         hipLaunchKernelGGL(cg_scatter_kernel, dim3((n + 255) / 256, b), dim3(256), 0, stream, n, qry, cap, ws + c.qcell_of, ws + c.qcounts,
                            ws + c.qcursor, reinterpret_cast<float4*>(ws + c.qsorted), meta);
         hipLaunchKernelGGL(cg_items_kernel, dim3((cap + 255) / 256, b), dim3(256), 0, stream, meta, cap, ws + c.qcounts, ws + c.items,
