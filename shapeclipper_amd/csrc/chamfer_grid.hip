@@ -24,8 +24,8 @@
 //     into the same grid by 2 x 2 x 2 tile of cells and one WAVE walks for up to 64 queries of a tile (cg_query_wave_kernel): uniform
 //     control flow, 64 candidate ranges looked up per round trip, 64 candidates per coalesced fetch, each broadcast to the 64 queries.
 // Measured at batch 1, 100,000 x 100,000 (tools/perf_chamfer_surface.py): uniform volumes 0.27 ms, coinciding surfaces 0.30 ms, surfaces
-// a mean 0.02 / 0.05 / 0.09 apart 0.38 / 0.76 / 1.6 ms, all pairs 2.7-2.9 ms; beyond that the walk is wasted effort in front of the scan
-// (3.4-3.9 ms at 0.15-0.25; at batch 8 the same cases cost what all pairs cost).
+// a mean 0.02 / 0.05 / 0.09 apart 0.38 / 0.76 / 1.7 ms, all pairs 2.7-2.9 ms; beyond that the walk is wasted effort in front of the scan
+// (3.1-3.2 ms at 0.15-0.25; at batch 8 the same cases cost what all pairs cost).
 // Bound: latency / L2 gathers; the brute-force line stays in bench.py's workloads.
 #include "chamfer_common.hpp"
 #include <limits.h>
@@ -39,7 +39,7 @@ constexpr int CG_RMAX = 5;         // rings before a query is handed to the brut
 constexpr int CG_BUDGET = 3072;    // candidates before a query is handed to the brute-force scan
 constexpr int CG_REMPTY = 2;       // rings without any candidate before a query is handed to the scan
 constexpr int CG_DENSE = 8;         // targets per occupied cell from which a cloud counts as surface-like
-constexpr int CG_WAVE_RMAX = 8;     // rings of the wave walk (its candidates cost ~1/50 of the thread walk's per query)
+constexpr int CG_WAVE_RMAX = 6;     // rings of the wave walk (its candidates cost ~1/50 of the thread walk's per query)
 constexpr int CG_WAVE_REMPTY = 4;   // rings without any candidate before the wave gives up
 constexpr int CG_WAVE_BUDGET = 16384;   // candidates per WAVE (64 queries of one cell) before its open queries are handed to the scan
 
