@@ -42,7 +42,8 @@ int sc_chamfer3d_forward_split(const float* xyz1, const float* xyz2, float* dist
  * grid and every query walks rings of cells around its own, evaluating candidates with the same expression and accepting on
  * d < best || (d == best && index < best_index); the walk stops only when no unseen target can tie or beat the best (rounding
  * of the binning and of d included).  Queries that do not terminate within a few rings (far outside the other cloud, one huge
- * cell, non-finite coordinates) are answered by the brute-force scan, so the worst case is sc_chamfer3d_forward's cost.
+ * cell, non-finite coordinates) are answered by the brute-force scan, so the worst case is about sc_chamfer3d_forward's cost.
+ * Surface-like targets (>= 8 per occupied cell: the evaluation's clouds) are walked one wave per 64 queries of a 2 x 2 x 2 tile of cells.
  * workspace: sc_chamfer3d_grid_workspace_bytes(b, n, m) bytes of device scratch (contents irrelevant on entry).       */
 long long sc_chamfer3d_grid_workspace_bytes(int b, int n, int m);
 int sc_chamfer3d_forward_grid(const float* xyz1, const float* xyz2, float* dist1, float* dist2,
