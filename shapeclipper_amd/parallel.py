@@ -78,6 +78,7 @@ class FlatGradAllReduce:
         self.collectives = 0                                   # data-path collectives issued so far (tests, bench)
         self._early_work, self._early_done, self._seen = None, False, 0
         self._comm_stream = torch.cuda.Stream(device=dev) if (self.overlap and dev.type == "cuda") else None
+        self._main_stream = None
         if self.overlap and late:
             for p in self.params[:self.n_early]:
                 p.register_post_accumulate_grad_hook(self._on_grad)
@@ -104,6 +105,8 @@ class FlatGradAllReduce:
         for p in self.params:
             p.grad = None
         self._early_work, self._early_done, self._seen = None, False, 0
+        if self._comm_stream is not None:
+            self._main_stream = torch.cuda.current_stream()    # the stream the step is enqueued on (see _launch_early)
 
     # ---- packing ---------------------------------------------------------------------------------------------------------
     def _pack_range(self, lo, hi):
@@ -137,13 +140,18 @@ class FlatGradAllReduce:
             self._early_work = dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True)
             self.collectives += 1
             return
-        cur = torch.cuda.current_stream()
         grads = [p.grad for p in self.params[:self.n_early] if p.grad is not None]
-        ev = torch.cuda.Event()
-        ev.record(cur)                                         # everything enqueued so far on the hook's stream ...
-        self._comm_stream.wait_event(ev)
-        for s in _known_streams(seg.device):                   # ... and on the second trunk's stream
-            self._comm_stream.wait_stream(s)
+        # The hook runs under the stream of the LAST early gradient's node -- the estimator trunk's side stream as often as the main
+        # one -- while the other early gradients were produced on every stream the step uses.  All of them have been enqueued by now
+        # (one autograd worker per device), so the side stream waits for the work queued so far on each: the hook's stream, the stream
+        # the step was started on, the device's default stream and the trunks' side stream.  (Waiting only for the hook's stream and
+        # the side stream let the pack read unfinished main-stream gradients whenever the hook fired under the side stream:
+        # tests/test_gpu_two_ranks.py.)
+        waited = set()
+        for s in [torch.cuda.current_stream(), self._main_stream, torch.cuda.default_stream(seg.device)] + _known_streams(seg.device):
+            if s is not None and s.cuda_stream not in waited and s.cuda_stream != self._comm_stream.cuda_stream:
+                waited.add(s.cuda_stream)
+                self._comm_stream.wait_stream(s)
         with torch.cuda.stream(self._comm_stream):
             for g in grads:
                 g.record_stream(self._comm_stream)             # produced on another stream, read here

@@ -1,0 +1,116 @@
+"""The data-parallel training step of the product Graph on TWO ranks with real kernels (model/runner.py:121,255 of the reference:
+DistributedDataParallel over NCCL).  The GPU box has one MI355X, so both ranks share cuda:0 and the collectives travel over gloo
+(RCCL refuses two ranks on one device); everything else -- the flat gradient buffer, the early segment issued from inside backward on
+a side stream, the persistent BatchNorm buffer broadcast, fused Adam on the flat views -- is the code path `bench.py --gpus N` runs.
+
+Checked per schedule (overlapped / one all-reduce after backward):
+  * ranks start from different initialisations and different batches and end two steps later with bit-identical parameters (the
+    data-parallel invariant); the BatchNorm running statistics follow rank 0 at the next step's broadcast;
+  * the exchanged gradient equals the mean of the ranks' local gradients, element for element (non-overlapped schedule, where the
+    local gradient is still observable before the exchange);
+  * the collective count per step (2 overlapped, 1 otherwise);
+and across schedules: the overlapped exchange ends in the SAME parameters, bit for bit, as the single all-reduce."""
+import os
+import socket
+import time
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, overlap, outdir, out):
+    import numpy as np
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    failed = []
+    try:
+        torch.cuda.set_device(0)
+        from shapeclipper_amd import synthetic
+        from shapeclipper_amd.model.runner import Runner
+        from shapeclipper_amd.utils import options, util
+        from shapeclipper_amd.utils.util import EasyDict as edict
+        per_rank = 2
+        extra = [] if overlap else ["--hip.overlap_allreduce!"]
+        opt = options.set(options.parse_arguments([
+            "--yaml=%s/options/pix3d/config.yaml" % ROOT, "--name=pytest_two_ranks", "--output_root=/tmp/sc_pytest_%d" % rank,
+            "--batch_size=%d" % (per_rank * world), "--tb!", "--arch.enc_pretrained!"] + extra), verbose=False)
+        opt.device, opt.world_size, opt.port = 0, world, 0
+        opt.freq.scalar, opt.freq.ckpt_latest = 0, 10 ** 9
+        torch.manual_seed(100 + rank); np.random.seed(0)      # different weights per rank: the reducer's broadcast must fix that
+        runner = Runner(opt)
+        if opt.batch_size != per_rank: failed.append("batch_size %d" % opt.batch_size)
+        runner.build_networks(opt)
+        runner.setup_optimizer(opt)
+        runner.graph.train()
+        runner.it, runner.ep, runner.best_val = 1, 0, 0.0
+        runner.timer = edict(start=time.time(), it_mean=None)
+        red = runner.reducer
+        if red is None or red.overlap != overlap: failed.append("reducer / schedule")
+        batch = util.move_to_device(synthetic.make_batch(opt, per_rank, seed=rank, training=True), "cuda:0")
+        if not overlap:                                      # the local gradient is observable just before the one all-reduce
+            orig = red.all_reduce
+            seen = {}
+
+            def checked():
+                local = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in red.params]).cpu()
+                orig()
+                gathered = [torch.zeros_like(local) for _ in range(world)]
+                dist.all_gather(gathered, local)
+                want = (gathered[0] + gathered[1]) * (1.0 / world)
+                seen["diff"] = float((red.flat.cpu() - want).abs().max())
+                seen["differ"] = float((gathered[0] - gathered[1]).abs().max())
+            red.all_reduce = checked
+        for _ in range(2):
+            opt.H, opt.W = opt.image_size
+            runner.train_iteration(opt, edict(batch), None)
+        runner.check_finite()
+        torch.cuda.synchronize()
+        if not overlap:
+            if seen.get("diff", 1.0) != 0.0: failed.append("exchanged gradient != mean of the local ones (%r)" % seen.get("diff"))
+            if not seen.get("differ", 0.0) > 0.0: failed.append("the ranks' local gradients do not differ: the check is vacuous")
+        if red.collectives != (4 if overlap else 2): failed.append("collectives %d" % red.collectives)
+        g = runner.graph.module
+        if not all(p.grad is None or p.grad.data_ptr() >= red.flat.data_ptr() for p in g.parameters()): failed.append("grads outside the flat buffer")
+        params = torch.cat([p.detach().reshape(-1) for p in g.parameters()]).cpu()      # module order (the flat buffer's order depends on the schedule)
+        # running statistics follow rank 0 at the START of every step (DDP's broadcast_buffers=True), so after the last step each rank
+        # holds its own batch's update: they differ now and agree after the next step's broadcast
+        mine = red.buf_flat.detach().cpu().clone()
+        theirs = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(theirs, mine)
+        if torch.equal(theirs[0], theirs[1]): failed.append("running statistics of the two ranks' different batches are equal: vacuous")
+        red.broadcast_buffers()
+        bufs = red.buf_flat.detach().cpu().clone()
+        if rank == 0 and not torch.equal(bufs, mine): failed.append("the broadcast changed rank 0's buffers")
+        for name, t in (("parameters", params), ("BatchNorm buffers", bufs)):
+            both = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(both, t)
+            if not torch.equal(both[0], both[1]): failed.append("%s differ between the ranks (max %g)" % (name, float((both[0] - both[1]).abs().max())))
+        if not bool(torch.isfinite(params).all()): failed.append("non-finite parameters")
+        if rank == 0:
+            torch.save(params, os.path.join(outdir, "params_%d.pt" % int(overlap)))
+    except Exception as e:      # noqa: BLE001
+        import traceback
+        failed.append("%s: %s\n%s" % (type(e).__name__, e, traceback.format_exc()))
+    out[rank] = failed
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_training_step_on_one_gpu(tmp_path):
+    outdir = str(tmp_path)
+    for overlap in (False, True):
+        mgr = mp.Manager()
+        out = mgr.dict()
+        mp.spawn(_worker, args=(2, _free_port(), overlap, outdir, out), nprocs=2, join=True)
+        assert out[0] == [] and out[1] == [], "overlap=%s: rank 0 %s, rank 1 %s" % (overlap, out[0], out[1])
+    a, b = torch.load(os.path.join(outdir, "params_0.pt")), torch.load(os.path.join(outdir, "params_1.pt"))
+    assert torch.equal(a, b), "overlapped exchange and single all-reduce end in different parameters: max %g" % float((a - b).abs().max())
