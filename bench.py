@@ -147,10 +147,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    # One rank per GPU over RCCL.  SC_BENCH_BACKEND=gloo (tests/test_gpu_bench_contract.py) runs the same N > 1 code path with
+    # several ranks sharing the GPUs that exist -- the build box has one MI355X and RCCL refuses two ranks on one device.
+    backend = os.environ.get("SC_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl")
+        torch.distributed.init_process_group(backend)
 
     from shapeclipper_amd import _lib
     from shapeclipper_amd.utils.util import EasyDict as edict

@@ -53,6 +53,26 @@ def test_bench_default_batch_reports_config1_beside_the_headline():
     assert len([l for l in r.stdout.splitlines() if l.startswith("{")]) == 1
 
 
+def test_bench_two_ranks_through_the_launcher():
+    """The driver's N > 1 invocation (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) on the one GPU of this
+    box: two ranks share cuda:0 and exchange over gloo (SC_BENCH_BACKEND), everything else is the code the scaling run executes --
+    barrier-bracketed timing, MAX over ranks, whole-job value, the overlapped flat all-reduce, ONE JSON line from rank 0."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MIOPEN_LOG_LEVEL="1", SC_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--sustained", "2"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len([l for l in r.stdout.splitlines() if l.startswith("{")]) == 1
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["global_batch"] == 4 and abs(d["value"] - 4 / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]       # whole-job images / s
+    assert d["allreduce"]["payload_bytes"] > 140e6 and d["allreduce"]["ms"] > 0
+    assert "cpu_baseline" not in d and "workloads" not in d                    # rank 0 does no extra work the other ranks would wait for
+    assert d["sustained"]["steps"] == 2
+
+
 def test_workloads_line():
     import importlib.util
     spec = importlib.util.spec_from_file_location("sc_workloads_test", os.path.join(ROOT, "tools", "workloads.py"))
