@@ -313,7 +313,9 @@ class Runner:
         from ..parallel import gather_eval_records
         self.graph.eval()
         opt.H, opt.W = opt.eval.image_size
-        rank = opt.device if isinstance(opt.device, int) else 0
+        # the reference's single-node convention is rank == device index; the process group's rank is the same number there and stays
+        # right when ranks and devices are numbered differently (several nodes; tests/test_gpu_two_ranks.py: two ranks on one GPU)
+        rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else (opt.device if isinstance(opt.device, int) else 0)
         recs = []
         for it in range(rank, len(self.test_data), opt.world_size):
             sample = self.test_data[it]
@@ -326,7 +328,7 @@ class Runner:
         records = torch.stack(recs) if recs else torch.zeros(0, 10, device=dev)
         allr = gather_eval_records(records.to(dev), opt.world_size).cpu()
         opt.H, opt.W = opt.image_size
-        if _rank0(opt):
+        if rank == 0:
             with open("{}/chamfer.txt".format(opt.output_path), "w") as f:
                 for r in allr:
                     f.write("{} {:.8f} {:.8f}\n".format(int(r[0]), r[1], r[2]))
