@@ -40,11 +40,23 @@ def _device_scope(opt):
 
 
 # ---- training ------------------------------------------------------------------------------------------------------
-def _train_worker(rank, world_size, port, opt):
+def _launcher_ranks():
+    """(rank, device index, world size) of a process started by torch.distributed.run: one rank per GPU over RCCL; with
+    SHAPECLIPPER_DIST_BACKEND=gloo the ranks share the GPUs that exist (tests/test_gpu_two_ranks.py on a one-GPU box)."""
+    from .utils import util
+    rank, local, world = int(os.environ.get("RANK", os.environ["LOCAL_RANK"])), int(os.environ["LOCAL_RANK"]), int(os.environ["WORLD_SIZE"])
+    if util.dist_backend() != "nccl" and torch.cuda.is_available():
+        local %= torch.cuda.device_count()
+    return rank, local, world
+
+
+def _train_worker(rank, world_size, port, opt, device=None):
     from .model.runner import Runner
-    opt.device, opt.world_size, opt.port = rank, world_size, port
+    opt.device, opt.world_size, opt.port = (rank if device is None else device), world_size, port
+    if device is not None:
+        opt.rank = rank
     if torch.cuda.is_available():
-        torch.cuda.set_device(rank)
+        torch.cuda.set_device(opt.device)
     runner = Runner(opt)
     for stage in ("load_dataset", "build_networks", "setup_optimizer", "restore_checkpoint", "setup_visualizer", "train"):
         getattr(runner, stage)(opt)
@@ -58,10 +70,11 @@ def train_main(argv=None):
     port = _free_port()
     if _under_torchrun():
         import torch.distributed as dist
-        local, world = int(os.environ["LOCAL_RANK"]), int(os.environ["WORLD_SIZE"])
+        from .utils import util
+        rank, local, world = _launcher_ranks()
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl")
-        _train_worker(local, world, port, opt)
+        dist.init_process_group(util.dist_backend())
+        _train_worker(rank, world, port, opt, device=local)
         return
     n_gpus = max(torch.cuda.device_count(), 1)
     if n_gpus == 1:
@@ -95,9 +108,10 @@ def evaluate_main(argv=None):
     sharded = _under_torchrun() and int(os.environ["WORLD_SIZE"]) > 1
     if sharded:
         import torch.distributed as dist
-        opt.device, opt.world_size = int(os.environ["LOCAL_RANK"]), int(os.environ["WORLD_SIZE"])
+        from .utils import util
+        opt.rank, opt.device, opt.world_size = _launcher_ranks()
         torch.cuda.set_device(opt.device)
-        dist.init_process_group("nccl")
+        dist.init_process_group(util.dist_backend())
     with _device_scope(opt):
         runner = Runner(opt)
         runner.load_dataset(opt, eval_split="test")

@@ -3,6 +3,7 @@ smoke runs: `--data.dataset=synthetic`.  The real Pix3D loader is out of scope (
 import torch
 
 from .. import synthetic
+from ..utils import util
 
 
 class Dataset(torch.utils.data.Dataset):
@@ -34,7 +35,7 @@ class Dataset(torch.utils.data.Dataset):
         sampler = None
         if self.training and allow_ddp and opt.get("world_size", 1) > 1:
             sampler = torch.utils.data.distributed.DistributedSampler(self, num_replicas=opt.world_size,
-                                                                      rank=opt.device if isinstance(opt.device, int) else 0)
+                                                                      rank=util.get_rank(opt))
         return torch.utils.data.DataLoader(self, batch_size=batch_size or opt.batch_size, num_workers=0,
                                            shuffle=shuffle if sampler is None else False, drop_last=drop_last, sampler=sampler)
 

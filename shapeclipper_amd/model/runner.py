@@ -32,6 +32,8 @@ except Exception:  # pragma: no cover
 
 
 def _rank0(opt):
+    if opt.get("rank", None) is not None:      # set by the launcher when ranks and device indices are numbered differently
+        return int(opt.rank) == 0
     return opt.device == 0 or opt.device in ("cuda:0", "cpu")
 
 
@@ -315,7 +317,7 @@ class Runner:
         opt.H, opt.W = opt.eval.image_size
         # the reference's single-node convention is rank == device index; the process group's rank is the same number there and stays
         # right when ranks and devices are numbered differently (several nodes; tests/test_gpu_two_ranks.py: two ranks on one GPU)
-        rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else (opt.device if isinstance(opt.device, int) else 0)
+        rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else util.get_rank(opt)
         recs = []
         for it in range(rank, len(self.test_data), opt.world_size):
             sample = self.test_data[it]

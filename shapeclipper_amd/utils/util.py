@@ -266,9 +266,24 @@ def compute_sampling_prob(opt, mask, uniform_fac=3):
     return torch.tensor(np.random.choice(h * w, opt.render.rand_sample, p=prob, replace=False))
 
 
+def dist_backend():
+    """'nccl' (= RCCL on ROCm, xGMI inside a node).  SHAPECLIPPER_DIST_BACKEND=gloo runs the same multi-rank code with several ranks
+    sharing a GPU, which RCCL refuses (tests on a one-GPU box)."""
+    return os.environ.get("SHAPECLIPPER_DIST_BACKEND", "nccl")
+
+
+def get_rank(opt):
+    """Rank of this process: `opt.rank` when the launcher set one, otherwise the reference's single-node convention rank == device
+    index (train.py:37-41 spawns worker i on GPU i)."""
+    r = opt.get("rank", None) if hasattr(opt, "get") else None
+    if r is not None:
+        return int(r)
+    return opt.device if isinstance(opt.device, int) else 0
+
+
 def setup(rank, world_size, port_no):
     """One process per GPU; backend 'nccl' is RCCL on ROCm (xGMI inside a node)."""
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:" + str(port_no), rank=rank, world_size=world_size)
+    dist.init_process_group(dist_backend(), init_method="tcp://127.0.0.1:" + str(port_no), rank=rank, world_size=world_size)
 
 
 def cleanup():
