@@ -72,6 +72,16 @@ class LaplaceDensity(Density):
         return self.beta.abs() + self.beta_min.to(self.beta.device)
 
 
+def _effective(lin, name):
+    """Parameter `name` of a Linear as the kernels must see it: with arch.*.weight_norm (reference model/implicit.py:131-132,213-214:
+    nn.utils.weight_norm) the weight is g * v / ||v|| per output row -- computed here from the weight_g / weight_v parameters the
+    reference's state dict holds (the `weight` attribute nn.utils.weight_norm leaves on the module is only refreshed by the module's
+    own forward, which this path never calls); differentiable w.r.t. both."""
+    if name == "weight" and hasattr(lin, "weight_g"):
+        return torch._weight_norm(lin.weight_v, lin.weight_g, 0)
+    return getattr(lin, name)
+
+
 class SDFNetwork(nn.Module):
     """Conditional SDF MLP (reference model/implicit.py:85-189)."""
 
@@ -110,10 +120,12 @@ class SDFNetwork(nn.Module):
                 else:
                     nn.init.constant_(lin.bias, 0.0)
                     nn.init.normal_(lin.weight, 0.0, std)
+            if a.weight_norm:          # reparameterise AFTER the geometric initialisation, as the reference does (:130-132)
+                lin = nn.utils.weight_norm(lin)
             setattr(self, "lin" + str(l), lin)
 
     def weight_dict(self):
-        return {"lin%d.%s" % (l, n): getattr(getattr(self, "lin%d" % l), n)
+        return {"lin%d.%s" % (l, n): _effective(getattr(self, "lin%d" % l), n)
                 for l in range(self.num_layers - 1) for n in ("weight", "bias")}
 
     def packed(self, proj_latent):
@@ -169,10 +181,13 @@ class RGBNetwork(nn.Module):
         self.num_layers = len(dims)
         self.posenc_res = a.pos_enc
         for l in range(self.num_layers - 1):
-            setattr(self, "lin" + str(l), nn.Linear(dims[l], dims[l + 1]))
+            lin = nn.Linear(dims[l], dims[l + 1])
+            if a.weight_norm:
+                lin = nn.utils.weight_norm(lin)
+            setattr(self, "lin" + str(l), lin)
 
     def weight_dict(self):
-        return {"lin%d.%s" % (l, n): getattr(getattr(self, "lin%d" % l), n)
+        return {"lin%d.%s" % (l, n): _effective(getattr(self, "lin%d" % l), n)
                 for l in range(self.num_layers - 1) for n in ("weight", "bias")}
 
     def packed(self, proj_latent):

@@ -55,13 +55,12 @@ def _slots(w_pe: torch.Tensor) -> torch.Tensor:
 def check_arch(opt) -> None:
     a = opt.arch
     ok = (a.impl_sdf.n_hidden_layers == 5 and a.impl_sdf.n_channels == 64 and a.impl_sdf.pos_enc == 6
-          and list(a.impl_sdf.skip_connection) == [1, 2] and not a.impl_sdf.weight_norm
-          and a.impl_rgb.n_hidden_layers == 3 and a.impl_rgb.n_channels == 64 and a.impl_rgb.pos_enc == 6
-          and not a.impl_rgb.weight_norm)
+          and list(a.impl_sdf.skip_connection) == [1, 2]
+          and a.impl_rgb.n_hidden_layers == 3 and a.impl_rgb.n_channels == 64 and a.impl_rgb.pos_enc == 6)
     if not ok:
         raise NotImplementedError(
             "shapeclipper_amd HIP kernels are specialised for the shipped architecture "
-            "(impl_sdf: 5x64, pos_enc 6, skip [1,2]; impl_rgb: 3x64, pos_enc 6; no weight_norm)")
+            "(impl_sdf: 5x64, pos_enc 6, skip [1,2]; impl_rgb: 3x64, pos_enc 6; weight_norm on or off)")
 
 
 # ---- gather plans ---------------------------------------------------------------------------------------------------------

@@ -437,6 +437,39 @@ def main():
          **{"train." + k: v for k, v in zip(("rgb", "mask", "mask_hard", "depth", "normal", "grad_eikonal"), tr[:6])},
          **{"cot." + k: v for k, v in cot12.items()}, **{"grad." + k: v for k, v in ref12.items()})
 
+    # ---------------- G14: the MLPs with arch.impl_*.weight_norm = true (model/implicit.py:130-132,212-214) -----------------
+    # Appended last, with its own generator and seed, so that no earlier fixture's random stream moves.
+    gen14 = torch.Generator().manual_seed(1414)
+    opt14 = ref_opt()
+    opt14.arch.impl_sdf.weight_norm = True
+    opt14.arch.impl_rgb.weight_norm = True
+    torch.manual_seed(14)
+    sdf14, rgb14 = ref_implicit.SDFNetwork(opt14), ref_implicit.RGBNetwork(opt14)
+    assert "lin0.weight_g" in sdf14.state_dict() and "lin0.weight_v" in rgb14.state_dict() and "lin0.weight" not in sdf14.state_dict()
+    perturb_(sdf14, 0.05, gen14)
+    perturb_(rgb14, 0.05, gen14)
+    B14, N14 = 2, 64
+    pts14 = (torch.rand(B14 * N14, 3, generator=gen14) * 2 - 1) * 0.8
+    zs14, zr14 = torch.randn(B14, 64, generator=gen14), torch.randn(B14, 64, generator=gen14)
+    lat14 = zr14.unsqueeze(1).repeat(1, N14, 1).view(B14 * N14, -1)
+    s14, f14, g14 = sdf14.get_conditional_output(opt14, B14, pts14.clone(), zs14, compute_grad=True)
+    c14 = rgb14(pts14, lat14, f14)
+    cot14 = dict(sdf=torch.randn(s14.shape, generator=gen14), feat=torch.randn(f14.shape, generator=gen14) * 0.1,
+                 grad=torch.randn(g14.shape, generator=gen14), rgb=torch.randn(c14.shape, generator=gen14))
+    L14 = (s14 * cot14["sdf"]).sum() + (f14 * cot14["feat"]).sum() + (g14 * cot14["grad"]).sum() + (c14 * cot14["rgb"]).sum()
+    names14 = ["sdf." + k for k, _ in sdf14.named_parameters()] + ["rgb." + k for k, _ in rgb14.named_parameters()]
+    grads14 = torch.autograd.grad(L14, list(sdf14.parameters()) + list(rgb14.parameters()))
+    # the oracle, fed the effective weights g * v / ||v|| (rows), reproduces the reference
+    eff = lambda sd: {(k[:-2] if k.endswith("_g") else k): (torch._weight_norm(sd[k[:-2] + "_v"], v, 0) if k.endswith("_g") else v)
+                      for k, v in sd.items() if not k.endswith("_v")}
+    We_s, We_r = eff(weights_from(sdf14)), eff(weights_from(rgb14))
+    o_s, o_f, o_g = R.sdf_conditional(cfg, We_s, B14, pts14.clone(), zs14, compute_grad=True)
+    close(o_s, s14, 1e-6, "G14 sdf"); close(o_f, f14, 1e-6, "G14 feat"); close(o_g, g14, 1e-5, "G14 grad")
+    close(R.rgb_mlp(cfg, We_r, pts14, lat14, f14.detach()), c14, 1e-6, "G14 rgb")
+    save("g14_weight_norm", pts=pts14, z_sdf=zs14, z_rgb=zr14, sdf=s14, feat=f14, grad=g14, rgb=c14,
+         **{"cot." + k: v for k, v in cot14.items()}, **{"w." + k: v for k, v in sd_np(sdf14, "sdf.").items()},
+         **{"w." + k: v for k, v in sd_np(rgb14, "rgb.").items()}, **{"grad." + n: g_ for n, g_ in zip(names14, grads14)})
+
     print("all oracle-vs-reference checks passed; fixtures written to", OUT)
 
 

@@ -167,13 +167,13 @@ def test_config0_pretrain_plumbing_on_cpu():
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference only exists in the build container")
 def test_golden_recipe_reproduces_committed_fixtures(tmp_path):
     """tests/golden/make_golden.py imports the reference's OWN modules (it asserts their origin), checks the oracle
-    against them and regenerates G1-G10 and G12: the arrays must equal the committed fixtures bit for bit."""
+    against them and regenerates G1-G10, G12 and G14: the arrays must equal the committed fixtures bit for bit."""
     script = os.path.join(GOLDEN_DIR, "make_golden.py")
     env = dict(os.environ, GOLDEN_OUT=str(tmp_path))
     r = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     made = sorted(p.name for p in tmp_path.glob("*.npz"))
-    assert len(made) == 11, made
+    assert len(made) == 12, made
     for name in made:
         a, b = np.load(tmp_path / name), np.load(os.path.join(GOLDEN_DIR, name))
         assert set(a.files) == set(b.files), name
@@ -193,3 +193,29 @@ def test_g12_render_with_hits(golden):
     for k in ("rgb", "mask", "mask_hard", "depth", "normal"):
         assert torch.allclose(o[k].detach(), T(g["eval." + k]), atol=1e-6), k
     assert 0.3 < float(g["hit_frac"]) < 0.9 and float(o["mask_hard"].mean()) == float(g["hit_frac"])
+
+
+def test_g14_weight_norm(golden):
+    """arch.impl_*.weight_norm = true (model/implicit.py:130-132,212-214): the reference's capture with the option on is reproduced by the
+    oracle fed the effective weights g * v / ||v|| (per output row), values and -- through autograd -- the gradients w.r.t. g, v and bias."""
+    g = golden("g14_weight_norm")
+    cfg = R.Cfg()
+    leaves, Ws = {}, {}
+    for net in ("sdf", "rgb"):
+        sd = {k[len("w.%s." % net):]: torch.tensor(g[k]).requires_grad_(True) for k in g.files if k.startswith("w.%s." % net)}
+        leaves.update({net + "." + k: v for k, v in sd.items()})
+        Ws[net] = {(k[:-2] if k.endswith("_g") else k): (torch._weight_norm(sd[k[:-2] + "_v"], v, 0) if k.endswith("_g") else v)
+                   for k, v in sd.items() if not k.endswith("_v")}
+    pts, zs, zr = torch.tensor(g["pts"]), torch.tensor(g["z_sdf"]), torch.tensor(g["z_rgb"])
+    B, N = zs.shape[0], pts.shape[0] // zs.shape[0]
+    s, f, gr = R.sdf_conditional(cfg, Ws["sdf"], B, pts.clone(), zs, compute_grad=True)
+    c = R.rgb_mlp(cfg, Ws["rgb"], pts, zr.unsqueeze(1).repeat(1, N, 1).view(B * N, -1), f)
+    for name, got in (("sdf", s), ("feat", f), ("grad", gr), ("rgb", c)):
+        want = torch.tensor(g[name])
+        assert (got - want).abs().max() <= 1e-5 * max(1.0, float(want.abs().max())), name
+    L = sum((got * torch.tensor(g["cot." + n])).sum() for n, got in (("sdf", s), ("feat", f), ("grad", gr), ("rgb", c)))
+    names = list(leaves)
+    grads = torch.autograd.grad(L, [leaves[n] for n in names])
+    for n, got in zip(names, grads):
+        want = torch.tensor(g["grad." + n])
+        assert (got - want).abs().max() <= 1e-4 * max(1.0, float(want.abs().max())), n
