@@ -42,6 +42,16 @@ def make_batch(opt, batch_size, seed=0, training=True, n_gt_points=2048, importa
     """One batch with the reference's keys; neighbour stacks carry a trailing K dimension.
     importance=True: ray_idx from the reference's silhouette importance sampler instead of a uniform permutation
     (needs opt.H == image height, consumes numpy's global RNG like the reference's loader)."""
+    # The generator is a few dozen CPU operators on image-sized tensors; with the 256 host threads of a GPU box every one of them pays
+    # the wake-up of an idle thread pool (24 ms per `norm`: 0.33 s per evaluation sample, tools/prof_eval_host.py).  Values do not depend
+    # on the thread count (element-wise operators and generator draws only).
+    n_threads = torch.get_num_threads()
+    if n_threads > 8:
+        torch.set_num_threads(8)
+        try:
+            return make_batch(opt, batch_size, seed, training, n_gt_points, importance)
+        finally:
+            torch.set_num_threads(n_threads)
     gen = torch.Generator().manual_seed(seed)
     H, W = opt.image_size
     R = opt.render.rand_sample if training else 0
