@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=0, help="images of the CPU baseline step (0: --batch if host memory allows)")
     ap.add_argument("--sustained", type=int, default=200, help="extra steps timed after the K-step region (0: off)")
     ap.add_argument("--no-workloads", action="store_true", help="skip the other SURVEY 8(d) workloads (tools/workloads.py)")
+    ap.add_argument("--with-reference-gpu", action="store_true", help="Chamfer workloads: also time the reference's own extension built for "
+                    "gfx950 (oracle/_ref; maps a binary built from the reference's sources into this process -- off by default)")
     ap.add_argument("--workloads-only", action="store_true", help="only those workloads (the rocprofv3 command of profiles/)")
     ap.add_argument("--no-alt", action="store_true", help="skip the second measurement with --hip.conv3x3_split! (fp32-MFMA convolutions)")
     ap.add_argument("--alt-steps", type=int, default=60)
@@ -160,7 +162,7 @@ def main():
     from shapeclipper_amd import _lib
     from shapeclipper_amd.utils.util import EasyDict as edict
     if a.workloads_only:
-        print(json.dumps(dict(workloads=_workloads().run_all(with_cpu=not a.no_cpu_baseline))))
+        print(json.dumps(dict(workloads=_workloads().run_all(with_cpu=not a.no_cpu_baseline, with_reference_gpu=a.with_reference_gpu))))
         return
     runner, opt, batch = build_runner(a.batch, rank, local, world, a.opt)
 
@@ -348,7 +350,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:      # reported at N = 1 only (the other ranks must not wait for rank 0)
             out["cpu_baseline"] = cpu_baseline(a.cpu_batch or a.batch)
         if not a.no_workloads and world == 1:
-            out["workloads"] = _workloads().run_all(with_cpu=not a.no_cpu_baseline)
+            out["workloads"] = _workloads().run_all(with_cpu=not a.no_cpu_baseline, with_reference_gpu=a.with_reference_gpu)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -82,8 +82,13 @@ def test_workloads_line():
     for k in ("workload", "ms", "algorithmic_flop", "algorithmic_bytes", "achieved", "peak", "unit", "bound", "frac"):
         assert k in out, k
     assert out["algorithmic_flop"] == 80640 * 101 ** 3 and 0 < out["frac"] < 1.0
-    c = w.chamfer(1, N=20000, with_cpu=False)
+    c = w.chamfer(1, N=20000, with_cpu=False, with_reference_gpu=True)
     assert c["all_pairs"]["algorithmic_flop"] == 16.0 * 20000 * 20000 and 0 < c["all_pairs"]["frac"] < 1.0
     assert c["same_results_as_all_pairs"] is True and c["speedup_vs_all_pairs"] > 0 and c["ms"] > 0
     sc = c["surface_clouds"]                       # the evaluation's kind of cloud: surfaces a few cells apart
     assert sc["same_results_as_all_pairs"] is True and sc["ms"] > 0 and sc["all_pairs_ms"] > 0
+    # the opt-in leg runs the reference's own kernels (oracle/_ref, prebuilt) on the SAME uniform clouds: bit-identical results.
+    # this flag read `false` in the driver's record because the product buffers had been reused for other clouds.
+    assert "reference_gpu" in c, "oracle/_ref/chamfer_3D_ref.so did not load"
+    assert c["reference_gpu"]["same_results"] is True and c["reference_gpu"]["ms"] > 0
+    assert "reference_gpu" not in w.chamfer(1, N=4096, with_cpu=False)          # never by default

@@ -64,17 +64,19 @@ def cpu_threads():
     return min(os.cpu_count() or 1, 32)
 
 
-def chamfer(B, N=100000, with_cpu=True):
+def chamfer(B, N=100000, with_cpu=True, with_reference_gpu=False):
     import chamfer_3D
     dev = torch.device("cuda")
     g = torch.Generator(device="cpu").manual_seed(B)
     a = (torch.rand(B, N, 3, generator=g) - 0.5).to(dev); b = (torch.rand(B, N, 3, generator=g) - 0.5).to(dev)
     d1 = torch.zeros(B, N, device=dev); d2 = torch.zeros(B, N, device=dev)
     i1 = torch.zeros(B, N, dtype=torch.int32, device=dev); i2 = torch.zeros(B, N, dtype=torch.int32, device=dev)
-    def run(search):
+    def run(search, x=None, y=None, outs=None):
+        x, y = (a, b) if x is None else (x, y)
+        o = (d1, d2, i1, i2) if outs is None else outs
         old, chamfer_3D.SEARCH = chamfer_3D.SEARCH, search
         try:
-            return _gpu_ms(lambda: chamfer_3D.forward(a, b, d1, d2, i1, i2), iters=5 if B > 1 else 20)
+            return _gpu_ms(lambda: chamfer_3D.forward(x, y, *o), iters=5 if B > 1 else 20)
         finally:
             chamfer_3D.SEARCH = old
     # all pairs (csrc/chamfer.hip): the reference's algorithm at the packed-fp32 issue floor -- the roofline line
@@ -101,15 +103,17 @@ def chamfer(B, N=100000, with_cpu=True):
         v = torch.randn(B, N, 3, device=dev, generator=gd)
         v = v / v.norm(dim=-1, keepdim=True)
         return (v * r * (1 + bumps * torch.sin(7 * v[..., :1]) * torch.cos(5 * v[..., 1:2]))).contiguous()
-    ua, ub = a, b
-    a, b = _sphere(0.4, 0.0), _sphere(0.45, 0.1)
-    sb_ms, _ = run("brute")
-    keep = [t.clone() for t in (d1, d2, i1, i2)]
-    sg_ms, _ = run("grid")
-    out["surface_clouds"] = dict(workload="two bumpy spheres (radius 0.4 / 0.45), mean nearest-neighbour distance %.3f" % float(d1.sqrt().mean()),
+    # the surface leg has its OWN clouds and result buffers: d1, d2, i1, i2 keep the uniform clouds' results, which the
+    # reference_gpu leg below is compared with (round 3 compared it with the surface results: a false `same_results: false`)
+    sa, sb = _sphere(0.4, 0.0), _sphere(0.45, 0.1)
+    so = (torch.zeros_like(d1), torch.zeros_like(d2), torch.zeros_like(i1), torch.zeros_like(i2))
+    sb_ms, _ = run("brute", sa, sb, so)
+    skeep = [t.clone() for t in so]
+    sg_ms, _ = run("grid", sa, sb, so)
+    out["surface_clouds"] = dict(workload="two bumpy spheres (radius 0.4 / 0.45), mean nearest-neighbour distance %.3f" % float(so[0].sqrt().mean()),
                                  ms=round(sg_ms, 3), all_pairs_ms=round(sb_ms, 3), speedup_vs_all_pairs=round(sb_ms / sg_ms, 2),
-                                 same_results_as_all_pairs=bool(all(torch.equal(x, y) for x, y in zip(keep, (d1, d2, i1, i2)))))
-    a, b = ua, ub
+                                 same_results_as_all_pairs=bool(all(torch.equal(x, y) for x, y in zip(skeep, so))))
+    del sa, sb, so, skeep
     if with_cpu:
         n = N                                   # B = 1, N = M = 100,000
         x, y = a[0, :n].cpu(), b[0, :n].cpu()
@@ -126,19 +130,24 @@ def chamfer(B, N=100000, with_cpu=True):
         out["cpu"] = dict(value=round(2.0 * n * n / dt / 1e9, 3), unit="Gpairs/s", cores=cpu_threads(), kind="port", seconds=round(dt, 1),
                           sample="chunked torch.cdist + min/argmin, B=1, N=M=%d, both directions (BASELINE.md section 3), 1 timed run without warm-up" % n,
                           gpu_value=round(pairs / (ms * 1e-3) / 1e9, 1))
-    # baseline leg: the reference's OWN extension built for this GPU (oracle/_ref, checker of tests/test_gpu_chamfer_ref.py),
-    # same tensors, same device -- what a user of the reference would get here without this build
-    try:
-        from oracle import build_chamfer_ref
-        ref = build_chamfer_ref.load_module()
-    except Exception:        # noqa: BLE001
-        ref = None
+    # baseline leg, OPT-IN (`bench.py --with-reference-gpu`): the reference's OWN extension built for this GPU (oracle/_ref, checker of
+    # tests/test_gpu_chamfer_ref.py) on the same tensors and device -- what a user of the reference would get here without this
+    # build.  It maps a binary compiled from the reference's (untrusted) sources into the bench process, so it never runs by default.
+    ref = None
+    if with_reference_gpu:
+        try:
+            from oracle import build_chamfer_ref
+            ref = build_chamfer_ref.load_module()
+        except Exception:        # noqa: BLE001
+            ref = None
     if ref is not None:
+        assert all(torch.equal(x, y) for x, y in zip(keep, (d1, d2, i1, i2))), "d1/d2/i1/i2 must still hold the uniform clouds' results"
         e1, e2, j1, j2 = torch.zeros_like(d1), torch.zeros_like(d2), torch.zeros_like(i1), torch.zeros_like(i2)
         rms, _ = _gpu_ms(lambda: ref.forward(a, b, e1, e2, j1, j2), iters=3, warm=1)
         out["reference_gpu"] = dict(ms=round(rms, 3), kind="reference", speedup=round(rms / ms, 2), same_results=bool(
             torch.equal(e1, d1) and torch.equal(e2, d2) and torch.equal(j1, i1) and torch.equal(j2, i2)),
-            sample="external/chamfer3D of the reference built for gfx950 (oracle/build_chamfer_ref.py), same tensors on the same GPU")
+            sample="external/chamfer3D of the reference built for gfx950 (oracle/build_chamfer_ref.py), same uniform clouds on the same GPU; "
+                   "same_results compares dist1, dist2, idx1, idx2 bit for bit with chamfer_3D.forward's")
     return out
 
 
@@ -358,9 +367,10 @@ def resnet_conv3x3(with_cpu=True):
     return out
 
 
-def run_all(with_cpu=True):
+def run_all(with_cpu=True, with_reference_gpu=False):
     out = {}
-    for name, fn in (("chamfer_b1", lambda: chamfer(1, with_cpu=with_cpu)), ("chamfer_b32", lambda: chamfer(32, with_cpu=False)),
+    for name, fn in (("chamfer_b1", lambda: chamfer(1, with_cpu=with_cpu, with_reference_gpu=with_reference_gpu)),
+                     ("chamfer_b32", lambda: chamfer(32, with_cpu=False, with_reference_gpu=with_reference_gpu)),
                      ("clip_vit_b32", lambda: clip_vit(32, with_cpu=with_cpu)), ("clip_vit_b32_batch256", lambda: clip_vit(256, with_cpu=False)),
                      ("clip_vit_l14_b32", lambda: clip_vit(32, with_cpu=False, model="ViT-L/14")), ("render_eval_128", lambda: render_eval_128(32, with_cpu=with_cpu)),
                      ("level_grid_100", lambda: level_grid_100(with_cpu=with_cpu)), ("marching_cubes_100", lambda: marching_cubes_100(32)),
@@ -372,4 +382,4 @@ def run_all(with_cpu=True):
 
 if __name__ == "__main__":
     import json
-    print(json.dumps(run_all("--no-cpu" not in sys.argv)))
+    print(json.dumps(run_all("--no-cpu" not in sys.argv, "--with-reference-gpu" in sys.argv)))
