@@ -139,6 +139,7 @@ def build_runner(batch_per_gpu, rank=0, local=0, world=1, extra=()):
     runner.graph.train()
     runner.it, runner.ep, runner.best_val = 1, 0, 0.0
     runner.timer = edict(start=time.time(), it_mean=None)
+    synthetic.cap_host_threads()
     batch = util.move_to_device(synthetic.make_batch(opt, batch_per_gpu, seed=rank, training=True), "cuda:%d" % local)
     return runner, opt, batch
 

@@ -13,6 +13,7 @@ class Dataset(torch.utils.data.Dataset):
         self.opt, self.split = opt, split
         self.n = int(opt.data.get("synthetic_len", 64 if split == "train" else 4))
         self.training = split == "train"
+        synthetic.cap_host_threads()         # once, from the thread that builds the loaders (see synthetic.make_batch)
 
     def __len__(self):
         return self.n

@@ -10,6 +10,7 @@ train, evaluate, ...).  Differences that matter on MI355X:
 """
 from __future__ import annotations
 
+import contextlib
 import importlib
 import os
 import shutil
@@ -235,7 +236,21 @@ class Runner:
             bad = bad | var.pop("_bad_choice").to(bad.device)
         self._pending_check = None
         if bad is not None and opt.get("check_finite", True):
-            if defer_check and bad.is_cuda:
+            reducer = getattr(self, "reducer", None)
+            if defer_check and reducer is not None and reducer.comm:
+                # multi-rank: MAX of the flag over the ranks, so that every rank raises (or none does) before optim.step()
+                flag = reducer.reduce_flag(bad)
+                stream = reducer._comm_stream
+                if flag.is_cuda:
+                    host = torch.empty((1,), dtype=torch.float32, pin_memory=True)
+                    with torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext():
+                        host.copy_(flag, non_blocking=True)
+                        done = torch.cuda.Event()
+                        done.record()
+                    self._pending_check = (host, done, {k: v.detach() for k, v in loss.items()})
+                elif bool(flag.item() > 0):
+                    self._raise_not_finite(loss, any_rank=True)
+            elif defer_check and bad.is_cuda:
                 host = torch.empty((), dtype=torch.bool, pin_memory=True)
                 host.copy_(bad, non_blocking=True)
                 done = torch.cuda.Event()
@@ -247,13 +262,15 @@ class Runner:
         return loss
 
     @staticmethod
-    def _raise_not_finite(loss):
+    def _raise_not_finite(loss, any_rank=False):
         for key in loss:
             if key == "all":
                 continue
             v = loss[key].mean()
             assert not torch.isinf(v), "loss {} is Inf".format(key)
             assert not torch.isnan(v), "loss {} is NaN".format(key)
+        # multi-rank: the flag is the MAX over the ranks -- this rank's losses are finite, another rank's are not; every rank stops here
+        assert not any_rank, "a loss is NaN / Inf on another rank"
 
     def check_finite(self, loss=None):
         """Raise the reference's NaN/Inf assertions (runner.py:296-302) for the step whose flag is pending.  train_iteration
@@ -263,8 +280,8 @@ class Runner:
         if pending is not None:
             host, done, pending_loss = pending
             done.synchronize()
-            if bool(host):
-                self._raise_not_finite(loss if loss is not None else pending_loss)
+            if bool(host.reshape(-1)[0] > 0):
+                self._raise_not_finite(loss if loss is not None else pending_loss, any_rank=host.dtype != torch.bool)
 
     # ---- evaluation -----------------------------------------------------------------------------------
     @torch.no_grad()

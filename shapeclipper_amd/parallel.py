@@ -50,7 +50,10 @@ class FlatGradAllReduce:
     backward pass produces last -- and the all-reduce of the EARLY segment (94.5 % of the 147 MB) is issued from a
     post-accumulate-grad hook on a side stream as soon as its last gradient exists, so it travels over xGMI while the early trunk
     layers are still being differentiated; after backward only the 8 MB late segment remains: two collectives per step instead of one,
-    the same bytes, the same result (each element is summed over the ranks exactly once).
+    the same bytes, the same result (each element is summed over the ranks exactly once).  The schedule is STATIC: with overlap on,
+    every rank issues exactly [early segment, late segment] in that order every step -- if an early parameter received no gradient
+    on this rank (or a hook was missed), all_reduce() issues the early collective itself before the late one, so ranks can never
+    disagree on the number or the sizes of the collectives of a step.
     BatchNorm running statistics follow rank 0 (DDP's broadcast_buffers=True): the floating-point buffers are re-homed once into a
     persistent flat tensor (they become views of it), so the per-step broadcast is ONE collective on that tensor, no cat / copy-back."""
 
@@ -76,12 +79,15 @@ class FlatGradAllReduce:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
         self.collectives = 0                                   # data-path collectives issued so far (tests, bench)
-        self._early_work, self._early_done, self._seen = None, False, 0
+        self._early_work, self._early_done, self._seen = None, False, set()
         self._comm_stream = torch.cuda.Stream(device=dev) if (self.overlap and dev.type == "cuda") else None
         self._main_stream = None
-        if self.overlap and late:
+        self.split = bool(self.overlap and late)               # two collectives per step (static), else one
+        self._hooks = []
+        if self.split:
+            self._early_ids = {id(p) for p in self.params[:self.n_early]}
             for p in self.params[:self.n_early]:
-                p.register_post_accumulate_grad_hook(self._on_grad)
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
         # persistent flat home of the floating-point buffers
         self.buffers, self.buf_flat = [], None
         if broadcast_buffers:
@@ -101,10 +107,25 @@ class FlatGradAllReduce:
     def nbytes(self):
         return self.flat.numel() * 4
 
+    def close(self):
+        """Remove the gradient hooks (a second reducer on the same module must not trigger this one's collectives)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001
+            pass
+
+    def _reset_step(self):
+        self._early_work, self._early_done, self._seen = None, False, set()
+
     def zero_grad(self):
         for p in self.params:
             p.grad = None
-        self._early_work, self._early_done, self._seen = None, False, 0
+        self._reset_step()
         if self._comm_stream is not None:
             self._main_stream = torch.cuda.current_stream()    # the stream the step is enqueued on (see _launch_early)
 
@@ -128,8 +149,10 @@ class FlatGradAllReduce:
 
     # ---- early segment: issued from inside backward ---------------------------------------------------------------------------
     def _on_grad(self, param):
-        self._seen += 1
-        if self._seen == self.n_early and not self._early_done and self.comm:
+        if not self._hooks:                                    # closed
+            return
+        self._seen.add(id(param))                              # distinct parameters, not hook firings
+        if len(self._seen) == self.n_early and not self._early_done and self.comm:
             self._launch_early()
 
     def _launch_early(self):
@@ -176,13 +199,22 @@ class FlatGradAllReduce:
 
     def all_reduce(self):
         """Call after backward(): mean of the gradients over all ranks."""
-        if not self._early_done:                               # no overlap, or an early gradient never arrived: everything now
+        if not self.split:                                     # one segment, one collective
             self.pack()
             if self.comm:
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
                 self.collectives += 1
                 self.flat.mul_(1.0 / self.world)
+            self._reset_step()
             return
+        if not self._early_done:
+            # an early parameter received no gradient on this rank (its slot contributes zeros): the SAME two collectives as on
+            # every other rank, the early one simply starts here instead of inside the backward pass
+            self._pack_range(0, self.n_early)
+            if self.comm:
+                dist.all_reduce(self.flat[:self.early_numel], op=dist.ReduceOp.SUM)
+                self.collectives += 1
+            self._early_done = True
         self._pack_range(self.n_early, len(self.params))
         if self.comm:
             dist.all_reduce(self.flat[self.early_numel:], op=dist.ReduceOp.SUM)
@@ -192,6 +224,24 @@ class FlatGradAllReduce:
             if self._comm_stream is not None:
                 torch.cuda.current_stream().wait_stream(self._comm_stream)
             self.flat.mul_(1.0 / self.world)
+        self._reset_step()
+
+    def reduce_flag(self, bad: torch.Tensor):
+        """MAX over the ranks of a NaN/Inf flag (one element): every rank takes the SAME decision before optim.step() -- with a local
+        flag only the poisoned rank raised and the others stepped on the all-reduced (poisoned) gradients, then hung in the next
+        collective.  A control message, not part of the gradient exchange: issued right after the forward pass (on the side stream
+        when there is one), so it is long complete when the host asks for it.  Returns a device tensor (float, > 0 = bad)."""
+        f = bad.detach().reshape(1).to(torch.float32)
+        if not self.comm:
+            return f
+        if self._comm_stream is None:
+            dist.all_reduce(f, op=dist.ReduceOp.MAX)
+            return f
+        self._comm_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._comm_stream):
+            f.record_stream(self._comm_stream)
+            dist.all_reduce(f, op=dist.ReduceOp.MAX)
+        return f
 
 
 def _known_streams(device):

@@ -3,6 +3,8 @@ encoders are not available offline, so benchmarks / smoke tests / multi-process 
 images with disc masks in exactly the batch-dict schema of the reference's data/pix3d.py:110-228."""
 from __future__ import annotations
 
+import threading
+
 import numpy as np
 import torch
 
@@ -38,20 +40,26 @@ def _views(n, H, W, R, gen, opt=None, importance=False):
     return out
 
 
+_CAP_LOCK = threading.Lock()
+
+
+def cap_host_threads(limit=8):
+    """Cap torch's intra-op CPU thread pool once, from the main thread of an entry point (values never depend on the thread count:
+    element-wise operators and generator draws only).  Returns the thread count in effect."""
+    with _CAP_LOCK:
+        if threading.current_thread() is threading.main_thread() and torch.get_num_threads() > limit:
+            torch.set_num_threads(limit)
+    return torch.get_num_threads()
+
+
 def make_batch(opt, batch_size, seed=0, training=True, n_gt_points=2048, importance=False):
     """One batch with the reference's keys; neighbour stacks carry a trailing K dimension.
     importance=True: ray_idx from the reference's silhouette importance sampler instead of a uniform permutation
     (needs opt.H == image height, consumes numpy's global RNG like the reference's loader)."""
     # The generator is a few dozen CPU operators on image-sized tensors; with the 256 host threads of a GPU box every one of them pays
-    # the wake-up of an idle thread pool (24 ms per `norm`: 0.33 s per evaluation sample, tools/prof_eval_host.py).  Values do not depend
-    # on the thread count (element-wise operators and generator draws only).
-    n_threads = torch.get_num_threads()
-    if n_threads > 8:
-        torch.set_num_threads(8)
-        try:
-            return make_batch(opt, batch_size, seed, training, n_gt_points, importance)
-        finally:
-            torch.set_num_threads(n_threads)
+    # the wake-up of an idle thread pool (24 ms per `norm`: 0.33 s per evaluation sample, tools/prof_eval_host.py).  The intra-op
+    # thread count is process-global, so it is capped ONCE per process by the entry points (`cap_host_threads()`: cli.py, bench.py),
+    # never switched back and forth here (a DataLoader / autograd thread would see the change, racing restores could stick).
     gen = torch.Generator().manual_seed(seed)
     H, W = opt.image_size
     R = opt.render.rand_sample if training else 0

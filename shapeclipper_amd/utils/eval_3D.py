@@ -107,9 +107,14 @@ def surface_points_device(level, lo, hi, num_points, seed=0, iso=0.0, method="cu
     cdf0 = torch.cat([cdf.new_zeros(1), cdf])                           # cdf0[k] = area of the first k triangles
     st, en = starts.to(dev), ends.to(dev)
     base, total = cdf0[st], cdf0[en] - cdf0[st]                         # [B]
+    # image b draws from its own generator seeded seed + b: the sharded evaluation (one sample per call, seed = idx) and a batched one
+    # (eval.batch_size > 1, seed = first idx) sample the SAME surface points for the same image (a single [B, N, 3] draw does not: the
+    # device Philox stream assigns values per thread of the whole launch).  B small rand launches, still no host synchronisation.
     gen = torch.Generator(device=dev)
-    gen.manual_seed(seed)
-    u = torch.rand(B, num_points, 3, device=dev, generator=gen)
+    u = torch.empty(B, num_points, 3, device=dev)
+    for b in range(B):
+        gen.manual_seed(seed + b)
+        torch.rand(num_points, 3, device=dev, generator=gen, out=u[b])
     target = base[:, None] + u[..., 0].double() * total[:, None]
     pick = torch.searchsorted(cdf, target.reshape(-1), right=True).view(B, num_points)
     pick = torch.minimum(torch.maximum(pick, st[:, None]), (en - 1).clamp_min(0)[:, None])      # stays inside the image's segment

@@ -125,6 +125,37 @@ def _worker_graph(rank, world, port, out):
             chk(12, torch.allclose(red.flat, 2 * mean_coef * flat_params, rtol=1e-5, atol=1e-7))
             chk(13, all(p.grad.data_ptr() >= red.flat.data_ptr() for p in g.parameters()))
             results[overlap] = torch.cat([p.detach().reshape(-1) for p in g.parameters()]).clone()
+            if overlap:
+                # an early parameter WITHOUT a gradient on one rank only.  The schedule is static: both ranks still issue
+                # [early, late] (rank 1 starts its early collective from all_reduce() instead of from the hook) and the sum is right.
+                calls.clear()
+                red.zero_grad()
+                skip = red.params[0] if rank == 1 else None
+                loss = sum((p * p).sum() * coef for p in g.parameters() if p is not skip)
+                loss.backward()
+                chk(14, len(calls) == (0 if rank == 1 else 1))                          # rank 1's hook count never completes
+                red.all_reduce()
+                chk(15, [c for c in calls if c[0] == "all_reduce"] ==
+                    [("all_reduce", red.early_numel), ("all_reduce", red.flat.numel() - red.early_numel)])
+                want0 = 2 * red.params[0].detach() * (1.0 / world)                       # only rank 0 contributed (coef 1), mean over 2 ranks
+                chk(16, torch.allclose(red.views[0], want0, rtol=1e-5, atol=1e-7))
+                want1 = 2 * mean_coef * red.params[1].detach()
+                chk(17, torch.allclose(red.views[1], want1, rtol=1e-5, atol=1e-7))
+                # a backward() without zero_grad() in between must not launch duplicate early collectives or leave a stale handle
+                calls.clear()
+                sum((p * p).sum() for p in g.parameters()).backward()
+                red.all_reduce()
+                chk(18, len([c for c in calls if c[0] == "all_reduce"]) == 2)
+                # NaN/Inf flag: MAX over the ranks -- every rank sees rank 1's bad step
+                f = red.reduce_flag(torch.tensor(rank == 1))
+                chk(19, float(f) > 0)
+                f = red.reduce_flag(torch.tensor(False))
+                chk(20, float(f) == 0)
+                # hooks are removed by close(): a closed reducer launches nothing from a later backward pass
+                red.close()
+                calls.clear()
+                sum((p * p).sum() for p in g.parameters()).backward()
+                chk(21, calls == [])
             del red, optim
         out[rank] = list(failed)
     finally:

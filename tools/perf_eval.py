@@ -17,6 +17,7 @@ opt = options.set(options.parse_arguments(["--yaml=%s/options/pix3d/config.yaml"
 opt.device = 0
 torch.manual_seed(0)
 graph = Graph(opt).cuda().eval()
+synthetic.cap_host_threads()
 batch = util.move_to_device(synthetic.make_batch(opt, 1, seed=1, training=False, n_gt_points=100000), "cuda:0")
 opt.H, opt.W = opt.eval.image_size
 
