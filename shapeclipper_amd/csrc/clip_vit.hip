@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include "gemm8p.hpp"
 
 namespace sc {
 
@@ -1015,6 +1016,23 @@ static int launch_gemm(int epi, const bf16_t* A, const bf16_t* Wt, const float* 
     const long long main_mt = (t128 / 512) * 512 / ntn128;            // whole row tiles inside the full rounds
     const bool tail64 = !peel && rem == 0 && t128 > 512 && (t128 % 512) != 0 && (t128 % 512) * 100 < 512 * tail_pct && main_mt > 0;
     const int M0t = (int)main_mt * 128;
+    // Round 4: the hand-scheduled 256 x 256 kernel of gemm8p.hpp (two wave groups a barrier apart, continuous LDS-DMA stream with counted
+    // vmcnt, persistent tiles) where its tile count fills the chip: measured against the kernels below (tools/micro/gemm_lab) it wins from
+    // ~200 tiles up (12,800 x 2,304 x 768: 58.7 vs 62.9 us; 12,800 x 3,072 x 768: 82.9 vs 105.9; ViT-L/14 qkv / fc1: 67.5 vs 79.7, 98.2 vs
+    // 115.7) and loses below (N = 768 / 1,024 at these M: 150 / 132 tiles on 256 CUs).
+    static const long long g8_min = [] { const char* e = getenv("SC_GEMM_G8_MIN"); return e ? atoll(e) : 200LL; }();              // tuning override
+    if ((N % 256) == 0 && M >= 2048 && t256 >= g8_min && (unsigned long long)(M + 256) * N * 4ull < (1ull << 32) &&
+        (unsigned long long)(M + 256) * K * 2ull < (1ull << 32) && (unsigned long long)N * K * 2ull < (1ull << 32)) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+        static int cu_cache[64] = {0};
+        if (dev >= 0 && dev < 64 && cu_cache[dev]) cus = cu_cache[dev];
+        else {
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return (int)hipGetLastError();
+            if (dev >= 0 && dev < 64) cu_cache[dev] = cus;
+        }
+        return g8::launch_gemm8p<H16>(epi, A, Wt, bias, out, M, N, K, cus, st);
+    }
 #define SC_LAUNCH(E)                                                                                                          \
     if (big) {                                                                                                         \
         (void)hipFuncSetAttribute((const void*)gemm256_kernel<E, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);        \
