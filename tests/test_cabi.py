@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
@@ -41,3 +43,27 @@ def test_product_does_not_import_the_oracle():
                 assert "oracle" not in re.sub(r"#.*", "", src).replace("oracle/", ""), os.path.join(dirpath, f)
     for f in ("chamfer_3D.py", "train.py", "evaluate.py", "pretrain.py"):
         assert "import oracle" not in open(os.path.join(ROOT, f)).read() and "from oracle" not in open(os.path.join(ROOT, f)).read()
+
+
+def test_device_guard_raises_when_a_tensor_is_not_on_the_current_device(monkeypatch):
+    """Kernels are launched on the CURRENT device's stream (shapeclipper_amd/_lib.py): every entry point passes its tensors through ptr()
+    and then asks for the stream, which refuses a tensor of another device (rank != device index in a multi-GPU process).  No GPU here:
+    the device queries are replaced, the tensor is a stand-in with the four methods ptr() uses."""
+    import torch
+    from shapeclipper_amd import _lib
+
+    class FakeCudaTensor:
+        is_cuda = True
+        def __init__(self, dev): self._dev = dev
+        def is_contiguous(self): return True
+        def get_device(self): return self._dev
+        def data_ptr(self): return 4096
+
+    monkeypatch.setattr(torch._C, "_cuda_getCurrentRawStream", lambda dev: 1234 + dev, raising=False)
+    monkeypatch.setattr(torch._C, "_cuda_getDevice", lambda: 1, raising=False)
+    assert _lib.ptr(FakeCudaTensor(1)).value == 4096
+    assert _lib.raw_stream() == 1235                       # tensor on cuda:1, current device cuda:1: the stream of device 1
+    _lib.ptr(FakeCudaTensor(0))
+    with pytest.raises(RuntimeError, match="current device is cuda:1"):
+        _lib.stream()
+    monkeypatch.setattr(_lib, "_last_device", -1)

@@ -73,6 +73,24 @@ def test_bench_two_ranks_through_the_launcher():
     assert d["sustained"]["steps"] == 2
 
 
+def test_bench_eight_ranks_config3_code_path():
+    """BASELINE config[3]'s rank count (8 processes, `--gpus 8`) on the one GPU of this box: all ranks share cuda:0 and exchange over gloo,
+    one image per rank -- the launcher / rank / barrier / MAX-over-ranks / flat all-reduce code the 8-GPU scaling run executes, inside GPUTEST
+    (VERDICT r03 next #4c; profiles/r03_config3_8ranks_one_gpu.json is the same run at bs32 per rank)."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MIOPEN_LOG_LEVEL="1", SC_BENCH_BACKEND="gloo", OMP_NUM_THREADS="4")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "1",
+                        "--sustained", "0"], capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len([l for l in r.stdout.splitlines() if l.startswith("{")]) == 1
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 8 and d["config"]["parallelism"] == "dp8" and d["config"]["global_batch"] == 8 and d["scaling"] == "weak"
+    assert abs(d["value"] - 8 / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]
+    assert d["allreduce"]["payload_bytes"] > 140e6 and "cpu_baseline" not in d and "workloads" not in d
+
+
 def test_workloads_line():
     import importlib.util
     spec = importlib.util.spec_from_file_location("sc_workloads_test", os.path.join(ROOT, "tools", "workloads.py"))
