@@ -305,7 +305,7 @@ def main():
         # (6.3 TB/s measured float4 copy, MI355X_MICROARCH.md) the HBM traffic it creates is what sets its time: say so.
         hbm_rate = traffic / (mean_big * 1e-3) / 1e9 if traffic else None
         # "mfma" = the fp32 matrix pipe is the roof this kernel is scored against (its algorithmic bytes are ~0); what holds it below
-        # that roof today is instruction issue -- fp32 MFMA and vector instructions of a SIMD add up on this chip (DESIGN.md section 4) --
+        # that roof today is instruction issue -- fp32 MFMA and vector instructions of a SIMD add up on this chip (DESIGN.md section 4.1) --
         # see `limiter`.
         bound = "hbm" if (hbm_rate and hbm_rate >= 0.75 * 6300.0) else "mfma"
         roofline = dict(kernel=dom, bound=bound, achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS,

@@ -14,7 +14,7 @@
 //   * the patch is channel-interleaved, [half][position][4 channels], and the weight image is [tap][half][channel out][4 channels in]:
 //     ONE ds_read_b128 per operand tile feeds FOUR MFMAs (the MFMA's two k of a lane half are k = (tap, 4 half + s), s = 0..3 over the
 //     four MFMAs).  This is what the kernel is built around: on this chip a vector or LDS instruction costs ~4.5 issue cycles that the
-//     matrix pipe cannot hide (DESIGN.md section 4), so the loop carries WM + WN reads per 4 WM WN MFMAs and nothing else;
+//     matrix pipe cannot hide (DESIGN.md section 4.1), so the loop carries WM + WN reads per 4 WM WN MFMAs and nothing else;
 //   * the weight image arrives by LDS-DMA as a verbatim copy of what sc_conv3x3_pack wrote (for the backward-data pass that is the
 //     transposed + flipped filter: the same kernel computes dL/dx from dL/dy).
 // Two LDS stages, one raw barrier per K-step.

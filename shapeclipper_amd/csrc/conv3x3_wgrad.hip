@@ -7,7 +7,7 @@
 // halves of the K-step's rows, each wave holding the 9 tap accumulators (144 registers) of its 32 x 32 tile.  MIOpen's fp32 weight
 // gradient kernels are NHWC-only (three layout transposes per call); this one reads NCHW as it lies.
 //
-// The inner loop follows the issue-cycle rule of DESIGN.md section 4 (every vector / LDS instruction costs ~4.5 cycles the matrix pipe
+// The inner loop follows the issue-cycle rule of DESIGN.md section 4.1 (every vector / LDS instruction costs ~4.5 cycles the matrix pipe
 // cannot hide): the k pair of an MFMA is (pixel x, pixel x + GS) of one row, so a lane needs GS consecutive pixels of gy -- one
 // ds_read_b128 / b64 / b32 -- and, per filter row ky, the GS + 2 consecutive patch values that serve all three kx: GS + 2 ds_read_b32
 // for 3 GS MFMAs, every address an immediate offset from two per-lane bases.

@@ -16,13 +16,13 @@
 //   1       A0 (8) + B0 (4)                 A0 x B0                     B1 of step g+1
 //   2       B1 (4)                          A0 x B1                     A1 of step g+1
 //   3       A1 (8)                          A1 x B1                     A0 of step g+2
-//   4       B0 again (4)                    A1 x B0                     B0 of step g+2
+//   4       --  (B0 stays in registers)     A1 x B0                     B0 of step g+2
 // A K-tile (64 KB) is four 16 KB PARTS ordered by when they are consumed: A0 / A1 = the first / second 64 rows of each wave's 128, B0 / B1 = the
-// first / second 32 columns of each wave's 64.  LDS holds two K-tiles (+ a third B0 slot: 144 KB); a part's slot is re-staged as soon as its last reader is through
+// first / second 32 columns of each wave's 64.  LDS holds two K-tiles (128 KB); a part's slot is re-staged as soon as its last reader is through
 // (A0, B0: phase 3 / 4 of the same step; B1, A1: phase 1 / 2 of the next), which keeps FOUR parts (64 KB per CU) in flight all the time: every
 // part has >= 5 phases (~0.7 us) to land, the only waits are `s_waitcnt vmcnt(8)` -- never 0 -- at the end of load segments 1, 2 and 4.
 // RAW: a part is waited for (by every wave, for its own pieces) in the load segment ONE PHASE BEFORE the one that reads it: with the two groups
-// a barrier apart that is what puts a barrier between the last wave's wait and the first wave's read.  WAR: argued per slot in DESIGN.md.
+// a barrier apart that is what puts a barrier between the last wave's wait and the first wave's read.  WAR: argued per slot in DESIGN.md section 4.3.
 // The stream of K-tiles is continuous ACROSS output tiles (persistent workgroups, one per CU, XCD-contiguous tile lists): the first parts of the
 // next tile are in flight during the epilogue, and the vmcnt arithmetic never changes (past the last tile the stream re-reads valid addresses
 // into slots nobody reads).
@@ -30,7 +30,8 @@
 // bit 5 of the byte offset XORed with bit 9 (rows 8-15 swap their 32-byte halves): the 16 lanes of a ds_read_b128 service group then hit 16
 // different 16-byte bank groups (conflict-free); the swizzle is applied to the SOURCE address of the DMA and to the read address.
 // MFMA operands are passed (W fragment, activation fragment): D[i][j] with i = output column, j = output row, so a lane holds FOUR CONSECUTIVE
-// COLUMNS of one output row -- the epilogue loads / stores 16 bytes (fp32) or 8 bytes (16-bit) per lane straight from the accumulators.
+// COLUMNS of one output row -- the epilogue stores 16 bytes per lane straight from the accumulators (16-bit outputs: two lanes 32 apart
+// pair their packed halves first, see the fragment read addresses below).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

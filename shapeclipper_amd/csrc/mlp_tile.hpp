@@ -88,7 +88,7 @@ __device__ __forceinline__ void mm_act_t(const float* wl, const float (&in)[ACT_
 // itself while it runs a transposed layer (the chain waves of sdf_bwdw in the V sweep: the wgrad partner is parked at a barrier)
 // hipcc's own schedule -- one ds_read2_b32, s_waitcnt lgkmcnt(0), two MFMAs, 32 times -- exposes an LDS round trip per MFMA pair
 // (measured 5.5 k cycles for the 64 MFMAs = 2 k of a layer).  Kernels with two chain waves per SIMD keep mm_act_t: there the partner
-// hides the latency and the 32 extra live registers cost more (DESIGN.md section 4).
+// hides the latency and the 32 extra live registers cost more (DESIGN.md section 4.1).
 template <int LD, int MT>
 __device__ __forceinline__ void mm_act_t_pipe(const float* wl, const float (&in)[ACT_STEPS], f32x4 (&acc)[MT]) {
     float wa[4 * MT], wb[4 * MT];

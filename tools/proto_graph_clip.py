@@ -1,5 +1,5 @@
 """hipGraph replay of the CLIP image tower against stream launches: python tools/proto_graph_clip.py [batch=32] [B/32 | L/14].
-The tower is ~90 dependent launches of 5-19 us at ViT-B/32, batch 32: does a captured graph close the gaps between them?"""
+The tower is ~90 dependent launches of 5-19 us at ViT-B/32, batch 32 (docs/LAB_NOTEBOOK.md section 7): does a captured graph close the gaps between them?"""
 import os, sys, time
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import torch
