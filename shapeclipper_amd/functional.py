@@ -362,6 +362,75 @@ def conv3x3(conv, x, packs=None):
     return Conv3x3Function.apply(x, conv.weight, None, None, bool(resnet.HIP_CONV3X3_SPLIT))
 
 
+class BasicBlockFunction(torch.autograd.Function):
+    """One autograd node for a whole torchvision BasicBlock with stride 1 and no shortcut convolution:
+        out = relu( bn2( conv2( relu( bn1( conv1(x) ) ) ) ) + x )
+    Round 4: the step was host-paced -- 34.6 ms of enqueue work for a 34.8 ms step, ~150 autograd.Function applies
+    at 25-33 us each and as many backward-node dispatches.  This node runs the SAME eight ops launches in the SAME order as the four
+    nodes it replaces (Conv3x3Function, BnActFunction, Conv3x3Function, BnActFunction) plus the gradient addition autograd did for x
+    (convolution input and residual), so values and gradients are bit-identical; what goes away is three applies, four backward
+    dispatches and one AccumulateGrad-style add node per block (18 of the 24 blocks of the two trunks take this path)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, pf1, pb1, pf2, pb2, split, bn1_state, bn2_state, groups):
+        x = ops._aligned(x)
+        rm1, rv1, nt1, training, mom1, eps1 = bn1_state
+        rm2, rv2, nt2, _, mom2, eps2 = bn2_state
+        y1 = ops.conv3x3_apply(x, pf1, w1.shape[0], split)
+        a1, st1 = ops.bn_act_forward(y1, None, g1, b1, rm1, rv1, nt1, training, mom1, eps1, True, groups)
+        y2 = ops.conv3x3_apply(a1, pf2, w2.shape[0], split)
+        out, st2 = ops.bn_act_forward(y2, x, g2, b2, rm2, rv2, nt2, training, mom2, eps2, True, groups)
+        ctx.meta = (split, training, groups)
+        # w1 / w2 are saved for the reason Conv3x3Function gives: a backward pass after an in-place update of the filters must fail in
+        # ctx.saved_tensors instead of using the pack set's rewritten images
+        ctx.save_for_backward(x, y1, a1, y2, out, st1, st2, g1, b1, g2, b2, pb1, pb2, w1, w2)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        split, training, groups = ctx.meta
+        x, y1, a1, y2, out, st1, st2, g1, b1, g2, b2, pb1, pb2, w1, w2 = ctx.saved_tensors
+        d_out = ops._aligned(d_out)
+        need_x = ctx.needs_input_grad[0]
+        dy2, dres, dg2, db2 = ops.bn_act_backward(d_out, y2, out, g2, b2, st2, training, True, True, need_x, groups)
+        da1 = ops.conv3x3_apply(dy2, pb2, w2.shape[1], split)
+        gw2 = ops.conv3x3_backward_weight(dy2, a1, split=split) if ctx.needs_input_grad[4] else None
+        dy1, _, dg1, db1 = ops.bn_act_backward(da1, y1, None, g1, b1, st1, training, True, True, False, groups)
+        dx = None
+        if need_x:
+            dx = ops.conv3x3_apply(dy1, pb1, w1.shape[1], split)
+            dx += dres                                                  # the sum autograd formed for the two uses of x
+        gw1 = ops.conv3x3_backward_weight(dy1, x, split=split) if ctx.needs_input_grad[1] else None
+        return dx, gw1, dg1, db1, gw2, dg2, db2, None, None, None, None, None, None, None, None
+
+
+def _bn_state(bn):
+    training = bn.training or not bn.track_running_stats
+    track = bn.track_running_stats
+    return (bn.running_mean if track else None, bn.running_var if track else None,
+            bn.num_batches_tracked if (track and training) else None, training, float(bn.momentum), float(bn.eps))
+
+
+def basic_block_takes(block, x, packs):
+    """Stride-1 block without shortcut convolution whose two filters are in the pack set and whose BatchNorms take the fused path."""
+    if packs is None or block.downsample is not None or block.conv1.stride != (1, 1):
+        return False
+    if id(block.conv1.weight) not in packs.index or id(block.conv2.weight) not in packs.index:
+        return False
+    if not (conv3x3_takes(block.conv1, x) and conv3x3_takes(block.conv2, x) and _bn_fusable(block.bn1, x) and _bn_fusable(block.bn2, x)):
+        return False
+    if not (ops.conv3x3_wgrad_supported(x.shape, block.conv1.weight.shape) and ops.conv3x3_wgrad_supported(x.shape, block.conv2.weight.shape)):
+        return False
+    return block.bn1.training == block.bn2.training
+
+
+def basic_block(block, x, packs, groups=1):
+    c1, c2 = block.conv1.weight, block.conv2.weight
+    return BasicBlockFunction.apply(x, c1, block.bn1.weight, block.bn1.bias, c2, block.bn2.weight, block.bn2.bias,
+                                    packs.get(c1, 0), packs.get(c1, 1), packs.get(c2, 0), packs.get(c2, 1), packs.split,
+                                    _bn_state(block.bn1), _bn_state(block.bn2), groups)
+
+
 class CameraRaysFunction(torch.autograd.Function):
     """pose [B,3,4], intr [B,3,3], ray_idx [B,R] | None -> cam_loc [B*R,3], ray_dirs [B*R,3] (unit), depth_fac [B*R]
     (reference utils/camera.py:157-196 + model/renderer.py:69-76, perspective camera) in one launch each way."""

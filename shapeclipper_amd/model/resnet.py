@@ -10,7 +10,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from ..functional import bn_act, bn_relu_maxpool, conv1x1s2, conv3x3, conv3x3s2, conv_stem
+from ..functional import basic_block, basic_block_takes, bn_act, bn_relu_maxpool, conv1x1s2, conv3x3, conv3x3s2, conv_stem
 
 FUSED_BN = True
 HIP_CONV3X3 = True       # 3x3 / stride-1 convolutions on csrc/conv3x3.hip (`--hip.conv3x3!` keeps them on MIOpen)
@@ -18,6 +18,7 @@ HIP_CONV_STEM = True      # the 7x7 / 2 stem on csrc/conv_stem.hip (`--hip.conv_
 HIP_CONV3X3_S2 = True    # forward of the 3x3 / stride-2 conv1 of layer2-4 on the stride-2 instance of conv3x3.hip (`--hip.conv3x3s2!`)
 HIP_CONV3X3_S2_GRADS = True  # ... and their two gradients on conv3x3.hip (four parity sub-convolutions) / conv3x3_wgrad.hip (`--hip.conv3x3s2_grads!`: MIOpen)
 HIP_CONV_1X1 = True       # the 1x1 / stride-2 shortcuts on csrc/conv1x1s2.hip (`--hip.conv1x1!`)
+FUSED_BLOCK = True        # stride-1 blocks without shortcut convolution as ONE autograd node (functional.BasicBlockFunction; `--hip.fused_block!`)
 HIP_CONV3X3_SPLIT = True  # their forward / backward-data / backward-weight products on the bf16 matrix pipe from exact three-piece operand splits, fp32 accumulate
                           # (default since round 3, VERDICT r02 ruling; `--hip.conv3x3_split!` selects the fp32-MFMA kernels)
 
@@ -42,6 +43,8 @@ class BasicBlock(nn.Module):
             out = self.bn2(self.conv2(out))
             return self.relu(out + identity)
         use_hip = HIP_CONV3X3 if hip_conv is None else hip_conv
+        if use_hip and FUSED_BLOCK and basic_block_takes(self, x, packs):
+            return basic_block(self, x, packs, groups)
         identity = x if self.downsample is None else bn_act(
             self.downsample[1], conv1x1s2(self.downsample[0], x) if (use_hip and HIP_CONV_1X1) else self.downsample[0](x), relu=False, groups=groups)
         conv = (lambda m, t: conv3x3s2(m, t) if (m.stride == (2, 2) and HIP_CONV3X3_S2) else conv3x3(m, t, packs)) if use_hip else (lambda m, t: m(t))

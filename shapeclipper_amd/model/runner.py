@@ -78,9 +78,12 @@ class Runner:
         dev = torch.device("cuda", opt.device) if isinstance(opt.device, int) else torch.device(opt.device)
         self.graph = ModuleHolder(module.Graph(opt).to(dev))
         if opt.world_size > 1:
-            # hip.overlap_allreduce: the early 94.5 % of the gradient bytes travel while the trunks' first layers are still differentiated
+            # Default (round 4): north_star's SINGLE flat all-reduce after backward.  `--hip.overlap_allreduce` lays the buffer out
+            # [early 94.5 % | late] and issues the early segment from inside backward on a side stream; on one rank its hooks and stream
+            # juggling cost 1.1 ms of host time per step more than the single collective (profiles/r04_overlap_1rank.txt) on a step that
+            # is host-paced, against ~0.7-1 ms of xGMI time it could hide: not the default until a multi-GPU run says otherwise.
             self.reducer = FlatGradAllReduce(self.graph.module, opt.world_size,
-                                             overlap=None if opt.get("hip", {}).get("overlap_allreduce", True) else False)
+                                             overlap=None if opt.get("hip", {}).get("overlap_allreduce", False) else False)
 
     def setup_optimizer(self, opt):
         if _rank0(opt): log.info("setting up optimizers...")

@@ -39,7 +39,7 @@ def _worker(rank, world, port, overlap, outdir, out):
         from shapeclipper_amd.utils import options, util
         from shapeclipper_amd.utils.util import EasyDict as edict
         per_rank = 2
-        extra = [] if overlap else ["--hip.overlap_allreduce!"]
+        extra = ["--hip.overlap_allreduce"] if overlap else ["--hip.overlap_allreduce!"]      # the default is the single all-reduce (round 4)
         opt = options.set(options.parse_arguments([
             "--yaml=%s/options/pix3d/config.yaml" % ROOT, "--name=pytest_two_ranks", "--output_root=/tmp/sc_pytest_%d" % rank,
             "--batch_size=%d" % (per_rank * world), "--tb!", "--arch.enc_pretrained!"] + extra), verbose=False)
