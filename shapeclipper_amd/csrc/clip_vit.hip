@@ -743,7 +743,13 @@ __global__ __launch_bounds__(64 * ATT_NW) void attention_kernel(const bf16_t* __
     };
     const float c2 = scale * 1.44269504088896341f;            // exp(scale s - m) = exp2(c2 s - c2 max s): one fma + v_exp_f32 per score
     const int Tfull = T & ~31;                                // keys below Tfull need no mask
-    for (int qb = wave; qb * 32 < T; qb += ATT_NW) {
+    // Query blocks go round-robin over the eight waves.  T = 257 (ViT-L/14 at 224 x 224) is 8 full blocks + ONE query: left to wave 0 as a
+    // ninth block it doubled the kernel (seven waves idle for a whole block time: 35 us per layer).  A single left-over block is instead
+    // split over the KEYS: every wave takes the key chunks wave, wave + 8, ... for those queries, the partial (max, sum, O) of the eight
+    // waves are combined in wave order through the (by then free) LDS -- round 4.
+    const int nqb = (T + 31) >> 5;
+    const bool ksplit = k_lds && nqb > ATT_NW && (nqb % ATT_NW) == 1;
+    for (int qb = wave; qb < (ksplit ? nqb - 1 : nqb); qb += ATT_NW) {
         const int q = qb * 32 + n;
         bf16x8 qf[4];
 #pragma unroll
@@ -834,6 +840,88 @@ __global__ __launch_bounds__(64 * ATT_NW) void attention_kernel(const bf16_t* __
 #pragma unroll
             for (int t = 0; t < 2; ++t)
                 if (qq < T) out[((size_t)b * T + qq) * D + hd * 64 + 32 * t + n] = cvt16<H16>(O[t][r] * iq);
+        }
+    }
+    if (ksplit) {
+        const int qb = nqb - 1, q = qb * 32 + n;
+        bf16x8 qf[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) qf[s4] = frag(q, 16 * s4);
+        auto scores = [&](int kc) -> f32x16 {
+            f32x16 S;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[r] = 0.f;
+            const bf16_t* kp = Ks + (kc + n) * ATT_KLD + 8 * h;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+                S = mfma16<H16>(__builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(kp + 16 * s4)), qf[s4], S);
+            return S;
+        };
+        float smax = -3.0e38f;
+        for (int kc = 32 * wave; kc < T; kc += 32 * ATT_NW) {
+            const f32x16 S = scores(kc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kc + (r & 3) + 8 * (r >> 2) + 4 * h < T) smax = fmaxf(smax, S[r]);
+        }
+        smax = fmaxf(smax, __shfl_xor(smax, 32));
+        const float mc = smax * c2;
+        f32x16 O[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[t][r] = 0.f;
+        float l = 0.f;
+        for (int kc = 32 * wave; kc < T; kc += 32 * ATT_NW) {
+            const f32x16 S = scores(kc);
+            float pr[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                pr[r] = kc + (r & 3) + 8 * (r >> 2) + 4 * h < T ? __builtin_amdgcn_exp2f(fmaf(S[r], c2, -mc)) : 0.f;
+                l += pr[r];
+            }
+            bf16x8 pf[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bf16_t tmp[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) tmp[e] = cvt16<H16>(pr[8 * j + e]);
+                pf[j] = __builtin_bit_cast(bf16x8, tmp);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const bf16_t* vp = Vt + (32 * t + n) * ldv + kc + 16 * j + 4 * h;
+                    const uint2 lo = *reinterpret_cast<const uint2*>(vp), hi = *reinterpret_cast<const uint2*>(vp + 8);
+                    O[t] = mfma16<H16>(pf[j], __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y)), O[t]);
+                }
+        }
+        l += __shfl_xor(l, 32);
+        __syncthreads();                                      // every wave is through with K and V^T: the LDS takes the partial results
+        float* part = reinterpret_cast<float*>(Vt);           // [wave][query 0..31][66] = raw maximum, sum, O[64]: 67.6 KB <= V^T + K
+        if (h == 0) { part[(wave * 32 + n) * 66] = smax; part[(wave * 32 + n) * 66 + 1] = l; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ql = (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) part[(wave * 32 + ql) * 66 + 2 + 32 * t + n] = O[t][r];
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 32 * 64; idx += 64 * ATT_NW) {
+            const int ql = idx >> 6, d = idx & 63, qq = qb * 32 + ql;
+            if (qq >= T) continue;
+            float M = -3.0e38f;
+#pragma unroll
+            for (int w = 0; w < ATT_NW; ++w) M = fmaxf(M, part[(w * 32 + ql) * 66]);
+            float L = 0.f, acc = 0.f;
+#pragma unroll
+            for (int w = 0; w < ATT_NW; ++w) {                // wave order: a fixed summation order
+                const float f = __builtin_amdgcn_exp2f((part[(w * 32 + ql) * 66] - M) * c2);
+                L += part[(w * 32 + ql) * 66 + 1] * f;
+                acc += part[(w * 32 + ql) * 66 + 2 + d] * f;
+            }
+            out[((size_t)b * T + qq) * D + hd * 64 + d] = cvt16<H16>(acc / L);
         }
     }
 }
