@@ -146,9 +146,13 @@ def test_gemm_16bit_transpose_detecting(M, N, K, dtype):
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 @pytest.mark.parametrize("M,N,K", [(12800, 768, 3072), (8224, 1024, 1024), (2049, 256, 64), (12800, 3072, 768),
-                                   (8224, 3072, 1024), (8288, 1024, 4096), (8224, 4096, 1024)])
+                                   (8224, 3072, 1024), (8288, 1024, 4096), (8224, 4096, 1024),
+                                   (2049, 6144, 64), (4100, 3328, 192)])     # gemm8p with ONE / three K-tiles per output tile and one / four valid rows in the last row tile
 def test_gemm_256_tiles_all_epilogues(M, N, K, dtype):
-    """The 256 x 256 tile kernel (M >= 2048, N % 256 == 0) and the persistent 128 x 128 kernel with its ragged last rows peeled off into
+    """Round 4: shapes with >= 200 tiles of 256 x 256 (12800 x 3072, 8224 x 3072 / 4096, the last two) run on csrc/gemm8p.hpp -- hand-counted
+    vmcnt, residual tile as accumulator init, paired 16-byte 16-bit stores through a buffer resource that ends at row M (tools/micro/gemm_lab
+    `stress` is its race screen: profiles/r04_gemm_stress.txt).
+    The 256 x 256 tile kernel (M >= 2048, N % 256 == 0) and the persistent 128 x 128 kernel with its ragged last rows peeled off into
     gemm_thin_kernel (8224 = 64 x 128 + 32 rows: ViT-L/14 at batch 32; 8288: 96 rows): every epilogue (fp32, residual accumulate,
     QuickGELU -> 16 bit, 16 bit) against float64; the residual epilogue must read its rows before it writes them, nothing is written
     past row M."""

@@ -58,6 +58,9 @@ int main(int argc, char** argv) {
         {"B32  qkv ", 1600, 2304, 768, 3},  {"B32  proj", 1600, 768, 768, 1},   {"B32  fc1 ", 1600, 3072, 768, 2},  {"B32  fc2 ", 1600, 768, 3072, 1},
         {"sq 4096  ", 4096, 4096, 4096, 3}, {"sq 8192  ", 8192, 8192, 8192, 3}, {"ragged   ", 777, 512, 192, 1}, {"one tile ", 256, 256, 64, 0},
     };
+    const bool stress = argc > 1 && !strcmp(argv[1], "stress");
+    if (stress) shapes = {{"B256 qkv ", 12800, 2304, 768, 3}, {"B256 fc2 ", 12800, 768, 3072, 1}, {"L14  fc1 ", 8224, 4096, 1024, 2}, {"ragged   ", 777, 512, 192, 1},
+                          {"f32 out  ", 3000, 1024, 448, 0}, {"one step ", 1500, 2304, 64, 3}, {"two steps", 1500, 768, 128, 1}};
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float* d_err; CK(hipMalloc(&d_err, 8));
@@ -73,6 +76,29 @@ int main(int argc, char** argv) {
         auto reset = [&](void* o) { if (s.epi == 1) CK(hipMemcpyAsync(o, resid, nO * 4, hipMemcpyDeviceToDevice, st)); else CK(hipMemsetAsync(o, 0xFF, nO * (o16 ? 2 : 4), st)); };
         auto run_new = [&](void* o) { return sc::g8::launch_gemm8p<true>(s.epi, A, W, bias, o, s.M, s.N, s.K, cus, st); };
         auto run_old = [&](void* o) { return sc_gemm_f16(s.epi, A, W, bias, o, s.M, s.N, s.K, (void*)st); };
+        if (stress) {
+            // race screen of the hand-scheduled kernel: 40 launches per shape on fresh operands (a second, unrelated GEMM keeps the memory system
+            // busy on another stream for half of them), EVERY element of every launch checked against the plain reference
+            hipStream_t st2; CK(hipStreamCreate(&st2));
+            float worst = 0.f; int bad = 0;
+            for (int it = 0; it < 40; ++it) {
+                fill_f16<<<1024, 256, 0, st>>>(A, nA, 17u + 977u * it, 1.f); fill_f16<<<1024, 256, 0, st>>>(W, nW, 99u + 31u * it, sc);
+                ref_gemm<<<dim3((s.N + 63) / 64, (s.M + 3) / 4), 256, 0, st>>>(A, W, bias, resid, ref, s.M, s.N, s.K, s.epi);
+                reset(o_new);
+                CK(hipStreamSynchronize(st));
+                if (it & 1) for (int k = 0; k < 4; ++k) sc_gemm_f16(3, A, W, nullptr, o_old, s.M > 4096 ? 4096 : s.M, s.N, s.K, (void*)st2);
+                if (run_new(o_new)) { printf("launch refused\n"); break; }
+                CK(hipMemsetAsync(d_err, 0, 8, st));
+                cmp<<<1024, 256, 0, st>>>(o_new, ref, nO, o16, d_err, d_err + 1);
+                float h[2]; CK(hipMemcpyAsync(h, d_err, 8, hipMemcpyDeviceToHost, st)); CK(hipStreamSynchronize(st)); CK(hipStreamSynchronize(st2));
+                worst = h[0] > worst ? h[0] : worst;
+                if (h[0] > (o16 ? 2e-2f : 2e-4f)) ++bad;
+            }
+            printf("%s M=%5d N=%4d K=%4d epi=%d | 40 launches: worst max|err| %.3e, launches over tolerance %d\n", s.name, s.M, s.N, s.K, s.epi, worst, bad);
+            fflush(stdout);
+            hipFree(A); hipFree(W); hipFree(bias); hipFree(resid); hipFree(ref); hipFree(o_new); hipFree(o_old);
+            continue;
+        }
         const bool big = (size_t)s.M * s.N * s.K > (size_t)8192 * 8192 * 4096;
         float err_new = -1.f, err_old = -1.f, mref = 0.f;
 #ifdef LAB_NEW_ONLY
