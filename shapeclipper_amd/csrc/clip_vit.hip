@@ -1121,6 +1121,17 @@ static int launch_gemm(int epi, const bf16_t* A, const bf16_t* Wt, const float* 
         }
         return g8::launch_gemm8p<H16>(epi, A, Wt, bias, out, M, N, K, cus, st);
     }
+    // ... and its 256 x 192 form for the fp32-output GEMMs with N = 768 (proj / fc2 of ViT-B/32 at 12,800 tokens: 150 tiles of 256 x 256 on 256
+    // CUs, 200 of 256 x 192: 32.4 vs 34.4 us and 78.6 vs 90.9 us against the kernels below)
+    const long long t192 = (long long)(N / 192) * ((M + 255) / 256);
+    if ((epi == EPI_F32 || epi == EPI_RESID) && (N % 192) == 0 && M >= 2048 && t192 >= 180 && t192 <= 256 && g8_min < (1LL << 40) &&
+        (unsigned long long)(M + 256) * N * 4ull < (1ull << 32) && (unsigned long long)(M + 256) * K * 2ull < (1ull << 32) &&
+        (unsigned long long)N * K * 2ull < (1ull << 32)) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return (int)hipGetLastError();
+        return g8::launch_gemm8p<H16, 1>(epi, A, Wt, bias, out, M, N, K, cus, st);
+    }
 #define SC_LAUNCH(E)                                                                                                          \
     if (big) {                                                                                                         \
         (void)hipFuncSetAttribute((const void*)gemm256_kernel<E, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);        \

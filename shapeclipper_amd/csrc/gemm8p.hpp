@@ -106,6 +106,10 @@ __device__ __forceinline__ void wait4(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
 }
 template <int N>
+__device__ __forceinline__ void wait3(f32x4& a, f32x4& b, f32x4& c) {
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N) : "memory");
+}
+template <int N>
 __device__ __forceinline__ void wait8(f32x4& a, f32x4& b, f32x4& c, f32x4& d, f32x4& e, f32x4& f, f32x4& g, f32x4& h) {
     asm volatile("s_waitcnt vmcnt(%8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : "n"(N) : "memory");
 }
@@ -115,10 +119,16 @@ constexpr int PART = 16384, KTILE = 65536, LDS_BYTES = 2 * KTILE;       // bytes
 // Persistent grid: gridDim.x workgroups (a multiple of 8, <= one per CU), workgroup b on XCD b % 8 walks the tiles
 // t_lo(xcd) + (b >> 3) + i * (gridDim.x >> 3) of its XCD's contiguous range of the row-major (m tile, n tile) list.
 // Requires K % 64 == 0, N % 256 == 0 (host checks); rows past M are clamped on load and masked on store.
-template <int EPI, bool H16>
+// NB1 = 16-column blocks in a wave's B1 half: 2 -> 256-column tiles (the layout described above); 1 -> 192-column tiles (a wave owns 128 x 48:
+// B1 is an 8 KB part of ONE piece per wave, 7 pieces per wave and K-step instead of 8) for N = 768: 12,800 x 768 is 150 tiles of 256 x 256 on 256
+// CUs but 200 of 256 x 192.  fp32 outputs only (the paired 16-bit stores want an even number of column blocks).
+template <int EPI, bool H16, int NB1 = 2>
 __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm8p_kernel(
     const h16_t* __restrict__ A, const h16_t* __restrict__ Wt, const float* __restrict__ bias, void* __restrict__ out, int M, int N, int K,
     int ntn, int tiles) {
+    static_assert(NB1 == 2 || (NB1 == 1 && (EPI == EPI_F32 || EPI == EPI_RESID)), "192-column tiles: fp32 epilogues only");
+    constexpr int WCOLS = 32 + 16 * NB1, BN = 4 * WCOLS, NBLK = 2 + NB1;      // columns per wave / per tile, 16-column blocks per wave
+    constexpr int NPC = 6 + NB1;                                              // LDS-DMA pieces per wave and K-step = pieces in flight at every wait
     extern __shared__ uint4 Sbuf[];                 // 128 KB: [2 K-tiles][A0 | A1 | B0 | B1] x 16 KB
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wr = wave >> 2, wc = wave & 3;
@@ -127,6 +137,17 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int t_lo = xcd < trem ? xcd * (tq + 1) : trem * (tq + 1) + (xcd - trem) * tq;
     const int t_hi = t_lo + tq + (xcd < trem ? 1 : 0);
     const int kt1 = K >> 6;
+    // Tile order: panels of 4 row tiles, column-major inside a panel, so that the ~32 consecutive tiles an XCD works on at a time form a
+    // 4 x 8 block (4 A bands + 8 W bands per K-step in its L2: 5.3x reuse) instead of 1 x 32 (1.9x: at 8192^3 the K loop was memory-side bound,
+    // tools/micro/l2_stream).  The CLIP shapes (9-16 column tiles) are indifferent to it.
+    const int ntm = tiles / ntn;
+    auto tile_mn = [&](int tile, int& bm, int& bn) {
+        const int per = 4 * ntn, panel = tile / per, within = tile - panel * per;
+        const int rows = min(4, ntm - 4 * panel);
+        const int nt = within / rows;
+        bm = (4 * panel + (within - nt * rows)) * 256;
+        bn = nt * BN;
+    };
     const int n_my = t_lo + wloc < t_hi ? (t_hi - t_lo - wloc + wpx - 1) / wpx : 0;
     if (n_my == 0 || kt1 == 0) return;
 
@@ -139,14 +160,16 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const int pr = 16 * wave + (ln >> 2);                            // part row 0..127
         const int kch = (ln & 3) ^ (((ln >> 5) & 1) << 1);               // logical 16-byte chunk whose data belongs at this lane's LDS position
         const int ra0 = pr + 64 * (pr >> 6);                             // tile row of part row pr in A0 (A1: + 64)
-        const int rb0 = 64 * (pr >> 5) + (pr & 31);                      // tile column in B0 (B1: + 32)
+        const int rb0 = WCOLS * (pr >> 5) + (pr & 31);                   // tile column in B0 (256-column tiles: B1 = + 32)
         const int tile = t_lo + wloc + min(i, n_my - 1) * wpx;           // past the end: the last tile again (valid addresses, unread slots)
-        const int bm = (tile / ntn) * 256, bn = (tile % ntn) * 256;
+        int bm, bn;
+        tile_mn(tile, bm, bn);
         const unsigned rowb = (unsigned)K * 2u;
         sA0 = (unsigned)min(bm + ra0, M - 1) * rowb + kch * 16;
         sA1 = (unsigned)min(bm + ra0 + 64, M - 1) * rowb + kch * 16;
         sB0 = (unsigned)(bn + rb0) * rowb + kch * 16;
-        sB1 = (unsigned)(bn + rb0 + 32) * rowb + kch * 16;
+        if (NB1 == 2) sB1 = (unsigned)(bn + rb0 + 32) * rowb + kch * 16;
+        else sB1 = (unsigned)(bn + WCOLS * (wave >> 1) + 32 + (ln >> 2)) * rowb + (wave & 1) * 64 + kch * 16;   // ONE piece: row block wave >> 1, k half wave & 1
     };
     const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lptr_t)Sbuf);
     const unsigned stage_w = lds0 + (unsigned)wave * 2048u;
@@ -157,8 +180,12 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const unsigned v = src + (unsigned)s_kt * 128u;
         const void* base = P < 2 ? (const void*)A : (const void*)Wt;
         if (!(SC_G8_ABLATE & 1)) {
-            glds(base, v, dst);
-            glds(base, v + 64u, dst + 1024u);
+            if (NB1 == 1 && P == 3) {
+                glds(base, v, dst - (unsigned)wave * 2048u + (unsigned)(wave >> 1) * 2048u + (unsigned)(wave & 1) * 1024u);
+            } else {
+                glds(base, v, dst);
+                glds(base, v + 64u, dst + 1024u);
+            }
         }
     };
     auto advance = [&]() {
@@ -170,19 +197,20 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // W fragments are read with the rows of a 16-row block permuted: fragment row i is block row pi(i) = i with bits 2 and 3 swapped, so that
     // lane group fc (= i >> 2) of the D layout holds block COLUMNS 4 * {0, 2, 1, 3}[fc] .. + 3 -- what lets two lanes 32 apart pair their
     // packed halves into 8 consecutive 16-bit columns (v_permlane32_swap) and store 16 bytes per lane.  Same 16 rows per instruction, same banks.
-    unsigned offA, offB;                                                 // + part * PART + i * 2048 + kh * 1024
+    unsigned offA, offB, offB1;                                          // + part * PART + i * 2048 + kh * 1024
     {
         const int ln = lane_id(), fr = ln & 15, fc = ln >> 4;           // MFMA fragment row / 16-byte k chunk
         const int frp = (fr & 3) | ((fr & 4) << 1) | ((fr & 8) >> 1);
         offA = (unsigned)(4 * wr) * 2048u + (unsigned)(fr * 64 + ((fc ^ ((fr >> 3) << 1)) * 16));
         offB = 2u * PART + (unsigned)(2 * wc) * 2048u + (unsigned)(frp * 64 + ((fc ^ ((frp >> 3) << 1)) * 16));
+        offB1 = 3u * PART + (unsigned)(NB1 * wc) * 2048u + (unsigned)(frp * 64 + ((fc ^ ((frp >> 3) << 1)) * 16));
     }
     const char* S = reinterpret_cast<const char*>(Sbuf);
     auto rd = [&](unsigned byte) -> uint4 { return *reinterpret_cast<const uint4*>(S + byte); };
 
-    uint4 af[4][2], b0f[2][2], b1f[2][2];
-    f32x4 acc[8][4];
-    f32x4 bv[4];
+    uint4 af[4][2], b0f[2][2], b1f[NB1][2];
+    f32x4 acc[8][NBLK];
+    f32x4 bv[NBLK];
 
     // ---- per-tile register loads and the epilogue ---------------------------------------------------------------------------------------
     // Loads hipcc must not count (asm; waited for by hand with counted vmcnt), issued right after the PREVIOUS tile's stores (before the
@@ -196,17 +224,18 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // three counted waits of the step behind a tile boundary are raised by it: nothing waits for the stores (vmcnt retires in issue order).
     constexpr bool OUT32 = EPI == EPI_F32 || EPI == EPI_RESID;
     constexpr unsigned ESZ = OUT32 ? 4u : 2u;
-    constexpr int NE = (OUT32 ? 32 : 16) + (EPI == EPI_RESID ? 32 : 0);   // stores (+ residual loads); the 4 bias loads are not counted (stricter)
+    constexpr int NE = (OUT32 ? 8 * NBLK : 4 * NBLK) + (EPI == EPI_RESID ? 8 * NBLK : 0);   // stores (+ residual loads); the 4 bias loads are not counted (stricter)
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((size_t)M * N * ESZ), 0x00020000);
     auto tile_init = [&](int i) {
         const int tile = t_lo + wloc + i * wpx;
-        const int bm = (tile / ntn) * 256, bn = (tile % ntn) * 256;
+        int bm, bn;
+        tile_mn(tile, bm, bn);
         const int ln = lane_id(), fr = ln & 15, fc = ln >> 4;
         const int cq = 4 * (((fc & 1) << 1) | (fc >> 1));               // this lane's first column inside a 16-column block
-        const int col0 = bn + 64 * wc + cq;
+        const int col0 = bn + WCOLS * wc + cq;
         if (bias) {
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) { const float* bp = bias + col0 + 16 * nb; SC_G8_LD4(bv[nb], bp); }
+            for (int nb = 0; nb < NBLK; ++nb) { const float* bp = bias + col0 + 16 * nb; SC_G8_LD4(bv[nb], bp); }
         }
         if (EPI == EPI_RESID) {
             const float* base = reinterpret_cast<const float*>(out) + col0;
@@ -218,13 +247,13 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                     const int mb = 4 * mh + i4;
                     const float* rp = base + (size_t)min(bm + 128 * wr + 16 * mb + fr, M - 1) * N;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) { const float* p = rp + 16 * (2 * nh + j); SC_G8_LD4(acc[mb][2 * nh + j], p); }
+                    for (int j = 0; j < (nh ? NB1 : 2); ++j) { const float* p = rp + 16 * (2 * nh + j); SC_G8_LD4(acc[mb][2 * nh + j], p); }
                 }
             }
         }
     };
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) bv[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nb = 0; nb < NBLK; ++nb) bv[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     tile_init(0);
 
     // ---- prologue: step 0 complete + A0, B0 of step 1 (the steady-state issue order) ----
@@ -232,7 +261,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     issue(sA0, 0); issue(sB0, 2); issue(sB1, 3); issue(sA1, 1);
     advance();
     issue(sA0, 0); issue(sB0, 2);
-    SC_G8_VM(8);                                    // A0, B0 of step 0 have landed (this wave's pieces)
+    SC_G8_VM(NPC);                                  // A0, B0 of step 0 have landed (this wave's pieces)
     SC_G8_BARRIER();
     if (wr == 1) SC_G8_BARRIER();                   // the second M half runs one barrier behind the first
 
@@ -253,10 +282,10 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
             for (int kh = 0; kh < 2; ++kh) b0f[j][kh] = rd(buf + offB + j * 2048 + kh * 1024);
         issue(sB1, 3);
-        if (p1) SC_G8_VM(8 + NE); else SC_G8_VM(8);
+        if (p1) SC_G8_VM(NPC + NE); else SC_G8_VM(NPC);
         SC_G8_BARRIER();
         SC_G8_LGKM0();
-        if (rfirst) wait8<26>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], acc[2][0], acc[2][1], acc[3][0], acc[3][1]);
+        if (rfirst) wait8<9 * NB1 + 8>(acc[0][0], acc[0][1], acc[1][0], acc[1][1], acc[2][0], acc[2][1], acc[3][0], acc[3][1]);
         __builtin_amdgcn_s_setprio(1);
         if (first) {
 #pragma unroll
@@ -277,31 +306,34 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         SC_G8_BARRIER();
         // ---------------- phase 2 ----------------
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NB1; ++j)
 #pragma unroll
-            for (int kh = 0; kh < 2; ++kh) b1f[j][kh] = rd(buf + offB + PART + j * 2048 + kh * 1024);
+            for (int kh = 0; kh < 2; ++kh) b1f[j][kh] = rd(buf + offB1 + j * 2048 + kh * 1024);
         issue(sA1, 1);
-        if (p1) SC_G8_VM(8 + NE); else SC_G8_VM(8);
+        if (p1) SC_G8_VM(NPC + NE); else SC_G8_VM(NPC);
         advance();
         SC_G8_BARRIER();
         SC_G8_LGKM0();
-        if (rfirst) wait8<20>(acc[0][2], acc[0][3], acc[1][2], acc[1][3], acc[2][2], acc[2][3], acc[3][2], acc[3][3]);
+        if (rfirst) {
+            if constexpr (NB1 == 2) wait8<5 * NB1 + 10>(acc[0][2], acc[0][3], acc[1][2], acc[1][3], acc[2][2], acc[2][3], acc[3][2], acc[3][3]);
+            else wait4<5 * NB1 + 10>(acc[0][2], acc[1][2], acc[2][2], acc[3][2]);
+        }
         __builtin_amdgcn_s_setprio(1);
         if (first) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][2 + j] = mfma32<H16>(b1f[j][0], af[i][0], f32x4{0.f, 0.f, 0.f, 0.f});
+                for (int j = 0; j < NB1; ++j) acc[i][2 + j] = mfma32<H16>(b1f[j][0], af[i][0], f32x4{0.f, 0.f, 0.f, 0.f});
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][2 + j] = mfma32<H16>(b1f[j][0], af[i][0], acc[i][2 + j]);
+                for (int j = 0; j < NB1; ++j) acc[i][2 + j] = mfma32<H16>(b1f[j][0], af[i][0], acc[i][2 + j]);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][2 + j] = mfma32<H16>(b1f[j][1], af[i][1], acc[i][2 + j]);
+            for (int j = 0; j < NB1; ++j) acc[i][2 + j] = mfma32<H16>(b1f[j][1], af[i][1], acc[i][2 + j]);
         __builtin_amdgcn_s_setprio(0);
         SC_G8_BARRIER();
         // ---------------- phase 3 ----------------
@@ -312,30 +344,33 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         issue(sA0, 0);
         SC_G8_BARRIER();
         SC_G8_LGKM0();
-        if (rfirst) wait8<14>(acc[4][2], acc[4][3], acc[5][2], acc[5][3], acc[6][2], acc[6][3], acc[7][2], acc[7][3]);
+        if (rfirst) {
+            if constexpr (NB1 == 2) wait8<12 + NB1>(acc[4][2], acc[4][3], acc[5][2], acc[5][3], acc[6][2], acc[6][3], acc[7][2], acc[7][3]);
+            else wait4<12 + NB1>(acc[4][2], acc[5][2], acc[6][2], acc[7][2]);
+        }
         __builtin_amdgcn_s_setprio(1);
         if (first) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = mfma32<H16>(b1f[j][0], af[i][0], f32x4{0.f, 0.f, 0.f, 0.f});
+                for (int j = 0; j < NB1; ++j) acc[4 + i][2 + j] = mfma32<H16>(b1f[j][0], af[i][0], f32x4{0.f, 0.f, 0.f, 0.f});
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = mfma32<H16>(b1f[j][0], af[i][0], acc[4 + i][2 + j]);
+                for (int j = 0; j < NB1; ++j) acc[4 + i][2 + j] = mfma32<H16>(b1f[j][0], af[i][0], acc[4 + i][2 + j]);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = mfma32<H16>(b1f[j][1], af[i][1], acc[4 + i][2 + j]);
+            for (int j = 0; j < NB1; ++j) acc[4 + i][2 + j] = mfma32<H16>(b1f[j][1], af[i][1], acc[4 + i][2 + j]);
         __builtin_amdgcn_s_setprio(0);
         SC_G8_BARRIER();
         // ---------------- phase 4 ----------------
         issue(sB0, 2);
-        if (p1) SC_G8_VM(8 + NE); else SC_G8_VM(8);
+        if (p1) SC_G8_VM(NPC + NE); else SC_G8_VM(NPC);
         SC_G8_BARRIER();
-        if (rfirst) wait8<8>(acc[4][0], acc[4][1], acc[5][0], acc[5][1], acc[6][0], acc[6][1], acc[7][0], acc[7][1]);
+        if (rfirst) wait8<NPC>(acc[4][0], acc[4][1], acc[5][0], acc[5][1], acc[6][0], acc[6][1], acc[7][0], acc[7][1]);
         __builtin_amdgcn_s_setprio(1);
         if (first) {
 #pragma unroll
@@ -356,22 +391,24 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         if (++c_kt == kt1) {
             // ---- epilogue of tile c_i: straight from the accumulators (a lane holds 4 consecutive columns of one row per block) ----
             const int tile = t_lo + wloc + c_i * wpx;
-            const int bm = (tile / ntn) * 256, bn = (tile % ntn) * 256;
+            int bm, bn;
+            tile_mn(tile, bm, bn);
             const int ln = lane_id(), fr = ln & 15, fc = ln >> 4;
             const int cq = 4 * (((fc & 1) << 1) | (fc >> 1));
-            wait4<8>(bv[0], bv[1], bv[2], bv[3]);                        // requested a whole tile ago; 8 = the stream pieces in flight
+            if constexpr (NB1 == 2) wait4<NPC>(bv[0], bv[1], bv[2], bv[3]);  // requested a whole tile ago; NPC = the stream pieces in flight
+            else wait3<NPC>(bv[0], bv[1], bv[2]);
 #pragma unroll
             for (int mb = 0; mb < 8; ++mb) {
                 const unsigned row = (unsigned)(bm + 128 * wr + 16 * mb + fr);
-                const unsigned rowoff = row * (unsigned)N + (unsigned)(bn + 64 * wc);
-                if (OUT32) {
+                const unsigned rowoff = row * (unsigned)N + (unsigned)(bn + WCOLS * wc);
+                if constexpr (OUT32) {
 #pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) {
+                    for (int nb = 0; nb < NBLK; ++nb) {
                         const f32x4 v = acc[mb][nb] + bv[nb];
                         if (SC_G8_ABLATE & 4) { if (v[0] == 1.2345f) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[1]), orsrc, rowoff * 4u, 0, 0); continue; }
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, (rowoff + 16u * nb + (unsigned)cq) * 4u, 0, 0);
                     }
-                } else {
+                } else if constexpr (NB1 == 2) {
 #pragma unroll
                     for (int np = 0; np < 2; ++np) {                     // column blocks 2 np, 2 np + 1: one 16-byte store per lane
                         u32x2 pk[2];
@@ -410,26 +447,35 @@ __global__ __launch_bounds__(512, 1) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #undef SC_G8_LGKM0
 
 // Host side.  `cus`: compute units of the device (the grid is one workgroup per CU, rounded down to a multiple of 8).
-template <bool H16>
+template <bool H16, int NB1 = 2>
 static inline int launch_gemm8p(int epi, const h16_t* A, const h16_t* Wt, const float* bias, void* out, int M, int N, int K, int cus,
                                 hipStream_t st) {
     // the buffer resource addresses the output with 32 bits, the LDS-DMA the operands with 32-bit offsets
     if ((unsigned long long)(M + 256) * K * 2ull >= (1ull << 32) || (unsigned long long)N * K * 2ull >= (1ull << 32)) return (int)hipErrorInvalidValue;
-    if ((K % 64) || (N % 256) || M <= 0 || (unsigned long long)(M + 256) * N * 4ull >= (1ull << 32)) return (int)hipErrorInvalidValue;
-    const int ntn = N / 256, ntm = (M + 255) / 256, tiles = ntn * ntm;
+    constexpr int BN = 4 * (32 + 16 * NB1);
+    if ((K % 64) || (N % BN) || M <= 0 || (unsigned long long)(M + 256) * N * 4ull >= (1ull << 32)) return (int)hipErrorInvalidValue;
+    const int ntn = N / BN, ntm = (M + 255) / 256, tiles = ntn * ntm;
     int grid = (cus / 8) * 8;
     if (grid < 8) grid = 8;
     if (grid > ((tiles + 7) / 8) * 8) grid = ((tiles + 7) / 8) * 8;
 #define SC_G8_LAUNCH(E)                                                                                                         \
     do {                                                                                                                        \
-        (void)hipFuncSetAttribute((const void*)gemm8p_kernel<E, H16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);   \
-        hipLaunchKernelGGL((gemm8p_kernel<E, H16>), dim3(grid), dim3(512), LDS_BYTES, st, A, Wt, bias, out, M, N, K, ntn, tiles); \
+        (void)hipFuncSetAttribute((const void*)gemm8p_kernel<E, H16, NB1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);   \
+        hipLaunchKernelGGL((gemm8p_kernel<E, H16, NB1>), dim3(grid), dim3(512), LDS_BYTES, st, A, Wt, bias, out, M, N, K, ntn, tiles); \
     } while (0)
-    switch (epi) {
-        case EPI_F32: SC_G8_LAUNCH(EPI_F32); break;
-        case EPI_RESID: SC_G8_LAUNCH(EPI_RESID); break;
-        case EPI_GELU_BF16: SC_G8_LAUNCH(EPI_GELU_BF16); break;
-        default: SC_G8_LAUNCH(EPI_BF16); break;
+    if constexpr (NB1 == 2) {
+        switch (epi) {
+            case EPI_F32: SC_G8_LAUNCH(EPI_F32); break;
+            case EPI_RESID: SC_G8_LAUNCH(EPI_RESID); break;
+            case EPI_GELU_BF16: SC_G8_LAUNCH(EPI_GELU_BF16); break;
+            default: SC_G8_LAUNCH(EPI_BF16); break;
+        }
+    } else {
+        switch (epi) {
+            case EPI_F32: SC_G8_LAUNCH(EPI_F32); break;
+            case EPI_RESID: SC_G8_LAUNCH(EPI_RESID); break;
+            default: return (int)hipErrorInvalidValue;
+        }
     }
 #undef SC_G8_LAUNCH
     return (int)hipGetLastError();

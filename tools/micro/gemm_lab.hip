@@ -46,7 +46,7 @@ __global__ void cmp(const void* got, const float* ref, size_t n, int is16, float
     atomicMax((int*)maxerr, __float_as_int(e)); atomicMax((int*)maxref, __float_as_int(r));
 }
 
-struct Shape { const char* name; int M, N, K, epi; };
+struct Shape { const char* name; int M, N, K, epi; int nb1 = 2; };
 int main(int argc, char** argv) {
     const bool check = argc > 1 && !strcmp(argv[1], "check");
     int dev = 0; hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, dev));
@@ -56,11 +56,13 @@ int main(int argc, char** argv) {
         {"B256 qkv ", 12800, 2304, 768, 3}, {"B256 proj", 12800, 768, 768, 1}, {"B256 fc1 ", 12800, 3072, 768, 2}, {"B256 fc2 ", 12800, 768, 3072, 1},
         {"L14  qkv ", 8224, 3072, 1024, 3}, {"L14  proj", 8224, 1024, 1024, 1}, {"L14  fc1 ", 8224, 4096, 1024, 2}, {"L14  fc2 ", 8224, 1024, 4096, 1},
         {"B32  qkv ", 1600, 2304, 768, 3},  {"B32  proj", 1600, 768, 768, 1},   {"B32  fc1 ", 1600, 3072, 768, 2},  {"B32  fc2 ", 1600, 768, 3072, 1},
+        {"B256 proj 192", 12800, 768, 768, 1, 1}, {"B256 fc2 192 ", 12800, 768, 3072, 1, 1}, {"ragged 192   ", 777, 576, 192, 1, 1}, {"f32 192      ", 3000, 960, 448, 0, 1},
         {"sq 4096  ", 4096, 4096, 4096, 3}, {"sq 8192  ", 8192, 8192, 8192, 3}, {"ragged   ", 777, 512, 192, 1}, {"one tile ", 256, 256, 64, 0},
     };
     const bool stress = argc > 1 && !strcmp(argv[1], "stress");
     if (stress) shapes = {{"B256 qkv ", 12800, 2304, 768, 3}, {"B256 fc2 ", 12800, 768, 3072, 1}, {"L14  fc1 ", 8224, 4096, 1024, 2}, {"ragged   ", 777, 512, 192, 1},
-                          {"f32 out  ", 3000, 1024, 448, 0}, {"one step ", 1500, 2304, 64, 3}, {"two steps", 1500, 768, 128, 1}};
+                          {"f32 out  ", 3000, 1024, 448, 0}, {"one step ", 1500, 2304, 64, 3}, {"two steps", 1500, 768, 128, 1},
+                          {"proj 192 ", 12800, 768, 768, 1, 1}, {"fc2 192  ", 12800, 768, 3072, 1, 1}, {"ragged192", 777, 576, 192, 1, 1}, {"f32 192  ", 3000, 960, 64, 0, 1}};
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float* d_err; CK(hipMalloc(&d_err, 8));
@@ -74,7 +76,8 @@ int main(int argc, char** argv) {
         fill_f16<<<1024, 256, 0, st>>>(A, nA, 17u, 1.f); fill_f16<<<1024, 256, 0, st>>>(W, nW, 99u, sc);
         fill_f32<<<64, 256, 0, st>>>(bias, s.N, 5u, 1.f); fill_f32<<<1024, 256, 0, st>>>(resid, nO, 7u, 2.f);
         auto reset = [&](void* o) { if (s.epi == 1) CK(hipMemcpyAsync(o, resid, nO * 4, hipMemcpyDeviceToDevice, st)); else CK(hipMemsetAsync(o, 0xFF, nO * (o16 ? 2 : 4), st)); };
-        auto run_new = [&](void* o) { return sc::g8::launch_gemm8p<true>(s.epi, A, W, bias, o, s.M, s.N, s.K, cus, st); };
+        auto run_new = [&](void* o) { return s.nb1 == 1 ? sc::g8::launch_gemm8p<true, 1>(s.epi, A, W, bias, o, s.M, s.N, s.K, cus, st)
+                                                        : sc::g8::launch_gemm8p<true>(s.epi, A, W, bias, o, s.M, s.N, s.K, cus, st); };
         auto run_old = [&](void* o) { return sc_gemm_f16(s.epi, A, W, bias, o, s.M, s.N, s.K, (void*)st); };
         if (stress) {
             // race screen of the hand-scheduled kernel: 40 launches per shape on fresh operands (a second, unrelated GEMM keeps the memory system
@@ -110,7 +113,7 @@ int main(int argc, char** argv) {
             for (int which = 0; which < 2; ++which) {
                 void* o = which ? o_old : o_new;
                 reset(o);
-                const int rc = which ? run_old(o) : ((s.N % 256) ? 1 : run_new(o));
+                const int rc = which ? run_old(o) : ((s.N % (s.nb1 == 1 ? 192 : 256)) ? 1 : run_new(o));
                 if (rc) { if (which == 0) err_new = -2.f; continue; }
                 CK(hipMemsetAsync(d_err, 0, 8, st));
                 cmp<<<1024, 256, 0, st>>>(o, ref, nO, o16, d_err, d_err + 1);
@@ -120,7 +123,7 @@ int main(int argc, char** argv) {
         }
         float ms_new = -1.f, ms_old = -1.f;
         for (int which = 0; which < 2; ++which) {
-            if (which == 0 && (s.N % 256)) continue;
+            if (which == 0 && (s.N % (s.nb1 == 1 ? 192 : 256))) continue;
 #ifdef LAB_NEW_ONLY
             if (which == 1) continue;
 #endif
