@@ -8,6 +8,7 @@
 #include <string.h>
 #include <vector>
 #include "gemm8p.hpp"
+#include "gemm_rect.hpp"      // tools/micro: an experiment, see its header
 extern "C" int sc_gemm_f16(int epi, const uint16_t* A, const uint16_t* Wt, const float* bias, void* out, int M, int N, int K, void* stream);
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -46,7 +47,7 @@ __global__ void cmp(const void* got, const float* ref, size_t n, int is16, float
     atomicMax((int*)maxerr, __float_as_int(e)); atomicMax((int*)maxref, __float_as_int(r));
 }
 
-struct Shape { const char* name; int M, N, K, epi; int nb1 = 2; };
+struct Shape { const char* name; int M, N, K, epi; int nb1 = 2; int rect = 0; };   // rect: 1 = 128x128 NS4, 2 = 128x256 NS3, 3 = 64x128 NS6, 4 = 64x256 NS4, 5 = 128x128 NS5
 int main(int argc, char** argv) {
     const bool check = argc > 1 && !strcmp(argv[1], "check");
     int dev = 0; hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, dev));
@@ -60,6 +61,13 @@ int main(int argc, char** argv) {
         {"sq 4096  ", 4096, 4096, 4096, 3}, {"sq 8192  ", 8192, 8192, 8192, 3}, {"ragged   ", 777, 512, 192, 1}, {"one tile ", 256, 256, 64, 0},
     };
     const bool stress = argc > 1 && !strcmp(argv[1], "stress");
+    if (argc > 1 && !strcmp(argv[1], "rect")) {
+        shapes.clear();
+        const Shape base[4] = {{"B32 qkv ", 1600, 2304, 768, 3}, {"B32 proj", 1600, 768, 768, 1}, {"B32 fc1 ", 1600, 3072, 768, 2}, {"B32 fc2 ", 1600, 768, 3072, 1}};
+        for (const Shape& b : base)
+            for (int r = 1; r <= 5; ++r) { Shape t = b; t.rect = r; shapes.push_back(t); }
+        shapes.push_back({"ragged r1", 777, 512, 192, 1, 2, 1}); shapes.push_back({"ragged r3", 777, 384, 192, 0, 2, 3}); shapes.push_back({"ragged r2", 300, 512, 64, 2, 2, 2});
+    }
     if (stress) shapes = {{"B256 qkv ", 12800, 2304, 768, 3}, {"B256 fc2 ", 12800, 768, 3072, 1}, {"L14  fc1 ", 8224, 4096, 1024, 2}, {"ragged   ", 777, 512, 192, 1},
                           {"f32 out  ", 3000, 1024, 448, 0}, {"one step ", 1500, 2304, 64, 3}, {"two steps", 1500, 768, 128, 1},
                           {"proj 192 ", 12800, 768, 768, 1, 1}, {"fc2 192  ", 12800, 768, 3072, 1, 1}, {"ragged192", 777, 576, 192, 1, 1}, {"f32 192  ", 3000, 960, 64, 0, 1}};
@@ -76,7 +84,16 @@ int main(int argc, char** argv) {
         fill_f16<<<1024, 256, 0, st>>>(A, nA, 17u, 1.f); fill_f16<<<1024, 256, 0, st>>>(W, nW, 99u, sc);
         fill_f32<<<64, 256, 0, st>>>(bias, s.N, 5u, 1.f); fill_f32<<<1024, 256, 0, st>>>(resid, nO, 7u, 2.f);
         auto reset = [&](void* o) { if (s.epi == 1) CK(hipMemcpyAsync(o, resid, nO * 4, hipMemcpyDeviceToDevice, st)); else CK(hipMemsetAsync(o, 0xFF, nO * (o16 ? 2 : 4), st)); };
-        auto run_new = [&](void* o) { return s.nb1 == 1 ? sc::g8::launch_gemm8p<true, 1>(s.epi, A, W, bias, o, s.M, s.N, s.K, cus, st)
+        auto run_rect = [&](void* o) {
+            switch (s.rect) {
+                case 1: return sc::gr::launch_gemm_rect<128, 128, 4, true>(s.epi, A, W, bias, o, s.M, s.N, s.K, st);
+                case 2: return sc::gr::launch_gemm_rect<128, 256, 3, true>(s.epi, A, W, bias, o, s.M, s.N, s.K, st);
+                case 3: return sc::gr::launch_gemm_rect<64, 128, 6, true>(s.epi, A, W, bias, o, s.M, s.N, s.K, st);
+                case 4: return sc::gr::launch_gemm_rect<64, 256, 4, true>(s.epi, A, W, bias, o, s.M, s.N, s.K, st);
+                default: return sc::gr::launch_gemm_rect<128, 128, 5, true>(s.epi, A, W, bias, o, s.M, s.N, s.K, st);
+            }
+        };
+        auto run_new = [&](void* o) { return s.rect ? run_rect(o) : s.nb1 == 1 ? sc::g8::launch_gemm8p<true, 1>(s.epi, A, W, bias, o, s.M, s.N, s.K, cus, st)
                                                         : sc::g8::launch_gemm8p<true>(s.epi, A, W, bias, o, s.M, s.N, s.K, cus, st); };
         auto run_old = [&](void* o) { return sc_gemm_f16(s.epi, A, W, bias, o, s.M, s.N, s.K, (void*)st); };
         if (stress) {
@@ -113,7 +130,7 @@ int main(int argc, char** argv) {
             for (int which = 0; which < 2; ++which) {
                 void* o = which ? o_old : o_new;
                 reset(o);
-                const int rc = which ? run_old(o) : ((s.N % (s.nb1 == 1 ? 192 : 256)) ? 1 : run_new(o));
+                const int rc = which ? run_old(o) : ((!s.rect && (s.N % (s.nb1 == 1 ? 192 : 256))) ? 1 : run_new(o));
                 if (rc) { if (which == 0) err_new = -2.f; continue; }
                 CK(hipMemsetAsync(d_err, 0, 8, st));
                 cmp<<<1024, 256, 0, st>>>(o, ref, nO, o16, d_err, d_err + 1);
@@ -123,7 +140,8 @@ int main(int argc, char** argv) {
         }
         float ms_new = -1.f, ms_old = -1.f;
         for (int which = 0; which < 2; ++which) {
-            if (which == 0 && (s.N % (s.nb1 == 1 ? 192 : 256))) continue;
+            if (which == 0 && !s.rect && (s.N % (s.nb1 == 1 ? 192 : 256))) continue;
+            if (which == 0 && s.rect && run_new(o_new)) { (void)hipGetLastError(); continue; }
 #ifdef LAB_NEW_ONLY
             if (which == 1) continue;
 #endif
@@ -140,6 +158,7 @@ int main(int argc, char** argv) {
             (which ? ms_old : ms_new) = tot / reps;
         }
         const double fl = 2.0 * s.M * s.N * s.K;
+        if (s.rect) printf("rect %d ", s.rect);
         printf("%s M=%5d N=%4d K=%4d epi=%d | new %7.1f us %6.0f TF  err %.2e | old %7.1f us %6.0f TF  err %.2e | ref max %.2f\n", s.name, s.M, s.N, s.K, s.epi,
                ms_new * 1e3, ms_new > 0 ? fl / (ms_new * 1e-3) / 1e12 : 0.0, err_new, ms_old * 1e3, fl / (ms_old * 1e-3) / 1e12, err_old, mref);
         fflush(stdout);
