@@ -109,11 +109,11 @@ class SDFNetwork(nn.Module):
                 if l == self.num_layers - 2:
                     nn.init.normal_(lin.weight, mean=np.sqrt(np.pi) / np.sqrt(in_dim), std=0.0001)
                     nn.init.constant_(lin.bias, -a.init_sphere_radius)
-                elif l == 0:
+                elif a.pos_enc > 0 and l == 0:
                     nn.init.constant_(lin.bias, 0.0)
                     nn.init.constant_(lin.weight[:, 3:], 0.0)
                     nn.init.normal_(lin.weight[:, :3], 0.0, std)
-                elif l in self.skip_in:
+                elif a.pos_enc > 0 and l in self.skip_in:
                     nn.init.constant_(lin.bias, 0.0)
                     nn.init.normal_(lin.weight, 0.0, std)
                     nn.init.constant_(lin.weight[:, -(dims[0] - 3):], 0.0)
@@ -134,11 +134,14 @@ class SDFNetwork(nn.Module):
         built once and shared by the main render, the NN-view render and the eikonal calls (4 uses per step)."""
         cache = getattr(self, "_pack_cache", None)
         if cache is not None and cache[0] == torch.is_grad_enabled():
-            return cache[1], packing.sdf_cbias(None, proj_latent, gathered=cache[2])
+            return cache[1], packing.sdf_cbias(None, proj_latent, gathered=cache[2], arch=self._arch(proj_latent.shape[1]))
         w_pack, cbias, gathered = packing.pack_sdf(self.weight_dict(), proj_latent, return_gathered=True)
         if getattr(self, "_pack_cache_on", False):
             self._pack_cache = (torch.is_grad_enabled(), w_pack, gathered)
         return w_pack, cbias
+
+    def _arch(self, Z):
+        return (self.n_channel, self.lin0.in_features - Z, tuple(l for l in (1, 2) if l in self.skip_in))
 
     def begin_step(self, enable=True):
         """Start (or stop) sharing the packed weight image; call once per forward pass, before the first render."""
@@ -148,7 +151,7 @@ class SDFNetwork(nn.Module):
         """Per-point latent form of the reference ([N,3], [N,Z] -> [N,1+C]); every point is its own 'image'."""
         w_pack, cbias = self.packed(proj_latent)
         sdf, _, feat = SdfFunction.apply(points_raw, w_pack, cbias, 1, bool(self.force_symmetry), False, True)
-        return torch.cat([sdf[:, None], packing.tbl_to_rows(feat, points_raw.shape[0])], dim=1)
+        return torch.cat([sdf[:, None], packing.tbl_to_rows(feat, points_raw.shape[0])[:, :self.n_channel]], dim=1)
 
     def get_conditional_output(self, opt, batch_size, points_flat, proj_latent, compute_grad=True):
         """-> (sdf [N,1], impl_feat [N,C], gradients [N,3] | None), N = batch_size * points-per-image.
@@ -160,7 +163,7 @@ class SDFNetwork(nn.Module):
         w_pack, cbias = self.packed(proj_latent)
         sdf, grad, feat = SdfFunction.apply(points_flat, w_pack, cbias, n // batch_size, bool(self.force_symmetry),
                                             bool(compute_grad), True, bool(opt.get("hip", {}).get("fused_backward", True)))
-        return sdf[:, None], packing.tbl_to_rows(feat, n), (grad if compute_grad else None)
+        return sdf[:, None], packing.tbl_to_rows(feat, n)[:, :self.n_channel], (grad if compute_grad else None)
 
 
 class RGBNetwork(nn.Module):
@@ -193,8 +196,9 @@ class RGBNetwork(nn.Module):
     def packed(self, proj_latent):
         cache = getattr(self, "_pack_cache", None)
         if cache is not None and cache[0] == torch.is_grad_enabled():
-            return cache[1], packing.rgb_dbias(None, proj_latent, gathered=cache[2])
-        v_pack, dbias, gathered = packing.pack_rgb(self.weight_dict(), proj_latent, return_gathered=True)
+            return cache[1], packing.rgb_dbias(None, proj_latent, gathered=cache[2],
+                                               arch=(self.n_channel, 3 + 6 * self.posenc_res, self.n_sdf_channel))
+        v_pack, dbias, gathered = packing.pack_rgb(self.weight_dict(), proj_latent, return_gathered=True, n_sdf=self.n_sdf_channel)
         if getattr(self, "_pack_cache_on", False):
             self._pack_cache = (torch.is_grad_enabled(), v_pack, gathered)
         return v_pack, dbias

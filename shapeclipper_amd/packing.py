@@ -53,14 +53,22 @@ def _slots(w_pe: torch.Tensor) -> torch.Tensor:
 
 
 def check_arch(opt) -> None:
+    """What the HIP chain kernels take.  They are compiled for 5 hidden SDF layers / 3 hidden RGB layers of 64 channels with the positional
+    encoding in 48 slots (6 octaves) and optional skip inputs at SDF layers 1 and 2; every SMALLER member of the reference's config family
+    (model/implicit.py:89-113,197-214) is embedded exactly by the weight packing below -- unused rows / columns / octaves / skip inputs of
+    the kernel's image are exact zeros, so the extra channels carry softplus(0) or relu(0) into zero weights: n_channels <= 64 (both
+    networks, independently), pos_enc 0..6 (both), skip_connection any subset of [1, 2], any proj_latent_dim.  Depth is not embeddable
+    (a softplus layer cannot be made an identity) and wider layers / more octaves need other kernels: those raise."""
     a = opt.arch
-    ok = (a.impl_sdf.n_hidden_layers == 5 and a.impl_sdf.n_channels == 64 and a.impl_sdf.pos_enc == 6
-          and list(a.impl_sdf.skip_connection) == [1, 2]
-          and a.impl_rgb.n_hidden_layers == 3 and a.impl_rgb.n_channels == 64 and a.impl_rgb.pos_enc == 6)
+    ok = (a.impl_sdf.n_hidden_layers == 5 and 1 <= a.impl_sdf.n_channels <= 64 and 0 <= a.impl_sdf.pos_enc <= 6
+          and set(a.impl_sdf.skip_connection) <= {1, 2}
+          and a.impl_rgb.n_hidden_layers == 3 and 1 <= a.impl_rgb.n_channels <= 64 and 0 <= a.impl_rgb.pos_enc <= 6)
     if not ok:
         raise NotImplementedError(
-            "shapeclipper_amd HIP kernels are specialised for the shipped architecture "
-            "(impl_sdf: 5x64, pos_enc 6, skip [1,2]; impl_rgb: 3x64, pos_enc 6; weight_norm on or off)")
+            "shapeclipper_amd HIP kernels take impl_sdf: 5 hidden layers, n_channels <= 64, pos_enc <= 6, skip_connection within [1, 2]; "
+            "impl_rgb: 3 hidden layers, n_channels <= 64, pos_enc <= 6 (weight_norm on or off, any proj_latent_dim); got sdf %dx%d pos_enc %d skip %s, "
+            "rgb %dx%d pos_enc %d" % (a.impl_sdf.n_hidden_layers, a.impl_sdf.n_channels, a.impl_sdf.pos_enc, list(a.impl_sdf.skip_connection),
+                                      a.impl_rgb.n_hidden_layers, a.impl_rgb.n_channels, a.impl_rgb.pos_enc))
 
 
 # ---- gather plans ---------------------------------------------------------------------------------------------------------
@@ -76,16 +84,25 @@ def check_arch(opt) -> None:
 _PLANS = {}
 
 
-def _plan(kind: str, Z: int, device):
-    key = (kind, Z, str(device))
+def _plan(kind: str, Z: int, device, arch=None):
+    """arch: sdf -> (C, pe, skips) = channels, positional-encoding columns 3 + 6 L, tuple of skip layers; rgb -> (C, pe, C_sdf).
+    None = the shipped architecture."""
+    if arch is None:
+        arch = (64, 39, (1, 2)) if kind == "sdf" else (64, 39, 64)
+    key = (kind, Z, str(device), arch)
     if key in _PLANS:
         return _PLANS[key]
     r = 1.0 / math.sqrt(2.0)
     idx, scl = [], []
+    C, pe = arch[0], arch[1]
     if kind == "sdf":
-        shapes = [(64, 39 + Z), (64,), (64, 103 + Z), (64,), (64, 103 + Z), (64,), (64, 64), (64,), (64, 64), (64,), (65, 64), (65,)]
+        skips = tuple(arch[2])
+        d0 = pe + Z
+        win = lambda l: C + (d0 if l in skips else 0)
+        shapes = [(C, d0), (C,), (C, win(1)), (C,), (C, win(2)), (C,), (C, C), (C,), (C, C), (C,), (1 + C, C), (1 + C,)]
     else:
-        shapes = [(64, 39 + Z + 64), (64,), (64, 64), (64,), (64, 64), (64,), (3, 64), (3,)]
+        Cs = arch[2]
+        shapes = [(C, pe + Z + Cs), (C,), (C, C), (C,), (C, C), (C,), (3, C), (3,)]
     offs, o = [], 0
     for sh in shapes:
         offs.append(o)
@@ -97,43 +114,49 @@ def _plan(kind: str, Z: int, device):
 
     def put(i, sc=1.0):
         idx.append(i); scl.append(sc)
+
+    def slot(c):                                       # reference PE column of packed slot c, or -1 (pad / octave the network does not have)
+        return _SLOT_IDX[c] if _SLOT_IDX[c] < pe else -1
     if kind == "sdf":
         for row in range(64):                          # W0: PE slots
             for c in range(PE_COLS):
-                put(mat(0, row, _SLOT_IDX[c]) if _SLOT_IDX[c] < 39 else zero)
-        for k in (2, 4):                               # W1, W2: [hidden 64 | PE slots 48], both scaled
+                put(mat(0, row, slot(c)) if (row < C and slot(c) >= 0) else zero)
+        for l, k in ((1, 2), (2, 4)):                  # W1, W2: [hidden 64 | PE slots 48]; skip layers take [h, input] / sqrt 2
+            sc = r if l in skips else 1.0
             for row in range(64):
                 for c in range(64):
-                    put(mat(k, row, c), r)
+                    put(mat(k, row, c) if (row < C and c < C) else zero, sc)
                 for c in range(PE_COLS):
-                    put(mat(k, row, 64 + _SLOT_IDX[c]) if _SLOT_IDX[c] < 39 else zero, r)
-        for k, rows in ((6, 64), (8, 64), (10, 65)):   # W3, W4, W5
+                    put(mat(k, row, C + slot(c)) if (l in skips and row < C and slot(c) >= 0) else zero, sc)
+        for k, rows in ((6, 64), (8, 64), (10, 65)):   # W3, W4, W5 (row 0 = sdf, rows 1.. = feature)
+            nr = C if rows == 64 else 1 + C
             for row in range(rows):
                 for c in range(64):
-                    put(mat(k, row, c))
+                    put(mat(k, row, c) if (row < nr and c < C) else zero)
         for row in range(65):                          # b5
-            put(offs[11] + row)
+            put(offs[11] + row if row < 1 + C else zero)
         n_pack = len(idx)
         assert n_pack == SDF_PACK_FLOATS
-        for k, c0 in ((0, 39), (2, 103), (4, 103)):    # latent columns [3 x 64 rows][Z]
+        for l, k, c0 in ((0, 0, pe), (1, 2, C + pe), (2, 4, C + pe)):    # latent columns [3 x 64 rows][Z]
+            has = l == 0 or l in skips
             for row in range(64):
                 for c in range(Z):
-                    put(mat(k, row, c0 + c))
+                    put(mat(k, row, c0 + c) if (has and row < C) else zero)
         for k in (1, 3, 5, 7, 9):                      # bias rows b0..b4
             for row in range(64):
-                put(offs[k] + row)
+                put(offs[k] + row if row < C else zero)
         n_lat, n_bias = 3 * 64 * Z, 5 * 64
-        post = torch.tensor([1.0, r, r], device=device).view(1, 3, 1)       # (z @ W_lat^T) * r for the skip layers, as before
+        post = torch.tensor([1.0, r if 1 in skips else 1.0, r if 2 in skips else 1.0], device=device).view(1, 3, 1)    # (z @ W_lat^T) * r for the skip layers
     else:
         for row in range(64):                          # V0: [PE slots 48 | sdf feature 64]
             for c in range(PE_COLS):
-                put(mat(0, row, _SLOT_IDX[c]) if _SLOT_IDX[c] < 39 else zero)
+                put(mat(0, row, slot(c)) if (row < C and slot(c) >= 0) else zero)
             for c in range(64):
-                put(mat(0, row, 39 + Z + c))
+                put(mat(0, row, pe + Z + c) if (row < C and c < Cs) else zero)
         for k, rows in ((2, 64), (4, 64), (6, 3)):
             for row in range(rows):
                 for c in range(64):
-                    put(mat(k, row, c))
+                    put(mat(k, row, c) if ((rows == 3 or row < C) and c < C) else zero)
         for row in range(3):
             put(offs[7] + row)
         put(zero)
@@ -141,10 +164,10 @@ def _plan(kind: str, Z: int, device):
         assert n_pack == RGB_PACK_FLOATS
         for row in range(64):
             for c in range(Z):
-                put(mat(0, row, 39 + c))
+                put(mat(0, row, pe + c) if row < C else zero)
         for k in (1, 3, 5):
             for row in range(64):
-                put(offs[k] + row)
+                put(offs[k] + row if row < C else zero)
         n_lat, n_bias = 64 * Z, 3 * 64
         post = None
     scale = torch.tensor(scl, dtype=torch.float32)
@@ -154,16 +177,26 @@ def _plan(kind: str, Z: int, device):
     return plan
 
 
+def arch_of(kind: str, W: Dict[str, torch.Tensor], Z: int, n_sdf: int = 64):
+    """The architecture tuple _plan() wants, read off the parameter shapes (reference layer construction: model/implicit.py:93-113,199-214)."""
+    C, d_in = W["lin0.weight"].shape
+    if kind == "sdf":
+        pe = d_in - Z
+        skips = tuple(l for l in (1, 2) if W["lin%d.weight" % l].shape[1] == C + d_in)
+        return (C, pe, skips)
+    return (C, d_in - Z - n_sdf, n_sdf)
+
+
 def _names(kind):
     n = 6 if kind == "sdf" else 4
     return [k for l in range(n) for k in ("lin%d.weight" % l, "lin%d.bias" % l)]
 
 
-def gather_params(kind: str, W: Dict[str, torch.Tensor], Z: int) -> torch.Tensor:
+def gather_params(kind: str, W: Dict[str, torch.Tensor], Z: int, arch=None) -> torch.Tensor:
     """[ packed image | latent block | bias rows ] of a network in one gather (differentiable w.r.t. every parameter)."""
     names = _names(kind)
     dev = W[names[0]].device
-    plan = _plan(kind, Z, dev)
+    plan = _plan(kind, Z, dev, arch)
     for n, sh in zip(names, plan["shapes"]):
         assert tuple(W[n].shape) == tuple(sh), (n, tuple(W[n].shape), sh)
     src = torch.cat([W[n].reshape(-1) for n in names] + [W[names[0]].new_zeros(1)])
@@ -171,9 +204,9 @@ def gather_params(kind: str, W: Dict[str, torch.Tensor], Z: int) -> torch.Tensor
     return out * plan["scale"] if plan["scale"] is not None else out
 
 
-def _bias_from(kind: str, g: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+def _bias_from(kind: str, g: torch.Tensor, z: torch.Tensor, arch=None) -> torch.Tensor:
     B, Z = z.shape
-    plan = _plan(kind, Z, g.device)
+    plan = _plan(kind, Z, g.device, arch)
     n_pack, n_lat = plan["n_pack"], plan["n_lat"]
     L = n_lat // (64 * Z)                               # conditioned layers: 3 (sdf) / 1 (rgb)
     lat = g[n_pack:n_pack + n_lat].view(L * 64, Z)
@@ -185,30 +218,36 @@ def _bias_from(kind: str, g: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
     return torch.nn.functional.pad(zw, (0, 0, 0, NL - L)) + bias                 # = bias + z-term (fp32 addition commutes)
 
 
-def sdf_cbias(W: Dict[str, torch.Tensor], z: torch.Tensor, gathered: torch.Tensor = None) -> torch.Tensor:
+def sdf_cbias(W: Dict[str, torch.Tensor], z: torch.Tensor, gathered: torch.Tensor = None, arch=None) -> torch.Tensor:
     """Per-image biases c_l = b_l + W_l[:, latent] @ z (skip layers scaled by 1/sqrt2) -> [B, 5, 64]."""
-    g = gathered if gathered is not None else gather_params("sdf", W, z.shape[1])
-    return _bias_from("sdf", g, z)
+    if arch is None and W is not None:
+        arch = arch_of("sdf", W, z.shape[1])
+    g = gathered if gathered is not None else gather_params("sdf", W, z.shape[1], arch)
+    return _bias_from("sdf", g, z, arch)
 
 
 def pack_sdf(W: Dict[str, torch.Tensor], z: torch.Tensor, return_gathered: bool = False):
     """SDFNetwork parameters (state-dict names lin{l}.weight/.bias) + latent z [B, Z]
-    -> (w_pack [SDF_PACK_FLOATS], cbias [B, 5, 64])."""
-    g = gather_params("sdf", W, z.shape[1])
-    out = (g[:SDF_PACK_FLOATS], _bias_from("sdf", g, z))
+    -> (w_pack [SDF_PACK_FLOATS], cbias [B, 5, 64]).  The architecture (channels, octaves, skip inputs) is read off the shapes."""
+    arch = arch_of("sdf", W, z.shape[1])
+    g = gather_params("sdf", W, z.shape[1], arch)
+    out = (g[:SDF_PACK_FLOATS], _bias_from("sdf", g, z, arch))
     return out + (g,) if return_gathered else out
 
 
-def rgb_dbias(W: Dict[str, torch.Tensor], z: torch.Tensor, gathered: torch.Tensor = None) -> torch.Tensor:
-    g = gathered if gathered is not None else gather_params("rgb", W, z.shape[1])
-    return _bias_from("rgb", g, z)
+def rgb_dbias(W: Dict[str, torch.Tensor], z: torch.Tensor, gathered: torch.Tensor = None, arch=None, n_sdf: int = 64) -> torch.Tensor:
+    if arch is None and W is not None:
+        arch = arch_of("rgb", W, z.shape[1], n_sdf)
+    g = gathered if gathered is not None else gather_params("rgb", W, z.shape[1], arch)
+    return _bias_from("rgb", g, z, arch)
 
 
-def pack_rgb(W: Dict[str, torch.Tensor], z: torch.Tensor, return_gathered: bool = False):
+def pack_rgb(W: Dict[str, torch.Tensor], z: torch.Tensor, return_gathered: bool = False, n_sdf: int = 64):
     """RGBNetwork parameters + latent z_rgb [B, Z] -> (v_pack [RGB_PACK_FLOATS], dbias [B, 3, 64]).
     lin0 input order is [PE(39), z_rgb(Z), sdf_feature(64)] (model/implicit.py:231)."""
-    g = gather_params("rgb", W, z.shape[1])
-    out = (g[:RGB_PACK_FLOATS], _bias_from("rgb", g, z))
+    arch = arch_of("rgb", W, z.shape[1], n_sdf)
+    g = gather_params("rgb", W, z.shape[1], arch)
+    out = (g[:RGB_PACK_FLOATS], _bias_from("rgb", g, z, arch))
     return out + (g,) if return_gathered else out
 
 

@@ -167,13 +167,13 @@ def test_config0_pretrain_plumbing_on_cpu():
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference only exists in the build container")
 def test_golden_recipe_reproduces_committed_fixtures(tmp_path):
     """tests/golden/make_golden.py imports the reference's OWN modules (it asserts their origin), checks the oracle
-    against them and regenerates G1-G10, G12 and G14: the arrays must equal the committed fixtures bit for bit."""
+    against them and regenerates G1-G10, G12, G14 and G15a/b: the arrays must equal the committed fixtures bit for bit."""
     script = os.path.join(GOLDEN_DIR, "make_golden.py")
     env = dict(os.environ, GOLDEN_OUT=str(tmp_path))
     r = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     made = sorted(p.name for p in tmp_path.glob("*.npz"))
-    assert len(made) == 12, made
+    assert len(made) == 14, made
     for name in made:
         a, b = np.load(tmp_path / name), np.load(os.path.join(GOLDEN_DIR, name))
         assert set(a.files) == set(b.files), name
@@ -219,3 +219,60 @@ def test_g14_weight_norm(golden):
     for n, got in zip(names, grads):
         want = torch.tensor(g["grad." + n])
         assert (got - want).abs().max() <= 1e-4 * max(1.0, float(want.abs().max())), n
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g15_arch_variants(golden, tag):
+    """Two other members of the reference's config family (n_channels, pos_enc, skip_connection, proj_latent_dim; model/implicit.py:89-113,
+    197-214), captured from the reference's own networks: the oracle, configured through Cfg, reproduces values and gradients."""
+    g = golden("g15%s_arch_variant" % tag)
+    cs, ls, zs, cr, lr, zr, s1, s2 = (int(x) for x in g["arch"])
+    cfg = R.Cfg(hidden_sdf=cs, posenc_sdf=ls, skip_in=tuple(l for l, on in ((1, s1), (2, s2)) if on), latent_sdf=zs, hidden_rgb=cr, posenc_rgb=lr,
+                latent_rgb=zr)
+    Ws = {k: v.requires_grad_(True) for k, v in _W(g, "w.sdf.").items()}
+    Wr = {k: v.requires_grad_(True) for k, v in _W(g, "w.rgb.").items()}
+    pts, z_s, z_r = T(g["pts"]), T(g["z_sdf"]), T(g["z_rgb"])
+    B, N = z_s.shape[0], pts.shape[0] // z_s.shape[0]
+    s, f, gr = R.sdf_conditional(cfg, Ws, B, pts.clone(), z_s, compute_grad=True)
+    c = R.rgb_mlp(cfg, Wr, pts, z_r.unsqueeze(1).repeat(1, N, 1).view(B * N, -1), f)
+    assert f.shape[1] == cs
+    for got, k in ((s, "sdf"), (f, "feat"), (gr, "grad"), (c, "rgb")):
+        assert torch.allclose(got.detach(), T(g[k]), atol=1e-5 if k == "grad" else 1e-6), k
+    L = (s * T(g["cot.sdf"])).sum() + (f * T(g["cot.feat"])).sum() + (gr * T(g["cot.grad"])).sum() + (c * T(g["cot.rgb"])).sum()
+    L.backward()
+    for prefix, W in (("sdf.", Ws), ("rgb.", Wr)):
+        for k, v in W.items():
+            want = T(g["grad." + prefix + k])
+            assert float((v.grad - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max())), prefix + k
+
+
+def test_packing_embeds_smaller_architectures_with_exact_zeros():
+    """packing.py maps a network with fewer channels / octaves / skip inputs into the kernels' 64-channel image: every parameter appears
+    exactly once (possibly scaled by 1 / sqrt 2), everything else is an exact zero, and the gather is differentiable back to the parameters."""
+    from shapeclipper_amd import packing
+    torch.manual_seed(3)
+    C, L, Z, skips = 40, 3, 24, (2,)
+    pe, d0 = 3 + 6 * L, 3 + 6 * L + Z
+    shapes = {"lin0": (C, d0), "lin1": (C, C), "lin2": (C, C + d0), "lin3": (C, C), "lin4": (C, C), "lin5": (1 + C, C)}
+    W = {}
+    for n, sh in shapes.items():
+        W[n + ".weight"] = (torch.rand(sh) + 0.5).requires_grad_(True)          # strictly positive: zeros in the image are padding
+        W[n + ".bias"] = (torch.rand(sh[0]) + 0.5).requires_grad_(True)
+    assert packing.arch_of("sdf", W, Z) == (C, pe, skips)
+    z = torch.randn(2, Z)
+    w_pack, cbias = packing.pack_sdf(W, z)
+    assert w_pack.shape == (packing.SDF_PACK_FLOATS,) and cbias.shape == (2, 5, 64)
+    n_params = sum(W[n + ".weight"].numel() for n in shapes) + W["lin5.bias"].numel() - (W["lin0.weight"].shape[0] + W["lin2.weight"].shape[0]) * Z
+    assert int((w_pack != 0).sum()) == n_params                    # latent columns and b0..b4 live in cbias, not in the image
+    assert float(cbias[:, :, C:].abs().max()) == 0.0
+    r = 2 ** -0.5
+    got = w_pack[packing.SDF_OFF["W3"]:packing.SDF_OFF["W4"]].view(64, 64)
+    assert torch.equal(got[:C, :C], W["lin3.weight"]) and float(got[C:].abs().max()) == 0 and float(got[:, C:].abs().max()) == 0
+    w2 = w_pack[packing.SDF_OFF["W2"]:packing.SDF_OFF["W3"]].view(64, 112)
+    assert torch.equal(w2[:C, :C], W["lin2.weight"][:, :C] * r)    # skip layer: [h, input] / sqrt 2
+    w1 = w_pack[packing.SDF_OFF["W1"]:packing.SDF_OFF["W2"]].view(64, 112)
+    assert torch.equal(w1[:C, :C], W["lin1.weight"]) and float(w1[:, 64:].abs().max()) == 0      # no skip input at layer 1: unscaled, no PE columns
+    want_c2 = (z @ W["lin2.weight"][:, C + pe:].t()) * r + W["lin2.bias"]
+    assert torch.allclose(cbias[:, 2, :C], want_c2, atol=1e-5) and torch.allclose(cbias[:, 1, :C], W["lin1.bias"].expand(2, C))
+    (w_pack.sum() + cbias.sum()).backward()
+    assert all(t.grad is not None and bool((t.grad != 0).all()) for t in W.values())
