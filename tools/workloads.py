@@ -94,7 +94,11 @@ def chamfer(B, N=100000, with_cpu=True, with_reference_gpu=False):
                equivalent_tpairs_per_s=round(pairs / (ms * 1e-3) / 1e12, 2), algorithmic_bytes=B * 2 * N * (12 + 8),
                all_pairs=dict(ms=round(bms, 3), ms_best=round(bbest, 3), algorithmic_flop=CHAMFER_FLOP_PER_PAIR * pairs,
                               achieved=round(tf, 2), peak=PEAK_FP32, unit="TFLOP/s", bound="fp32 VALU (4 packed vector instructions per pair: the issue floor of the reference's expression)",
-                              frac=round(tf / PEAK_FP32, 4), tpairs_per_s=round(pairs / (bms * 1e-3) / 1e12, 3)))
+                              frac=round(tf / PEAK_FP32, 4), tpairs_per_s=round(pairs / (bms * 1e-3) / 1e12, 3),
+                              ceiling_frac=round(8.0 / 15.0, 4), frac_of_ceiling=round(tf / PEAK_FP32 / (8.0 / 15.0), 4),
+                              ceiling="the reference's expression costs 7 packed fp32 instructions + 1 v_min3 per TWO pairs = 7.5 issue slots per pair "
+                                      "for 8 algorithmic FLOP, against 2 FLOP per slot at the FMA peak: 8 / 15 of 157.3 TFLOP/s is the most any all-pairs "
+                                      "kernel with these bits can reach"))
     # the evaluation's clouds are SURFACES (100,000 samples of the predicted iso-surface against 100,000 ground-truth surface points,
     # utils/eval_3D.py:205), not volumes, and they do not coincide: the same search on two bumpy spheres a mean distance 0.047 apart
     # (tools/perf_chamfer_surface.py sweeps the distance: the grid search wins up to ~0.1, costs up to 1.6x all pairs beyond at B=1)
@@ -163,7 +167,9 @@ def clip_vit(B=32, with_cpu=True, model="ViT-B/32"):
     tf = B * gflop * 1e9 / (ms * 1e-3) / 1e12
     out = dict(workload="CLIP %s image tower forward, B=%d, 224x224" % (model, B), ms=round(ms, 3), ms_best=round(best, 3), dtype=tower.dtype16,
                algorithmic_flop=B * gflop * 1e9, achieved=round(tf, 1), peak=PEAK_BF16, unit="TFLOP/s", bound="fp16 MFMA (dense peak = bf16's)",
-               frac=round(tf / PEAK_BF16, 4), images_per_s=round(B / (ms * 1e-3), 1))
+               frac=round(tf / PEAK_BF16, 4), images_per_s=round(B / (ms * 1e-3), 1),
+               parity="unpinned against the reference (openai/CLIP is un-vendored, no weights offline: SURVEY 8c); checked against transformers' "
+                      "fp32 architecture with seeded random weights (tests/test_gpu_clip.py)")
     if with_cpu and model != "ViT-B/32":
         with_cpu = False
     if with_cpu:
@@ -302,7 +308,9 @@ def marching_cubes_100(B=32):
                 ms=round(ms, 3), ms_best=round(best, 3), algorithmic_bytes=nbytes, achieved=round(nbytes / (ms * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBPS,
                 unit="GB/s", bound="hbm / latency (count per 1,024-cube block + cumsum over blocks + emit; one host read of the per-image triangle counts)",
                 frac=round(nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), mcubes_per_s=round(B * (S - 1) ** 3 / (ms * 1e-3) / 1e6, 1),
-                with_sampling_ms=round(ms_s, 3), triangles_per_image=int(tris.shape[0] // B))
+                with_sampling_ms=round(ms_s, 3), triangles_per_image=int(tris.shape[0] // B),
+                parity="triangulation unpinned against PyMCubes / trimesh (absent: SURVEY 8c); vertex set and triangles checked against "
+                       "oracle/isosurface_ref.py (tests/test_gpu_isosurface.py)")
 
 
 def resnet_conv3x3(with_cpu=True):
