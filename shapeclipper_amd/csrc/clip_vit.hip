@@ -1119,6 +1119,25 @@ static int launch_gemm(int epi, const bf16_t* A, const bf16_t* Wt, const float* 
             if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return (int)hipGetLastError();
             if (dev >= 0 && dev < 64) cu_cache[dev] = cus;
         }
+        // A ragged last row tile that opens another ROUND of the one-workgroup-per-CU grid goes to gemm_thin_kernel instead (ViT-L/14 at batch
+        // 32: 8,224 rows = 32 row tiles + 32 rows; fc1 = 33 x 16 = 528 tiles = three rounds of 256, 32 x 16 = 512 = exactly two)
+        const int rem8 = M % 256, ntn8 = N / 256;
+        const long long t_main = (long long)(M / 256) * ntn8, gridw = (cus / 8) * 8;
+        if (rem8 != 0 && rem8 <= 64 && t_main > 0 && gridw > 0 && (N % 32) == 0 && (K % 256) == 0 &&
+            (t256 + gridw - 1) / gridw > (t_main + gridw - 1) / gridw) {
+            const int rc8 = g8::launch_gemm8p<H16>(epi, A, Wt, bias, out, M - rem8, N, K, cus, st);
+            if (rc8) return rc8;
+            const size_t esz = (epi == EPI_F32 || epi == EPI_RESID) ? 4 : 2;
+            const bf16_t* A2 = A + (size_t)(M - rem8) * K;
+            void* out2 = (char*)out + (size_t)(M - rem8) * N * esz;
+            switch (epi) {
+                case EPI_F32: hipLaunchKernelGGL((gemm_thin_kernel<EPI_F32, H16>), dim3(N / 32, (rem8 + 31) / 32), dim3(64 * THIN_NW), 0, st, A2, Wt, bias, out2, rem8, N, K); break;
+                case EPI_RESID: hipLaunchKernelGGL((gemm_thin_kernel<EPI_RESID, H16>), dim3(N / 32, (rem8 + 31) / 32), dim3(64 * THIN_NW), 0, st, A2, Wt, bias, out2, rem8, N, K); break;
+                case EPI_GELU_BF16: hipLaunchKernelGGL((gemm_thin_kernel<EPI_GELU_BF16, H16>), dim3(N / 32, (rem8 + 31) / 32), dim3(64 * THIN_NW), 0, st, A2, Wt, bias, out2, rem8, N, K); break;
+                default: hipLaunchKernelGGL((gemm_thin_kernel<EPI_BF16, H16>), dim3(N / 32, (rem8 + 31) / 32), dim3(64 * THIN_NW), 0, st, A2, Wt, bias, out2, rem8, N, K); break;
+            }
+            return (int)hipGetLastError();
+        }
         return g8::launch_gemm8p<H16>(epi, A, Wt, bias, out, M, N, K, cus, st);
     }
     // ... and its 256 x 192 form for the fp32-output GEMMs with N = 768 (proj / fc2 of ViT-B/32 at 12,800 tokens: 150 tiles of 256 x 256 on 256
