@@ -804,11 +804,11 @@ __global__ __launch_bounds__(64 * ATT_NW) void attention_kernel(const bf16_t* __
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    // B operand: keys kc + 16j + 4h + {0..3} and {8..11} of head-dim column 32t + n
+                    // A operand: keys kc + 16j + 4h + {0..3} and {8..11} of head-dim row 32t + n (V^T); B operand: P of query n
                     const bf16_t* vp = Vt + (32 * t + n) * ldv + kc + 16 * j + 4 * h;
                     const uint2 lo = *reinterpret_cast<const uint2*>(vp), hi = *reinterpret_cast<const uint2*>(vp + 8);
                     const uint4 pk = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                    O[t] = mfma16<H16>(pf[j], __builtin_bit_cast(bf16x8, pk), O[t]);
+                    O[t] = mfma16<H16>(__builtin_bit_cast(bf16x8, pk), pf[j], O[t]);      // O^T[dim][query]: a lane holds ITS query's dims
                 }
         };
         for (int kc = 0; kc < Tfull; kc += 32) {
@@ -832,14 +832,19 @@ __global__ __launch_bounds__(64 * ATT_NW) void attention_kernel(const bf16_t* __
             accumulate(Tfull, pr);
         }
         l += __shfl_xor(l, 32);
-        const float inv = 1.f / l;                            // of query n (this lane's column of S^T); O's rows are queries (r, h)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ql = (r & 3) + 8 * (r >> 2) + 4 * h, qq = qb * 32 + ql;
-            const float iq = __shfl(inv, ql);
+        const float inv = 1.f / l;                            // of query n: this lane's column of S^T AND of O^T
+        // O^T[t][r] = dim 32 t + (r & 3) + 8 (r >> 2) + 4 h of query n: four consecutive dims per r >> 2 -> 8-byte stores (the 2-byte
+        // stores of the [query][dim] form cost 4 of the kernel's 35 us at T = 257)
+        if (q < T) {
+            bf16_t* orow = out + ((size_t)b * T + q) * D + hd * 64 + 4 * h;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
-                if (qq < T) out[((size_t)b * T + qq) * D + hd * 64 + 32 * t + n] = cvt16<H16>(O[t][r] * iq);
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const uint32_t lo = (uint32_t)cvt16<H16>(O[t][4 * r4] * inv) | ((uint32_t)cvt16<H16>(O[t][4 * r4 + 1] * inv) << 16);
+                    const uint32_t hi = (uint32_t)cvt16<H16>(O[t][4 * r4 + 2] * inv) | ((uint32_t)cvt16<H16>(O[t][4 * r4 + 3] * inv) << 16);
+                    *reinterpret_cast<uint2*>(orow + 32 * t + 8 * r4) = make_uint2(lo, hi);
+                }
         }
     }
     if (ksplit) {
@@ -894,18 +899,19 @@ __global__ __launch_bounds__(64 * ATT_NW) void attention_kernel(const bf16_t* __
                 for (int t = 0; t < 2; ++t) {
                     const bf16_t* vp = Vt + (32 * t + n) * ldv + kc + 16 * j + 4 * h;
                     const uint2 lo = *reinterpret_cast<const uint2*>(vp), hi = *reinterpret_cast<const uint2*>(vp + 8);
-                    O[t] = mfma16<H16>(pf[j], __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y)), O[t]);
+                    O[t] = mfma16<H16>(__builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y)), pf[j], O[t]);
                 }
         }
         l += __shfl_xor(l, 32);
         __syncthreads();                                      // every wave is through with K and V^T: the LDS takes the partial results
         float* part = reinterpret_cast<float*>(Vt);           // [wave][query 0..31][66] = raw maximum, sum, O[64]: 67.6 KB <= V^T + K
-        if (h == 0) { part[(wave * 32 + n) * 66] = smax; part[(wave * 32 + n) * 66 + 1] = l; }
+        if (q < T) {                                          // only the left-over queries (ONE at T = 257) leave anything
+            float* pq = part + (wave * 32 + n) * 66;
+            if (h == 0) { pq[0] = smax; pq[1] = l; }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ql = (r & 3) + 8 * (r >> 2) + 4 * h;
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) part[(wave * 32 + ql) * 66 + 2 + 32 * t + n] = O[t][r];
+                for (int r = 0; r < 16; ++r) pq[2 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h] = O[t][r];
         }
         __syncthreads();
         for (int idx = threadIdx.x; idx < 32 * 64; idx += 64 * ATT_NW) {
