@@ -1013,16 +1013,20 @@ __global__ __launch_bounds__(128) void attention_small_kernel(const bf16_t* __re
                 const bf16_t* vp = Vt + (32 * t + n) * ldv + 32 * c + 16 * j + 4 * h;
                 const uint2 lo = *reinterpret_cast<const uint2*>(vp), hi = *reinterpret_cast<const uint2*>(vp + 8);
                 const uint4 pk = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                O[t] = mfma16<H16>(pf, __builtin_bit_cast(bf16x8, pk), O[t]);
+                O[t] = mfma16<H16>(__builtin_bit_cast(bf16x8, pk), pf, O[t]);          // O^T[dim][query], as in attention_kernel
             }
         }
+    if (q < T) {                                        // four consecutive dims per r >> 2: 8-byte stores
+        bf16_t* orow = out + ((size_t)b * T + q) * D + hd * 64 + 4 * h;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qq = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (qq < T) out[((size_t)b * T + qq) * D + hd * 64 + 32 * t + n] = cvt16<H16>(O[t][r]);
-        }
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const uint32_t lo = (uint32_t)cvt16<H16>(O[t][4 * r4]) | ((uint32_t)cvt16<H16>(O[t][4 * r4 + 1]) << 16);
+                const uint32_t hi = (uint32_t)cvt16<H16>(O[t][4 * r4 + 2]) | ((uint32_t)cvt16<H16>(O[t][4 * r4 + 3]) << 16);
+                *reinterpret_cast<uint2*>(orow + 32 * t + 8 * r4) = make_uint2(lo, hi);
+            }
+    }
 }
 
 template <bool H16>
