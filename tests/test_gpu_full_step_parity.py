@@ -1,4 +1,5 @@
-"""Numeric parity of a FULL training step's graph wiring at BASELINE config[1] (bs16, 512 rays x 64 samples, 2 renders + eikonal).
+"""Numeric parity of a FULL training step's graph wiring at BASELINE config[1] (bs16) and at the headline batch (bs32): 512 rays x 64 samples,
+2 renders + eikonal.
 
 The reference's model/graph.py cannot be imported (torchvision), so the step is pinned at the level SURVEY 8c prescribes:
 the product's own encoder / estimator outputs (both latent projections, the colour code of the neighbour view, poses, intrinsics,
@@ -36,14 +37,14 @@ pytestmark = pytest.mark.gpu
 os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 
 
-def test_full_step_losses_and_gradients_bs16():
+@pytest.mark.parametrize("B", [16, 32], ids=["bs16", "bs32"])
+def test_full_step_losses_and_gradients(B):
     from oracle import reference_ops as R
     from shapeclipper_amd import synthetic
     from shapeclipper_amd.model.graph import Graph
     from shapeclipper_amd.utils import options, util
     from shapeclipper_amd.utils.util import EasyDict as edict
 
-    B = 16
     opt = options.set(options.parse_arguments(["--yaml=options/pix3d/config.yaml", "--name=pytest_fullstep", "--output_root=/tmp/sc_pytest",
                                                "--batch_size=%d" % B, "--tb!", "--arch.enc_pretrained!"]
                                               + os.environ.get("SC_FULLSTEP_OPTS", "").split()), verbose=False)
@@ -122,7 +123,7 @@ def test_full_step_losses_and_gradients_bs16():
         worst[k] = abs(got_loss[k] - ref_loss[k]) / max(abs(ref_loss[k]), 1e-12)
     ref_total = sum(weights[k] * ref_loss[k] for k in ref_loss)
     worst["all"] = abs(float(total) - ref_total) / abs(ref_total)
-    print("bs16 step, loss values product vs oracle (relative):", {k: "%.1e" % v for k, v in worst.items()})
+    print("bs%d step, loss values" % B, " product vs oracle (relative):", {k: "%.1e" % v for k, v in worst.items()})
     print("   values:", {k: "%.6f" % v for k, v in ref_loss.items()})
     for k, v in worst.items():
         assert v < (2e-4 if "normal" in k else 2e-5), (k, v, got_loss.get(k), ref_loss.get(k))
@@ -146,6 +147,6 @@ def test_full_step_losses_and_gradients_bs16():
             ref = W[k].grad
             gerr["%s.%s" % ("sdf" if net is g.sdf_network else "rgb", k)] = float((p.grad.cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-12))
     gerr["beta"] = float((g.renderer.density.beta.grad.cpu().reshape(()) - beta.grad).abs() / beta.grad.abs().clamp_min(1e-12))
-    print("bs16 step, gradients of loss.all product vs oracle (max abs / max |ref|):", {k: "%.1e" % v for k, v in gerr.items()})
+    print("bs%d step," % B, "gradients of loss.all product vs oracle (max abs / max |ref|):", {k: "%.1e" % v for k, v in gerr.items()})
     for k, v in gerr.items():
         assert v < (1e-3 if k.startswith("pose") else 2e-4), (k, v)

@@ -1,6 +1,6 @@
 """Chamfer grid search vs all pairs on SURFACE clouds (what the evaluation compares: 100,000 samples of the predicted iso-surface against
 100,000 ground-truth surface points, batch 1), as a function of how far apart the two surfaces are.
-    python tools/perf_chamfer_surface.py [B]"""
+    python tools/perf_chamfer_surface.py [B [delta]]      (delta: only that row, e.g. under rocprofv3 --kernel-trace --stats)"""
 import os
 import sys
 import time
@@ -36,8 +36,11 @@ def run(x1, x2, mode, iters=5):
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    only = float(sys.argv[2]) if len(sys.argv) > 2 else None
     gen = torch.Generator(device="cuda").manual_seed(0)
     for delta, bumps in ((0.0, 0.0), (0.005, 0.0), (0.02, 0.05), (0.05, 0.1), (0.1, 0.1), (0.2, 0.2), (0.4, 0.3)):
+        if only is not None and abs(delta - only) > 1e-9:
+            continue
         a, b = sphere(B, 100000, 0.4, gen), sphere(B, 100000, 0.4 + delta, gen, bumps)
         tg, og = run(a, b, "grid")
         tb, ob = run(a, b, "brute")
