@@ -42,6 +42,9 @@ constexpr int CG_DENSE = 8;         // targets per occupied cell from which a cl
 constexpr int CG_WAVE_RMAX = 6;     // rings of the wave walk (its candidates cost ~1/50 of the thread walk's per query)
 constexpr int CG_WAVE_REMPTY = 4;   // rings without any candidate before the wave gives up
 constexpr int CG_WAVE_BUDGET = 16384;   // candidates per WAVE (64 queries of one cell) before its open queries are handed to the scan
+constexpr int CG_NEAR = 3;          // wave walk: a tile of queries with no target within this many cells of it (and a query this many cells outside
+                                    // the targets' box) goes straight to the scan -- see cg_items_kernel
+constexpr int CG_FAR_ITEM = 1 << 30;    // flag on an item's chunk number: do not walk
 
 struct GridMeta {                  // one per batch element
     float lo[3], h[3], inv_h[3];
@@ -317,17 +320,38 @@ __global__ __launch_bounds__(256) void cg_query_kernel(int n, const float* __res
 // ground truth, mean distance 0.05-0.1) the grid search took 6-9 ms where all pairs take 2.9.  Same acceptance rule, same stopping
 // rule per lane; the wave stops when all its lanes have.
 __global__ __launch_bounds__(256) void cg_items_kernel(const GridMeta* __restrict__ meta, int cap, const int* __restrict__ qstart_all,
-                                                       int* __restrict__ items_all, int* __restrict__ item_count, int max_items) {
+                                                       const int* __restrict__ tstart_all, int near, int* __restrict__ items_all,
+                                                       int* __restrict__ item_count, int max_items) {
     const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
     const GridMeta& g = meta[b];
-    if (!g.dense || c >= g.g[0] * g.g[1] * g.g[2]) return;
+    const int tgx = (g.g[0] + 1) >> 1, tgy = (g.g[1] + 1) >> 1, tgz = (g.g[2] + 1) >> 1;
+    if (!g.dense || c >= tgx * tgy * tgz) return;
     const int* qs = qstart_all + (size_t)b * (cap + 1);
     const int cnt = qs[c + 1] - qs[c];
     if (cnt <= 0) return;
+    // Is the walk worth starting?  A target that is k cells away is confirmed around ring k + 1, and every ring costs the candidates of its
+    // whole shell: with nothing within `near` cells of the tile the walk would evaluate thousands of candidates per wave and still hand most
+    // of its queries to the scan (two surfaces 0.15-0.25 apart: 0.36-0.51 ms of walk per direction in front of a scan of nearly every query,
+    // profiles/r04_chamfer_regimes.txt).  Those tiles skip the walk.  One thread per tile: <= (2 + 2 near)^2 rows, two `start` entries each.
+    int flag = 0;
+    if (near > 0) {
+        const int* ts = tstart_all + (size_t)b * (cap + 1);
+        const int lx = 2 * (c % tgx), ly = 2 * ((c / tgx) % tgy), lz = 2 * (c / (tgx * tgy));
+        const int x0 = max(lx - near, 0), x1 = min(lx + 1 + near, g.g[0] - 1);
+        const int y0 = max(ly - near, 0), y1 = min(ly + 1 + near, g.g[1] - 1);
+        const int z0 = max(lz - near, 0), z1 = min(lz + 1 + near, g.g[2] - 1);
+        int found = 0;
+        for (int z = z0; z <= z1 && !found; ++z)
+            for (int y = y0; y <= y1; ++y) {
+                const int row = (z * g.g[1] + y) * g.g[0];
+                found |= ts[row + x1 + 1] - ts[row + x0];
+            }
+        flag = found ? 0 : CG_FAR_ITEM;
+    }
     const int chunks = (cnt + 63) >> 6;
     const int at = atomicAdd(&item_count[b], chunks);
     int* items = items_all + (size_t)b * max_items * 2;
-    for (int k = 0; k < chunks; ++k) { items[2 * (at + k)] = c; items[2 * (at + k) + 1] = k; }
+    for (int k = 0; k < chunks; ++k) { items[2 * (at + k)] = c; items[2 * (at + k) + 1] = k | flag; }
 }
 
 __global__ __launch_bounds__(256) void cg_query_wave_kernel(int n, int m, const GridMeta* __restrict__ meta, int cap,
@@ -336,7 +360,7 @@ __global__ __launch_bounds__(256) void cg_query_wave_kernel(int n, int m, const 
                                                             const int* __restrict__ items_all, const int* __restrict__ item_count,
                                                             int max_items, float* __restrict__ dist, int* __restrict__ idx,
                                                             int* __restrict__ todo, int* __restrict__ todo_count,
-                                                            unsigned long long* __restrict__ keys) {
+                                                            unsigned long long* __restrict__ keys, int near) {
 #define CG_TEST(t)                                                                              \
     {                                                                                           \
         const float d = dist2((t).x, (t).y, (t).z, q[0], q[1], q[2]);                           \
@@ -353,7 +377,9 @@ __global__ __launch_bounds__(256) void cg_query_wave_kernel(int n, int m, const 
     const float4* sorted = sorted_all + (size_t)b * m;
     const int* qstart = qstart_all + (size_t)b * (cap + 1);
     const int cell = __builtin_amdgcn_readfirstlane(items_all[((size_t)b * max_items + item) * 2]);      // a 2 x 2 x 2 TILE of cells
-    const int chunk = __builtin_amdgcn_readfirstlane(items_all[((size_t)b * max_items + item) * 2 + 1]);
+    const int chunk_flag = __builtin_amdgcn_readfirstlane(items_all[((size_t)b * max_items + item) * 2 + 1]);
+    const int chunk = chunk_flag & ~CG_FAR_ITEM;
+    const bool far_tile = (chunk_flag & CG_FAR_ITEM) != 0;      // nothing within `near` cells of the tile: straight to the scan (cg_items_kernel)
     const int q0 = qstart[cell] + chunk * 64, q1 = qstart[cell + 1];
     const bool live = q0 + lane < q1;
     const float4 qv = qsorted_all[(size_t)b * n + (live ? q0 + lane : q0)];
@@ -365,10 +391,13 @@ __global__ __launch_bounds__(256) void cg_query_wave_kernel(int n, int m, const 
     lo[1] = 2 * ((cell / tgx) % tgy);
     lo[2] = 2 * (cell / (tgx * tgy));
     for (int a = 0; a < 3; ++a) hi[a] = min(lo[a] + 1, g.g[a] - 1);
-    // (no "outside the bounding box" shortcut here: a wave's candidates are cheap, and a cloud that encloses the other one -- every query
-    // of one direction outside the other's box -- is the common case at evaluation)
     const bool skip = !(g.valid && fabsf(q[0]) < 1.0e15f && fabsf(q[1]) < 1.0e15f && fabsf(q[2]) < 1.0e15f);
-    bool done = false, hopeless = false;
+    bool done = false, hopeless = far_tile;
+    // a query more than `near` cells outside the targets' box sits in a boundary tile it does not belong to (the binning clamps): its
+    // nearest target is at least that far away, the same situation as a far tile
+    if (near > 0)
+        for (int a = 0; a < 3; ++a)
+            hopeless |= fmaxf(g.lo[a] - q[a], q[a] - (g.lo[a] + (float)g.g[a] * g.h[a])) > (float)near * g.h[a];
     float best = __builtin_inff();
     int bidx = INT_MAX, seen = 0;
     const float hinv = fmaxf(g.inv_h[0], fmaxf(g.inv_h[1], g.inv_h[2]));       // 1 / smallest cell side
@@ -436,14 +465,23 @@ __global__ __launch_bounds__(256) void cg_query_wave_kernel(int n, int m, const 
             hopeless |= (float)r + (sqrtf(best) - safe) * hinv > (float)CG_WAVE_RMAX;
         if (r >= CG_WAVE_REMPTY && seen == 0) break;                    // empty rings: the scan is the cheaper way (uniform)
     }
-    if (!live) continue;
-    if (done && !skip) {
+    const bool answered = done && !skip;
+    if (live && answered) {
         dist[(size_t)b * n + j] = best;
         idx[(size_t)b * n + j] = bidx;
-    } else {
-        const int pos = atomicAdd(&todo_count[b], 1);
-        todo[(size_t)b * n + pos] = j;
-        keys[(size_t)b * n + pos] = ~0ull;
+    }
+    // the others go on the scan's list: one atomic per wave (a far tile lists all 64 of its queries)
+    const unsigned long long listed = __ballot(live && !answered);
+    if (listed) {
+        const int leader = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(listed));
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&todo_count[b], __builtin_popcountll(listed));
+        base = __builtin_amdgcn_readlane(base, leader);
+        if (live && !answered) {
+            const int pos = base + __builtin_popcountll(listed & ((1ull << lane) - 1ull));
+            todo[(size_t)b * n + pos] = j;
+            keys[(size_t)b * n + pos] = ~0ull;
+        }
     }
     }
 #undef CG_TEST
@@ -581,12 +619,13 @@ int cg_one_direction(const float* qry, int n, const float* tgt, int m, int b, fl
                            (int)c.nblk, ws + c.occupied, 0, 0);
         hipLaunchKernelGGL(cg_scatter_kernel, dim3((n + 255) / 256, b), dim3(256), 0, stream, n, qry, cap, ws + c.qcell_of, ws + c.qcounts,
                            ws + c.qcursor, reinterpret_cast<float4*>(ws + c.qsorted), meta);
-        hipLaunchKernelGGL(cg_items_kernel, dim3((cap + 255) / 256, b), dim3(256), 0, stream, meta, cap, ws + c.qcounts, ws + c.items,
-                           ws + c.item_count, (int)c.max_items);
+        static const int near = [] { const char* e = getenv("SC_CHAMFER_GRID_NEAR"); return e ? atoi(e) : CG_NEAR; }();      // tuning override; 0 = always walk
+        hipLaunchKernelGGL(cg_items_kernel, dim3((cap + 255) / 256, b), dim3(256), 0, stream, meta, cap, ws + c.qcounts, ws + c.counts, near,
+                           ws + c.items, ws + c.item_count, (int)c.max_items);
         hipLaunchKernelGGL(cg_query_wave_kernel, dim3((unsigned)((c.max_items + 3) / 4 < 4096 ? (c.max_items + 3) / 4 : 4096), b), dim3(256), 0, stream, n, m, meta, cap, ws + c.counts,
                            reinterpret_cast<const float4*>(ws + c.sorted), ws + c.qcounts, reinterpret_cast<const float4*>(ws + c.qsorted),
                            ws + c.items, ws + c.item_count, (int)c.max_items, dist, idx, ws + c.todo, ws + c.todo_count,
-                           reinterpret_cast<unsigned long long*>(ws + c.keys));
+                           reinterpret_cast<unsigned long long*>(ws + c.keys), near);
     }
     hipLaunchKernelGGL(cg_query_kernel, dim3((n + 255) / 256, b), dim3(256), 0, stream, n, qry, m, meta, cap, ws + c.counts,
                        reinterpret_cast<const float4*>(ws + c.sorted), dist, idx, ws + c.todo, ws + c.todo_count,
