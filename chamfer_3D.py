@@ -24,6 +24,7 @@ from shapeclipper_amd import _lib
 
 SEARCH = os.environ.get("SHAPECLIPPER_CHAMFER_SEARCH", "grid")
 GRID_MIN_POINTS = 2048
+NSPLIT = int(os.environ.get("SHAPECLIPPER_CHAMFER_NSPLIT", "0"))      # all pairs: target slices per cloud (0: chosen by the library)
 
 
 def _dims(xyz1, xyz2):
@@ -67,14 +68,13 @@ def _forward(lib, b, n, m, xyz1, xyz2, dist1, dist2, idx1, idx2):
                                              _lib.stream())
         _lib.check(code, "sc_chamfer3d_forward_grid")
         return 1
-    blocks = b * ((min(n, m) + 1023) // 1024)
-    if 0 < blocks < 1024 and max(n, m) >= 4096:
-        # too few workgroups to fill 256 CUs (evaluation: b = 1): split the target cloud over workgroup slices
-        nsplit = max(1, min(32, 2048 // blocks))
+    if max(n, m) >= 4096:
+        # all pairs with the target cloud cut into slices so that the launch is a whole number of full rounds of the chip (nsplit 0: the
+        # library chooses per direction; evaluation at b = 1: 13 slices -> one round; b = 32: 2 slices -> 4.9 rounds instead of 2.45)
         ws = torch.empty(b * (n + m), dtype=torch.int64, device=xyz1.device)
         code = lib.sc_chamfer3d_forward_split(_lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(dist1), _lib.ptr(dist2),
                                               _lib.ptr(idx1), _lib.ptr(idx2), ctypes.c_int(b), ctypes.c_int(n),
-                                              ctypes.c_int(m), ctypes.c_int(nsplit), _lib.ptr(ws), _lib.stream())
+                                              ctypes.c_int(m), ctypes.c_int(NSPLIT), _lib.ptr(ws), _lib.stream())
         _lib.check(code, "sc_chamfer3d_forward_split")
         return 1
     code = lib.sc_chamfer3d_forward(_lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(dist1), _lib.ptr(dist2),

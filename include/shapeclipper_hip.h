@@ -32,8 +32,9 @@ extern "C" {
 int sc_chamfer3d_forward(const float* xyz1, const float* xyz2, float* dist1, float* dist2,
                          int32_t* idx1, int32_t* idx2, int b, int n, int m, void* stream);
 
-/* Same results (bit for bit), for small batches: the targets are split over `nsplit` workgroup slices and merged
- * with 64-bit atomicMin on (distance bits, index) keys.  workspace: (b*n + b*m) * 8 bytes of device scratch.   */
+/* Same results (bit for bit): the targets are split over `nsplit` workgroup slices and merged with 64-bit atomicMin on
+ * (distance bits, index) keys; nsplit <= 0: chosen per direction so that the launch is a whole number of full rounds of the
+ * chip (5 workgroups per CU at a time).  workspace: (b*n + b*m) * 8 bytes of device scratch.   */
 int sc_chamfer3d_forward_split(const float* xyz1, const float* xyz2, float* dist1, float* dist2,
                                int32_t* idx1, int32_t* idx2, int b, int n, int m, int nsplit,
                                void* workspace, void* stream);

@@ -24,6 +24,7 @@
 //     instruction in its disassembly and bit for bit on 100,000 x 100,000 points, tests/test_gpu_chamfer_ref.py), written
 //     with explicit fma and contraction switched off so that host oracle, packed and scalar device code agree exactly.
 #include "chamfer_common.hpp"
+#include <stdlib.h>
 
 namespace sc {
 
@@ -195,6 +196,18 @@ __global__ __launch_bounds__(CH_THREADS) void chamfer_grad_kernel(
     atomicAdd(&grad_xyz2[o2 + 2], -(g * (z1 - z2)));
 }
 
+// workgroups of the all-pairs kernels the chip runs at a time: 32 KiB of LDS each, 160 KiB per CU (SC_CHAMFER_SLOTS_PER_CU: tuning override)
+int chamfer_slots() {
+    static const int slots = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const char* e = getenv("SC_CHAMFER_SLOTS_PER_CU");
+        const int per_cu = e && atoi(e) > 0 ? atoi(e) : 5;
+        return (cus > 0 ? cus : 256) * per_cu;
+    }();
+    return slots;
+}
+
 }  // namespace sc
 
 extern "C" {
@@ -219,32 +232,30 @@ int sc_chamfer3d_forward(const float* xyz1, const float* xyz2, float* dist1, flo
     return (int)hipGetLastError();
 }
 
-// Same contract as sc_chamfer3d_forward, plus `workspace`: (b*n + b*m) uint64 of scratch.  Splits the target
-// cloud over `nsplit` workgroup slices (use when b*ceil(n/1024) workgroups cannot fill the chip, e.g. evaluation b=1).
+// Same contract as sc_chamfer3d_forward, plus `workspace`: (b*n + b*m) uint64 of scratch.  Splits the target cloud over `nsplit`
+// workgroup slices; nsplit <= 0: chosen per direction so that the launch is a whole number of full rounds of the chip (ch_auto_split).
 int sc_chamfer3d_forward_split(const float* xyz1, const float* xyz2, float* dist1, float* dist2, int32_t* idx1,
                                int32_t* idx2, int b, int n, int m, int nsplit, void* workspace, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (b <= 0 || n <= 0 || m <= 0) return 0;
-    if (nsplit < 1) nsplit = 1;
     unsigned long long* k1 = (unsigned long long*)workspace;
     unsigned long long* k2 = k1 + (size_t)b * n;
     (void)hipMemsetAsync(workspace, 0xFF, ((size_t)b * n + (size_t)b * m) * sizeof(unsigned long long), stream);
-    auto slice = [&](int cnt) { int s = (cnt + nsplit - 1) / nsplit; return (s + sc::CH_SUB - 1) / sc::CH_SUB * sc::CH_SUB; };
     const int per = sc::CH_THREADS * sc::CH_Q;
-    {
-        const int sl = slice(m);
-        dim3 g((n + per - 1) / per, b, (m + sl - 1) / sl);
-        hipLaunchKernelGGL(sc::chamfer_nn_split_kernel, g, dim3(sc::CH_THREADS), 0, stream, n, xyz1, m, xyz2, sl, k1);
-        const size_t t = (size_t)b * n;
-        hipLaunchKernelGGL(sc::chamfer_unpack_kernel, dim3((unsigned)((t + sc::CH_THREADS - 1) / sc::CH_THREADS)), dim3(sc::CH_THREADS), 0, stream, t, k1, dist1, idx1);
-    }
-    {
-        const int sl = slice(n);
-        dim3 g((m + per - 1) / per, b, (n + sl - 1) / sl);
-        hipLaunchKernelGGL(sc::chamfer_nn_split_kernel, g, dim3(sc::CH_THREADS), 0, stream, m, xyz2, n, xyz1, sl, k2);
-        const size_t t = (size_t)b * m;
-        hipLaunchKernelGGL(sc::chamfer_unpack_kernel, dim3((unsigned)((t + sc::CH_THREADS - 1) / sc::CH_THREADS)), dim3(sc::CH_THREADS), 0, stream, t, k2, dist2, idx2);
-    }
+    const int slots = sc::chamfer_slots();
+    auto one = [&](const float* q, int nq, const float* t, int mt, unsigned long long* keys, float* dist, int32_t* idx) {
+        const int groups = (nq + per - 1) / per;
+        const int ns = nsplit > 0 ? nsplit : sc::ch_auto_split((long long)groups * b, mt, slots);
+        int sl = (mt + ns - 1) / ns;
+        sl = (sl + sc::CH_SUB - 1) / sc::CH_SUB * sc::CH_SUB;
+        dim3 g(groups, b, (mt + sl - 1) / sl);
+        hipLaunchKernelGGL(sc::chamfer_nn_split_kernel, g, dim3(sc::CH_THREADS), 0, stream, nq, q, mt, t, sl, keys);
+        const size_t tot = (size_t)b * nq;
+        hipLaunchKernelGGL(sc::chamfer_unpack_kernel, dim3((unsigned)((tot + sc::CH_THREADS - 1) / sc::CH_THREADS)), dim3(sc::CH_THREADS), 0, stream, tot,
+                           keys, dist, idx);
+    };
+    one(xyz1, n, xyz2, m, k1, dist1, idx1);
+    one(xyz2, m, xyz1, n, k2, dist2, idx2);
     return (int)hipGetLastError();
 }
 

@@ -15,6 +15,23 @@ constexpr float CH_FAR = 1.0e18f;  // padding coordinate: d ~ 3e36, finite, neve
 
 typedef float ch_f2 __attribute__((ext_vector_type(2)));
 
+// How many target slices for `wgs` workgroups' worth of queries (b * ceil(n / 1024)) against m targets?  A workgroup holds a 32 KiB chunk
+// of targets in LDS, so `slots` = 5 per CU run at a time, all of the same length: the launch runs in rounds of `slots` workgroups and takes
+// about rounds x (slice length + a fixed cost per workgroup).  100,000 x 100,000 at batch 1 (98 workgroups of queries): 13 slices = 1,274
+// workgroups = ONE full round of 7,696 targets, where 20 slices (the old "about 2,048 workgroups" rule) ran two rounds of 5,008 with the
+// second one a third full.  Slices stay at least one LDS chunk long and at most 64 per cloud.
+__host__ __device__ inline int ch_auto_split(long long wgs, int m, int slots) {
+    int best = 1;
+    long long best_cost = -1;
+    for (int s = 1; s <= 64; ++s) {
+        if (s > 1 && m / s < CH_TCHUNK) break;
+        const long long rounds = (wgs * s + slots - 1) / slots;
+        const long long cost = rounds * ((m + s - 1) / s + 384);        // 384: query loads, index resolution and the key atomics, in targets
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = s; }
+    }
+    return best;
+}
+
 #pragma clang fp contract(off)
 __device__ __forceinline__ float dist2(float tx, float ty, float tz, float qx, float qy, float qz) {
     const float dx = tx - qx, dy = ty - qy, dz = tz - qz;
@@ -27,6 +44,8 @@ __device__ __forceinline__ ch_f2 dist2_pk(ch_f2 tx, ch_f2 ty, ch_f2 tz, float qx
     const ch_f2 xx = dx * dx, zz = dz * dz;
     return __builtin_elementwise_fma(dy, dy, xx) + zz;
 }
+int chamfer_slots();      // chamfer.hip
+
 // LDS image of a target pair (a, b): {xa, xb, ya, yb} {za, zb, -, -}
 struct ChPair { float4 xy, z; };
 __device__ __forceinline__ void stage_targets(float4* tgt, const float* t_ptr, int k0, int cnt, int cnt_pad, int tid) {

@@ -23,9 +23,12 @@
 //     all-pairs kernels' pair rate (it was 2-3x SLOWER than all pairs at a mean distance of 0.05-0.1).  There the queries are binned
 //     into the same grid by 2 x 2 x 2 tile of cells and one WAVE walks for up to 64 queries of a tile (cg_query_wave_kernel): uniform
 //     control flow, 64 candidate ranges looked up per round trip, 64 candidates per coalesced fetch, each broadcast to the 64 queries.
-// Measured at batch 1, 100,000 x 100,000 (tools/perf_chamfer_surface.py): uniform volumes 0.27 ms, coinciding surfaces 0.30 ms, surfaces
-// a mean 0.02 / 0.05 / 0.09 apart 0.38 / 0.76 / 1.7 ms, all pairs 2.7-2.9 ms; beyond that the walk is wasted effort in front of the scan
-// (3.1-3.2 ms at 0.15-0.25; at batch 8 the same cases cost what all pairs cost).
+// Measured at batch 1, 100,000 x 100,000 (tools/perf_chamfer_surface.py, profiles/r04_chamfer_regimes.txt): uniform volumes 0.27 ms,
+// coinciding surfaces 0.30 ms, surfaces a mean 0.02 / 0.05 / 0.09 apart 0.38 / 0.77 / 1.37 ms, all pairs 2.6-2.9 ms; at 0.15-0.25 the walk
+// answers a fifth of the queries and the scan the rest: 2.63-2.68 ms, what all pairs cost (it was 3.1-3.2 ms while the scan's slicing was
+// fixed on the host for the longest possible list; batch 8: 13.5-15.6 ms against 19.6).  Tried and dropped: sending query tiles with no
+// target within 2-4 cells straight to the scan -- the walk is not where those cases spend their time, and at 0.05-0.09 it made the search
+// 1.3-2x slower (profiles/r04_chamfer_far_tile_rule_experiment.txt).
 // Bound: latency / L2 gathers; the brute-force line stays in bench.py's workloads.
 #include "chamfer_common.hpp"
 #include <limits.h>
@@ -42,9 +45,6 @@ constexpr int CG_DENSE = 8;         // targets per occupied cell from which a cl
 constexpr int CG_WAVE_RMAX = 6;     // rings of the wave walk (its candidates cost ~1/50 of the thread walk's per query)
 constexpr int CG_WAVE_REMPTY = 4;   // rings without any candidate before the wave gives up
 constexpr int CG_WAVE_BUDGET = 16384;   // candidates per WAVE (64 queries of one cell) before its open queries are handed to the scan
-constexpr int CG_NEAR = 3;          // wave walk: a tile of queries with no target within this many cells of it (and a query this many cells outside
-                                    // the targets' box) goes straight to the scan -- see cg_items_kernel
-constexpr int CG_FAR_ITEM = 1 << 30;    // flag on an item's chunk number: do not walk
 
 struct GridMeta {                  // one per batch element
     float lo[3], h[3], inv_h[3];
@@ -320,38 +320,17 @@ __global__ __launch_bounds__(256) void cg_query_kernel(int n, const float* __res
 // ground truth, mean distance 0.05-0.1) the grid search took 6-9 ms where all pairs take 2.9.  Same acceptance rule, same stopping
 // rule per lane; the wave stops when all its lanes have.
 __global__ __launch_bounds__(256) void cg_items_kernel(const GridMeta* __restrict__ meta, int cap, const int* __restrict__ qstart_all,
-                                                       const int* __restrict__ tstart_all, int near, int* __restrict__ items_all,
-                                                       int* __restrict__ item_count, int max_items) {
+                                                       int* __restrict__ items_all, int* __restrict__ item_count, int max_items) {
     const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
     const GridMeta& g = meta[b];
-    const int tgx = (g.g[0] + 1) >> 1, tgy = (g.g[1] + 1) >> 1, tgz = (g.g[2] + 1) >> 1;
-    if (!g.dense || c >= tgx * tgy * tgz) return;
+    if (!g.dense || c >= g.g[0] * g.g[1] * g.g[2]) return;
     const int* qs = qstart_all + (size_t)b * (cap + 1);
     const int cnt = qs[c + 1] - qs[c];
     if (cnt <= 0) return;
-    // Is the walk worth starting?  A target that is k cells away is confirmed around ring k + 1, and every ring costs the candidates of its
-    // whole shell: with nothing within `near` cells of the tile the walk would evaluate thousands of candidates per wave and still hand most
-    // of its queries to the scan (two surfaces 0.15-0.25 apart: 0.36-0.51 ms of walk per direction in front of a scan of nearly every query,
-    // profiles/r04_chamfer_regimes.txt).  Those tiles skip the walk.  One thread per tile: <= (2 + 2 near)^2 rows, two `start` entries each.
-    int flag = 0;
-    if (near > 0) {
-        const int* ts = tstart_all + (size_t)b * (cap + 1);
-        const int lx = 2 * (c % tgx), ly = 2 * ((c / tgx) % tgy), lz = 2 * (c / (tgx * tgy));
-        const int x0 = max(lx - near, 0), x1 = min(lx + 1 + near, g.g[0] - 1);
-        const int y0 = max(ly - near, 0), y1 = min(ly + 1 + near, g.g[1] - 1);
-        const int z0 = max(lz - near, 0), z1 = min(lz + 1 + near, g.g[2] - 1);
-        int found = 0;
-        for (int z = z0; z <= z1 && !found; ++z)
-            for (int y = y0; y <= y1; ++y) {
-                const int row = (z * g.g[1] + y) * g.g[0];
-                found |= ts[row + x1 + 1] - ts[row + x0];
-            }
-        flag = found ? 0 : CG_FAR_ITEM;
-    }
     const int chunks = (cnt + 63) >> 6;
     const int at = atomicAdd(&item_count[b], chunks);
     int* items = items_all + (size_t)b * max_items * 2;
-    for (int k = 0; k < chunks; ++k) { items[2 * (at + k)] = c; items[2 * (at + k) + 1] = k | flag; }
+    for (int k = 0; k < chunks; ++k) { items[2 * (at + k)] = c; items[2 * (at + k) + 1] = k; }
 }
 
 __global__ __launch_bounds__(256) void cg_query_wave_kernel(int n, int m, const GridMeta* __restrict__ meta, int cap,
@@ -360,7 +339,7 @@ __global__ __launch_bounds__(256) void cg_query_wave_kernel(int n, int m, const 
                                                             const int* __restrict__ items_all, const int* __restrict__ item_count,
                                                             int max_items, float* __restrict__ dist, int* __restrict__ idx,
                                                             int* __restrict__ todo, int* __restrict__ todo_count,
-                                                            unsigned long long* __restrict__ keys, int near) {
+                                                            unsigned long long* __restrict__ keys) {
 #define CG_TEST(t)                                                                              \
     {                                                                                           \
         const float d = dist2((t).x, (t).y, (t).z, q[0], q[1], q[2]);                           \
@@ -377,9 +356,7 @@ __global__ __launch_bounds__(256) void cg_query_wave_kernel(int n, int m, const 
     const float4* sorted = sorted_all + (size_t)b * m;
     const int* qstart = qstart_all + (size_t)b * (cap + 1);
     const int cell = __builtin_amdgcn_readfirstlane(items_all[((size_t)b * max_items + item) * 2]);      // a 2 x 2 x 2 TILE of cells
-    const int chunk_flag = __builtin_amdgcn_readfirstlane(items_all[((size_t)b * max_items + item) * 2 + 1]);
-    const int chunk = chunk_flag & ~CG_FAR_ITEM;
-    const bool far_tile = (chunk_flag & CG_FAR_ITEM) != 0;      // nothing within `near` cells of the tile: straight to the scan (cg_items_kernel)
+    const int chunk = __builtin_amdgcn_readfirstlane(items_all[((size_t)b * max_items + item) * 2 + 1]);
     const int q0 = qstart[cell] + chunk * 64, q1 = qstart[cell + 1];
     const bool live = q0 + lane < q1;
     const float4 qv = qsorted_all[(size_t)b * n + (live ? q0 + lane : q0)];
@@ -391,13 +368,10 @@ __global__ __launch_bounds__(256) void cg_query_wave_kernel(int n, int m, const 
     lo[1] = 2 * ((cell / tgx) % tgy);
     lo[2] = 2 * (cell / (tgx * tgy));
     for (int a = 0; a < 3; ++a) hi[a] = min(lo[a] + 1, g.g[a] - 1);
+    // (no "outside the bounding box" shortcut here: a wave's candidates are cheap, and a cloud that encloses the other one -- every query
+    // of one direction outside the other's box -- is the common case at evaluation)
     const bool skip = !(g.valid && fabsf(q[0]) < 1.0e15f && fabsf(q[1]) < 1.0e15f && fabsf(q[2]) < 1.0e15f);
-    bool done = false, hopeless = far_tile;
-    // a query more than `near` cells outside the targets' box sits in a boundary tile it does not belong to (the binning clamps): its
-    // nearest target is at least that far away, the same situation as a far tile
-    if (near > 0)
-        for (int a = 0; a < 3; ++a)
-            hopeless |= fmaxf(g.lo[a] - q[a], q[a] - (g.lo[a] + (float)g.g[a] * g.h[a])) > (float)near * g.h[a];
+    bool done = false, hopeless = false;
     float best = __builtin_inff();
     int bidx = INT_MAX, seen = 0;
     const float hinv = fmaxf(g.inv_h[0], fmaxf(g.inv_h[1], g.inv_h[2]));       // 1 / smallest cell side
@@ -470,7 +444,7 @@ __global__ __launch_bounds__(256) void cg_query_wave_kernel(int n, int m, const 
         dist[(size_t)b * n + j] = best;
         idx[(size_t)b * n + j] = bidx;
     }
-    // the others go on the scan's list: one atomic per wave (a far tile lists all 64 of its queries)
+    // the others go on the scan's list: one atomic per wave
     const unsigned long long listed = __ballot(live && !answered);
     if (listed) {
         const int leader = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(listed));
@@ -495,13 +469,19 @@ __global__ __launch_bounds__(256) void cg_query_wave_kernel(int n, int m, const 
 // distances resolve to the lowest index -- the all-pairs kernels' rule; cg_fallback_unpack_kernel writes the winners out.
 __global__ __launch_bounds__(CH_THREADS) void cg_fallback_kernel(int n, const float* __restrict__ qry, int m, const float* __restrict__ tgt_all,
                                                                  const int* __restrict__ todo, const int* __restrict__ todo_count,
-                                                                 int slice_len, unsigned long long* __restrict__ keys) {
+                                                                 int slots, unsigned long long* __restrict__ keys) {
     __shared__ float4 tgt[CH_TCHUNK];
     const int b = blockIdx.y, tid = threadIdx.x;
     const int cnt_q = todo_count[b];
-    const int qbase = blockIdx.x * (CH_THREADS * CH_Q);
-    if (qbase >= cnt_q) return;
-    const int t_begin = blockIdx.z * slice_len, t_end = min(m, t_begin + slice_len);
+    // The list length is only known here: the slicing is chosen on the device, by the rule of the all-pairs entry point (whole rounds of
+    // the chip; the other images of the batch are taken to have lists of about this length).  blockIdx.x = slice * groups + group.
+    const int groups = (cnt_q + CH_THREADS * CH_Q - 1) / (CH_THREADS * CH_Q);
+    if (groups == 0) return;
+    const int nsl = ch_auto_split((long long)groups * gridDim.y, m, slots);
+    if ((int)blockIdx.x >= groups * nsl) return;
+    const int slice_len = (((m + nsl - 1) / nsl) + CH_SUB - 1) / CH_SUB * CH_SUB;
+    const int qbase = ((int)blockIdx.x % groups) * (CH_THREADS * CH_Q);
+    const int t_begin = ((int)blockIdx.x / groups) * slice_len, t_end = min(m, t_begin + slice_len);
     if (t_begin >= t_end) return;
     const float* q_ptr = qry + (size_t)b * n * 3;
     const float* t_ptr = tgt_all + (size_t)b * m * 3;
@@ -619,26 +599,27 @@ int cg_one_direction(const float* qry, int n, const float* tgt, int m, int b, fl
                            (int)c.nblk, ws + c.occupied, 0, 0);
         hipLaunchKernelGGL(cg_scatter_kernel, dim3((n + 255) / 256, b), dim3(256), 0, stream, n, qry, cap, ws + c.qcell_of, ws + c.qcounts,
                            ws + c.qcursor, reinterpret_cast<float4*>(ws + c.qsorted), meta);
-        static const int near = [] { const char* e = getenv("SC_CHAMFER_GRID_NEAR"); return e ? atoi(e) : CG_NEAR; }();      // tuning override; 0 = always walk
-        hipLaunchKernelGGL(cg_items_kernel, dim3((cap + 255) / 256, b), dim3(256), 0, stream, meta, cap, ws + c.qcounts, ws + c.counts, near,
-                           ws + c.items, ws + c.item_count, (int)c.max_items);
+        hipLaunchKernelGGL(cg_items_kernel, dim3((cap + 255) / 256, b), dim3(256), 0, stream, meta, cap, ws + c.qcounts, ws + c.items,
+                           ws + c.item_count, (int)c.max_items);
         hipLaunchKernelGGL(cg_query_wave_kernel, dim3((unsigned)((c.max_items + 3) / 4 < 4096 ? (c.max_items + 3) / 4 : 4096), b), dim3(256), 0, stream, n, m, meta, cap, ws + c.counts,
                            reinterpret_cast<const float4*>(ws + c.sorted), ws + c.qcounts, reinterpret_cast<const float4*>(ws + c.qsorted),
                            ws + c.items, ws + c.item_count, (int)c.max_items, dist, idx, ws + c.todo, ws + c.todo_count,
-                           reinterpret_cast<unsigned long long*>(ws + c.keys), near);
+                           reinterpret_cast<unsigned long long*>(ws + c.keys));
     }
     hipLaunchKernelGGL(cg_query_kernel, dim3((n + 255) / 256, b), dim3(256), 0, stream, n, qry, m, meta, cap, ws + c.counts,
                        reinterpret_cast<const float4*>(ws + c.sorted), dist, idx, ws + c.todo, ws + c.todo_count,
                        reinterpret_cast<unsigned long long*>(ws + c.keys), wave_walk);
-    // target slices: enough workgroups to fill the chip even when only one group of queries is listed (~2,048 at most in all), each
-    // slice a whole number of LDS chunks
+    // the scan of the listed queries: as many workgroups as the longest possible list needs under the slicing rule (the kernel picks the
+    // slicing from the actual list length; the rest exit at once)
     const int groups = (n + CH_THREADS * CH_Q - 1) / (CH_THREADS * CH_Q);
-    int nsplit = 2048 / (groups * b);
-    nsplit = nsplit < 1 ? 1 : nsplit > 32 ? 32 : nsplit;
-    int slice = (m + nsplit - 1) / nsplit;
-    slice = (slice + CH_TCHUNK - 1) / CH_TCHUNK * CH_TCHUNK;
-    hipLaunchKernelGGL(cg_fallback_kernel, dim3(groups, b, (m + slice - 1) / slice), dim3(CH_THREADS), 0, stream, n, qry, m, tgt, ws + c.todo,
-                       ws + c.todo_count, slice, reinterpret_cast<unsigned long long*>(ws + c.keys));
+    const int slots = chamfer_slots();
+    long long max_wgs = 1;
+    for (int gq = 1; gq <= groups; ++gq) {
+        const long long w = (long long)gq * ch_auto_split((long long)gq * b, m, slots);
+        max_wgs = w > max_wgs ? w : max_wgs;
+    }
+    hipLaunchKernelGGL(cg_fallback_kernel, dim3((unsigned)max_wgs, b), dim3(CH_THREADS), 0, stream, n, qry, m, tgt, ws + c.todo,
+                       ws + c.todo_count, slots, reinterpret_cast<unsigned long long*>(ws + c.keys));
     hipLaunchKernelGGL(cg_fallback_unpack_kernel, dim3(groups < 64 ? groups : 64, b), dim3(256), 0, stream, n, ws + c.todo, ws + c.todo_count,
                        reinterpret_cast<const unsigned long long*>(ws + c.keys), dist, idx);
     return (int)hipGetLastError();

@@ -98,6 +98,9 @@ class Runner:
                 view.append(v)
         self.optim_full = self.optimizer([dict(params=full, lr=opt.optim.lr)], **kwargs)
         self.optim_V = self.optimizer([dict(params=view, lr=opt.optim.lr)], **kwargs)
+        # hip.guarded_step: the fused optimizer takes the step's NaN / Inf flag as its `found_inf` tensor (the hook torch's GradScaler uses) and
+        # skips the update ON THE DEVICE; the host then reads the flag one step late instead of waiting for it before every optim.step()
+        self._guarded_step = bool(kwargs.get("fused")) and bool(opt.get("hip", {}).get("guarded_step", True))
 
     def restore_checkpoint(self, opt, best=False, evaluate=False):
         epoch_start, iter_start = None, None
@@ -192,9 +195,16 @@ class Runner:
         if self.reducer is not None:
             self.reducer.all_reduce()
         # The reference asserts on NaN / Inf losses before it back-propagates (runner.py:296-302).  Here the flag left for pinned memory
-        # right after the forward pass; reading it now -- the whole backward pass is queued behind it, so the GPU has ~20 ms of work while
-        # the host waits for an event that is usually long complete -- keeps the weights and the Adam state of a poisoned step untouched.
-        self.check_finite()
+        # right after the forward pass.  Guarded step (default with the fused optimizer): the flag is also the optimizer's `found_inf`, so a
+        # poisoned step leaves the weights, the Adam moments and the step counters untouched without the host knowing yet; the host reads
+        # the flag of the PREVIOUS step here (complete long ago: no wait -- the per-step wait cost 1.0 ms of 36.6 at bs32, 0.3 of 22.0 at
+        # bs16, profiles/r04_guarded_step.txt) and raises the reference's assertion one step late, before this step's update is applied.
+        # Otherwise (foreach / CPU optimizers): wait for this step's flag now, before optim.step().
+        if getattr(self, "_guarded_step", False):
+            optim.grad_scale, optim.found_inf = None, getattr(self, "_step_found_inf", None)
+            self.check_finite(keep_last=True)
+        else:
+            self.check_finite()
         optim.step()
 
         if _rank0(opt):
@@ -237,7 +247,7 @@ class Runner:
                 total = total + w * value
         if "_bad_choice" in var and bad is not None:          # NaN neighbour probabilities (np.random.choice would have raised)
             bad = bad | var.pop("_bad_choice").to(bad.device)
-        self._pending_check = None
+        self._step_found_inf = None
         if bad is not None and opt.get("check_finite", True):
             reducer = getattr(self, "reducer", None)
             if defer_check and reducer is not None and reducer.comm:
@@ -250,7 +260,8 @@ class Runner:
                         host.copy_(flag, non_blocking=True)
                         done = torch.cuda.Event()
                         done.record()
-                    self._pending_check = (host, done, {k: v.detach() for k, v in loss.items()})
+                    self._pending().append((host, done, {k: v.detach() for k, v in loss.items()}))
+                    self._step_found_inf = flag.reshape(())  # exactly 1.0 where any rank's loss is NaN / Inf (MAX of 0 / 1 flags)
                 elif bool(flag.item() > 0):
                     self._raise_not_finite(loss, any_rank=True)
             elif defer_check and bad.is_cuda:
@@ -258,7 +269,8 @@ class Runner:
                 host.copy_(bad, non_blocking=True)
                 done = torch.cuda.Event()
                 done.record()
-                self._pending_check = (host, done, {k: v.detach() for k, v in loss.items()})
+                self._pending().append((host, done, {k: v.detach() for k, v in loss.items()}))
+                self._step_found_inf = bad.detach().reshape(()).to(torch.float32)      # 0-dim, as GradScaler's
             elif bool(bad):
                 self._raise_not_finite(loss)
         loss.update(all=total)
@@ -275,15 +287,23 @@ class Runner:
         # multi-rank: the flag is the MAX over the ranks -- this rank's losses are finite, another rank's are not; every rank stops here
         assert not any_rank, "a loss is NaN / Inf on another rank"
 
-    def check_finite(self, loss=None):
-        """Raise the reference's NaN/Inf assertions (runner.py:296-302) for the step whose flag is pending.  train_iteration
-        calls this between the (queued) backward pass and the optimizer step: the flag was copied to pinned memory right after
-        the forward pass, so the wait is for an event that has usually completed, and never for the backward pass."""
-        pending, self._pending_check = getattr(self, "_pending_check", None), None
-        if pending is not None:
-            host, done, pending_loss = pending
+    def _pending(self):
+        if not hasattr(self, "_pending_checks"):
+            self._pending_checks = []
+        return self._pending_checks
+
+    def check_finite(self, loss=None, keep_last=False):
+        """Raise the reference's NaN/Inf assertions (runner.py:296-302) for the steps whose flags are pending, oldest first.
+        train_iteration calls this between the (queued) backward pass and the optimizer step: each flag was copied to pinned memory
+        right after its forward pass.  keep_last (guarded step): the newest flag stays pending -- its step is protected on the device
+        by the optimizer's `found_inf` -- so the wait is for the previous step's event, which completed long ago.  Without keep_last
+        (end of an epoch, before a checkpoint, unguarded optimizers) every pending flag is waited for."""
+        queue = self._pending()
+        while len(queue) > (1 if keep_last else 0):
+            host, done, pending_loss = queue.pop(0)
             done.synchronize()
             if bool(host.reshape(-1)[0] > 0):
+                queue.clear()
                 self._raise_not_finite(loss if loss is not None else pending_loss, any_rank=host.dtype != torch.bool)
 
     # ---- evaluation -----------------------------------------------------------------------------------

@@ -95,7 +95,7 @@ def test_full_size_properties():
     assert np.array_equal(e2, d1) and np.array_equal(j2, i1)
 
 
-@pytest.mark.parametrize("B,N,M,nsplit", [(1, 5000, 7001, 8), (2, 4099, 4100, 3), (1, 100, 50, 4)])
+@pytest.mark.parametrize("B,N,M,nsplit", [(1, 5000, 7001, 8), (2, 4099, 4100, 3), (1, 100, 50, 4), (1, 5000, 70001, 0), (3, 9000, 4100, 0)])
 def test_split_entry_point_is_bit_identical(B, N, M, nsplit):
     import ctypes
     from oracle import chamfer_ref

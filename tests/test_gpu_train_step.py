@@ -46,22 +46,28 @@ def test_two_training_iterations():
     pickle.dumps(runner.graph.state_dict())
 
 
-def test_non_finite_loss_raises_before_the_optimizer_step():
-    """The reference asserts on NaN / Inf losses in summarize_loss, before backward (runner.py:296-302).  Here the flag is read between the
-    queued backward pass and optim.step(): the assertion names the loss, and neither the weights nor the Adam state of the poisoned step
-    change; the next (clean) step trains normally."""
+@pytest.mark.parametrize("guarded", [True, False], ids=["guarded_step", "host_wait"])
+def test_non_finite_loss_never_reaches_the_weights(guarded):
+    """The reference asserts on NaN / Inf losses in summarize_loss, before backward (runner.py:296-302).  Here the assertion names the loss
+    and neither the weights nor the Adam state (moments, step counters) of the poisoned step change:
+      * hip.guarded_step (default): the flag is the fused optimizer's `found_inf`, the update is skipped on the device; the host raises
+        one step later (before the NEXT update is applied) or at the next flush (`check_finite()`: end of epoch, checkpoint);
+      * --hip.guarded_step!: the host waits for the flag between the queued backward pass and optim.step() and raises in the same step.
+    The next clean step trains normally."""
     from shapeclipper_amd import synthetic
     from shapeclipper_amd.model.runner import Runner
     from shapeclipper_amd.utils import options, util
     from shapeclipper_amd.utils.util import EasyDict as edict
     opt = options.set(options.parse_arguments(["--yaml=options/pix3d/config.yaml", "--name=pytest_nan", "--output_root=/tmp/sc_pytest",
-                                               "--batch_size=2", "--tb!", "--arch.enc_pretrained!"]), verbose=False)
+                                               "--batch_size=2", "--tb!", "--arch.enc_pretrained!"]
+                                              + ([] if guarded else ["--hip.guarded_step!"])), verbose=False)
     opt.device, opt.world_size, opt.port = 0, 1, 0
     opt.freq.scalar, opt.freq.ckpt_latest = 0, 10 ** 9
     torch.manual_seed(0)
     runner = Runner(opt)
     runner.build_networks(opt)
     runner.setup_optimizer(opt)
+    assert runner._guarded_step == guarded
     runner.graph.train()
     runner.it, runner.ep, runner.best_val = 1, 0, 0.0
     runner.timer = edict(start=time.time(), it_mean=None)
@@ -70,18 +76,32 @@ def test_non_finite_loss_raises_before_the_optimizer_step():
     runner.train_iteration(opt, edict(batch), None)                    # one clean step: the Adam state exists
     g = runner.graph.module
     state = lambda: ({n: p.detach().clone() for n, p in g.named_parameters()},
-                     [v["exp_avg"].clone() for v in runner.optim_full.state.values() if "exp_avg" in v])
+                     [v["exp_avg"].clone() for v in runner.optim_full.state.values() if "exp_avg" in v],
+                     [float(v["step"]) for v in runner.optim_full.state.values() if "step" in v])
+    same = lambda a, b: (all(torch.equal(a[0][n], b[0][n]) for n in b[0]) and all(torch.equal(x, y) for x, y in zip(a[1], b[1]))
+                         and a[2] == b[2])
     poisoned = edict(batch)
     poisoned.rgb_input_map = batch["rgb_input_map"].clone()
     poisoned.rgb_input_map[0, 0, 5, 5] = float("nan")                 # through the encoders into every loss
-    before_p, before_m = state()
-    with pytest.raises(AssertionError, match="is NaN|is Inf"):
+    before = state()
+    if guarded:
+        runner.train_iteration(opt, poisoned, None)                    # returns: the device skipped the update, the host does not know yet
+        assert same(state(), before), "a non-finite step changed the weights or the Adam state"
+        with pytest.raises(AssertionError, match="is NaN|is Inf"):
+            runner.train_iteration(opt, edict(batch), None)            # raised before this (clean) step's update
+        assert same(state(), before), "the step behind a non-finite one was applied before the assertion"
         runner.train_iteration(opt, poisoned, None)
-    after_p, after_m = state()
-    assert all(torch.equal(after_p[n], before_p[n]) for n in before_p), "weights were updated by a non-finite step"
-    assert all(torch.equal(a, b) for a, b in zip(after_m, before_m)), "Adam moments were updated by a non-finite step"
+        with pytest.raises(AssertionError, match="is NaN|is Inf"):
+            runner.check_finite()                                       # the flush of train_epoch / the checkpoint path
+    else:
+        with pytest.raises(AssertionError, match="is NaN|is Inf"):
+            runner.train_iteration(opt, poisoned, None)
+    assert same(state(), before), "weights / Adam state were updated by a non-finite step"
     loss = runner.train_iteration(opt, edict(batch), None)             # BatchNorm running statistics are poisoned like in the reference;
     assert set(loss.keys()) >= {"render", "all"}                       # the step itself runs (training-mode BN uses batch statistics)
+    runner.check_finite()
+    after = state()
+    assert after[2] == [s + 1 for s in before[2]] and not same(after, before)
 
 
 def test_batched_encoder_passes_equal_sequential_passes():
