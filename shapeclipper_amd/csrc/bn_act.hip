@@ -399,6 +399,211 @@ __global__ __launch_bounds__(BN_T) void bn_relu_pool_bwd_gather_kernel(PoolBwdAr
     if (threadIdx.x == 0) store_partial(a.partial, c, sh, a.G, sg, sgx);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Small maps with many channels (14 x 14 x 256, 7 x 7 x 512, the 1 x 1 maps of the heads): ONE launch per pass.  A channel of such a
+// layer is 12-75 KB for the whole batch, so the two-launch form above spends more time on its second launch (grid fill / drain plus the
+// dependent-kernel boundary) than on the bytes: 13-16 us per BatchNorm where the data moves in 3-5.  Here one 512-thread block owns a
+// channel and keeps ALL of it in registers (at most BNF_V vectors per thread): one load phase for every group at once, the per-group
+// sums (block reductions of 2 G values), the apply pass from registers, one store phase.  The block applies the G running-statistics
+// updates in group order and sums dgamma / dbeta over the groups itself: same results contract as the two-launch form (fixed summation
+// order; values differ from it in the last bits only because the partial sums are grouped differently).
+constexpr int BNF_T = 512, BNF_V = 10, BNF_G = 4;
+
+// sums of v[0 .. NV-1] over the block; every thread gets the totals (red: NV * (BNF_T / 64) floats)
+template <int NV>
+__device__ __forceinline__ void block_sum_f(float (&v)[NV], float* red) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+        for (int d = 32; d >= 1; d >>= 1) v[k] += __shfl_xor(v[k], d);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) red[k * (BNF_T / 64) + w] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        float t = 0.f;
+        for (int j = 0; j < BNF_T / 64; ++j) t += red[k * (BNF_T / 64) + j];
+        v[k] = t;
+    }
+}
+
+// vector j of this thread: element offset and group (-1: past the end).  W = 4: HW % 4 == 0, a vector never straddles two images.
+template <int W>
+__device__ __forceinline__ bool bnf_slot(int j, int N, int C, int HW, int Ng, int c, size_t& off, int& g) {
+    const int per = HW / W, idx = threadIdx.x + j * BNF_T;
+    if (idx >= N * per) return false;
+    const int n = idx / per, i = idx - n * per;
+    off = ((size_t)n * C + c) * HW + (size_t)W * i;
+    g = n / Ng;
+    return true;
+}
+
+template <int W>
+__global__ __launch_bounds__(BNF_T) void bn_fused_fwd_kernel(BnFwdArgs a) {
+    __shared__ float red[2 * BNF_G * BNF_T / 64];
+    const int c = blockIdx.x, C = a.st.C, HW = a.st.HW, G = a.st.G, N = a.st.N, Ng = N / G;
+    const float n = (float)Ng * (float)HW;
+    const float* x = a.st.x;
+    const float gamma = a.gamma[c], beta = a.beta[c];
+    Vec<W> xv[BNF_V];
+    size_t off[BNF_V];
+    int grp[BNF_V];
+#pragma unroll
+    for (int j = 0; j < BNF_V; ++j) {
+        grp[j] = -1;
+        if (bnf_slot<W>(j, N, C, HW, Ng, c, off[j], grp[j])) xv[j] = Vec<W>::ld(x + off[j]);
+    }
+    float mean[BNF_G], rstd[BNF_G];
+    if (a.st.training) {
+        float K[BNF_G], s[2 * BNF_G];
+#pragma unroll
+        for (int g = 0; g < BNF_G; ++g) {
+            K[g] = g < G ? x[((size_t)g * Ng * C + c) * HW] : 0.f;
+            s[2 * g] = 0.f;
+            s[2 * g + 1] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < BNF_V; ++j)
+#pragma unroll
+            for (int g = 0; g < BNF_G; ++g)
+                if (grp[j] == g) {
+#pragma unroll
+                    for (int k = 0; k < W; ++k) {
+                        const float d = xv[j].v[k] - K[g];
+                        s[2 * g] += d;
+                        s[2 * g + 1] += d * d;
+                    }
+                }
+        block_sum_f(s, red);
+#pragma unroll
+        for (int g = 0; g < BNF_G; ++g) {
+            const float dm = s[2 * g] / n, v0 = s[2 * g + 1] / n - dm * dm;
+            const float var = v0 < 0.f ? 0.f : v0;                 // (not fmaxf: a NaN variance stays NaN, as in torch)
+            mean[g] = K[g] + dm;
+            rstd[g] = rsqrtf(var + a.st.eps);
+            if (g < G && threadIdx.x == 0 && a.st.run_mean) {      // the G momentum updates, in group order
+                a.st.run_mean[c] = (1.f - a.st.momentum) * a.st.run_mean[c] + a.st.momentum * mean[g];
+                a.st.run_var[c] = (1.f - a.st.momentum) * a.st.run_var[c] + a.st.momentum * (n > 1.f ? var * n / (n - 1.f) : var);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < BNF_G; ++g) {
+            mean[g] = a.st.run_mean[c];
+            rstd[g] = rsqrtf(a.st.run_var[c] + a.st.eps);
+        }
+    }
+    if (threadIdx.x == 0) {
+        for (int g = 0; g < G; ++g) {
+            a.st.save_mean[(size_t)g * C + c] = mean[g < BNF_G ? g : 0];
+            a.st.save_rstd[(size_t)g * C + c] = rstd[g < BNF_G ? g : 0];
+        }
+        if (a.st.training && a.st.n_tracked && c == 0) *a.st.n_tracked += G;
+    }
+#pragma unroll
+    for (int j = 0; j < BNF_V; ++j) {
+        if (grp[j] < 0) continue;
+        float m = mean[0], r = rstd[0];
+#pragma unroll
+        for (int g = 1; g < BNF_G; ++g)
+            if (grp[j] == g) { m = mean[g]; r = rstd[g]; }
+        const float scale = gamma * r, shift = beta - m * scale;
+        Vec<W> v = xv[j];
+        if (a.res) {
+            const auto rv = Vec<W>::ld(a.res + off[j]);
+#pragma unroll
+            for (int k = 0; k < W; ++k) v.v[k] = fmaf(v.v[k], scale, shift) + rv.v[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < W; ++k) v.v[k] = fmaf(v.v[k], scale, shift);
+        }
+        if (a.relu) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) v.v[k] = v.v[k] < 0.f ? 0.f : v.v[k];      // relu(NaN) = NaN, as torch
+        }
+        v.st(a.y + off[j]);
+    }
+}
+
+template <int W>
+__global__ __launch_bounds__(BNF_T) void bn_fused_bwd_kernel(BnBwdArgs a) {
+    __shared__ float red[2 * BNF_G * BNF_T / 64];
+    const int c = blockIdx.x, C = a.C, HW = a.HW, G = a.G, N = a.N, Ng = N / G;
+    const float n = (float)Ng * (float)HW;
+    const float gamma = a.gamma[c], beta = a.beta[c];
+    float mean[BNF_G], rstd[BNF_G];
+#pragma unroll
+    for (int g = 0; g < BNF_G; ++g) {
+        mean[g] = a.mean[(size_t)(g < G ? g : 0) * C + c];
+        rstd[g] = a.rstd[(size_t)(g < G ? g : 0) * C + c];
+    }
+    Vec<W> xh[BNF_V], gr[BNF_V];                                  // xhat and the masked gradient of this thread's elements
+    size_t off[BNF_V];
+    int grp[BNF_V];
+    float s[2 * BNF_G];
+#pragma unroll
+    for (int g = 0; g < 2 * BNF_G; ++g) s[g] = 0.f;
+#pragma unroll
+    for (int j = 0; j < BNF_V; ++j) {
+        grp[j] = -1;
+        if (!bnf_slot<W>(j, N, C, HW, Ng, c, off[j], grp[j])) continue;
+        float m = mean[0], r = rstd[0];
+#pragma unroll
+        for (int g = 1; g < BNF_G; ++g)
+            if (grp[j] == g) { m = mean[g]; r = rstd[g]; }
+        const float scale = gamma * r, shift = beta - m * scale;
+        const auto xv = Vec<W>::ld(a.x + off[j]);
+        gr[j] = bn_masked_grad<W>(a, off[j], xv, scale, shift);
+        if (a.dres) gr[j].st(a.dres + off[j]);
+#pragma unroll
+        for (int k = 0; k < W; ++k) xh[j].v[k] = (xv.v[k] - m) * r;
+#pragma unroll
+        for (int g = 0; g < BNF_G; ++g)
+            if (grp[j] == g) {
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    s[2 * g] += gr[j].v[k];
+                    s[2 * g + 1] += gr[j].v[k] * xh[j].v[k];
+                }
+            }
+    }
+    block_sum_f(s, red);
+    if (threadIdx.x == 0) {                                        // parameters are shared by the groups: sums in group order
+        float tg = 0.f, tgx = 0.f;
+#pragma unroll
+        for (int g = 0; g < BNF_G; ++g)
+            if (g < G) { tg += s[2 * g]; tgx += s[2 * g + 1]; }
+        a.dgamma[c] = tgx;
+        a.dbeta[c] = tg;
+    }
+    if (!a.dx) return;
+#pragma unroll
+    for (int j = 0; j < BNF_V; ++j) {
+        if (grp[j] < 0) continue;
+        float r = rstd[0], sg = s[0], sgx = s[1];
+#pragma unroll
+        for (int g = 1; g < BNF_G; ++g)
+            if (grp[j] == g) { r = rstd[g]; sg = s[2 * g]; sgx = s[2 * g + 1]; }
+        const float scale = gamma * r, mg = a.training ? sg / n : 0.f, mgx = a.training ? sgx / n : 0.f;
+        Vec<W> o;
+#pragma unroll
+        for (int k = 0; k < W; ++k) o.v[k] = scale * (gr[j].v[k] - mg - xh[j].v[k] * mgx);
+        o.st(a.dx + off[j]);
+    }
+}
+
+// one launch when a whole channel of the batch fits the block's registers and there are enough channels to fill the chip
+static inline bool bn_fused_takes(int N, int C, int HW, int G) {
+#ifdef SC_BN_NO_FUSED
+    return false;
+#endif
+    const long long vecs = (HW & 3) ? (long long)N * HW : (long long)N * (HW >> 2);
+    return C >= 256 && G <= BNF_G && vecs <= (long long)BNF_T * BNF_V;
+}
+
 static inline int bn_splits(int Ng, int C, int G) {      // blocks per (channel, group); C * G * S ~ 2048 blocks
     int S = (2048 + C * G - 1) / (C * G);
     if (S > Ng) S = Ng;
@@ -419,10 +624,15 @@ extern "C" int sc_bn_act_forward(const float* x, const float* res, const float* 
     if (N <= 0 || C <= 0 || HW <= 0) return 0;
     if (bn_bad(N, C, HW, groups)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream_;
-    const dim3 grid(C, groups * sc::bn_splits(N / groups, C, groups));
-    if (training) hipLaunchKernelGGL(sc::bn_stats_kernel, grid, dim3(sc::BN_T), 0, st, x, N, C, HW, groups, partial);
     sc::BnFwdArgs a{{x, partial, save_mean, save_rstd, run_mean, run_var, n_tracked, N, C, HW, groups, training, eps, momentum},
                     res, gamma, beta, y, relu};
+    if (sc::bn_fused_takes(N, C, HW, groups)) {
+        if (HW & 3) hipLaunchKernelGGL(sc::bn_fused_fwd_kernel<1>, dim3(C), dim3(sc::BNF_T), 0, st, a);
+        else hipLaunchKernelGGL(sc::bn_fused_fwd_kernel<4>, dim3(C), dim3(sc::BNF_T), 0, st, a);
+        return (int)hipGetLastError();
+    }
+    const dim3 grid(C, groups * sc::bn_splits(N / groups, C, groups));
+    if (training) hipLaunchKernelGGL(sc::bn_stats_kernel, grid, dim3(sc::BN_T), 0, st, x, N, C, HW, groups, partial);
     hipLaunchKernelGGL(sc::bn_apply_fwd_kernel, grid, dim3(sc::BN_T), 0, st, a);
     return (int)hipGetLastError();
 }
@@ -434,9 +644,14 @@ extern "C" int sc_bn_act_backward(const float* dy, const float* x, const float* 
     if (N <= 0 || C <= 0 || HW <= 0) return 0;
     if (bn_bad(N, C, HW, groups)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream_;
-    const dim3 grid(C, groups * sc::bn_splits(N / groups, C, groups));
     sc::BnBwdArgs a{dy, x, y, gamma, beta, mean, rstd, partial, dx, dres, dgamma, dbeta, N, C, HW, groups, relu, training,
                     (y != nullptr) ? 1 : 0};
+    if (sc::bn_fused_takes(N, C, HW, groups)) {
+        if (HW & 3) hipLaunchKernelGGL(sc::bn_fused_bwd_kernel<1>, dim3(C), dim3(sc::BNF_T), 0, st, a);
+        else hipLaunchKernelGGL(sc::bn_fused_bwd_kernel<4>, dim3(C), dim3(sc::BNF_T), 0, st, a);
+        return (int)hipGetLastError();
+    }
+    const dim3 grid(C, groups * sc::bn_splits(N / groups, C, groups));
     hipLaunchKernelGGL(sc::bn_bwd_stats_kernel, grid, dim3(sc::BN_T), 0, st, a);
     hipLaunchKernelGGL(sc::bn_bwd_apply_kernel, grid, dim3(sc::BN_T), 0, st, a);
     return (int)hipGetLastError();

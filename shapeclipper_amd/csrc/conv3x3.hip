@@ -32,6 +32,14 @@
 
 namespace sc {
 
+#ifdef SC_CONV_PROFILE           // profile build (tools/prof_conv_phases.py; tools/build_variants.sh conv3x3.hip SC_CONV_PROFILE 1): s_memrealtime
+                                 // stamps (100 MHz) of thread 0 of every workgroup
+__device__ unsigned long long* conv_prof_buf = nullptr;
+#define CV_STAMP(ID) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); if (conv_prof_buf && tid == 0) conv_prof_buf[(size_t)g * 32 + (ID)] = t_; }
+#else
+#define CV_STAMP(ID)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 cv_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 cv_bf16x2 __attribute__((ext_vector_type(2)));
@@ -214,6 +222,7 @@ __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const flo
     const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lptr_cv_t)S);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
+    CV_STAMP(0)
     for (int it = 0; it < sp.rounds + 2; ++it) {
         // the second workgroup of a CU starts with its shared tiles: the two never store / restart at the same time
         const int item = (C::WGS_PER_CU == 2 && g >= (G >> 1)) ? (it + sp.rounds) % (sp.rounds + 2) : it;
@@ -314,13 +323,23 @@ __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const flo
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+        [[maybe_unused]] const int sid = 1 + 8 * (item < sp.rounds ? 0 : item - sp.rounds + 1);      // profile stamps of this item (whole tile | first | second shared tile)
+        CV_STAMP(sid)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave is done with the previous item's stages
         issue_w(kb0, 0);
         load_x(kb0);
         store_x(0);
+        CV_STAMP(sid + 1)
         for (int kb = kb0; kb < kb1; ++kb) {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // this step's stage complete, the other one free
+            // (builtins, not inline asm: hipcc's wait-count pass must SEE that nothing is in flight here.  Behind an asm barrier it assumed
+            //  the previous step's patch loads could still be pending and put `s_waitcnt vmcnt(0)` in front of the first register they
+            //  had targeted -- which then waited for the filter DMA issued two instructions earlier: 2.7 % of the kernel.)
+            __builtin_amdgcn_s_waitcnt(0x0070);                // vmcnt(0) lgkmcnt(0): this step's stage complete ...
+            __builtin_amdgcn_s_barrier();                      // ... for every wave, the other stage free
             const int st = (kb - kb0) & 1;
+#ifdef SC_CONV_PROFILE
+            if (kb == kb0 + 1) CV_STAMP(sid + 5)
+#endif
             if (kb + 1 < kb1) { issue_w(kb + 1, st ^ 1); load_x(kb + 1); }
             const float* Ws = S + st * C::STAGE;
             const float* Xs = Ws + C::WIMG;
@@ -378,6 +397,7 @@ __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const flo
             if (kb + 1 < kb1) store_x(st ^ 1);
         }
 
+        CV_STAMP(sid + 2)
         if (kb0 == 0 && kb1 == nk) {
             conv_store_tile<C>(out, acc, tile, nct, npix, cout, wm, wn, lane);
         } else {                                            // partial tile, in register order (coalesced 256-byte rows)
@@ -389,7 +409,13 @@ __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const flo
 #pragma unroll
                     for (int r = 0; r < 16; ++r) dst[(((wave * WM + i) * WN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
         }
+#ifdef SC_CONV_PROFILE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CV_STAMP(sid + 3)
+        if (conv_prof_buf && tid == 0) conv_prof_buf[(size_t)g * 32 + sid + 4] = (unsigned long long)(kb1 - kb0);
+#endif
     }
+    CV_STAMP(25)
 }
 
 // Four workgroups per shared tile (each takes 4 of the 16 accumulator rows of every 32x32 block): add the partial tiles of the
@@ -402,6 +428,9 @@ __global__ __launch_bounds__(C::NT) void conv3x3_fixup_kernel(const float* __res
     const int npix = batch * C::HWO, nct = (cout + C::CT - 1) / C::CT, tiles = ((npix + C::PT - 1) / C::PT) * nct * (C::BD2 ? 4 : 1);
     const int nk = cin / C::CB;
     const ConvSplit sp = conv_split(tiles, nk, G);
+#ifdef SC_CONV_PROFILE
+    if (conv_prof_buf && tid == 0) conv_prof_buf[(size_t)(8192 + blockIdx.x * 4 + blockIdx.y) * 2] = __builtin_amdgcn_s_memrealtime();
+#endif
     const int t = blockIdx.x, r0 = 4 * blockIdx.y;
     const long long u0 = (long long)t * nk, u1 = u0 + nk;
     const int g_first = (int)(u0 / sp.per_wg), g_last = (int)((u1 - 1) / sp.per_wg);
@@ -440,6 +469,10 @@ __global__ __launch_bounds__(C::NT) void conv3x3_fixup_kernel(const float* __res
                 if (co < cout) ob[(size_t)co * cs] = acc[i][j][r];
             }
     }
+#ifdef SC_CONV_PROFILE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (conv_prof_buf && tid == 0) conv_prof_buf[(size_t)(8192 + blockIdx.x * 4 + blockIdx.y) * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // w [cout][cin][3][3] -> w_pack [ct][kb][tap][half][CT][4]: element (co = ct CT + cl, ci = 8 kb + 4 half + s).  transpose_flip: the filter
@@ -696,6 +729,11 @@ static int launch_conv(const float* x, const float* wpack, float* out, float* wo
         default: return -1;                          \
     }
 // floats of the filter image sc_conv3x3s2_bd_pack writes for a forward filter [cout][cin][3][3]
+#ifdef SC_CONV_PROFILE
+extern "C" int sc_conv_debug_set_prof(unsigned long long* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(sc::conv_prof_buf), &buf, sizeof(buf));
+}
+#endif
 extern "C" long long sc_conv3x3s2_bd_pack_floats(int cin, int cout, int hw) {
 #define CALL(C) (cout % C::CB ? -1 : 5LL * ((cin + C::CT - 1) / C::CT) * (cout / C::CB) * C::PSZ)
     SC_CONV_DISPATCH_BD(hw, CALL)
