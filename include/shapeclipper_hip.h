@@ -495,6 +495,34 @@ int sc_conv1x1s2_forward(const float* x, const float* w, float* out, int batch, 
 int sc_conv1x1s2_backward_data(const float* gy, const float* w, float* gx, int batch, int cin, int cout, int hin, void* stream);
 int sc_conv1x1s2_wgrad(const float* gy, const float* x, float* dw, float* workspace, int batch, int cin, int cout, int hin, void* stream);
 
+/* ---- one call per BasicBlock (csrc/block.hip) ------------------------------------------------------------------------------------------
+ * torchvision BasicBlock with stride 1 and no shortcut convolution, as the reference's ResNet-18 / 34 trunks run it (model/graph.py:50-54,
+ * model/view_estimator.py:40-42):   out = relu( bn2( conv2( relu( bn1( conv1(x) ) ) ) ) + x ),   x, y1, a1, y2, out: [batch][channels][hw][hw].
+ * Host glue over the entry points above (same launches, same order, same results): the caller fills one argument block per call.
+ *   forward : reads x, pf1, pf2 (filter images of sc_conv3x3_pack, forward orientation), the BatchNorm parameters / running statistics
+ *             (rm / rv / nt may be NULL); writes y1 = conv1(x), a1 = relu(bn1(y1)), y2 = conv2(a1), out, st1, st2 ([2][groups][channels]:
+ *             save_mean | save_rstd).
+ *   backward: reads d_out and what the forward wrote, pb1 / pb2 (backward-data filter images); writes dy2, da1, dy1 (scratch the caller
+ *             provides), dgb1 / dgb2 ([2][channels]: dgamma | dbeta), gw1 / gw2 ([channels][channels][3][3], NULL: skipped) and -- when
+ *             need_dx -- dres (scratch) and dx = dL/dx (both uses of x summed).
+ * Workspaces: conv_ws sc_conv3x3_workspace_floats[_split](hw), bn_ws 2 * (2048 + channels * groups), wgrad_ws
+ * sc_conv3x3_wgrad_workspace_floats(channels, channels) floats.  split != 0: the bf16x3-split arithmetic of sc_conv3x3_forward_split /
+ * sc_conv3x3_wgrad_split.  Returns the first non-zero status of the calls it makes.                                                       */
+typedef struct sc_block_args {
+    const float *x, *pf1, *pf2, *pb1, *pb2;
+    const float *g1, *b1, *g2, *b2;
+    float *rm1, *rv1, *rm2, *rv2;
+    int64_t *nt1, *nt2;
+    float *y1, *a1, *y2, *out, *st1, *st2;
+    float *conv_ws, *bn_ws, *wgrad_ws;
+    const float* d_out;
+    float *dy2, *dres, *da1, *dy1, *dx, *gw1, *gw2, *dgb1, *dgb2;
+    int batch, channels, hw, groups, training, split, need_dx;
+    float mom1, eps1, mom2, eps2;
+} sc_block_args;
+int sc_basic_block_forward(const sc_block_args* args, void* stream);
+int sc_basic_block_backward(const sc_block_args* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -809,6 +809,93 @@ def conv3x3_backward_weight(gy, x, split=False):
     return dw
 
 
+# ---- one C call per BasicBlock (csrc/block.hip; include/shapeclipper_hip.h: sc_block_args) ---------------------------------------------
+_P = ctypes.c_void_p
+
+
+class BlockArgs(ctypes.Structure):
+    """ctypes mirror of sc_block_args (field order and types of include/shapeclipper_hip.h)."""
+    _fields_ = ([(n, _P) for n in ("x", "pf1", "pf2", "pb1", "pb2", "g1", "b1", "g2", "b2", "rm1", "rv1", "rm2", "rv2", "nt1", "nt2",
+                                   "y1", "a1", "y2", "out", "st1", "st2", "conv_ws", "bn_ws", "wgrad_ws", "d_out",
+                                   "dy2", "dres", "da1", "dy1", "dx", "gw1", "gw2", "dgb1", "dgb2")]
+                + [(n, ctypes.c_int) for n in ("batch", "channels", "hw", "groups", "training", "split", "need_dx")]
+                + [(n, ctypes.c_float) for n in ("mom1", "eps1", "mom2", "eps2")])
+
+
+_block_fn = {}
+
+
+def _block(name):
+    fn = _block_fn.get(name)
+    if fn is None:
+        fn = getattr(_lib.load()._cdll, name)
+        fn.argtypes, fn.restype = (ctypes.POINTER(BlockArgs), ctypes.c_void_p), ctypes.c_int
+        _block_fn[name] = fn
+    return fn
+
+
+def _wgrad_workspace(x, cin, cout):
+    n = _lib.load().sc_conv3x3_wgrad_workspace_floats(cin, cout)
+    key = (x.device.index, _lib.raw_stream(), "wgrad")
+    ws = _conv_ws.get(key)
+    if ws is None or ws.numel() < n:
+        ws = _conv_ws[key] = torch.empty(n, device=x.device, dtype=torch.float32)
+    return ws
+
+
+def basic_block_forward(x, pf1, pf2, g1, b1, g2, b2, bn1_state, bn2_state, split, groups):
+    """out = relu(bn2(conv2(relu(bn1(conv1(x))))) + x) in one C call (sc_basic_block_forward): returns (out, saved) with saved =
+    (y1, a1, y2, st1, st2) for basic_block_backward.  x must be what _aligned returns; the launches are those of conv3x3_apply /
+    bn_act_forward, in their order."""
+    B, C, H, _ = x.shape
+    rm1, rv1, nt1, training, mom1, eps1 = bn1_state
+    rm2, rv2, nt2, _, mom2, eps2 = bn2_state
+    y1, a1, y2, out = (torch.empty_like(x) for _ in range(4))
+    st = torch.empty(2, 2, groups, C, device=x.device, dtype=torch.float32)
+    _lib._last_device = x.get_device()
+    stream = _lib.raw_stream()
+    a = BlockArgs()
+    a.x, a.pf1, a.pf2 = x.data_ptr(), pf1.data_ptr(), pf2.data_ptr()
+    a.g1, a.b1, a.g2, a.b2 = g1.data_ptr(), b1.data_ptr(), g2.data_ptr(), b2.data_ptr()
+    a.rm1, a.rv1, a.nt1, a.rm2, a.rv2, a.nt2 = _p(rm1), _p(rv1), _p(nt1), _p(rm2), _p(rv2), _p(nt2)
+    a.y1, a.a1, a.y2, a.out = y1.data_ptr(), a1.data_ptr(), y2.data_ptr(), out.data_ptr()
+    a.st1, a.st2 = st[0].data_ptr(), st[1].data_ptr()
+    a.conv_ws, a.bn_ws = _conv_workspace(x.device, H, split).data_ptr(), _bn_partial(x, groups)
+    a.batch, a.channels, a.hw, a.groups, a.training, a.split = B, C, H, groups, 1 if training else 0, 1 if split else 0
+    a.mom1, a.eps1, a.mom2, a.eps2 = mom1, eps1, mom2, eps2
+    code = _block("sc_basic_block_forward")(ctypes.byref(a), stream)
+    if code:
+        _lib.check(code, "sc_basic_block_forward")
+    return out, (y1, a1, y2, st[0], st[1])
+
+
+def basic_block_backward(d_out, x, saved, out, pb1, pb2, g1, b1, g2, b2, training, split, groups, need_dx, need_w1, need_w2):
+    """Gradients of basic_block_forward in one C call (sc_basic_block_backward): (dx | None, gw1 | None, dgamma1, dbeta1, gw2 | None,
+    dgamma2, dbeta2)."""
+    y1, a1, y2, st1, st2 = saved
+    B, C, H, _ = x.shape
+    dy2, da1, dy1 = (torch.empty_like(x) for _ in range(3))
+    dx, dres = (torch.empty_like(x), torch.empty_like(x)) if need_dx else (None, None)
+    gw1 = torch.empty(C, C, 3, 3, device=x.device, dtype=torch.float32) if need_w1 else None
+    gw2 = torch.empty(C, C, 3, 3, device=x.device, dtype=torch.float32) if need_w2 else None
+    dgb = torch.empty(2, 2, C, device=x.device, dtype=torch.float32)
+    _lib._last_device = x.get_device()
+    stream = _lib.raw_stream()
+    a = BlockArgs()
+    a.x, a.pb1, a.pb2, a.d_out = x.data_ptr(), pb1.data_ptr(), pb2.data_ptr(), d_out.data_ptr()
+    a.g1, a.b1, a.g2, a.b2 = g1.data_ptr(), b1.data_ptr(), g2.data_ptr(), b2.data_ptr()
+    a.y1, a.a1, a.y2, a.out, a.st1, a.st2 = y1.data_ptr(), a1.data_ptr(), y2.data_ptr(), out.data_ptr(), st1.data_ptr(), st2.data_ptr()
+    a.dy2, a.da1, a.dy1, a.dres, a.dx = dy2.data_ptr(), da1.data_ptr(), dy1.data_ptr(), _p(dres), _p(dx)
+    a.gw1, a.gw2, a.dgb1, a.dgb2 = _p(gw1), _p(gw2), dgb[0].data_ptr(), dgb[1].data_ptr()
+    a.conv_ws, a.bn_ws = _conv_workspace(x.device, H, split).data_ptr(), _bn_partial(x, groups)
+    a.wgrad_ws = _wgrad_workspace(x, C, C).data_ptr() if (need_w1 or need_w2) else None
+    a.batch, a.channels, a.hw, a.groups, a.training, a.split, a.need_dx = B, C, H, groups, 1 if training else 0, 1 if split else 0, 1 if need_dx else 0
+    code = _block("sc_basic_block_backward")(ctypes.byref(a), stream)
+    if code:
+        _lib.check(code, "sc_basic_block_backward")
+    return dx, gw1, dgb[0, 0], dgb[0, 1], gw2, dgb[1, 0], dgb[1, 1]
+
+
 def conv_stem_supported(x_shape, w_shape, stride=2, padding=3) -> bool:
     """Shapes sc_conv_stem_* take: [B, 3, 224, 224] inputs, a [64, 3, 7, 7] filter, stride 2, pad 3."""
     return (tuple(x_shape[1:]) == (3, 224, 224) and tuple(w_shape) == (64, 3, 7, 7) and stride in (2, (2, 2)) and padding in (3, (3, 3)))
