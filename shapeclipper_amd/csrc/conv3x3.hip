@@ -28,7 +28,16 @@
 // out (<= 0.1 byte per FLOP), i.e. compute bound by two orders of magnitude.
 #include <hip/hip_runtime.h>
 
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
 #include "shapeclipper_hip.h"
+
+#ifndef SC_CONV_SPANS
+#define SC_CONV_SPANS 1
+#endif
 
 namespace sc {
 
@@ -107,7 +116,9 @@ __host__ __device__ constexpr int bd2_patch_tap(int phase, int pair, int h) {
          : pair == 0 ? (h == 0 ? 8 : 7) : (h == 0 ? 5 : 4);
 }
 
-// The tiles of the last, incomplete round of the grid are cut into equal spans of K-steps ("units").
+// The tiles of the last, incomplete round of the grid are cut into spans of K-steps ("units"), one span per workgroup: the units [U[g],
+// U[g + 1]) of the tile-major unit sequence, from a table the host builds once per (tiles, K-steps, grid) (conv_spans below; a null
+// table = equal spans of per_wg units).  A span is at most one tile's worth of units long, i.e. it touches one or two tiles.
 struct ConvSplit {
     int rounds;          // whole rounds: workgroup g computes tiles r * G + g, r < rounds, completely
     int tail_tiles;      // tiles rounds * G .. rounds * G + tail_tiles - 1 are shared
@@ -119,6 +130,21 @@ __host__ __device__ inline ConvSplit conv_split(int tiles, int nk, int G) {
     s.tail_tiles = tiles - s.rounds * G;
     s.per_wg = (int)(((long long)s.tail_tiles * nk + G - 1) / G);
     return s;
+}
+
+// first unit of workgroup g's span (g == G: the end of the sequence)
+__device__ __forceinline__ long long conv_span_at(const int* __restrict__ spans, const ConvSplit& sp, int g, int nk) {
+    return spans ? (long long)spans[g] : min((long long)g * sp.per_wg, (long long)sp.tail_tiles * nk);
+}
+// the workgroup whose span holds unit u
+__device__ __forceinline__ int conv_span_owner(const int* __restrict__ spans, const ConvSplit& sp, long long u, int G) {
+    if (!spans) return (int)(u / sp.per_wg);
+    int lo = 0, hi = G - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (spans[mid] <= u) lo = mid; else hi = mid - 1;
+    }
+    return lo;
 }
 
 // acc[r] of a 32x32 C/D tile is row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31
@@ -205,7 +231,7 @@ __device__ __forceinline__ void conv_bd2_step(const float* Ws, const float* Xs, 
 template <class C>
 __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const float* __restrict__ x, const float* __restrict__ wpack,
                                                              float* __restrict__ out, float* __restrict__ partial, int batch, int cin,
-                                                             int cout) {
+                                                             int cout, const int* __restrict__ spans) {
     constexpr int W = C::W, Wp = C::Wp, HW = C::HW, Sp = C::Sp, CT = C::CT, PT = C::PT, CB = C::CB, NT = C::NT;
     constexpr int WM = C::WM, WN = C::WN, LX = C::LX, NXE = C::NXE;
     extern __shared__ float4 conv_smem[];
@@ -218,7 +244,7 @@ __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const flo
     // workgroup b runs on XCD b % 8: give every XCD a contiguous range of each round's tiles (shared patches / weights stay in its L2)
     const int xq = G >> 3, xr = G & 7, xcd = g & 7;
     const int gperm = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (g >> 3);
-    const long long unit_lo = (long long)g * sp.per_wg, unit_hi = min((long long)(g + 1) * sp.per_wg, (long long)sp.tail_tiles * nk);
+    const long long unit_lo = conv_span_at(spans, sp, g, nk), unit_hi = conv_span_at(spans, sp, g + 1, nk);
     const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lptr_cv_t)S);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
@@ -422,7 +448,7 @@ __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const flo
 // workgroups whose spans cover it, in K order, and store the result.
 template <class C>
 __global__ __launch_bounds__(C::NT) void conv3x3_fixup_kernel(const float* __restrict__ partial, float* __restrict__ out, int batch,
-                                                              int cin, int cout, int G) {
+                                                              int cin, int cout, int G, const int* __restrict__ spans) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / C::WGN, wn = wave % C::WGN;
     const int npix = batch * C::HWO, nct = (cout + C::CT - 1) / C::CT, tiles = ((npix + C::PT - 1) / C::PT) * nct * (C::BD2 ? 4 : 1);
@@ -433,8 +459,8 @@ __global__ __launch_bounds__(C::NT) void conv3x3_fixup_kernel(const float* __res
 #endif
     const int t = blockIdx.x, r0 = 4 * blockIdx.y;
     const long long u0 = (long long)t * nk, u1 = u0 + nk;
-    const int g_first = (int)(u0 / sp.per_wg), g_last = (int)((u1 - 1) / sp.per_wg);
-    if (g_first == g_last && (long long)g_first * sp.per_wg == u0 && sp.per_wg == nk) return;      // computed whole, already stored
+    const int g_first = conv_span_owner(spans, sp, u0, G), g_last = conv_span_owner(spans, sp, u1 - 1, G);
+    if (g_first == g_last && conv_span_at(spans, sp, g_first, nk) == u0 && conv_span_at(spans, sp, g_first + 1, nk) == u1) return;   // computed whole, already stored
     float acc[C::WM][C::WN][4];
 #pragma unroll
     for (int i = 0; i < C::WM; ++i)
@@ -443,7 +469,7 @@ __global__ __launch_bounds__(C::NT) void conv3x3_fixup_kernel(const float* __res
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
     for (int g = g_first; g <= g_last; ++g) {
-        const int which = (int)(((long long)g * sp.per_wg) / nk) == t ? 0 : 1;      // first or second tile of that workgroup's span
+        const int which = (int)(conv_span_at(spans, sp, g, nk) / nk) == t ? 0 : 1;  // first or second tile of that workgroup's span
         const float* src = partial + ((size_t)g * 2 + which) * C::TILE;
 #pragma unroll
         for (int i = 0; i < C::WM; ++i)
@@ -679,16 +705,63 @@ static int launch_pack(const float* w, float* wpack, int cin, int cout, int tf, 
     return (int)hipGetLastError();
 }
 
+// Span table of the shared tiles.  Every tile a workgroup touches costs it a fixed overhead besides the K-steps -- staging the first
+// stage, a slower first K-step, the partial-tile store: ~5 us measured (tools/prof_conv_phases.py), the time of `ov2` HALF K-steps -- so
+// equal spans leave the workgroups whose span crosses a tile boundary (40 % of them at 14 x 14) one overhead behind the others and the
+// launch waits for them.  Here a span's cost is 2 * units + ov2 * tiles touched, and the spans are the greedy cut at the smallest cost
+// bound that still covers all units with G workgroups.  Built once per (device, tail tiles, K-steps, grid, ov2) and kept on the device.
+static const int* conv_spans(int tail_tiles, int nk, int G, int ov2) {
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int, int, int>, int*> cache;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_tuple(dev, tail_tiles, nk, G, ov2);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    const int total = tail_tiles * nk;
+    std::vector<int> U(G + 1), best;
+    auto build = [&](int bound) {
+        int pos = 0;
+        for (int g = 0; g < G; ++g) {
+            U[g] = pos;
+            int end = pos;
+            while (end < total && end - pos < nk) {
+                const int e1 = end + 1, items = (e1 - 1) / nk - pos / nk + 1;
+                if (end > pos && 2 * (e1 - pos) + ov2 * items > bound) break;     // (a span holds at least one unit)
+                end = e1;
+            }
+            pos = end;
+        }
+        U[G] = total;
+        return pos >= total;
+    };
+    int lo = 2 * ((total + G - 1) / G), hi = lo + 4 * ov2 + 4;       // hi: the equal cut fits (<= per_wg units, <= 2 tiles)
+    while (!build(hi)) hi += 2 * nk;
+    while (lo < hi) {
+        const int mid = (lo + hi) / 2;
+        if (build(mid)) hi = mid; else lo = mid + 1;
+    }
+    (void)build(hi);
+    int* d = nullptr;
+    if (hipMalloc(&d, (size_t)(G + 1) * sizeof(int)) != hipSuccess || hipMemcpy(d, U.data(), (size_t)(G + 1) * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+        d = nullptr;                                                  // (null: the kernels fall back to equal spans)
+    cache[key] = d;
+    return d;
+}
+
 template <class C>
 static int launch_conv(const float* x, const float* wpack, float* out, float* workspace, int batch, int cin, int cout, hipStream_t st) {
     if (cin % C::CB || batch <= 0) return (int)hipErrorInvalidValue;
     const int tiles = ((batch * C::HWO + C::PT - 1) / C::PT) * ((cout + C::CT - 1) / C::CT) * (C::BD2 ? 4 : 1), nk = cin / C::CB;
     const int G = conv_grid() * C::WGS_PER_CU;
     (void)hipFuncSetAttribute((const void*)conv3x3_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-    hipLaunchKernelGGL((conv3x3_kernel<C>), dim3(G), dim3(C::NT), C::LDS_BYTES, st, x, wpack, out, workspace, batch, cin, cout);
     const ConvSplit sp = conv_split(tiles, nk, G);
+    // overhead of a touched tile in half K-steps: a K-step of the 512-pixel tiles takes ~5.3 us, of the 256-pixel tiles ~3.2
+    const int* spans = (SC_CONV_SPANS && sp.tail_tiles > 0 && sp.per_wg <= nk) ? conv_spans(sp.tail_tiles, nk, G, C::PT >= 512 ? 2 : 3) : nullptr;
+    hipLaunchKernelGGL((conv3x3_kernel<C>), dim3(G), dim3(C::NT), C::LDS_BYTES, st, x, wpack, out, workspace, batch, cin, cout, spans);
     if (sp.tail_tiles > 0)
-        hipLaunchKernelGGL((conv3x3_fixup_kernel<C>), dim3(sp.tail_tiles, 4), dim3(C::NT), 0, st, workspace, out, batch, cin, cout, G);
+        hipLaunchKernelGGL((conv3x3_fixup_kernel<C>), dim3(sp.tail_tiles, 4), dim3(C::NT), 0, st, workspace, out, batch, cin, cout, G, spans);
     return (int)hipGetLastError();
 }
 
