@@ -429,7 +429,8 @@ long long sc_conv3x3_workspace_floats(int hw);
 int sc_conv3x3_tile_channels(int hw);
 int sc_conv3x3_pack_multi(const long long* table, int n, float* dst, long long total, void* stream);
 /* The same table, for the case that EVERY row is a split image (transpose_flip bit 1) with 64-channel tiles (sc_conv3x3_tile_channels_split
- * = 64): one workgroup per 64 x 8 x 9 unit of a filter, contiguous reads and writes (byte-identical images); total % 7680 must be 0.  */
+ * = 64): one workgroup per 64 x 16 x 9 unit of a filter (a pair of K-steps: nine tap-pair images, see csrc/conv3x3.hip), contiguous reads
+ * and writes (byte-identical images); total % 13824 must be 0.                                                                          */
 int sc_conv3x3_pack_multi_units(const long long* table, int n, float* dst, long long total, void* stream);
 int sc_conv3x3_pack(const float* w, float* w_pack, int cin, int cout, int hw, int transpose_flip, void* stream);
 int sc_conv3x3_forward(const float* x, const float* w_pack, float* out, float* workspace, int batch, int cin, int cout, int hw,

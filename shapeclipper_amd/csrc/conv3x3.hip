@@ -71,12 +71,17 @@ struct ConvCfg {
     static constexpr bool SPLIT = SPLIT_;            // operands as three bf16 pieces on the bf16 matrix pipe (see conv3x3 SPLIT below)
     static constexpr bool BD2 = BD2_;
     static constexpr int PSZ = 3 * 2 * CT * 4;       // floats of one tap-pair image (SPLIT): [piece][half][CT][8 bf16]
+    // PAIRED (the split stride-1 instance): no zero tap.  Taps 0..7 of a K-step are four tap pairs; tap 8 of an EVEN step shares its
+    // MFMAs with tap 8 of the following odd step (lane half 0: the even step's channels, half 1: the odd step's), computed in the odd
+    // step from the two patch stages: 9 tap-pair products per two K-steps instead of 10.  K-steps come in pairs: an odd channel-block
+    // count is rounded up with a step of zero weights over zero inputs.
+    static constexpr bool PAIRED = SPLIT && !BD2_;
     static_assert(!BD2 || (SPLIT && S_ == 1), "the stride-2 backward-data instance exists in the split arithmetic only");
     static constexpr int Wp = W + 2, HW = W * W, Sp = Wp * Wp;             // geometry of the INPUT map (W x W, one pad ring)
     static constexpr int S = S_, WO = W / S, HWO = WO * WO;                  // stride and output map (stride 2: the three conv1 of layer2-4)
     static constexpr int NT = 64 * WGM * WGN;
     static constexpr int WM = CT / (32 * WGM), WN = PT / (32 * WGN);        // 32x32 MFMA tiles per wave
-    // floats (4-byte units) of one weight stage: fp32 [tap][half][CT][4]; SPLIT [tap pair (5)][piece (3)][half][CT][8 bf16]
+    // floats (4-byte units) of one weight stage: fp32 [tap][half][CT][4]; SPLIT up to five tap-pair images [piece (3)][half][CT][8 bf16]
     static constexpr int WIMG = BD2 ? 2 * PSZ : (SPLIT ? 5 * PSZ : 9 * CB * CT);
     // longest padded-flat span of PT consecutive (output) pixels plus the halo.  Stride 1: 2 pad columns per row crossed, 2 pad rows
     // per image crossed.  Stride S: S positions per pixel, S (Wp - WO) extra per row crossed, Sp - S (WO - 1)(Wp + 1) per image crossed.
@@ -115,6 +120,10 @@ __host__ __device__ constexpr int bd2_patch_tap(int phase, int pair, int h) {
          : phase == 2 ? (h == 0 ? 7 : 4)
          : pair == 0 ? (h == 0 ? 8 : 7) : (h == 0 ? 5 : 4);
 }
+
+// K-steps of a tile: channel blocks of CB, rounded up to a pair for the PAIRED instances
+template <class C>
+__host__ __device__ constexpr int conv_nk(int cin) { return C::PAIRED ? ((cin / C::CB + 1) & ~1) : cin / C::CB; }
 
 // The tiles of the last, incomplete round of the grid are cut into spans of K-steps ("units"), one span per workgroup: the units [U[g],
 // U[g + 1]) of the tile-major unit sequence, from a table the host builds once per (tiles, K-steps, grid) (conv_spans below; a null
@@ -239,7 +248,7 @@ __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const flo
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const int wm = wave / C::WGN, wn = wave % C::WGN;
     const int npix = batch * C::HWO, nct = (cout + CT - 1) / CT, tiles = ((npix + PT - 1) / PT) * nct * (C::BD2 ? 4 : 1);
-    const int nk = cin / CB, G = gridDim.x, g = blockIdx.x;
+    const int nk = conv_nk<C>(cin), nk_real = cin / CB, G = gridDim.x, g = blockIdx.x;
     const ConvSplit sp = conv_split(tiles, nk, G);
     // workgroup b runs on XCD b % 8: give every XCD a contiguous range of each round's tiles (shared patches / weights stay in its L2)
     const int xq = G >> 3, xr = G & 7, xcd = g & 7;
@@ -293,25 +302,46 @@ __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const flo
         }
 
         // filter image of one K-step: [ct][kb][tap][half][CT][4]; BD2: [phase][ct][kb][pair][piece][half][CT][8 bf16], 1 or 2 pairs per phase
+        // PAIRED: [ct][K-step pair][9 images]: images 0..3 the even step's tap pairs, 4..7 the odd step's, 8 the shared tap-8 pair -- an even
+        // step stages 4 images, an odd step 5 (its own four and the shared one)
         const int wimg = C::BD2 ? bd2_pairs(phase) * C::PSZ : C::WIMG;
-        const float* wsrc = wpack + (C::BD2 ? (size_t)bd2_pair_base(phase) * nct * nk * C::PSZ : 0) + (size_t)ct * nk * wimg;
+        const float* wsrc = wpack + (C::BD2 ? (size_t)bd2_pair_base(phase) * nct * nk * C::PSZ : 0) +
+                            (C::PAIRED ? (size_t)ct * (nk >> 1) * 9 * C::PSZ : (size_t)ct * nk * wimg);
         auto issue_w = [&](int kb, int stage) {
-            const int CHUNKS = wimg / 4;
-            const char* src = reinterpret_cast<const char*>(wsrc + (size_t)kb * wimg);
+            const int CHUNKS = C::PAIRED ? ((kb & 1) ? 5 : 4) * C::PSZ / 4 : wimg / 4;
+            const char* src = reinterpret_cast<const char*>(wsrc + (C::PAIRED ? ((size_t)(kb >> 1) * 9 + (kb & 1) * 4) * C::PSZ : (size_t)kb * wimg));
             const unsigned dst = lds0 + (unsigned)stage * (C::STAGE * 4);
 #pragma unroll
-            for (int c = 0; c < (CHUNKS + NT - 1) / NT; ++c) {
+            for (int c = 0; c < (C::WIMG / 4 + NT - 1) / NT; ++c) {
                 const int chunk0 = c * NT + wave_u * 64;                     // wave-uniform
                 if (chunk0 + lane < CHUNKS) conv_glds16(src + (size_t)(chunk0 + lane) * 16, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + chunk0 * 16)));
             }
         };
         float xv[NXE][CB];
+        unsigned xkeep = 0xffffffffu;
+        // SPLIT: x through a buffer resource -- a position outside the images carries an out-of-range offset (the load returns 0, no
+        // branch), the channel plane is the scalar offset.  The zero step that completes a pair (kb >= nk_real, odd cin / 8 only) reads
+        // whatever follows its block (0 past the end of x) and store_x masks the values: zero weights would not silence an Inf.
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(x), 0, (int)min((long long)batch * cin * HW * 4, 0x7fffffffLL), 0x00020000);
+        int xoffb[NXE];
+#pragma unroll
+        for (int i = 0; i < NXE; ++i) xoffb[i] = xoff[i] >= 0 ? xoff[i] * 4 : (int)0x80000000;
         auto load_x = [&](int kb) {
-            const float* xb = x + (size_t)kb * CB * HW;
+            if constexpr (C::SPLIT) {
+                xkeep = kb < nk_real ? 0xffffffffu : 0u;
 #pragma unroll
-            for (int i = 0; i < NXE; ++i)
+                for (int i = 0; i < NXE; ++i)
 #pragma unroll
-                for (int c = 0; c < CB; ++c) xv[i][c] = xoff[i] >= 0 ? xb[xoff[i] + c * HW] : 0.f;
+                    for (int c = 0; c < CB; ++c)
+                        xv[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xoffb[i], (kb * CB + c) * HW * 4, 0));
+            } else {
+                const float* xb = x + (size_t)kb * CB * HW;
+#pragma unroll
+                for (int i = 0; i < NXE; ++i)
+#pragma unroll
+                    for (int c = 0; c < CB; ++c) xv[i][c] = xoff[i] >= 0 ? xb[xoff[i] + c * HW] : 0.f;
+            }
         };
         auto store_x = [&](int stage) {
             float4* Xs = reinterpret_cast<float4*>(S + stage * C::STAGE + C::WIMG);
@@ -323,7 +353,7 @@ __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const flo
                         cv_bf16x8 p0, p1, p2;
 #pragma unroll
                         for (int c = 0; c < CB; ++c) {
-                            const float v = xv[i][c];
+                            const float v = C::PAIRED ? __uint_as_float(__float_as_uint(xv[i][c]) & xkeep) : xv[i][c];
                             const __bf16 h0 = (__bf16)v;
                             const float r1 = v - (float)h0;
                             const __bf16 h1 = (__bf16)r1;
@@ -352,6 +382,13 @@ __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const flo
         [[maybe_unused]] const int sid = 1 + 8 * (item < sp.rounds ? 0 : item - sp.rounds + 1);      // profile stamps of this item (whole tile | first | second shared tile)
         CV_STAMP(sid)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave is done with the previous item's stages
+        // A span that starts on an odd step needs the even partner's patch in the other stage (the shared tap-8 pair reads it).  Staged
+        // unconditionally (an even start re-stages its own block there: nobody reads it) and before the filter DMA: straight-line code --
+        // with a conditional staging hipcc's wait-count pass put `s_waitcnt vmcnt(0)` between the loads, one round trip each.
+        if constexpr (C::PAIRED) {
+            load_x(kb0 - (kb0 & 1));
+            store_x(1);
+        }
         issue_w(kb0, 0);
         load_x(kb0);
         store_x(0);
@@ -377,13 +414,31 @@ __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const flo
                     default: conv_bd2_step<C, 3>(Ws, Xs, aoff, boff, half, acc); break;
                 }
             } else if constexpr (C::SPLIT) {
-                // k block of an MFMA (32x32x16): lane half h holds the 8 channels of tap 2 tp + h (tap 9: zero weights).  Per tap pair:
-                // WM + WN operand tiles x 3 pieces, six products a_p b_q with p + q <= 2 (what is dropped is < 2^-23 of |a||b|)
+                // k block of an MFMA (32x32x16): lane half h holds the 8 channels of tap 2 tp + h.  Per tap pair: WM + WN operand tiles x 3
+                // pieces, six products a_p b_q with p + q <= 2 (what is dropped is < 2^-23 of |a||b|)
                 float4 a[WM][3], b[WN][3];
+                if (kb & 1) {
+                    // the shared tap-8 pair of K-steps kb - 1 (lane half 0: its patch is still in the OTHER stage) and kb (half 1).  It
+                    // goes first, and a barrier separates its reads from this step's store_x into that stage: the workgroup's waves were
+                    // released together a few instructions ago, the barrier costs no skew here.
+                    constexpr int o8 = 2 * Wp + 2;
+                    const int xother = half ? 0 : (st ? -C::STAGE : C::STAGE);
 #pragma unroll
-                for (int tp = 0; tp < 5; ++tp) {
-                    constexpr int DUMMY = 8;                                   // the 10th "tap" reads tap 8's patch values (finite), weights 0
-                    const int t0 = 2 * tp, t1 = 2 * tp + 1 < 9 ? 2 * tp + 1 : DUMMY;
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc) a[i][pc] = *reinterpret_cast<const float4*>(Ws + aoff[i] + (4 * 3 + pc) * 2 * CT * 4);
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc)
+                            b[j][pc] = *reinterpret_cast<const float4*>(Xs + xother + boff[j] + (pc * LX + o8) * 4);
+                    __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0) (vmcnt, expcnt: no wait): the reads of the other stage are done ...
+                    __builtin_amdgcn_s_barrier();                  // ... in every wave
+                    conv_split_terms<C>(a, b, acc);
+                }
+#pragma unroll
+                for (int tp = 0; tp < 4; ++tp) {
+                    const int t0 = 2 * tp, t1 = 2 * tp + 1;
                     const int o0 = (t0 / 3) * Wp + t0 % 3, o1 = (t1 / 3) * Wp + t1 % 3;
 #pragma unroll
                     for (int i = 0; i < WM; ++i)
@@ -452,7 +507,7 @@ __global__ __launch_bounds__(C::NT) void conv3x3_fixup_kernel(const float* __res
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / C::WGN, wn = wave % C::WGN;
     const int npix = batch * C::HWO, nct = (cout + C::CT - 1) / C::CT, tiles = ((npix + C::PT - 1) / C::PT) * nct * (C::BD2 ? 4 : 1);
-    const int nk = cin / C::CB;
+    const int nk = conv_nk<C>(cin);
     const ConvSplit sp = conv_split(tiles, nk, G);
 #ifdef SC_CONV_PROFILE
     if (conv_prof_buf && tid == 0) conv_prof_buf[(size_t)(8192 + blockIdx.x * 4 + blockIdx.y) * 2] = __builtin_amdgcn_s_memrealtime();
@@ -517,7 +572,8 @@ __device__ __forceinline__ unsigned conv_bf16_piece(float v, int pc) {
     return (unsigned)__builtin_bit_cast(unsigned short, h);
 }
 // one 4-byte word of a packed filter image.  fp32: [tap][half][CT][4]: element (co = ct CT + cl, ci = 8 kb + 4 half + s).
-// split: [tap pair][piece][half][CT][8 bf16]: lane half h of tap pair tp holds tap 2 tp + h (tap 9 = zeros), channels 8 kb .. 8 kb + 7.
+// split: per pair of K-steps nine images [piece][half][CT][8 bf16]: pairs (0,1) .. (6,7) of the even step, of the odd step, then the
+// tap-8 pair (lane half 0: channels of the even step, half 1: of the odd step); a missing odd step (odd cin / 8) is zeros.
 // (t is a 32-bit offset inside ONE filter's image: at most 512 x 512 x 10 x 3 / 2 words -- 64-bit divisions by the run-time CT / nk
 // made the all-filters pack kernel compute-bound: 284 us per network)
 __device__ __forceinline__ float conv_pack_word(const float* __restrict__ w, unsigned t, int CT, int nk, int cin, int cout, int flip,
@@ -543,12 +599,14 @@ __device__ __forceinline__ float conv_pack_word(const float* __restrict__ w, uns
     t >>= 1;
     const int pc = (int)(t % 3);
     t /= 3;
-    const int tp = (int)(t % 5);
-    t /= 5;
-    const int kb = (int)(t % nk), ct = (int)(t / nk);
-    const int tap = 2 * tp + h, co = ct * CT + cl, ci = kb * 8 + 2 * wi;
+    // nine tap-pair images per PAIR of K-steps: pairs 0..3 of the even step, pairs 0..3 of the odd step, the shared tap-8 pair
+    const int slot = (int)(t % 9);
+    t /= 9;
+    const int nkp = (nk + 1) >> 1, kp = (int)(t % nkp), ct = (int)(t / nkp);
+    const int kb = 2 * kp + (slot < 4 ? 0 : (slot < 8 ? 1 : h)), tap = slot < 8 ? 2 * (slot & 3) + h : 8;
+    const int co = ct * CT + cl, ci = kb * 8 + 2 * wi;
     unsigned lo = 0, hi = 0;
-    if (tap < 9 && co < cout) {
+    if (kb < nk && co < cout) {
         lo = conv_bf16_piece(conv_w_at(w, cin, cout, co, ci, tap, flip), pc);
         hi = conv_bf16_piece(conv_w_at(w, cin, cout, co, ci + 1, tap, flip), pc);
     }
@@ -589,7 +647,7 @@ __global__ void conv3x3_pack_bd2_kernel(const float* __restrict__ w, float* __re
 template <class C>
 __global__ void conv3x3_pack_kernel(const float* __restrict__ w, float* __restrict__ wpack, int cin, int cout, int transpose_flip) {
     const int nk = cin / C::CB, nct = (cout + C::CT - 1) / C::CT;
-    const long long total = (long long)nct * nk * C::WIMG;
+    const long long total = C::PAIRED ? (long long)nct * ((nk + 1) / 2) * 9 * C::PSZ : (long long)nct * nk * C::WIMG;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
         wpack[i] = conv_pack_word(w, (unsigned)i, C::CT, nk, cin, cout, transpose_flip, C::SPLIT);
 }
@@ -616,7 +674,11 @@ using Conv14BD = ConvCfg<14, 64, 512, 1, 8, true, 1, true>;
 using Conv7BD = ConvCfg<7, 64, 256, 1, 8, true, 1, true>;
 
 template <class C>
-static long long pack_floats(int cin, int cout) { return cin % C::CB ? -1 : (long long)((cout + C::CT - 1) / C::CT) * (cin / C::CB) * C::WIMG; }
+static long long pack_floats(int cin, int cout) {
+    if (cin % C::CB) return -1;
+    const long long nct = (cout + C::CT - 1) / C::CT, nk = cin / C::CB;
+    return C::PAIRED ? nct * ((nk + 1) / 2) * 9 * C::PSZ : nct * nk * C::WIMG;
+}
 
 // All filters of a network in ONE launch (they change once per optimizer step): table row e = {address of w, first float of its image
 // in dst, cin, cout, CT of the map side's tile shape, transpose_flip}; rows sorted by their first float, `total` = end of the last one.
@@ -637,12 +699,13 @@ __global__ void conv3x3_pack_multi_kernel(const long long* __restrict__ table_g,
     }
 }
 
-// The same for tables whose rows are all SPLIT images with 64-channel tiles (the default arithmetic): one workgroup per (filter, ct, kb)
-// unit = 64 output channels x 8 reduction channels x 9 taps.  The 4608 weights of a unit arrive in LDS through contiguous segments (72
-// floats per output channel; 576 per reduction channel in the transposed orientation) and leave as the unit's 7680 contiguous words
-// [tap pair][piece][half][64][4]: the word-driven kernel above gathers two weights per word from 64 different cache lines per wave.
+// The same for tables whose rows are all SPLIT images with 64-channel tiles (the default arithmetic): one workgroup per (filter, ct,
+// pair of K-steps) unit = 64 output channels x 16 reduction channels x 9 taps.  The 9216 weights of a unit arrive in LDS through
+// contiguous segments (144 floats per output channel; 576 per reduction channel in the transposed orientation) and leave as the unit's
+// 13824 contiguous words [9 images][piece][half][64][4]: the word-driven kernel above gathers two weights per word from 64 different
+// cache lines per wave.
 __global__ __launch_bounds__(256) void conv3x3_pack_multi_split_kernel(const long long* __restrict__ table_g, int n, float* __restrict__ dst) {
-    constexpr int CT = 64, UNIT = 5 * 3 * 2 * CT * 4, LST = 73;
+    constexpr int CT = 64, UNIT = 9 * 3 * 2 * CT * 4, LST = 145;
     __shared__ float wl[CT * LST];
     __shared__ long long row_s[6];
     const int tid = threadIdx.x;
@@ -657,32 +720,30 @@ __global__ __launch_bounds__(256) void conv3x3_pack_multi_split_kernel(const lon
     }
     __syncthreads();
     const float* w = reinterpret_cast<const float*>(row_s[0]);
-    const int cin = (int)row_s[2], cout = (int)row_s[3], flip = (int)row_s[5] & 1, nk = cin / 8;
-    const int unit = (int)((i0 - row_s[1]) / UNIT), ct = unit / nk, kb = unit - ct * nk;
-    for (int e = tid; e < 8 * CT * 9; e += 256) {
+    const int cin = (int)row_s[2], cout = (int)row_s[3], flip = (int)row_s[5] & 1, nkp = (cin / 8 + 1) / 2;
+    const int unit = (int)((i0 - row_s[1]) / UNIT), ct = unit / nkp, kp = unit - ct * nkp;
+    for (int e = tid; e < 16 * CT * 9; e += 256) {
         int cl, sc, tap;
         float v = 0.f;
         if (flip) {      // w[ci][co][8 - tap]: per reduction channel 64 x 9 contiguous floats
             sc = e / (CT * 9);
             const int r = e - sc * (CT * 9);
             cl = r / 9; tap = 8 - (r - cl * 9);
-            if (ct * CT + cl < cout) v = w[((size_t)(kb * 8 + sc) * cout + ct * CT) * 9 + r];
-        } else {         // w[co][ci][tap]: per output channel 8 x 9 contiguous floats
-            cl = e / 72;
-            const int r = e - cl * 72;
+            if (ct * CT + cl < cout && kp * 16 + sc < cin) v = w[((size_t)(kp * 16 + sc) * cout + ct * CT) * 9 + r];
+        } else {         // w[co][ci][tap]: per output channel 16 x 9 contiguous floats
+            cl = e / 144;
+            const int r = e - cl * 144;
             sc = r / 9; tap = r - sc * 9;
-            if (ct * CT + cl < cout) v = w[((size_t)(ct * CT + cl) * cin + kb * 8) * 9 + r];
+            if (ct * CT + cl < cout && kp * 16 + sc < cin) v = w[((size_t)(ct * CT + cl) * cin + kp * 16) * 9 + r];
         }
         wl[cl * LST + sc * 9 + tap] = v;
     }
     __syncthreads();
     for (int v = tid; v < UNIT; v += 256) {
-        const int wi = v & 3, cl = (v >> 2) & 63, h = (v >> 8) & 1, q = v >> 9, pc = q % 3, tp = q / 3, tap = 2 * tp + h;
-        unsigned lo = 0, hi = 0;
-        if (tap < 9) {
-            lo = conv_bf16_piece(wl[cl * LST + (2 * wi) * 9 + tap], pc);
-            hi = conv_bf16_piece(wl[cl * LST + (2 * wi + 1) * 9 + tap], pc);
-        }
+        const int wi = v & 3, cl = (v >> 2) & 63, h = (v >> 8) & 1, q = v >> 9, pc = q % 3, slot = q / 3;
+        const int kl = slot < 4 ? 0 : (slot < 8 ? 1 : h), tap = slot < 8 ? 2 * (slot & 3) + h : 8;       // K-step of the pair, tap
+        const unsigned lo = conv_bf16_piece(wl[cl * LST + (8 * kl + 2 * wi) * 9 + tap], pc);
+        const unsigned hi = conv_bf16_piece(wl[cl * LST + (8 * kl + 2 * wi + 1) * 9 + tap], pc);
         dst[i0 + v] = __uint_as_float(lo | (hi << 16));
     }
 }
@@ -753,7 +814,7 @@ static const int* conv_spans(int tail_tiles, int nk, int G, int ov2) {
 template <class C>
 static int launch_conv(const float* x, const float* wpack, float* out, float* workspace, int batch, int cin, int cout, hipStream_t st) {
     if (cin % C::CB || batch <= 0) return (int)hipErrorInvalidValue;
-    const int tiles = ((batch * C::HWO + C::PT - 1) / C::PT) * ((cout + C::CT - 1) / C::CT) * (C::BD2 ? 4 : 1), nk = cin / C::CB;
+    const int tiles = ((batch * C::HWO + C::PT - 1) / C::PT) * ((cout + C::CT - 1) / C::CT) * (C::BD2 ? 4 : 1), nk = conv_nk<C>(cin);
     const int G = conv_grid() * C::WGS_PER_CU;
     (void)hipFuncSetAttribute((const void*)conv3x3_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     const ConvSplit sp = conv_split(tiles, nk, G);
@@ -901,8 +962,8 @@ extern "C" int sc_conv3x3_tile_channels(int hw) {
 // `unit_form` != 0: the caller guarantees that every row is a split image with 64-channel tiles (flags & 2, CT = 64): the unit kernel.
 extern "C" int sc_conv3x3_pack_multi_units(const long long* table, int n, float* dst, long long total, void* stream) {
     if (n <= 0 || total <= 0) return 0;
-    if (n > 128 || total % 7680) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(sc::conv3x3_pack_multi_split_kernel, dim3((unsigned)(total / 7680)), dim3(256), 0, (hipStream_t)stream, table, n, dst);
+    if (n > 128 || total % 13824) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(sc::conv3x3_pack_multi_split_kernel, dim3((unsigned)(total / 13824)), dim3(256), 0, (hipStream_t)stream, table, n, dst);
     return (int)hipGetLastError();
 }
 

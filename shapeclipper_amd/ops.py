@@ -1060,7 +1060,7 @@ class Conv3x3PackSet:
         dev = self.weights[0].device
         self.total = off
         # all rows split images with 64-channel tiles: the unit-per-workgroup pack kernel (coalesced reads, contiguous writes)
-        self.units = bool(split) and all(r[4] == 64 for r in rows) and off % 7680 == 0
+        self.units = bool(split) and all(r[4] == 64 for r in rows) and off % 13824 == 0
         self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
         self.buf = torch.empty(off, device=dev, dtype=torch.float32)
         self.index = {id(w): k for k, w in enumerate(self.weights)}
