@@ -237,8 +237,9 @@ def main():
                             "instead of the exact bf16x3 split; not the headline")
         finally:
             resnet.HIP_CONV3X3_SPLIT = True
-    # BASELINE config[1] ("Pix3D train.py bs16, 1 x MI355X") beside the headline: the same step at 16 images per GPU on its own runner.  At this
-    # size the step is paced by the host (enqueue work per step does not shrink with the batch), which is what the object says.
+    # BASELINE config[1] ("Pix3D train.py bs16, 1 x MI355X") beside the headline: the same step at 16 images per GPU on its own runner.  The
+    # step is GPU-bound at this size too (2 ms less host work per step did not move it: DESIGN.md section 6); what does not shrink with the
+    # batch is the fixed part of every launch (~33 us per convolution outside its K loop), which is what the object says.
     config1 = None
     if world == 1 and not a.no_alt and a.batch == 32:
         import gc
@@ -257,8 +258,8 @@ def main():
         torch.cuda.synchronize()
         cdt = (time.time() - t1) / a.alt_steps
         config1 = dict(workload="BASELINE config[1]: the same training step at bs16 on one GPU", steps=a.alt_steps, ms_per_step=round(cdt * 1e3, 3),
-                       value=round(16 / cdt, 2), unit="images/s", note="host-paced at this batch size: ~17 ms of enqueue work per step whatever the batch "
-                       "(tools/host_profile.py); not the headline")
+                       value=round(16 / cdt, 2), unit="images/s", note="GPU-bound like bs32 (A/B with 2 ms less host work per step: no change); the per-launch fixed costs of ~960 kernels "
+                       "do not shrink with the batch (DESIGN.md 4.2); not the headline")
         del r16, o16, b16, step16
         gc.collect()
         torch.cuda.empty_cache()

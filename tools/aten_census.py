@@ -24,5 +24,10 @@ for e in prof.key_averages(group_by_input_shape=True):
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print("operators with device time: %d kinds, %.2f ms of device time, %d calls" % (len(rows), tot / 1e3, sum(r[1] for r in rows)))
-for dev, n, k, sh in rows[:60]:
+rows2 = sorted([r for r in rows if r[2].startswith("aten::")], key=lambda r: -r[1])
+print("--- stock operators by call count")
+for dev, n, k, sh in rows2[:45]:
+    print("%8.1f us %4d x  %-28s %s" % (dev, n, k, sh))
+print("--- by device time")
+for dev, n, k, sh in rows[:25]:
     print("%8.1f us %4d x  %-28s %s" % (dev, n, k, sh))
