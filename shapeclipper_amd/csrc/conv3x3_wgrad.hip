@@ -26,6 +26,15 @@ namespace sc {
 
 typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef SC_WGRAD_PROFILE          // profile build (tools/prof_wgrad_phases.py; tools/build_variants.sh conv3x3_wgrad.hip SC_WGRAD_PROFILE 1):
+                                 // s_memrealtime stamps (100 MHz) of thread 0 of every workgroup of the split kernel
+__device__ unsigned long long* wgrad_prof_buf = nullptr;
+#define WG_STAMP(ID) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); if (wgrad_prof_buf && tid == 0) wgrad_prof_buf[(size_t)blockIdx.x * 16 + (ID)] = t_; }
+#define WG_ACCUM(ID, T0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); if (wgrad_prof_buf && tid == 0) wgrad_prof_buf[(size_t)blockIdx.x * 16 + (ID)] += t_ - (T0); }
+#else
+#define WG_STAMP(ID)
+#endif
+
 // S = 2: the weight gradient of the three 3x3 / stride-2 / pad-1 convolutions per trunk (BasicBlock.conv1 of layer2-4): gy lives on the
 // W x W OUTPUT map, x on the 2W x 2W input map; output pixel (y, x) meets input (2y + ky - 1, 2x + kx - 1), so the patch of NR output
 // rows holds 2 NR + 1 input rows (only a top halo) of 2W + 1 positions (only a left pad), and the 3 kx of GS consecutive output pixels
@@ -376,11 +385,20 @@ __global__ __launch_bounds__(768, 1) void conv3x3_wgrad_split_kernel(const float
     const __bf16* Ab = As + ((wt >> 1) * 32 + (lane & 31)) * C::ASTR + 8 * half;
     const unsigned* Bb = reinterpret_cast<const unsigned*>(Xs + ((wt & 1) * 32 + (lane & 31)) * C::BSTR + ky * Wp);
 
+    WG_STAMP(0)
     if (k_lo < k_hi) load(k_lo);
     __syncthreads();                                                          // zero fill done
+    WG_STAMP(1)
     for (int kstep = k_lo; kstep < k_hi; ++kstep) {
+#ifdef SC_WGRAD_PROFILE
+        const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
+#endif
         store();
         __syncthreads();
+#ifdef SC_WGRAD_PROFILE
+        WG_ACCUM(4, ts0)                                                      // staging: wait for the loads, split, LDS writes, barrier
+        const unsigned long long ts1 = __builtin_amdgcn_s_memrealtime();
+#endif
         if (kstep + 1 < k_hi) load(kstep + 1);
 #pragma unroll
         for (int g = 0; g < C::G; ++g) {
@@ -407,12 +425,21 @@ __global__ __launch_bounds__(768, 1) void conv3x3_wgrad_split_kernel(const float
             }
         }
         __syncthreads();                                                      // every wave is done reading this K-step's tiles
+#ifdef SC_WGRAD_PROFILE
+        WG_ACCUM(5, ts1)                                                      // load issue + MFMA loop + barrier
+#endif
     }
+    WG_STAMP(2)
     float* dst = partial + (size_t)blockIdx.x * (64 * 64 * 9);
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dst[((wt * 9 + ky * 3 + t) * 16 + r) * 64 + lane] = acc[t][r];
+#ifdef SC_WGRAD_PROFILE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WG_STAMP(3)
+    if (wgrad_prof_buf && tid == 0) wgrad_prof_buf[(size_t)blockIdx.x * 16 + 6] = (unsigned long long)(k_hi - k_lo);
+#endif
 }
 
 using Ws56 = WsCfg<56, 2, 1>;
@@ -452,6 +479,11 @@ static int launch_wgrad_split(const float* gy, const float* x, float* dw, float*
 
 }  // namespace sc
 
+#ifdef SC_WGRAD_PROFILE
+extern "C" int sc_wgrad_debug_set_prof(unsigned long long* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(sc::wgrad_prof_buf), &buf, sizeof(buf));
+}
+#endif
 // sc_conv3x3_wgrad with fp32-accurate products on the bf16 matrix pipe (exact three-way bf16 split of both operands, six piece
 // products, fp32 accumulate): same arguments, workspace and summation order over the pixel ranges.
 extern "C" int sc_conv3x3_wgrad_split(const float* gy, const float* x, float* dw, float* workspace, int batch, int cin, int cout, int hw, void* stream) {
