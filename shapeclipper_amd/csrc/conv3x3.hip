@@ -481,14 +481,18 @@ __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const flo
         CV_STAMP(sid + 2)
         if (kb0 == 0 && kb1 == nk) {
             conv_store_tile<C>(out, acc, tile, nct, npix, cout, wm, wn, lane);
-        } else {                                            // partial tile, in register order (coalesced 256-byte rows)
-            float* dst = partial + ((size_t)g * 2 + (item - sp.rounds)) * C::TILE;
+        } else {                                            // partial tile, in register order: [wave][i][j][r / 4][lane][4], 16-byte stores
+            float4* dst = reinterpret_cast<float4*>(partial + ((size_t)g * 2 + (item - sp.rounds)) * C::TILE);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) dst[(((wave * WM + i) * WN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                        float4* d = dst + (((wave * WM + i) * WN + j) * 4 + q) * 64 + lane;
+                        *d = v;        // (plain stores: write-through `sc1` stores, meant to shorten the dirty-L2 write-back at the kernel boundary, were 3 % slower)
+                    }
         }
 #ifdef SC_CONV_PROFILE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -525,13 +529,14 @@ __global__ __launch_bounds__(C::NT) void conv3x3_fixup_kernel(const float* __res
             for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
     for (int g = g_first; g <= g_last; ++g) {
         const int which = (int)(conv_span_at(spans, sp, g, nk) / nk) == t ? 0 : 1;  // first or second tile of that workgroup's span
-        const float* src = partial + ((size_t)g * 2 + which) * C::TILE;
+        const float4* src = reinterpret_cast<const float4*>(partial + ((size_t)g * 2 + which) * C::TILE);
 #pragma unroll
         for (int i = 0; i < C::WM; ++i)
 #pragma unroll
-            for (int j = 0; j < C::WN; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] += src[(((wave * C::WM + i) * C::WN + j) * 16 + r0 + r) * 64 + lane];
+            for (int j = 0; j < C::WN; ++j) {
+                const float4 v = src[(((wave * C::WM + i) * C::WN + j) * 4 + (r0 >> 2)) * 64 + lane];
+                acc[i][j][0] += v.x; acc[i][j][1] += v.y; acc[i][j][2] += v.z; acc[i][j][3] += v.w;
+            }
     }
     const int tile = sp.rounds * G + t;
     int phase, pt, ct;
