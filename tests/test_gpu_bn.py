@@ -27,8 +27,10 @@ def _stock(bn, x, res, relu):
     return torch.relu(out) if relu else out
 
 
-# (32, 512, 7, 7) and (8, 256, 14, 14): the one-launch form for many-channel small maps (scalar and float4 variants)
-@pytest.mark.parametrize("shape", [(8, 64, 56, 56), (4, 16, 7, 7), (3, 5, 6, 10), (32, 512, 7, 7), (8, 256, 14, 14), (1, 8, 4, 4)])
+# (32, 512, 7, 7) and (8, 256, 14, 14): the one-launch form for many-channel small maps (scalar and float4 variants);
+# (32, 512, 1, 1) and (6, 70, 1, 1): the 1 x 1 maps of the heads' BatchNorms (one-launch form / two-launch form)
+@pytest.mark.parametrize("shape", [(8, 64, 56, 56), (4, 16, 7, 7), (3, 5, 6, 10), (32, 512, 7, 7), (8, 256, 14, 14), (32, 512, 1, 1), (6, 70, 1, 1),
+                                   (1, 8, 4, 4)])
 @pytest.mark.parametrize("relu,with_res", [(True, False), (True, True), (False, False), (False, True)])
 @pytest.mark.parametrize("training", [True, False])
 def test_bn_act_matches_torch(shape, relu, with_res, training):
@@ -136,7 +138,7 @@ def test_resnet18_fused_equals_stock_operators():
         assert rel < 5e-3, "%s: relative L2 error %.3e" % (name, rel)
 
 
-@pytest.mark.parametrize("shape,groups", [((6, 16, 14, 14), 3), ((8, 64, 28, 28), 2), ((96, 512, 1, 1), 3), ((12, 256, 14, 14), 3), ((8, 512, 7, 7), 4), ((4, 8, 5, 7), 4)])
+@pytest.mark.parametrize("shape,groups", [((6, 16, 14, 14), 3), ((8, 64, 28, 28), 2), ((96, 512, 1, 1), 3), ((12, 256, 14, 14), 3), ((8, 512, 7, 7), 4), ((128, 96, 1, 1), 4), ((4, 8, 5, 7), 4)])
 @pytest.mark.parametrize("with_res", [False, True])
 def test_grouped_bn_equals_consecutive_calls(shape, groups, with_res):
     """groups = G: the result (outputs, gradients, running statistics, num_batches_tracked) of G consecutive
