@@ -38,6 +38,9 @@
 #ifndef SC_CONV_SPANS
 #define SC_CONV_SPANS 1
 #endif
+#ifndef SC_CONV_ABLATE          // timing experiments only (wrong results): 1 no MFMAs, 2 no operand reads, 4 no patch staging, 8 no filter DMA
+#define SC_CONV_ABLATE 0
+#endif
 
 namespace sc {
 
@@ -208,8 +211,12 @@ __device__ __forceinline__ void conv_split_terms(const float4 (&a)[C::WM][3], co
         for (int i = 0; i < C::WM; ++i)
 #pragma unroll
             for (int j = 0; j < C::WN; ++j)
+#if SC_CONV_ABLATE & 1
+                acc[i][j][term] += a[i][PA[term]].x * b[j][PB[term]].x;
+#else
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cv_bf16x8, a[i][PA[term]]),
                                                                     __builtin_bit_cast(cv_bf16x8, b[j][PB[term]]), acc[i][j], 0, 0, 0);
+#endif
     }
 }
 // the tap pairs of one K-step of a BD2 tile of phase PHASE
@@ -403,7 +410,14 @@ __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const flo
 #ifdef SC_CONV_PROFILE
             if (kb == kb0 + 1) CV_STAMP(sid + 5)
 #endif
+#if SC_CONV_ABLATE & 12
+            if (kb + 1 < kb1) {
+                if (!(SC_CONV_ABLATE & 8)) issue_w(kb + 1, st ^ 1);
+                if (!(SC_CONV_ABLATE & 4)) load_x(kb + 1);
+            }
+#else
             if (kb + 1 < kb1) { issue_w(kb + 1, st ^ 1); load_x(kb + 1); }
+#endif
             const float* Ws = S + st * C::STAGE;
             const float* Xs = Ws + C::WIMG;
             if constexpr (C::BD2) {
@@ -440,6 +454,10 @@ __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const flo
                 for (int tp = 0; tp < 4; ++tp) {
                     const int t0 = 2 * tp, t1 = 2 * tp + 1;
                     const int o0 = (t0 / 3) * Wp + t0 % 3, o1 = (t1 / 3) * Wp + t1 % 3;
+#if SC_CONV_ABLATE & 2
+                    if (tp == 0 && kb == kb0)
+#endif
+                    {
 #pragma unroll
                     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -449,6 +467,7 @@ __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const flo
 #pragma unroll
                         for (int pc = 0; pc < 3; ++pc)
                             b[j][pc] = *reinterpret_cast<const float4*>(Xs + boff[j] + (pc * LX + o0) * 4 + half * (o1 - o0) * 4);
+                    }
                     conv_split_terms<C>(a, b, acc);
                 }
             } else {
@@ -475,7 +494,7 @@ __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const flo
                         }
             }
             }
-            if (kb + 1 < kb1) store_x(st ^ 1);
+            if (kb + 1 < kb1 && !(SC_CONV_ABLATE & 4)) store_x(st ^ 1);
         }
 
         CV_STAMP(sid + 2)
