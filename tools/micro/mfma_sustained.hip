@@ -28,6 +28,40 @@ __global__ __launch_bounds__(512) void k_bf16(float* out, int iters) {
     for (int a = 0; a < 4; ++a) s += acc[a][0] + acc[a][7];
     out[blockIdx.x * 512 + threadIdx.x] = s;
 }
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+// 16x16x32 (a quarter of the C registers per FLOP) and the f16 flavour of 32x32x16 (the CLIP GEMMs), random operands
+template <int KIND>
+__global__ __launch_bounds__(512) void k_alt(float* out, int iters) {
+    f32x4 acc4[8];
+    f32x16 acc[4];
+    for (int a = 0; a < 8; ++a) acc4[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < 4; ++a) for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    bf16x8 x[4], y[4];
+    f16x8 xh[4], yh[4];
+    for (int q = 0; q < 4; ++q) for (int e = 0; e < 8; ++e) {
+        const float u = rnd(threadIdx.x * 64 + q * 8 + e), v = rnd(blockIdx.x * 977 + threadIdx.x * 64 + 32 + q * 8 + e) * 0.01f;
+        x[q][e] = (__bf16)u; y[q][e] = (__bf16)v; xh[q][e] = (_Float16)u; yh[q][e] = (_Float16)v;
+    }
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (KIND == 0) {
+#pragma unroll
+                for (int a = 0; a < 8; ++a) acc4[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x[q], y[(q + a) & 3], acc4[a], 0, 0, 0);
+            } else if (KIND == 1) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[q], yh[(q + a) & 3], acc[a], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int a = 0; a < 8; ++a) acc4[a] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[q], yh[(q + a) & 3], acc4[a], 0, 0, 0);
+            }
+        }
+    }
+    float s = 0.f;
+    for (int a = 0; a < 8; ++a) s += acc4[a][0];
+    for (int a = 0; a < 4; ++a) s += acc[a][0];
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
 template <bool RANDOM>
 __global__ __launch_bounds__(512) void k_f32(float* out, int iters) {
     f32x4 acc[8];
@@ -61,6 +95,9 @@ static void run(const char* name, K kern, double flop_per_wave_iter, double nomi
 int main() {
     run("v_mfma_f32_32x32x16_bf16, constant operands", k_bf16<false>, 16.0 * 32 * 32 * 16 * 2, 2500.0, 60000);
     run("v_mfma_f32_32x32x16_bf16, random operands", k_bf16<true>, 16.0 * 32 * 32 * 16 * 2, 2500.0, 60000);
+    run("v_mfma_f32_16x16x32_bf16, random operands", k_alt<0>, 32.0 * 16 * 16 * 32 * 2, 2500.0, 60000);
+    run("v_mfma_f32_32x32x16_f16, random operands", k_alt<1>, 16.0 * 32 * 32 * 16 * 2, 2500.0, 60000);
+    run("v_mfma_f32_16x16x32_f16, random operands", k_alt<2>, 32.0 * 16 * 16 * 32 * 2, 2500.0, 60000);
     run("v_mfma_f32_16x16x4_f32, constant operands", k_f32<false>, 64.0 * 16 * 16 * 4 * 2, 157.3, 15000);
     run("v_mfma_f32_16x16x4_f32, random operands", k_f32<true>, 64.0 * 16 * 16 * 4 * 2, 157.3, 15000);
     return 0;
