@@ -336,16 +336,73 @@ __global__ __launch_bounds__(BN_T) void bn_relu_pool_fwd_kernel(PoolFwdArgs a) {
     }
 }
 
+// Even W (the 112 x 112 stem maps): a lane loads the column pair (2 wo, 2 wo + 1) of its three input rows as one 8-byte vector
+// (consecutive lanes = consecutive pairs: fully coalesced, every input element of a row loaded once) and takes column 2 wo - 1 -- already
+// normalised and rectified -- from the lane to its left; only a wave's first lane fetches it itself.  Same fma, same comparisons in the
+// same scan order as the kernel above: identical values and indices.  (The scalar form reads nine 4-byte values per output at a lane
+// stride of two floats: 1.7 TB/s on a pass that moves 307 MB.)
+__global__ __launch_bounds__(BN_T) void bn_relu_pool_fwd2_kernel(PoolFwdArgs a) {
+    const int c = blockIdx.x;
+    const BnShare sh = bn_share(a.st.N, a.st.G);
+    const int HW = a.H * a.W, C = a.st.C, W = a.W;
+    float mean, rstd;
+    bn_forward_stats(a.st, c, sh, mean, rstd);
+    const float scale = a.gamma[c] * rstd, shift = a.beta[c] - mean * scale;
+    const int HoWo = a.Ho * a.Wo;
+    const int cnt = (sh.Ng - sh.s + sh.S - 1) / sh.S, total = cnt * HoWo;
+    const int lane = threadIdx.x & 63;
+    for (int t0 = 0; t0 < total; t0 += BN_T) {
+        const int t = t0 + threadIdx.x;
+        const bool on = t < total;
+        const int tt = on ? t : total - 1;
+        const int nl = tt / HoWo, o = tt - nl * HoWo;
+        const int ho = o / a.Wo, wo = o - ho * a.Wo;
+        const size_t plane = ((size_t)(sh.n0 + sh.s + nl * sh.S) * C + c);
+        const float* xp = a.st.x + plane * HW;
+        float best = -__builtin_inff();
+        int bi = -1;
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+            const int h = 2 * ho - 1 + dh;
+            const bool hv = h >= 0 && h < a.H;
+            float2 v = make_float2(0.f, 0.f);
+            if (hv) v = *reinterpret_cast<const float2*>(xp + h * W + 2 * wo);
+            const float u0 = fmaf(v.x, scale, shift), u1 = fmaf(v.y, scale, shift);
+            const float r0 = u0 < 0.f ? 0.f : u0, r1 = u1 < 0.f ? 0.f : u1;               // relu(NaN) = NaN
+            float left = __shfl_up(r1, 1);                                                // the left neighbour's column 2 wo - 1 (same row when wo > 0)
+            if (lane == 0 && wo > 0 && hv) {
+                const float ul = fmaf(xp[h * W + 2 * wo - 1], scale, shift);
+                left = ul < 0.f ? 0.f : ul;
+            }
+            if (!hv) continue;
+            if (wo > 0 && (left > best || bi < 0 || left != left)) { best = left; bi = h * W + 2 * wo - 1; }
+            if (r0 > best || bi < 0 || r0 != r0) { best = r0; bi = h * W + 2 * wo; }      // strict >: first maximum in scan order; a NaN wins
+            if (r1 > best || bi < 0 || r1 != r1) { best = r1; bi = h * W + 2 * wo + 1; }
+        }
+        if (on) {
+            a.y[plane * HoWo + o] = best;
+            a.idx[plane * HoWo + o] = bi;
+        }
+    }
+}
+
 struct PoolBwdArgs {
     const float* dy; const int* idx; const float* x; const float* gamma; const float* beta; const float* mean;
     const float* rstd; float* partial; float* dx;
     int N, C, H, W, Ho, Wo, G;
+    float* dgamma; float* dbeta;
+    int training;
 };
 
 // Pass 1 of the stem backward.  One thread owns a 2x2 block of BN-output positions (rows 2i,2i+1, cols 2j,2j+1): the
 // only pooling windows that can have their argmax there are (i..i+1) x (j..j+1), so 4 idx/dy reads serve 4 inputs
 // (gather form, no atomics).  The gradient is gated by the ReLU (recomputed from x), written to dx as a temporary and
 // reduced into the per-channel sums; pass 2 (bn_bwd_apply_kernel with dres == dx) finishes dx in place.
+// V2 (even W): the two columns of the thread's 2 x 2 block are one 8-byte load of x and one 8-byte store of dx per row.
+// MODE 0: as described (g to dx + sums; bn_bwd_apply_kernel follows).  MODE 1 / 2 (even W): the gather runs twice instead -- 1: sums only,
+// 2: g again and dx = scale * (g - mean(g) - xhat * mean(g xhat)) directly (the same expressions: identical values) -- so that the
+// full-resolution g is neither written nor read back: 819 MB instead of 1,127 MB per stem backward at 64 images.
+template <bool V2, int MODE>
 __global__ __launch_bounds__(BN_T) void bn_relu_pool_bwd_gather_kernel(PoolBwdArgs a) {
     __shared__ float red[2 * BN_T / 64];
     const int c = blockIdx.x;
@@ -355,6 +412,25 @@ __global__ __launch_bounds__(BN_T) void bn_relu_pool_bwd_gather_kernel(PoolBwdAr
     const float mean = a.mean[(size_t)sh.g * a.C + c], rstd = a.rstd[(size_t)sh.g * a.C + c];
     const float scale = a.gamma[c] * rstd, shift = a.beta[c] - mean * scale;
     float sg = 0.f, sgx = 0.f;
+    float mg = 0.f, mgx = 0.f;
+    if (MODE == 2) {
+        float tsg, tsgx;
+        combine_partials(a.partial, c, sh.g, sh.S, a.G, tsg, tsgx);
+        if (blockIdx.y == 0 && threadIdx.x == 0) {      // parameters are shared by the groups: sum over all of them
+            float tg = 0.f, tgx = 0.f;
+            for (int g = 0; g < a.G; ++g) {
+                float u, v;
+                combine_partials(a.partial, c, g, sh.S, a.G, u, v);
+                tg += u;
+                tgx += v;
+            }
+            a.dgamma[c] = tgx;
+            a.dbeta[c] = tg;
+        }
+        const float n = (float)sh.Ng * (float)HW;
+        mg = a.training ? tsg / n : 0.f;
+        mgx = a.training ? tsgx / n : 0.f;
+    }
     const int cnt = (sh.Ng - sh.s + sh.S - 1) / sh.S, total = cnt * Q;
     for (int t = threadIdx.x; t < total; t += BN_T) {
         const int nl = t / Q, q = t - nl * Q;
@@ -375,12 +451,14 @@ __global__ __launch_bounds__(BN_T) void bn_relu_pool_bwd_gather_kernel(PoolBwdAr
         for (int eh = 0; eh < 2; ++eh) {
             const int h = 2 * i + eh;
             if (h >= a.H) continue;
+            float2 xrow = make_float2(0.f, 0.f), grow;
+            if (V2) xrow = *reinterpret_cast<const float2*>(a.x + plane * HW + h * a.W + 2 * j);
 #pragma unroll
             for (int ew = 0; ew < 2; ++ew) {
                 const int w = 2 * j + ew;
                 if (w >= a.W) continue;
                 const int pos = h * a.W + w;
-                const float xv = a.x[plane * HW + pos];
+                const float xv = V2 ? (ew ? xrow.y : xrow.x) : a.x[plane * HW + pos];
                 float g = 0.f;
                 // even row/col: covered only by window i (j); odd: by windows i and i+1 (j and j+1)
 #pragma unroll
@@ -389,12 +467,16 @@ __global__ __launch_bounds__(BN_T) void bn_relu_pool_bwd_gather_kernel(PoolBwdAr
                     for (int dj = 0; dj <= ew; ++dj)
                         if (wi[di][dj] == pos) g += wd[di][dj];
                 if (!(fmaf(xv, scale, shift) > 0.f)) g = 0.f;        // ReLU gate (a max of 0 carries no gradient)
-                a.dx[plane * HW + pos] = g;
+                const float o = MODE == 2 ? scale * (g - mg - (xv - mean) * rstd * mgx) : g;
+                if (V2) { if (ew) grow.y = o; else grow.x = o; }
+                else if (MODE != 1) a.dx[plane * HW + pos] = o;
                 sg += g;
                 sgx += g * ((xv - mean) * rstd);
             }
+            if (V2 && MODE != 1) *reinterpret_cast<float2*>(a.dx + plane * HW + h * a.W + 2 * j) = grow;
         }
     }
+    if (MODE == 2) return;
     block_sum2(sg, sgx, red);
     if (threadIdx.x == 0) store_partial(a.partial, c, sh, a.G, sg, sgx);
 }
@@ -668,7 +750,8 @@ extern "C" int sc_bn_relu_pool_forward(const float* x, const float* gamma, const
     if (training) hipLaunchKernelGGL(sc::bn_stats_kernel, grid, dim3(sc::BN_T), 0, st, x, N, C, H * W, groups, partial);
     sc::PoolFwdArgs a{{x, partial, save_mean, save_rstd, run_mean, run_var, n_tracked, N, C, H * W, groups, training, eps, momentum},
                       gamma, beta, y, idx, H, W, (H + 2 - 3) / 2 + 1, (W + 2 - 3) / 2 + 1};
-    hipLaunchKernelGGL(sc::bn_relu_pool_fwd_kernel, grid, dim3(sc::BN_T), 0, st, a);
+    if ((W & 1) == 0) hipLaunchKernelGGL(sc::bn_relu_pool_fwd2_kernel, grid, dim3(sc::BN_T), 0, st, a);
+    else hipLaunchKernelGGL(sc::bn_relu_pool_fwd_kernel, grid, dim3(sc::BN_T), 0, st, a);
     return (int)hipGetLastError();
 }
 
@@ -680,8 +763,13 @@ extern "C" int sc_bn_relu_pool_backward(const float* dy, const int* idx, const f
     if (bn_bad(N, C, H * W, groups)) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream_;
     const dim3 grid(C, groups * sc::bn_splits(N / groups, C, groups));
-    sc::PoolBwdArgs a{dy, idx, x, gamma, beta, mean, rstd, partial, dx, N, C, H, W, (H + 2 - 3) / 2 + 1, (W + 2 - 3) / 2 + 1, groups};
-    hipLaunchKernelGGL(sc::bn_relu_pool_bwd_gather_kernel, grid, dim3(sc::BN_T), 0, st, a);
+    sc::PoolBwdArgs a{dy, idx, x, gamma, beta, mean, rstd, partial, dx, N, C, H, W, (H + 2 - 3) / 2 + 1, (W + 2 - 3) / 2 + 1, groups, dgamma, dbeta, training};
+    if ((W & 1) == 0) {      // two gather passes, no full-resolution temporary
+        hipLaunchKernelGGL((sc::bn_relu_pool_bwd_gather_kernel<true, 1>), grid, dim3(sc::BN_T), 0, st, a);
+        hipLaunchKernelGGL((sc::bn_relu_pool_bwd_gather_kernel<true, 2>), grid, dim3(sc::BN_T), 0, st, a);
+        return (int)hipGetLastError();
+    }
+    hipLaunchKernelGGL((sc::bn_relu_pool_bwd_gather_kernel<false, 0>), grid, dim3(sc::BN_T), 0, st, a);
     // pass 2: dx = scale * (g - mean(g) - xhat * mean(g xhat)) in place (g was left in dx)
     sc::BnBwdArgs b{nullptr, x, nullptr, gamma, beta, mean, rstd, partial, dx, dx, dgamma, dbeta, N, C, H * W, groups, 0, training, 0};
     hipLaunchKernelGGL(sc::bn_bwd_apply_kernel, grid, dim3(sc::BN_T), 0, st, b);
