@@ -40,8 +40,10 @@ __global__ __launch_bounds__(256) void conv1x1s2_gemm_kernel(const float* __rest
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
 
-    for (int k0 = 0; k0 < K; k0 += KS) {
-        float av[4], bv[8];
+    // the operands of K-step k0 + KS are fetched into registers while the MFMAs of step k0 run (round 4: each of the 4-16 K-steps used
+    // to expose a global-load round trip between two barriers -- these launches are latency-bound, not bandwidth-bound)
+    float av[4], bv[8];
+    auto fetch = [&](int k0) {
         if (MODE == 0) {
             const float4 t = *reinterpret_cast<const float4*>(w + (size_t)(m0 + am) * cin + k0 + 4 * ak);
             av[0] = t.x, av[1] = t.y, av[2] = t.z, av[3] = t.w;
@@ -51,12 +53,16 @@ __global__ __launch_bounds__(256) void conv1x1s2_gemm_kernel(const float* __rest
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) bv[i] = bsrc[(size_t)(k0 + (tid >> 7) + 2 * i) * bstride];
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += KS) {
         __syncthreads();                                      // every wave is done with the previous K-step's tiles
 #pragma unroll
         for (int i = 0; i < 4; ++i) As[(MODE == 0 ? 4 * ak + i : ak + 4 * i) * ALD + am] = av[i];
 #pragma unroll
         for (int i = 0; i < 8; ++i) Bs[((tid >> 7) + 2 * i) * BLD + (tid & 127)] = bv[i];
         __syncthreads();
+        if (k0 + KS < K) fetch(k0 + KS);
 #pragma unroll
         for (int j = 0; j < KS / 2; ++j) {
             const float b = Bs[(2 * j + half) * BLD + 32 * wave + (lane & 31)];
@@ -105,20 +111,24 @@ __global__ __launch_bounds__(256) void conv1x1s2_wgrad_kernel(const float* __res
     const float* Ab = Gs + ((wave >> 1) * 32 + (lane & 31)) * LD + 4 * half;
     const float* Bb = Xs + ((wave & 1) * 32 + (lane & 31)) * LD + 4 * half;
 
-    for (int ks = k_lo; ks < k_hi; ++ks) {
+    // (the operands of K-step ks + 1 are fetched while the MFMAs of step ks run, as in the GEMM kernel above)
+    float gv[16], xv[16];
+    auto fetch = [&](int ks) {
         // staging: pixel column tid & 63, channel rows (tid >> 6) + 4 i
         const int p = ks * PK + (tid & 63);
         const bool ok = p < npix;
         const int pc = ok ? p : npix - 1, b = pc / hwo, po = pc - b * hwo, yo = po / hout, xo = po - yo * hout;
         const float* gsrc = gy + ((size_t)b * cout + co0) * hwo + po;
         const float* xsrc = x + ((size_t)b * cin + ci0) * hwi + 2 * yo * hin + 2 * xo;
-        float gv[16], xv[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int c = (tid >> 6) + 4 * i;
             gv[i] = ok ? gsrc[(size_t)c * hwo] : 0.f;
             xv[i] = ok ? xsrc[(size_t)c * hwi] : 0.f;
         }
+    };
+    if (k_lo < k_hi) fetch(k_lo);
+    for (int ks = k_lo; ks < k_hi; ++ks) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -127,6 +137,7 @@ __global__ __launch_bounds__(256) void conv1x1s2_wgrad_kernel(const float* __res
             Xs[c * LD + (tid & 63)] = xv[i];
         }
         __syncthreads();
+        if (ks + 1 < k_hi) fetch(ks + 1);
 #pragma unroll
         for (int g8 = 0; g8 < PK / 8; ++g8) {                 // k pair of an MFMA: (pixel, pixel + 4)
             const float4 a = *reinterpret_cast<const float4*>(Ab + 8 * g8), bq = *reinterpret_cast<const float4*>(Bb + 8 * g8);
