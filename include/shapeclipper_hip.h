@@ -115,6 +115,17 @@ int sc_rgb_composite_backward(
     const float* G_rgb, const float* G_mask, const float* G_depth, const float* G_normal,
     float* g_sdf, float* g_grad, float* g_feat, float* g_points, float* g_z, float* g_depth_fac, float* g_beta,
     float* gy, float* rr, float* gy3, void* stream);
+/* The same with the gradient of the 3-row output layer folded in: v3_part [SC_RGB_BWD_BETA_PARTS][196] (fully written) holds, per wave of
+ * the grid, the sums over its points of gy3_j * r2[ch] (dV3 [3][64]), of gy3_j (db3 [3]) and a zero; the gradient is their sum in index
+ * order (sc_partial_reduce(v3_part, SC_RGB_BWD_BETA_PARTS, 196, 196, out)).  rr[2] and gy3 are then NOT written (may be NULL past rr[1]).
+ * v3_part == NULL: exactly sc_rgb_composite_backward.                                                                                  */
+int sc_rgb_composite_backward_v3(
+    const float* points, const float* z_vals, const float* depth_fac, const float* sdf, const float* grad,
+    const float* feat, const float* v_pack, const float* dbias, const float* beta_param, const float* rgb_flat,
+    int n_rays, int rays_per_image, int n_images, int symmetric, float beta_min, float bgcolor, float normal_pow,
+    const float* G_rgb, const float* G_mask, const float* G_depth, const float* G_normal,
+    float* g_sdf, float* g_grad, float* g_feat, float* g_points, float* g_z, float* g_depth_fac, float* g_beta,
+    float* gy, float* rr, float* gy3, float* v3_part, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Weight-gradient GEMM  dW[64][nb0+nb1] = sum_points A(p) (x) [B0(p) | B1(p)]  over one or two terms.

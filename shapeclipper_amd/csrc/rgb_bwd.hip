@@ -35,6 +35,9 @@ struct RgbBwdArgs {
     float* gy;           // 3 x TBL64: pre-activation gradients Gy0, Gy1, Gy2
     float* rr;           // 3 x TBL64: post-ReLU activations r0, r1, r2
     float* gy3;          // [P][3]: gradient at the pre-sigmoid output
+    float* v3_part;      // null, or [SC_RGB_BWD_BETA_PARTS][196]: per wave of the grid the sums over its points of gy3_j * r2[ch] (= dV3 [3][64]),
+                         // of gy3_j (= db3 [3]) and one zero -- fully written; their sum in index order (sc_partial_reduce) is the gradient of
+                         // the output layer.  With it rr[2] and gy3 are NOT written (nobody else reads them): 280 MB less per launch.
 };
 
 __global__ __launch_bounds__(256) void rgb_composite_bwd_kernel(RgbBwdArgs a) {
@@ -49,6 +52,11 @@ __global__ __launch_bounds__(256) void rgb_composite_bwd_kernel(RgbBwdArgs a) {
     const float dbeta_dbp = bp > 0.f ? 1.f : (bp < 0.f ? -1.f : 0.f);
     const size_t tbl = (size_t)a.n_rays * 4 * 1024;
     float gbeta_acc = 0.f;
+    float v3acc[3][ACT_STEPS], b3acc[3] = {0.f, 0.f, 0.f};     // this lane's share of dV3 (channels kp(s) + 4 g of its point column) and db3
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int s2 = 0; s2 < ACT_STEPS; ++s2) v3acc[j][s2] = 0.f;
 
     for (int ray = blockIdx.x * 4 + wave; ray < a.n_rays; ray += gridDim.x * 4) {
         const int img = min(ray / a.rays_per_image, a.n_images - 1);
@@ -147,11 +155,21 @@ __global__ __launch_bounds__(256) void rgb_composite_bwd_kernel(RgbBwdArgs a) {
             rgb_chain(L, db, e, f, r, col);
             tbl_store(a.rr + 0 * tbl, tile, p, g, r[0]);
             tbl_store(a.rr + 1 * tbl, tile, p, g, r[1]);
-            tbl_store(a.rr + 2 * tbl, tile, p, g, r[2]);
             const float y0 = gc0 * col[0] * (1.f - col[0]);
             const float y1 = gc1 * col[1] * (1.f - col[1]);
             const float y2 = gc2 * col[2] * (1.f - col[2]);
-            if (g == 0) { a.gy3[pt * 3 + 0] = y0; a.gy3[pt * 3 + 1] = y1; a.gy3[pt * 3 + 2] = y2; }
+            if (a.v3_part) {
+#pragma unroll
+                for (int s2 = 0; s2 < ACT_STEPS; ++s2) {
+                    v3acc[0][s2] = __builtin_fmaf(y0, r[2][s2], v3acc[0][s2]);
+                    v3acc[1][s2] = __builtin_fmaf(y1, r[2][s2], v3acc[1][s2]);
+                    v3acc[2][s2] = __builtin_fmaf(y2, r[2][s2], v3acc[2][s2]);
+                }
+                b3acc[0] += y0; b3acc[1] += y1; b3acc[2] += y2;       // (every lane group of a point holds the same y: group 0 is taken below)
+            } else {
+                tbl_store(a.rr + 2 * tbl, tile, p, g, r[2]);
+                if (g == 0) { a.gy3[pt * 3 + 0] = y0; a.gy3[pt * 3 + 1] = y1; a.gy3[pt * 3 + 2] = y2; }
+            }
             float gyv[ACT_STEPS];
 #pragma unroll
             for (int s2 = 0; s2 < ACT_STEPS; ++s2) {
@@ -195,9 +213,48 @@ __global__ __launch_bounds__(256) void rgb_composite_bwd_kernel(RgbBwdArgs a) {
     if (lane == 0) a.g_beta[blockIdx.x * 4 + wave] = gb * dbeta_dbp;
     if (blockIdx.x == 0 && wave == 0)               // the waves of the blocks that were not launched (small renders)
         for (int e = gridDim.x * 4 + lane; e < 2048; e += 64) a.g_beta[e] = 0.f;
+    if (a.v3_part) {
+        // sum over the 16 point columns of a lane group (xor shuffles stay inside the group of 16), then lane p == 0 of group g writes
+        // its 16 channels of every row: a fixed order, per wave
+        float* dst = a.v3_part + (size_t)(blockIdx.x * 4 + wave) * 196;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+#pragma unroll
+            for (int s2 = 0; s2 < ACT_STEPS; ++s2) {
+                float v = v3acc[j][s2];
+                for (int d = 8; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+                if (p == 0) dst[j * 64 + kp(s2) + 4 * g] = v;
+            }
+            float bsum = b3acc[j];
+            for (int d = 8; d >= 1; d >>= 1) bsum += __shfl_xor(bsum, d);
+            if (lane == 0) dst[192 + j] = bsum;
+        }
+        if (lane == 0) dst[195] = 0.f;
+        if (blockIdx.x == 0 && wave == 0)
+            for (int e = gridDim.x * 4 * 196 + lane; e < 2048 * 196; e += 64) a.v3_part[e] = 0.f;
+    }
 }
 
 }  // namespace sc
+
+extern "C" int sc_rgb_composite_backward_v3(
+    const float* points, const float* z_vals, const float* depth_fac, const float* sdf, const float* grad,
+    const float* feat, const float* v_pack, const float* dbias, const float* beta_param, const float* rgb_flat,
+    int n_rays, int rays_per_image, int n_images, int symmetric, float beta_min, float bgcolor, float normal_pow,
+    const float* G_rgb, const float* G_mask, const float* G_depth, const float* G_normal,
+    float* g_sdf, float* g_grad, float* g_feat, float* g_points, float* g_z, float* g_depth_fac, float* g_beta,
+    float* gy, float* rr, float* gy3, float* v3_part, void* stream_) {
+    if (n_rays <= 0) return 0;
+    sc::RgbBwdArgs a{points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta_param, rgb_flat,
+                     n_rays, rays_per_image, n_images, symmetric, beta_min, bgcolor, normal_pow,
+                     G_rgb, G_mask, G_depth, G_normal, g_sdf, g_grad, g_feat, g_points, g_z, g_depth_fac, g_beta,
+                     gy, rr, gy3, v3_part};
+    int blocks = (n_rays + 3) / 4;
+    if (blocks > 512) blocks = 512;
+    const size_t lds_bytes = sc::RgbLds::TOTAL * sizeof(float);
+    hipLaunchKernelGGL(sc::rgb_composite_bwd_kernel, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream_, a);
+    return (int)hipGetLastError();
+}
 
 extern "C" int sc_rgb_composite_backward(
     const float* points, const float* z_vals, const float* depth_fac, const float* sdf, const float* grad,
@@ -206,14 +263,7 @@ extern "C" int sc_rgb_composite_backward(
     const float* G_rgb, const float* G_mask, const float* G_depth, const float* G_normal,
     float* g_sdf, float* g_grad, float* g_feat, float* g_points, float* g_z, float* g_depth_fac, float* g_beta,
     float* gy, float* rr, float* gy3, void* stream_) {
-    if (n_rays <= 0) return 0;
-    sc::RgbBwdArgs a{points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta_param, rgb_flat,
-                     n_rays, rays_per_image, n_images, symmetric, beta_min, bgcolor, normal_pow,
-                     G_rgb, G_mask, G_depth, G_normal, g_sdf, g_grad, g_feat, g_points, g_z, g_depth_fac, g_beta,
-                     gy, rr, gy3};
-    int blocks = (n_rays + 3) / 4;
-    if (blocks > 512) blocks = 512;
-    const size_t lds_bytes = sc::RgbLds::TOTAL * sizeof(float);
-    hipLaunchKernelGGL(sc::rgb_composite_bwd_kernel, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream_, a);
-    return (int)hipGetLastError();
+    return sc_rgb_composite_backward_v3(points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta_param, rgb_flat, n_rays, rays_per_image,
+                                        n_images, symmetric, beta_min, bgcolor, normal_pow, G_rgb, G_mask, G_depth, G_normal, g_sdf, g_grad, g_feat,
+                                        g_points, g_z, g_depth_fac, g_beta, gy, rr, gy3, nullptr, stream_);
 }

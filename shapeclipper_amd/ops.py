@@ -285,17 +285,17 @@ def rgb_composite_backward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, d
              points=torch.empty(P, 3, **f32), z_vals=torch.empty(n_rays, 64, **f32),
              depth_fac=torch.empty(n_rays, **f32), beta=torch.empty(RGB_BWD_BETA_PARTS, **f32))
     gy = torch.empty(3 * T, **f32)
-    rr = torch.empty(3 * T, **f32)
-    gy3 = torch.empty(P, 3, **f32)
-    code = lib.sc_rgb_composite_backward(
+    rr = torch.empty(2 * T, **f32)         # r0, r1 (operands of dV1 / dV2); r2 and gy3 only feed the output layer's gradient, formed in the kernel:
+    v3_part = torch.empty(RGB_BWD_BETA_PARTS * 196, **f32)     # per-wave partial sums of dV3 [3][64] | db3 [3] | 0
+    code = lib.sc_rgb_composite_backward_v3(
         _lib.ptr(points), _lib.ptr(z_vals), _lib.ptr(depth_fac), _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(feat),
         _lib.ptr(v_pack), _lib.ptr(dbias), _lib.ptr(beta_param), _lib.ptr(rgb_flat), c_int(n_rays),
         c_int(rays_per_image), c_int(n_images), c_int(1 if symmetric else 0), ctypes.c_float(beta_min),
         ctypes.c_float(bgcolor), ctypes.c_float(normal_pow), _lib.ptr(G_rgb), _lib.ptr(G_mask), _lib.ptr(G_depth),
         _lib.ptr(G_normal), _lib.ptr(g["sdf"]), _lib.ptr(g["grad"]), _lib.ptr(g["feat"]), _lib.ptr(g["points"]),
         _lib.ptr(g["z_vals"]), _lib.ptr(g["depth_fac"]), _lib.ptr(g["beta"]), _lib.ptr(gy), _lib.ptr(rr),
-        _lib.ptr(gy3), _lib.stream())
-    _lib.check(code, "sc_rgb_composite_backward")
+        None, _lib.ptr(v3_part), _lib.stream())
+    _lib.check(code, "sc_rgb_composite_backward_v3")
 
     GY = lambda l: gy[l * T:(l + 1) * T]
     RR = lambda l: rr[l * T:(l + 1) * T]
@@ -312,11 +312,9 @@ def rgb_composite_backward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, d
     _wgrad(lib, [(GY(2), None, OP_PLAIN, RR(1), OP_PLAIN, None, OP_NONE)], *common, 64, 0, partial, stride, RGB_OFF["V2"], 64, *rs(2))
     g_v = _partial_reduce(lib, partial, WGRAD_PARTS, stride, stride, torch.empty(stride, **f32))
     g["beta"] = _partial_reduce(lib, g["beta"], RGB_BWD_BETA_PARTS, 1, 1, torch.empty(1, **f32))     # per-wave partials, index order
-    g_v[RGB_OFF["V3"]:RGB_OFF["V3"] + 192] = tbl_sum(RR(2), P, P, 1, coef=gy3).view(192)
-    # column sums of a [P,3] tensor: a plain sum(dim=0) runs on 4 workgroups (435 us at P = 1M); split the rows first
-    chunks = 1024 if P % 1024 == 0 else 1
-    g_v[RGB_OFF["B3"]:RGB_OFF["B3"] + 3] = gy3.view(chunks, P // chunks, 3).sum(dim=1).sum(dim=0)
-    g_v[RGB_OFF["B3"] + 3:RGB_OFF["B3"] + 4].zero_()       # (indexing with a python scalar would synchronise)
+    # the 3-row output layer: [V3 (192) | b3 (3) | pad] is contiguous in the pack -- the per-wave partials of the kernel, summed in index order
+    assert RGB_OFF["B3"] == RGB_OFF["V3"] + 192 and RGB_PACK_FLOATS == RGB_OFF["B3"] + 4
+    _partial_reduce(lib, v3_part, RGB_BWD_BETA_PARTS, 196, 196, g_v[RGB_OFF["V3"]:])
     g["v_pack"] = g_v
     g["dbias"] = g_d3.permute(1, 0, 2).contiguous()
     return g
