@@ -40,7 +40,7 @@ struct RgbBwdArgs {
                          // the output layer.  With it rr[2] and gy3 are NOT written (nobody else reads them): 280 MB less per launch.
 };
 
-__global__ __launch_bounds__(256) void rgb_composite_bwd_kernel(RgbBwdArgs a) {
+__global__ __launch_bounds__(256, 2) void rgb_composite_bwd_kernel(RgbBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     stage_rgb_weights(lds, a.v, threadIdx.x, 256);
     __syncthreads();
