@@ -2,7 +2,8 @@
 """bench.py -- train-step images/sec of the ShapeClipper hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1, either way:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (the driver's command)
+                        python bench.py --gpus N ...   (no launcher environment: bench.py starts the N ranks itself, self_launch())
 
 A "step" is one full training iteration on a synthetic Pix3D-shaped batch that is already resident in
 HBM: Graph.forward(training=True) (ResNet-34 encoder, ResNet-18 estimator on stock PyTorch-ROCm; TWO
@@ -147,12 +148,40 @@ def build_runner(batch_per_gpu, rank=0, local=0, world=1, extra=()):
     return runner, opt, batch
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` (N > 1) WITHOUT a launcher environment: start the N ranks ourselves -- re-exec this file under
+    `python -m torch.distributed.run` exactly as the driver's N > 1 command does (one rank per GPU, rendezvous on 127.0.0.1, a free
+    port), pass every argument through, forward the ranks' output and return their exit code.  Rank 0 prints the one JSON line."""
+    import socket
+    import subprocess
+    backend = os.environ.get("SC_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < a.gpus:
+        sys.exit("bench.py --gpus %d: this node exposes %d GPU(s); RCCL takes one rank per device (SC_BENCH_BACKEND=gloo runs the same "
+                 "code path with the ranks sharing the GPUs that exist -- a functional check, not a measurement)" % (a.gpus, have))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # the host driver only supports dmabuf IPC (RCCL needs it across processes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: no launcher environment, starting %d ranks: %s\n" % (a.gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    if world != a.gpus:
+        sys.exit("bench.py --gpus %d started with WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d, or with no "
+                 "launcher at all (bench.py starts its own ranks)" % (a.gpus, world, a.gpus))
     # One rank per GPU over RCCL.  SC_BENCH_BACKEND=gloo (tests/test_gpu_bench_contract.py) runs the same N > 1 code path with
     # several ranks sharing the GPUs that exist -- the build box has one MI355X and RCCL refuses two ranks on one device.
     backend = os.environ.get("SC_BENCH_BACKEND", "nccl")
@@ -189,7 +218,18 @@ def main():
     torch.cuda.synchronize()
     dt = time.time() - t0
     timing, _lib.TIMING = _lib.TIMING, None
+    ranks = None
     if world > 1:
+        # every rank's own clock over the K steps (its barrier wait included) and its host enqueue time: the line prints min / max so that
+        # a straggler (a slower box, a starved RCCL kernel) is visible beside the MAX the contract asks for
+        mine = torch.tensor([dt, host_dt], device="cuda")
+        every = [torch.empty_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(every, mine)
+        per_rank = [t[0].item() / a.steps * 1e3 for t in every]
+        ranks = dict(ms_per_step_min=round(min(per_rank), 3), ms_per_step_max=round(max(per_rank), 3),
+                     host_enqueue_ms_per_step_max=round(max(t[1].item() for t in every) / a.steps * 1e3, 3),
+                     backend=torch.distributed.get_backend(), backend_world_size=torch.distributed.get_world_size(),
+                     devices_visible=torch.cuda.device_count())
         t = torch.tensor([dt], device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
@@ -275,8 +315,17 @@ def main():
         torch.cuda.synchronize()
         ar = (time.time() - t1) / 10
         nbytes = flat.numel() * 4
-        allreduce = dict(ms=round(ar * 1e3, 3), payload_bytes=nbytes,
-                         bus_GBps=round(2 * (world - 1) / world * nbytes / ar / 1e9, 1), peak_per_link_GBps=153.0)
+        t = torch.tensor([ar], device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        ar = t.item()
+        from shapeclipper_amd import ops as _ops
+        allreduce = dict(ms=round(ar * 1e3, 3), payload_bytes=nbytes, algo_GBps=round(nbytes / ar / 1e9, 1),
+                         bus_GBps=round(2 * (world - 1) / world * nbytes / ar / 1e9, 1), peak_per_link_GBps=153.0,
+                         note="the step's only exchange, timed ALONE (10 back-to-back collectives of the flat gradient buffer, MAX over ranks); "
+                              "bus_GBps = 2 (w-1)/w x payload / time, the ring figure to hold against 7 xGMI links x 153 GB/s per GPU",
+                         schedule="overlapped [early | late]" if runner.reducer.overlap else "single flat all-reduce after backward",
+                         reserved_cus=int(opt.get("hip", {}).get("reserve_cus", 0) or 0), persistent_grid_cus=_ops.set_reserved_cus(
+                             int(opt.get("hip", {}).get("reserve_cus", 0) or 0)))
 
     if rank == 0:
         ms = dt / a.steps * 1e3
@@ -350,6 +399,8 @@ def main():
                    sustained=sustained)
         if allreduce is not None:
             out["allreduce"] = allreduce
+        if ranks is not None:
+            out["ranks"] = ranks
         if alt is not None:
             out["fp32_mfma_convolutions"] = alt
         if config1 is not None:

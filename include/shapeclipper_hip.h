@@ -535,6 +535,19 @@ typedef struct sc_block_args {
 int sc_basic_block_forward(const sc_block_args* args, void* stream);
 int sc_basic_block_backward(const sc_block_args* args, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Launch policy (csrc/device.hip) -- the one process-level setting of the library.  The persistent one-workgroup-per-CU grids
+ * (stream-K 3x3 convolutions and their weight gradients, stem / 1x1 / stride-2 gradients) are sized for
+ * sc_grid_cus() = device CUs - reserved.  Reserve CUs when another stream must make progress beside them: RCCL's
+ * all-reduce kernels in a multi-GPU step (the reference leaves this to DDP / NCCL: model/runner.py:121).  Call before sizing
+ * workspaces (the *_workspace_floats queries follow the grid); default 0, or SHAPECLIPPER_RESERVE_CUS.  Host-only calls.       */
+int sc_set_reserved_cus(int n);
+int sc_grid_cus(void);
+/* The convolution launches keep one small device table per (device, shape, grid) -- the stream-K span cut -- created by the first launch
+ * of a shape outside a stream capture (stream-ordered copy on the launch stream).  This frees them all (rebuilt on demand); call
+ * with no convolution in flight.                                                                                               */
+int sc_conv3x3_release_tables(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,5 +54,14 @@ def load_module():
     return mod
 
 
+def load_or_build():
+    """load_module(), building the extension first when it is missing and the reference's sources are present."""
+    mod = load_module()
+    if mod is None and os.path.isdir(REF):
+        build()
+        mod = load_module()
+    return mod
+
+
 if __name__ == "__main__":
     print(build(verbose="-v" in sys.argv))

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 from typing import Optional
 
 import torch
@@ -30,7 +31,7 @@ SYMBOLS = (
     "sc_camera_prior_max_images", "sc_transform_normal_forward", "sc_transform_normal_backward", "sc_loss_total_forward",
     "sc_loss_total_backward",
     "sc_render_backward", "sc_sdf_backward_fused", "sc_sdf_backward_fused_parts", "sc_sdf_backward_fused_partial_floats", "sc_tbl_sum_blocks", "sc_conv3x3_pack", "sc_conv3x3_forward", "sc_conv3x3_pack_multi", "sc_conv3x3_pack_multi_units", "sc_conv3x3_tile_channels", "sc_conv3x3_wgrad", "sc_conv3x3_wgrad_split", "sc_conv3x3_forward_split", "sc_conv3x3_tile_channels_split", "sc_conv_stem_forward", "sc_conv_stem_wgrad", "sc_conv1x1s2_forward", "sc_conv1x1s2_backward_data", "sc_conv1x1s2_wgrad", "sc_conv3x3s2_forward", "sc_conv3x3s2_bd_pack", "sc_conv3x3s2_backward_data", "sc_conv3x3s2_wgrad",
-    "sc_basic_block_forward", "sc_basic_block_backward", "sc_rgb_composite_backward_v3",
+    "sc_basic_block_forward", "sc_basic_block_backward", "sc_rgb_composite_backward_v3", "sc_set_reserved_cus", "sc_grid_cus", "sc_conv3x3_release_tables",
 )
 # entry points that do not return an int status
 SYMBOLS_OTHER = ("sc_render_backward_workspace_bytes", "sc_chamfer3d_grid_workspace_bytes", "sc_clip_vit_workspace_bytes", "sc_conv3x3_pack_floats", "sc_conv3x3_workspace_floats", "sc_conv3x3_wgrad_workspace_floats", "sc_conv3x3_pack_floats_split", "sc_conv3x3_workspace_floats_split", "sc_conv_stem_wgrad_workspace_floats", "sc_conv1x1s2_wgrad_workspace_floats", "sc_conv3x3s2_pack_floats", "sc_conv3x3s2_workspace_floats", "sc_conv3x3s2_bd_pack_floats", "sc_conv3x3s2_bd_workspace_floats")
@@ -40,7 +41,7 @@ _lib: Optional[ctypes.CDLL] = None
 # Optional per-entry-point GPU timing (bench.py): when TIMING is a dict every C-ABI call is bracketed by
 # two events on torch's current stream (the stream the kernels are enqueued on).
 TIMING = None
-TIMING_SKIP = ("sc_bn_splits", "sc_isosurface_blocks_per_image", "sc_bn_act_forward", "sc_bn_act_backward", "sc_bn_relu_pool_forward", "sc_bn_relu_pool_backward",
+TIMING_SKIP = ("sc_set_reserved_cus", "sc_grid_cus", "sc_conv3x3_release_tables", "sc_bn_splits", "sc_isosurface_blocks_per_image", "sc_bn_act_forward", "sc_bn_act_backward", "sc_bn_relu_pool_forward", "sc_bn_relu_pool_backward",
                # the trunks' convolutions: ~250 calls per step -- two events each cost the step ~1 ms (rocprofv3 covers them: profiles/)
                "sc_conv3x3_forward", "sc_conv3x3_forward_split", "sc_conv3x3_wgrad", "sc_conv3x3_wgrad_split", "sc_conv3x3_pack", "sc_conv3x3_pack_multi", "sc_conv3x3_pack_multi_units",
                "sc_conv_stem_forward", "sc_conv_stem_wgrad", "sc_conv1x1s2_forward", "sc_conv1x1s2_backward_data", "sc_conv1x1s2_wgrad",
@@ -93,12 +94,11 @@ def load():
     return _lib
 
 
-_last_device = -1        # device index of the tensor ptr() saw last (checked by stream(): arguments are evaluated left to right, stream last)
+_tls = threading.local()    # .dev: device index of the tensor ptr() saw last ON THIS THREAD (autograd and side-stream threads have their own)
 
 
 def ptr(t: Optional[torch.Tensor]):
     """Device pointer of a contiguous CUDA/ROCm tensor (NULL for None)."""
-    global _last_device
     if t is None:
         return ctypes.c_void_p(0)
     if not t.is_cuda:
@@ -106,23 +106,27 @@ def ptr(t: Optional[torch.Tensor]):
                            "the product path has no CPU fallback")
     if not t.is_contiguous():
         raise RuntimeError("shapeclipper_amd: tensor must be contiguous")
-    _last_device = t.get_device()
+    _tls.dev = t.get_device()
     return ctypes.c_void_p(t.data_ptr())
 
 
-def raw_stream() -> int:
+def raw_stream(device: Optional[int] = None) -> int:
     """hipStream_t of torch's current stream on the current device as an integer.  (torch.cuda.current_stream() builds a Python Stream
     object per call, ~8 us: at ~280 entry-point calls per training step that was 2.4 ms of host time per step.)
 
-    Device guard (ADVICE r02 / VERDICT r03): the kernels are launched on the CURRENT device's stream, so a tensor that lives on another
-    device (rank != device index, a stray `cuda:0` default in a multi-GPU process) would be dereferenced by the wrong GPU.  Every entry
-    point passes its tensors through ptr() before it asks for the stream: the device of the last one must be the current device."""
-    dev = torch._C._cuda_getDevice()
-    if _last_device >= 0 and _last_device != dev:
+    Device guard: the kernels are launched on the CURRENT device's stream, so a tensor that lives on another device
+    (rank != device index, a stray `cuda:0` default in a multi-GPU process) would be dereferenced by the wrong GPU.  `device` = the
+    device index of the call's tensors: callers that take raw data_ptr()s (BatchNorm, block and workspace paths) pass it explicitly;
+    entry points that pass their tensors through ptr() leave it None and the device of the last ptr() of THIS thread is checked.  The
+    remembered device is consumed by the check, so a later, unrelated call is never judged by a stale tensor."""
+    cur = torch._C._cuda_getDevice()
+    want = getattr(_tls, "dev", -1) if device is None else device
+    _tls.dev = -1
+    if want is not None and want >= 0 and want != cur:
         raise RuntimeError("shapeclipper_amd: tensor on cuda:%d but the current device is cuda:%d -- call torch.cuda.set_device(rank's device) "
                            "(or wrap the call in `with torch.cuda.device(t.device)`); kernels launch on the current device's stream"
-                           % (_last_device, dev))
-    return torch._C._cuda_getCurrentRawStream(dev)
+                           % (want, cur))
+    return torch._C._cuda_getCurrentRawStream(cur)
 
 
 def stream():

@@ -10,6 +10,7 @@
 // operand and 4 MFMAs (k pair = (pixel, pixel + 4)), and sums its partial blocks in range order (fixed summation order).
 #include <hip/hip_runtime.h>
 
+#include "grid_cus.hpp"
 #include "shapeclipper_hip.h"
 
 namespace sc {
@@ -172,9 +173,7 @@ __global__ void conv1x1s2_wgrad_reduce_kernel(const float* __restrict__ partial,
 }
 
 static int ds_splits(int cin, int cout) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int s = (cus > 0 ? cus : 256) / ((cin / 64) * (cout / 64));
+    const int s = grid_cus() / ((cin / 64) * (cout / 64));
     return s > 0 ? s : 1;
 }
 static bool ds_ok(int batch, int cin, int cout, int hin) {

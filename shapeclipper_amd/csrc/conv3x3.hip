@@ -33,6 +33,7 @@
 #include <tuple>
 #include <vector>
 
+#include "grid_cus.hpp"
 #include "shapeclipper_hip.h"
 
 #ifndef SC_CONV_SPANS
@@ -772,11 +773,7 @@ __global__ __launch_bounds__(256) void conv3x3_pack_multi_split_kernel(const lon
     }
 }
 
-static int conv_grid() {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return cus > 0 ? cus : 256;
-}
+static int conv_grid() { return grid_cus(); }
 
 template <class C>
 static long long workspace_floats() { return (long long)conv_grid() * C::WGS_PER_CU * 2 * C::TILE; }
@@ -795,15 +792,30 @@ static int launch_pack(const float* w, float* wpack, int cin, int cout, int tf, 
 // equal spans leave the workgroups whose span crosses a tile boundary (40 % of them at 14 x 14) one overhead behind the others and the
 // launch waits for them.  Here a span's cost is 2 * units + ov2 * tiles touched, and the spans are the greedy cut at the smallest cost
 // bound that still covers all units with G workgroups.  Built once per (device, tail tiles, K-steps, grid, ov2) and kept on the device.
-static const int* conv_spans(int tail_tiles, int nk, int G, int ov2) {
-    static std::mutex mu;
-    static std::map<std::tuple<int, int, int, int, int>, int*> cache;
+//  The device copy is made ONCE per key, stream-ordered (hipMemcpyAsync on the launch stream from a host table the cache keeps
+// alive), never while that stream is being captured into a graph (hipMalloc is not capturable: a launch under capture that meets an
+// unseen shape runs with equal spans -- same values up to the summation order of the shared tiles' partials, which is fixed either way),
+// and sc_conv3x3_release_tables() frees every table.
+struct SpanTable {
+    int* dev = nullptr;
+    std::vector<int> host;
+};
+static std::mutex span_mu;
+static std::map<std::tuple<int, int, int, int, int>, SpanTable> span_cache;
+
+static const int* conv_spans(int tail_tiles, int nk, int G, int ov2, hipStream_t st) {
+    std::map<std::tuple<int, int, int, int, int>, SpanTable>& cache = span_cache;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lock(mu);
+    std::lock_guard<std::mutex> lock(span_mu);
     const auto key = std::make_tuple(dev, tail_tiles, nk, G, ov2);
     auto it = cache.find(key);
-    if (it != cache.end()) return it->second;
+    if (it != cache.end()) return it->second.dev;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return nullptr;                                               // not cached: built by the first launch outside a capture
+    }
     const int total = tail_tiles * nk;
     std::vector<int> U(G + 1), best;
     auto build = [&](int bound) {
@@ -828,11 +840,15 @@ static const int* conv_spans(int tail_tiles, int nk, int G, int ov2) {
         if (build(mid)) hi = mid; else lo = mid + 1;
     }
     (void)build(hi);
-    int* d = nullptr;
-    if (hipMalloc(&d, (size_t)(G + 1) * sizeof(int)) != hipSuccess || hipMemcpy(d, U.data(), (size_t)(G + 1) * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
-        d = nullptr;                                                  // (null: the kernels fall back to equal spans)
-    cache[key] = d;
-    return d;
+    SpanTable& t = cache[key];
+    t.host = U;                                                       // the source of the asynchronous copy outlives it
+    if (hipMalloc(&t.dev, (size_t)(G + 1) * sizeof(int)) != hipSuccess ||
+        hipMemcpyAsync(t.dev, t.host.data(), (size_t)(G + 1) * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) {
+        (void)hipGetLastError();
+        if (t.dev) (void)hipFree(t.dev);
+        t.dev = nullptr;                                              // (null: the kernels fall back to equal spans)
+    }
+    return t.dev;
 }
 
 template <class C>
@@ -840,10 +856,13 @@ static int launch_conv(const float* x, const float* wpack, float* out, float* wo
     if (cin % C::CB || batch <= 0) return (int)hipErrorInvalidValue;
     const int tiles = ((batch * C::HWO + C::PT - 1) / C::PT) * ((cout + C::CT - 1) / C::CT) * (C::BD2 ? 4 : 1), nk = conv_nk<C>(cin);
     const int G = conv_grid() * C::WGS_PER_CU;
+    // SPLIT instances read x through a buffer resource whose byte range is a 31-bit count: a larger input must be refused, not silently
+    // read as zeros past the clamp; 2 GiB of fp32 is 2,674 images of 64 x 56 x 56 -- far outside any batch of this path
+    if (C::SPLIT && (long long)batch * cin * C::HW * 4 > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     (void)hipFuncSetAttribute((const void*)conv3x3_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     const ConvSplit sp = conv_split(tiles, nk, G);
     // overhead of a touched tile in half K-steps: a K-step of the 512-pixel tiles takes ~5.3 us, of the 256-pixel tiles ~3.2
-    const int* spans = (SC_CONV_SPANS && sp.tail_tiles > 0 && sp.per_wg <= nk) ? conv_spans(sp.tail_tiles, nk, G, C::PT >= 512 ? 2 : 3) : nullptr;
+    const int* spans = (SC_CONV_SPANS && sp.tail_tiles > 0 && sp.per_wg <= nk) ? conv_spans(sp.tail_tiles, nk, G, C::PT >= 512 ? 2 : 3, st) : nullptr;
     hipLaunchKernelGGL((conv3x3_kernel<C>), dim3(G), dim3(C::NT), C::LDS_BYTES, st, x, wpack, out, workspace, batch, cin, cout, spans);
     if (sp.tail_tiles > 0)
         hipLaunchKernelGGL((conv3x3_fixup_kernel<C>), dim3(sp.tail_tiles, 4), dim3(C::NT), 0, st, workspace, out, batch, cin, cout, G, spans);
@@ -851,6 +870,21 @@ static int launch_conv(const float* x, const float* wpack, float* out, float* wo
 }
 
 }  // namespace sc
+
+// Frees the span tables of every device (they are rebuilt on demand).  The caller makes sure no launch that uses them is in flight.
+extern "C" int sc_conv3x3_release_tables(void) {
+    std::lock_guard<std::mutex> lock(sc::span_mu);
+    int dev0 = 0;
+    (void)hipGetDevice(&dev0);
+    for (auto& kv : sc::span_cache)
+        if (kv.second.dev) {
+            (void)hipSetDevice(std::get<0>(kv.first));
+            (void)hipFree(kv.second.dev);
+        }
+    sc::span_cache.clear();
+    (void)hipSetDevice(dev0);
+    return 0;
+}
 
 #define SC_CONV_DISPATCH(hw, CALL)                   \
     switch (hw) {                                    \

@@ -20,6 +20,7 @@
 // Roofline: 2 * 9 * Cin * Cout FLOP per pixel on the 157.3 TFLOP/s fp32 matrix pipe; one read of gy and of x from HBM.
 #include <hip/hip_runtime.h>
 
+#include "grid_cus.hpp"
 #include "shapeclipper_hip.h"
 
 namespace sc {
@@ -447,11 +448,7 @@ using Ws28 = WsCfg<28, 4, 1>;
 using Ws14 = WsCfg<14, 7, 1>;
 using Ws7 = WsCfg<7, 7, 2>;
 
-static int wg_cus() {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return cus > 0 ? cus : 256;
-}
+static int wg_cus() { return grid_cus(); }
 static int wg_splits(int cin, int cout) {
     const int nblk = (cin / 64) * (cout / 64), s = wg_cus() / nblk;
     return s > 0 ? s : 1;

@@ -15,6 +15,7 @@
 // each, summed in range order by conv_stem_wgrad_reduce_kernel (fixed summation order).
 #include <hip/hip_runtime.h>
 
+#include "grid_cus.hpp"
 #include "shapeclipper_hip.h"
 
 namespace sc {
@@ -253,11 +254,7 @@ __global__ void conv_stem_wgrad_reduce_kernel(const float* __restrict__ partial,
     if (k < ST_K) dw[co * ST_K + k] = (s0 + s1) + (s2 + s3);
 }
 
-static int stem_cus() {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return cus > 0 ? cus : 256;
-}
+static int stem_cus() { return grid_cus(); }
 
 }  // namespace sc
 

@@ -123,9 +123,10 @@ class ClipVisionTower(nn.Module):
     forward = encode_image
 
     @staticmethod
-    def from_openai_state_dict(sd, **cfg):
-        """Map openai/CLIP `visual.*` keys (clip.load(...).state_dict()) onto this module."""
-        m = ClipVisionTower(**cfg)
+    def from_openai_state_dict(sd, dtype="fp16", **cfg):
+        """Map openai/CLIP `visual.*` keys (clip.load(...).state_dict(), CLIP_anno.py:16) onto this module.  Geometry is read off the
+        tensor shapes (as the package's own build_model does) unless given; fp16 checkpoints are widened to fp32 parameters exactly."""
+        m = ClipVisionTower(dtype=dtype, **(cfg or geometry_from_openai_state_dict(sd)))
         W = m.cfg["width"]
         out = {"vision_model.embeddings.class_embedding": sd["visual.class_embedding"],
                "vision_model.embeddings.patch_embedding.weight": sd["visual.conv1.weight"],
@@ -145,3 +146,17 @@ class ClipVisionTower(nn.Module):
             out[dst + "mlp.fc2.weight"], out[dst + "mlp.fc2.bias"] = sd[src + "mlp.c_proj.weight"], sd[src + "mlp.c_proj.bias"]
         m.load_state_dict({k: v.float() for k, v in out.items()})
         return m
+
+
+def geometry_from_openai_state_dict(sd):
+    """ClipVisionTower(**geometry) of an openai/CLIP checkpoint, from its tensor shapes (ViT towers only; the package's ResNet towers
+    have no `visual.proj`): width / patch from `visual.conv1.weight`, depth from the resblock count, tokens from
+    `visual.positional_embedding`, heads = width / 64, the projection width from `visual.proj`."""
+    if "visual.proj" not in sd or "visual.conv1.weight" not in sd:
+        raise KeyError("not an openai/CLIP ViT checkpoint: no visual.proj / visual.conv1.weight")
+    width, _, patch, _ = sd["visual.conv1.weight"].shape
+    layers = len({k.split(".")[3] for k in sd if k.startswith("visual.transformer.resblocks.")})
+    grid = round((sd["visual.positional_embedding"].shape[0] - 1) ** 0.5)
+    mlp = sd["visual.transformer.resblocks.0.mlp.c_fc.weight"].shape[0]
+    return dict(image_size=int(grid * patch), patch=int(patch), width=int(width), layers=int(layers), heads=int(width // 64), mlp=int(mlp),
+                proj=int(sd["visual.proj"].shape[1]))

@@ -76,6 +76,13 @@ class Runner:
         name = "pretrainer" if opt.pretrain else "graph"
         module = importlib.import_module("shapeclipper_amd.model.{}".format(name))
         dev = torch.device("cuda", opt.device) if isinstance(opt.device, int) else torch.device(opt.device)
+        # `--hip.reserve_cus=N` (default 0): in a multi-GPU step the persistent one-workgroup-per-CU grids of the trunk convolutions are sized
+        # for (CUs - N), leaving N compute units to RCCL's all-reduce kernels.  Set before any workspace is sized;
+        # single-GPU runs keep every CU.
+        reserve = int(opt.get("hip", {}).get("reserve_cus", 0) or 0)
+        if dev.type == "cuda":
+            from .. import ops
+            ops.set_reserved_cus(reserve if opt.world_size > 1 else 0)
         self.graph = ModuleHolder(module.Graph(opt).to(dev))
         if opt.world_size > 1:
             # Default (round 4): north_star's SINGLE flat all-reduce after backward.  `--hip.overlap_allreduce` lays the buffer out
@@ -198,7 +205,7 @@ class Runner:
         # right after the forward pass.  Guarded step (default with the fused optimizer): the flag is also the optimizer's `found_inf`, so a
         # poisoned step leaves the weights, the Adam moments and the step counters untouched without the host knowing yet; the host reads
         # the flag of the PREVIOUS step here (complete long ago: no wait -- the per-step wait cost 1.0 ms of 36.6 at bs32, 0.3 of 22.0 at
-        # bs16, profiles/r04_guarded_step.txt) and raises the reference's assertion one step late, before this step's update is applied.
+        # bs16, measured round 4 with tools/step_times.py) and raises the reference's assertion one step late, before this step's update is applied.
         # Otherwise (foreach / CPU optimizers): wait for this step's flag now, before optim.step().
         if getattr(self, "_guarded_step", False):
             optim.grad_scale, optim.found_inf = None, getattr(self, "_step_found_inf", None)
@@ -207,9 +214,13 @@ class Runner:
             self.check_finite()
         optim.step()
 
+        # Never checkpoint a step whose losses were not verified -- and EVERY rank drains its pending flags at a checkpoint iteration, not
+        # only rank 0: the flag is MAX-reduced over the ranks, so all of them raise here together instead of rank 0 dying alone
+        # and the others walking into the next step's collectives against a dead peer.
+        if (self.it + 1) % opt.freq.ckpt_latest == 0:
+            self.check_finite()
         if _rank0(opt):
             if (self.it + 1) % opt.freq.ckpt_latest == 0:
-                self.check_finite()           # never checkpoint a step whose losses were not verified
                 self.save_checkpoint(opt, ep=self.ep, it=self.it + 1, best_val=self.best_val, latest=True)
             if opt.freq.scalar and self.it % opt.freq.scalar == 0 and self.tb is not None:
                 self.log_scalars(opt, var, loss, step=self.it, split="train")

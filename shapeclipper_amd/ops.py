@@ -17,7 +17,7 @@ _SCRATCH = {}
 
 def _sdf_scratch(dev):
     """[256 workgroups x 8 waves][5][1024] floats (42 MB), one per (device, stream): calls on a stream are ordered."""
-    key = (dev.type, dev.index, _lib.raw_stream() if dev.type == "cuda" else 0)
+    key = (dev.type, dev.index, _lib.raw_stream(dev.index) if dev.type == "cuda" else 0)
     if key not in _SCRATCH:
         _SCRATCH[key] = torch.empty(256 * 8 * 5 * 1024, device=dev, dtype=torch.float32)
     return _SCRATCH[key]
@@ -92,7 +92,7 @@ def _partial_reduce(lib, partial, nparts, stride, n, out):
 
 
 def _rowsum_scratch(dev, n_floats):
-    key = ("rowsum", dev.type, dev.index, _lib.raw_stream() if dev.type == "cuda" else 0)
+    key = ("rowsum", dev.type, dev.index, _lib.raw_stream(dev.index) if dev.type == "cuda" else 0)
     if key not in _SCRATCH or _SCRATCH[key].numel() < n_floats:
         _SCRATCH[key] = torch.empty(n_floats, device=dev, dtype=torch.float32)
     return _SCRATCH[key]
@@ -147,7 +147,7 @@ def tbl_sum(x, n_points, n_per_image, n_images, coef=None):
 
 def _park_scratch(dev, n_floats):
     """Per-(device, stream) scratch of the fused backward (parked second-order terms; L2-resident)."""
-    key = ("park", dev.type, dev.index, _lib.raw_stream() if dev.type == "cuda" else 0)
+    key = ("park", dev.type, dev.index, _lib.raw_stream(dev.index) if dev.type == "cuda" else 0)
     if key not in _SCRATCH or _SCRATCH[key].numel() < n_floats:
         _SCRATCH[key] = torch.empty(n_floats, device=dev, dtype=torch.float32)
     return _SCRATCH[key]
@@ -436,7 +436,7 @@ def _bn(name):
 
 def _bn_partial(x, groups=1):
     """Workspace for the per-(channel, group) partial sums: at most 2*(2048 + C*G) floats."""
-    key = (x.device.index, _lib.raw_stream())      # one per stream: calls on a stream are ordered
+    key = (x.device.index, _lib.raw_stream(x.device.index))      # one per stream: calls on a stream are ordered
     need = 2 * (2048 + x.shape[1] * groups)
     ws = _bn_ws.get(key)
     if ws is None or ws.numel() < need:
@@ -745,9 +745,22 @@ def conv3x3_pack(w, side, transpose_flip=False, split=False):
 _conv_ws = {}
 
 
+def set_reserved_cus(n: int) -> int:
+    """Size the persistent convolution grids for (device CUs - n) compute units (sc_set_reserved_cus; `--hip.reserve_cus`): leaves n CUs
+    to concurrently running kernels of other streams (RCCL's all-reduce in a multi-GPU step).  Returns the resulting grid size.  The cached
+    partial-tile workspaces are dropped when the value changes (their sizes follow the grid)."""
+    lib = _lib.load()
+    before = lib.sc_grid_cus()
+    _lib.check(lib.sc_set_reserved_cus(int(n)), "sc_set_reserved_cus")
+    after = lib.sc_grid_cus()
+    if after != before:
+        _conv_ws.clear()
+    return after
+
+
 def _conv_workspace(dev, side, split=False):
     """Scratch for the partial tiles of sc_conv3x3_forward, one per (device, stream, map side): calls on a stream are ordered."""
-    key = (dev.index, _lib.raw_stream(), side, split)
+    key = (dev.index, _lib.raw_stream(dev.index), side, split)
     ws = _conv_ws.get(key)
     if ws is None:
         lib = _lib.load()
@@ -797,7 +810,7 @@ def conv3x3_backward_weight(gy, x, split=False):
     n = lib.sc_conv3x3_wgrad_workspace_floats(cin, cout)
     if n < 0 or H not in CONV3X3_SIDES or x.shape[0] != B or tuple(x.shape[2:]) != (H, H):
         raise RuntimeError("shapeclipper_amd: sc_conv3x3_wgrad does not take gy %s with x %s" % (tuple(gy.shape), tuple(x.shape)))
-    key = (x.device.index, _lib.raw_stream(), "wgrad")
+    key = (x.device.index, _lib.raw_stream(x.device.index), "wgrad")
     ws = _conv_ws.get(key)
     if ws is None or ws.numel() < n:
         ws = _conv_ws[key] = torch.empty(n, device=x.device, dtype=torch.float32)
@@ -834,7 +847,7 @@ def _block(name):
 
 def _wgrad_workspace(x, cin, cout):
     n = _lib.load().sc_conv3x3_wgrad_workspace_floats(cin, cout)
-    key = (x.device.index, _lib.raw_stream(), "wgrad")
+    key = (x.device.index, _lib.raw_stream(x.device.index), "wgrad")
     ws = _conv_ws.get(key)
     if ws is None or ws.numel() < n:
         ws = _conv_ws[key] = torch.empty(n, device=x.device, dtype=torch.float32)
@@ -850,8 +863,7 @@ def basic_block_forward(x, pf1, pf2, g1, b1, g2, b2, bn1_state, bn2_state, split
     rm2, rv2, nt2, _, mom2, eps2 = bn2_state
     y1, a1, y2, out = (torch.empty_like(x) for _ in range(4))
     st = torch.empty(2, 2, groups, C, device=x.device, dtype=torch.float32)
-    _lib._last_device = x.get_device()
-    stream = _lib.raw_stream()
+    stream = _lib.raw_stream(x.get_device())
     a = BlockArgs()
     a.x, a.pf1, a.pf2 = x.data_ptr(), pf1.data_ptr(), pf2.data_ptr()
     a.g1, a.b1, a.g2, a.b2 = g1.data_ptr(), b1.data_ptr(), g2.data_ptr(), b2.data_ptr()
@@ -877,8 +889,7 @@ def basic_block_backward(d_out, x, saved, out, pb1, pb2, g1, b1, g2, b2, trainin
     gw1 = torch.empty(C, C, 3, 3, device=x.device, dtype=torch.float32) if need_w1 else None
     gw2 = torch.empty(C, C, 3, 3, device=x.device, dtype=torch.float32) if need_w2 else None
     dgb = torch.empty(2, 2, C, device=x.device, dtype=torch.float32)
-    _lib._last_device = x.get_device()
-    stream = _lib.raw_stream()
+    stream = _lib.raw_stream(x.get_device())
     a = BlockArgs()
     a.x, a.pb1, a.pb2, a.d_out = x.data_ptr(), pb1.data_ptr(), pb2.data_ptr(), d_out.data_ptr()
     a.g1, a.b1, a.g2, a.b2 = g1.data_ptr(), b1.data_ptr(), g2.data_ptr(), b2.data_ptr()
@@ -910,7 +921,7 @@ def conv_stem_forward(x, w):
 def conv_stem_backward_weight(gy, x):
     lib = _lib.load()
     gy, x = _aligned(gy), _aligned(x)
-    key = (x.device.index, _lib.raw_stream(), "stem")
+    key = (x.device.index, _lib.raw_stream(x.device.index), "stem")
     ws = _conv_ws.get(key)
     if ws is None:
         ws = _conv_ws[key] = torch.empty(lib.sc_conv_stem_wgrad_workspace_floats(), device=x.device, dtype=torch.float32)
@@ -950,7 +961,7 @@ def conv1x1s2_backward_weight(gy, x):
     B, cin, H, _ = x.shape
     cout = gy.shape[1]
     n = lib.sc_conv1x1s2_wgrad_workspace_floats(cin, cout)
-    key = (x.device.index, _lib.raw_stream(), "1x1s2")
+    key = (x.device.index, _lib.raw_stream(x.device.index), "1x1s2")
     ws = _conv_ws.get(key)
     if ws is None or ws.numel() < n:
         ws = _conv_ws[key] = torch.empty(n, device=x.device, dtype=torch.float32)
@@ -976,7 +987,7 @@ def conv3x3s2_forward(x, w):
         raise RuntimeError("shapeclipper_amd: sc_conv3x3s2 does not take [%d, %d, %d, %d] * %s" % (B, cin, H, H, tuple(w.shape)))
     w_pack = torch.empty(n, device=x.device, dtype=torch.float32)
     _lib.check(lib.sc_conv3x3_pack(_lib.ptr(w), _lib.ptr(w_pack), cin, cout, H, 4, _lib.stream()), "sc_conv3x3_pack")
-    key = (x.device.index, _lib.raw_stream(), H, "s2")
+    key = (x.device.index, _lib.raw_stream(x.device.index), H, "s2")
     ws = _conv_ws.get(key)
     if ws is None:
         ws = _conv_ws[key] = torch.empty(lib.sc_conv3x3s2_workspace_floats(H), device=x.device, dtype=torch.float32)
@@ -1002,7 +1013,7 @@ def conv3x3s2_backward_data(gy, w, hw):
         raise RuntimeError("shapeclipper_amd: sc_conv3x3s2_backward_data does not take gy %s with w %s" % (tuple(gy.shape), tuple(w.shape)))
     w_pack = torch.empty(n, device=gy.device, dtype=torch.float32)
     _lib.check(lib.sc_conv3x3s2_bd_pack(_lib.ptr(w), _lib.ptr(w_pack), cin, cout, hw, _lib.stream()), "sc_conv3x3s2_bd_pack")
-    key = (gy.device.index, _lib.raw_stream(), hw, "s2bd")
+    key = (gy.device.index, _lib.raw_stream(gy.device.index), hw, "s2bd")
     ws = _conv_ws.get(key)
     if ws is None:
         ws = _conv_ws[key] = torch.empty(lib.sc_conv3x3s2_bd_workspace_floats(hw), device=gy.device, dtype=torch.float32)
@@ -1021,7 +1032,7 @@ def conv3x3s2_backward_weight(gy, x):
     n = lib.sc_conv3x3_wgrad_workspace_floats(cin, cout)
     if n < 0 or hw not in (56, 28, 14) or tuple(gy.shape) != (B, cout, hw // 2, hw // 2):
         raise RuntimeError("shapeclipper_amd: sc_conv3x3s2_wgrad does not take gy %s with x %s" % (tuple(gy.shape), tuple(x.shape)))
-    key = (x.device.index, _lib.raw_stream(), "wgrad")
+    key = (x.device.index, _lib.raw_stream(x.device.index), "wgrad")
     ws = _conv_ws.get(key)
     if ws is None or ws.numel() < n:
         ws = _conv_ws[key] = torch.empty(n, device=x.device, dtype=torch.float32)

@@ -66,4 +66,18 @@ def test_device_guard_raises_when_a_tensor_is_not_on_the_current_device(monkeypa
     _lib.ptr(FakeCudaTensor(0))
     with pytest.raises(RuntimeError, match="current device is cuda:1"):
         _lib.stream()
-    monkeypatch.setattr(_lib, "_last_device", -1)
+    #  the remembered device is consumed by the check: an unrelated later call is not judged by the stale cuda:0 tensor ...
+    assert _lib.raw_stream() == 1235
+    # ... callers that take raw data_ptr()s name the device themselves (BatchNorm / block / workspace paths) ...
+    assert _lib.raw_stream(1) == 1235
+    with pytest.raises(RuntimeError, match="tensor on cuda:0"):
+        _lib.raw_stream(0)
+    # ... and the memory is per thread (autograd and side-stream threads launch concurrently)
+    import threading
+    _lib.ptr(FakeCudaTensor(0))
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(_lib.raw_stream()))
+    t.start(); t.join()
+    assert seen == [1235]
+    with pytest.raises(RuntimeError):
+        _lib.raw_stream()

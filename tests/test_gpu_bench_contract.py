@@ -73,6 +73,54 @@ def test_bench_two_ranks_through_the_launcher():
     assert d["sustained"]["steps"] == 2
 
 
+def test_bench_self_launches_its_ranks():
+    """VERDICT r04 next #1a/b: plain `python bench.py --gpus 2` -- no torch.distributed.run in front, no RANK / WORLD_SIZE in the environment
+    -- starts its own two ranks (gloo on the one GPU of this box) and prints ONE line with n_gpus == 2 and the multi-rank extras."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MIOPEN_LOG_LEVEL="1", SC_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--sustained", "0", "--opt=--hip.reserve_cus=16"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len([l for l in r.stdout.splitlines() if l.startswith("{")]) == 1
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 4
+    rk, ar = d["ranks"], d["allreduce"]
+    assert rk["backend"] == "gloo" and rk["backend_world_size"] == 2 and 0 < rk["ms_per_step_min"] <= rk["ms_per_step_max"]
+    assert abs(rk["ms_per_step_max"] - d["ms_per_step"]) < 0.02 * d["ms_per_step"]          # the line's time is the slowest rank's
+    assert ar["bus_GBps"] > 0 and ar["reserved_cus"] == 16 and ar["persistent_grid_cus"] == torch_cus() - 16
+    assert ar["schedule"].startswith("single flat")
+
+
+def torch_cus():
+    import torch
+    return torch.cuda.get_device_properties(0).multi_processor_count
+
+
+def test_reserved_cus_same_results():
+    """`--hip.reserve_cus`: the stream-K convolution, its weight gradient and the stride-2 / stem gradients on a (CUs - 32) grid give the
+    values of the full grid up to the summation order of the shared tiles (fp32 rounding), and the setting is undone by 0."""
+    import torch
+    from shapeclipper_amd import ops
+    torch.manual_seed(0)
+    x = torch.randn(8, 128, 28, 28, device="cuda")
+    w = torch.randn(128, 128, 3, 3, device="cuda") * 0.05
+    gy = torch.randn(8, 128, 28, 28, device="cuda")
+    try:
+        full = ops.set_reserved_cus(0)
+        y0, dw0 = ops.conv3x3_forward(x, w, split=True), ops.conv3x3_backward_weight(gy, x, split=True)
+        assert ops.set_reserved_cus(32) == full - 32
+        y1, dw1 = ops.conv3x3_forward(x, w, split=True), ops.conv3x3_backward_weight(gy, x, split=True)
+        y2 = ops.conv3x3_forward(x, w, split=True)
+    finally:
+        assert ops.set_reserved_cus(0) == full
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), None, 1, 1)
+    assert torch.equal(y1, y2)                                             # deterministic on the reduced grid
+    assert (y1.double() - ref).abs().max() < 2e-5 * ref.abs().max() and (y0 - y1).abs().max() < 2e-5 * ref.abs().max()
+    assert (dw0 - dw1).abs().max() < 2e-5 * dw0.abs().max()
+    y3 = ops.conv3x3_forward(x, w, split=True)
+    assert torch.equal(y0, y3)
+
+
 def test_bench_eight_ranks_config3_code_path():
     """BASELINE config[3]'s rank count (8 processes, `--gpus 8`) on the one GPU of this box: all ranks share cuda:0 and exchange over gloo,
     one image per rank -- the launcher / rank / barrier / MAX-over-ranks / flat all-reduce code the 8-GPU scaling run executes, inside GPUTEST
@@ -100,6 +148,8 @@ def test_workloads_line():
     for k in ("workload", "ms", "algorithmic_flop", "algorithmic_bytes", "achieved", "peak", "unit", "bound", "frac"):
         assert k in out, k
     assert out["algorithmic_flop"] == 80640 * 101 ** 3 and 0 < out["frac"] < 1.0
+    from oracle import build_chamfer_ref
+    assert build_chamfer_ref.load_or_build() is not None, "oracle/_ref/chamfer_3D_ref.so missing and /root/reference absent: reference leg cannot run"
     c = w.chamfer(1, N=20000, with_cpu=False, with_reference_gpu=True)
     assert c["all_pairs"]["algorithmic_flop"] == 16.0 * 20000 * 20000 and 0 < c["all_pairs"]["frac"] < 1.0
     assert c["same_results_as_all_pairs"] is True and c["speedup_vs_all_pairs"] > 0 and c["ms"] > 0

@@ -12,10 +12,13 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def ref():
+    # the strongest Chamfer evidence must not evaporate silently.  The binary is git-ignored and only exists where
+    # __graft_entry__.build() ran next to /root/reference; a GPU box without it FAILS here (built on demand when the reference is present).
     from oracle import build_chamfer_ref
-    mod = build_chamfer_ref.load_module()
+    mod = build_chamfer_ref.load_or_build()
     if mod is None:
-        pytest.skip("oracle/_ref/chamfer_3D_ref.so was not built (needs /root/reference at build time)")
+        pytest.fail("oracle/_ref/chamfer_3D_ref.so is missing and /root/reference is not here to build it from: the reference-kernel "
+                    "pin of Chamfer3D did not run (run __graft_entry__.build() in the build container before shipping the tree)")
     return mod
 
 
