@@ -119,7 +119,7 @@ def process_options(opt):
     resnet.HIP_CONV3X3_S2_GRADS = bool(opt.get("hip", {}).get("conv3x3s2_grads", True))
     resnet.FUSED_BLOCK = bool(opt.get("hip", {}).get("fused_block", True))
     # The ~83 small fp32 GEMMs of a step (estimator heads, latent projectors: [B..3B, 256..512] x [C, C]) through rocBLAS instead of torch's
-    # default hipBLASLt: 7 instead of 18 us of host time per call (tools/probe_blas.py: a host-paced B=8 step 16.3 -> 14.9 ms); process-global
+    # default hipBLASLt: 7 instead of 18 us of host time per call (tools/attic/probe_blas.py: a host-paced B=8 step 16.3 -> 14.9 ms); process-global
     # like cudnn.deterministic above, `--hip.rocblas!` leaves torch's choice alone.
     if bool(opt.get("hip", {}).get("rocblas", True)) and torch.cuda.is_available():
         try:

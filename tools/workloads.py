@@ -38,6 +38,11 @@ RENDER_EVAL_FLOP_PER_RAY = 64 * 199424
 GRID_FLOP_PER_POINT = 80640
 
 
+# share of the reference-dense count the kernels execute (latent columns folded into per-image biases: SURVEY section 7 hard part 2)
+EXECUTED_SHARE_RENDER = (2 * 28032 + 14976) / (2 * 40320 + 19072)
+EXECUTED_SHARE_GRID = 28032 / 40320
+
+
 def _gpu_ms(fn, iters, warm=2):
     for _ in range(warm):
         fn()
@@ -236,6 +241,12 @@ def render_eval_128(B=32, with_cpu=True):
     out = dict(workload="full-frame evaluation render 128x128, B=%d (%d rays x 64 samples)" % (B, rays), ms=round(ms, 3),
                ms_best=round(best, 3), algorithmic_flop=RENDER_EVAL_FLOP_PER_RAY * rays, algorithmic_bytes=rays * 44,
                achieved=round(tf, 2), peak=PEAK_FP32, unit="TFLOP/s", bound="fp32 MFMA", frac=round(tf / PEAK_FP32, 4),
+               # `frac` counts the reference-dense FLOPs of SURVEY 8(d); the kernels fold the 64 latent columns of the
+               # conditioned layers into per-image biases (28,032 of 40,320 SDF MACs -- value and d/dx sweep alike -- and 14,976 of 19,072 RGB
+               # MACs per point are executed), so the matrix pipe does EXECUTED_SHARE of the counted work: the real utilisation is the second figure
+               executed_flop=int(RENDER_EVAL_FLOP_PER_RAY * rays * EXECUTED_SHARE_RENDER), frac_executed=round(tf * EXECUTED_SHARE_RENDER / PEAK_FP32, 4),
+               frac_note="frac = reference-dense FLOPs (SURVEY 8d) / time / peak; frac_executed = the MACs the kernels execute after folding the "
+                         "latent columns into per-image biases (%.3f of the dense count) / time / peak = the matrix pipe's real utilisation" % EXECUTED_SHARE_RENDER,
                mrays_per_s=round(rays / (ms * 1e-3) / 1e6, 2))
     if with_cpu:
         from oracle import reference_ops as R
@@ -270,7 +281,11 @@ def level_grid_100(with_cpu=True):
     tf = GRID_FLOP_PER_POINT * n / (ms * 1e-3) / 1e12
     out = dict(workload="SDF level grid, vox_res=100, one image (%d points)" % n, ms=round(ms, 3), ms_best=round(best, 3),
                algorithmic_flop=GRID_FLOP_PER_POINT * n, algorithmic_bytes=4 * n, achieved=round(tf, 2), peak=PEAK_FP32, unit="TFLOP/s",
-               bound="fp32 MFMA", frac=round(tf / PEAK_FP32, 4), mpoints_per_s=round(n / (ms * 1e-3) / 1e6, 1))
+               bound="fp32 MFMA", frac=round(tf / PEAK_FP32, 4),
+               executed_flop=int(GRID_FLOP_PER_POINT * n * EXECUTED_SHARE_GRID), frac_executed=round(tf * EXECUTED_SHARE_GRID / PEAK_FP32, 4),
+               frac_note="frac = reference-dense 80,640 FLOP per point; frac_executed = the 28,032 of 40,320 MACs per point left after folding the "
+                         "latent columns into per-image biases (%.3f) = the matrix pipe's real utilisation" % EXECUTED_SHARE_GRID,
+               mpoints_per_s=round(n / (ms * 1e-3) / 1e6, 1))
     if with_cpu:
         from oracle import reference_ops as R
         torch.set_num_threads(cpu_threads())
@@ -355,7 +370,11 @@ def resnet_conv3x3(with_cpu=True):
     tf_s, tf_ws = 3 * flop1 / (ms_split * 1e-3) / 1e12, flop1 / (ms_wgs * 1e-3) / 1e12
     tf_w, tf_f = flop1 / (ms_wg * 1e-3) / 1e12, 2 * flop1 / (ms_f32 * 1e-3) / 1e12
     out = dict(workload="3x3 stride-1 convolutions of one bs32 step (ResNet-34 encoder x 64 images, ResNet-18 estimator x 96): fwd + bwd-data + bwd-weight of 42 layers",
-               ms=round(ms_hip, 3), ms_miopen=round(ms_lib, 3), algorithmic_flop=3 * flop1, achieved=round(tf_s, 2), peak=round(PEAK_SPLIT, 1),
+               ms=round(ms_hip, 3), ms_miopen=round(ms_lib, 3),
+               ms_miopen_note="torch / MIOpen in IMMEDIATE mode (MIOPEN_FIND_MODE=FAST: no tuning search) and WITHOUT a workspace (its log says "
+                              "'workspace required ... provided ptr: 0', so it falls back to fp32 Winograd F(2,3) / direct solvers): an untuned, "
+                              "workspace-less MIOpen, not MIOpen at its best -- context, not a claim",
+               algorithmic_flop=3 * flop1, achieved=round(tf_s, 2), peak=round(PEAK_SPLIT, 1),
                unit="TFLOP/s", dtype="f32 (bf16x3-split MFMA, fp32 accumulate, all three products)",
                bound="bf16 MFMA / 6 (exact 3-piece split: six bf16 products per fp32 product)", frac=round(tf_s / PEAK_SPLIT, 4),
                backward_weight=dict(ms=round(ms_wgs, 3), achieved=round(tf_ws, 2), peak=round(PEAK_SPLIT, 1), unit="TFLOP/s",
