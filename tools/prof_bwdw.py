@@ -19,7 +19,7 @@ pts = torch.rand(n, 3, device=dev) * 1.2 - 0.6
 sdf, grad, feat, sa, sp = ops.sdf_forward(pts, pack, cb, npi, stash=True)
 g_sdf, g_grad, g_feat = torch.randn(n, device=dev), torch.randn(n, 3, device=dev), torch.randn_like(feat) * 0.1
 
-lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "micro", "libbwdw_prof.so"))
+lib = ctypes.CDLL(os.environ.get("SC_BWDW_PROF_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "micro", "libbwdw_prof.so"))
 parts = lib.sc_sdf_backward_fused_parts(ctypes.c_int(n))
 park = torch.empty(256 * 4 * 4 * 1024, device=dev)
 partial = torch.empty(parts * lib.sc_sdf_backward_fused_partial_floats(ctypes.c_int(B)), device=dev)
