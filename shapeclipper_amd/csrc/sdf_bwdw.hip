@@ -57,40 +57,16 @@ struct SdfBwdwArgs {
 #define BW_STAMP(ID)
 #endif
 
-#ifndef SC_BWDW_VARIANT
-#define SC_BWDW_VARIANT 0
-#endif
-constexpr bool BW_PECACHE = (SC_BWDW_VARIANT & 1) != 0;
-// bit 1: the chain -> wgrad hand-over is a DATAFLOW of per-slot counters in LDS instead of two workgroup barriers per step (see BW_EXCHANGE)
-constexpr bool BW_FLAGS = (SC_BWDW_VARIANT & 2) != 0;
 constexpr int BW_CHAIN = 4;                          // chain waves (= wgrad waves) per workgroup
 constexpr int BW_WLDS = (SdfLds::TOTAL + 3) & ~3;    // weight image, floats
 constexpr int BW_XCH = BW_WLDS;                      // exchange slots: [chain wave][A|B][1024]
 constexpr int BW_PTS = BW_XCH + BW_CHAIN * 2 * 1024; // point stash: [chain wave][16 points][8] = x0 x1 x2 gam0 gam1 gam2 valid -
 constexpr int BW_RED = BW_PTS + BW_CHAIN * 16 * 8;   // [0..63] sum r0 (dW5 row 0), [64] sum Gs (db5[0])
-constexpr int BW_FLG = BW_RED + 68;                  // BW_FLAGS: [0..3] steps written by chain wave c, [4..7] consumptions of slot c (4 per step)
-constexpr int BW_LDS_FLOATS = BW_FLG + 8;
+constexpr int BW_LDS_FLOATS = BW_RED + 68;
 static_assert(BW_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 
 // LDS-only barrier: does NOT drain the global loads in flight (the stash prefetches must survive it)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// Wave-uniform wait for a monotonic LDS counter (one broadcast ds_read per poll).  Bounded: a protocol error ends in wrong results that
-// the parity tests catch, never in a hung GPU.
-__device__ __forceinline__ void lds_wait_ge(const int* flag, int target) {
-    int guard = 0;
-    while (true) {
-        const int v = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int*>(flag));
-        if (v >= target || ++guard > (1 << 22)) break;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    asm volatile("" ::: "memory");
-}
-// publish: everything this wave wrote to LDS before is complete, then the counter moves (LDS executes a wave's operations in order)
-__device__ __forceinline__ void lds_publish(int* flag, int value, int lane) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane == 0) *reinterpret_cast<volatile int*>(flag) = value;
-}
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
@@ -203,8 +179,6 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) wr[r] = (((p >> 2) * 64 + 4 * g + (r ^ (p >> 2))) << 2) + (p & 3);
         float* park = a.park + (size_t)(blockIdx.x * BW_CHAIN + cw) * 4 * 1024;
-        int* flg = reinterpret_cast<int*>(lds + BW_FLG);
-        int gstep = 0;                                       // steps this wave has handed over (wave-uniform)
 
         // Seven lane-dependent LDS offsets (made opaque so that hipcc keeps ONE register each and puts the matrix / column constants
         // into the 16-bit immediate of the ds_read -- it otherwise hoists a full address per matrix and orientation out of the tile
@@ -228,16 +202,16 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
 
 // the write phase of one step: B1 (the wgrad waves have finished reading the previous pair), write, B2 (visible).
 // VM is the validity mask of the lane's point: a compile-time 1 for full tiles (all but the last tile of a launch)
-// BW_FLAGS: no barrier.  Chain wave c owns slot pair c; it may overwrite the pair once all four wgrad waves have taken the previous
-// step's fragments out of it (cons[c] == 4 * steps so far) and announces the new pair by moving done[c]: each chain wave runs at its own
-// pace, up to one step ahead of the consumers of ITS slot, and the wgrad waves walk the four slots in a circle -- a 4-entry queue.
+// (Round 5 experiment, commit 2093f09: the two barriers replaced by per-slot LDS counters -- each chain wave hands over at its own pace, the
+// wgrad waves walk the four slots as a queue.  Correct, 4 % SLOWER: 2.69 vs 2.59 ms; profiles/r05_bwdw_phase_profile_flags_experiment.txt:
+// the wgrad waves then wait for each slot's flag and fragments in front of its MFMAs instead of reading ahead across the four tiles.)
 #define BW_EXCHANGE(K, WRITES)                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                   \
         BW_STAMP(4 * (K) + 1)                                                                \
-        if (BW_FLAGS) lds_wait_ge(flg + 4 + cw, 4 * gstep); else lds_barrier();              \
+        lds_barrier();                                                                       \
         BW_STAMP(4 * (K) + 2)                                                                \
         if (full) { constexpr float VM = 1.f; WRITES } else { const float VM = vmask; WRITES } \
-        if (BW_FLAGS) { ++gstep; lds_publish(flg + cw, gstep, lane); } else lds_barrier();   \
+        lds_barrier();                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                   \
         BW_STAMP(4 * (K) + 3)
 
@@ -278,12 +252,12 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
             const int tile = base + cw;
             if (tile >= t_end) {            // tail: nothing to do but keep the barrier count (11 steps) and feed zeros
                 for (int k = 0; k < 11; ++k) {
-                    if (BW_FLAGS) lds_wait_ge(flg + 4 + cw, 4 * gstep); else lds_barrier();
+                    lds_barrier();
                     if (k == 0) {
                         xch_zero(slotA, lane); xch_zero(slotB, lane);
                         if (lane < 32) reinterpret_cast<float4*>(ptsw)[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
                     }
-                    if (BW_FLAGS) { ++gstep; lds_publish(flg + cw, gstep, lane); } else lds_barrier();
+                    lds_barrier();
                 }
                 continue;
             }
@@ -524,11 +498,11 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
         float rs[5] = {0.f, 0.f, 0.f, 0.f, 0.f};            // per-image bias-gradient partials (this lane's 4 points of every tile)
         float rsf = 0.f;                                     // sum over all points of Gf (db5 feature rows)
         float rs0 = 0.f, gss = 0.f;                          // sum over all points of r0 (dW5 row 0, channel 16w + i) and of Gs (db5[0], tile w)
-        // The positional-encoding operand of a tile is the same in steps 0-2 (eps) and in steps 8-10 (E): with BW_PECACHE it is evaluated
-        // once per run of three steps and kept in 48 registers (4 tiles x 3 fragments) instead of six evaluations per tile.
-        float4 pec[BW_PECACHE ? BW_CHAIN : 1][3];
-        int* flg = reinterpret_cast<int*>(lds + BW_FLG);
-        int gstep = 0;                                       // steps begun (wave-uniform): slot c holds this step's pair once done[c] >= gstep
+        // The positional-encoding operand of a tile is the same in steps 0-2 (eps) and in steps 8-10 (E): it is evaluated once per run of
+        // three steps and kept in 48 registers (4 tiles x 3 fragments) instead of six evaluations per tile (round 5: 2.77 -> 2.59 ms per
+        // launch on one box, profiles/r05_bwdw_variants_ab.txt -- these ~50 vector instructions per tile and step were issue time of the
+        // SIMD the chain wave shares, and they sat in exactly the steps where the chain waves waited for this role).
+        float4 pec[BW_CHAIN][3];
         int cur_img = -1;                                    // >= 0: rs[] belongs to this image; -2: mixed iteration (direct atomics)
         auto flush = [&]() {
             if (cur_img >= 0) {
@@ -546,32 +520,24 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
             }
         };
 #ifdef SC_BWDW_PROFILE
-#define BW_STEP_BEGIN BW_STAMP(prof_k) if (!BW_FLAGS) { lds_barrier(); lds_barrier(); } ++gstep; BW_STAMP(prof_k + 1) prof_k += 2;
+#define BW_STEP_BEGIN BW_STAMP(prof_k) lds_barrier(); lds_barrier(); BW_STAMP(prof_k + 1) prof_k += 2;
 #else
-#define BW_STEP_BEGIN if (!BW_FLAGS) { lds_barrier(); lds_barrier(); } ++gstep;
+#define BW_STEP_BEGIN lds_barrier(); lds_barrier();
 #endif
 // one step over the four chain tiles.  HP: 64-wide B operand in slot B; PEM: 0 none, 1 E, 2 eps; RS: bias layer (-1 none, 5 = Gf)
-#define BW_CONSUME(ACCH, ACCE, HP, PEM, RS, EXTRA)                                                 \
+#define BW_CONSUME(ACCH, ACCE, HP, PEM, RS)                                                 \
         _Pragma("unroll") for (int c = 0; c < BW_CHAIN; ++c) {                               \
             const float* sA = lds + BW_XCH + (c * 2 + 0) * 1024;                             \
             const float* sB = lds + BW_XCH + (c * 2 + 1) * 1024;                             \
-            if (BW_FLAGS) lds_wait_ge(flg + c, gstep);       /* chain wave c has written this step's pair */ \
             const float4 af = xch_frag(sA, rd, w);                                           \
-            float4 bf[4];                                                                    \
-            if (HP) { _Pragma("unroll") for (int n = 0; n < 4; ++n) bf[n] = xch_frag(sB, rd, n); } \
-            float4 pf[3];                                                                    \
-            if (PEM && !BW_PECACHE) pe_frags<((PEM) < 0 ? -(PEM) : ((PEM) ? (PEM) : 1))>(lds + BW_PTS + c * 16 * 8, i, kg, symmetric, pf); \
-            if (PEM > 0 && BW_PECACHE) pe_frags<((PEM) > 0 ? (PEM) : 1)>(lds + BW_PTS + c * 16 * 8, i, kg, symmetric, pec[c]); \
-            if (BW_FLAGS) {                                                                  \
-                if (EXTRA == 1 && c == w) gss += kg == 0 ? ptsw[i * 8 + 7] : 0.f;   /* step 0: db5[0] = sum of Gs of chain tile w */ \
-                if (EXTRA == 2) { const float4 rf = xch_frag(sB, rd, w); rs0 += (rf.x + rf.y) + (rf.z + rf.w); }   /* step 10: r0 row sums */ \
-                /* every LDS read of this (step, slot) has landed: give the slot back to its chain wave */ \
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                           \
-                if (lane == 0) __hip_atomic_fetch_add(flg + 4 + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+            if (HP) {                                                                        \
+                float4 bf[4];                                                                \
+                _Pragma("unroll") for (int n = 0; n < 4; ++n) bf[n] = xch_frag(sB, rd, n);   \
+                outer16<4>(af, bf, ACCH);                                                    \
             }                                                                                \
-            if (HP) outer16<4>(af, bf, ACCH);                                                \
-            if (PEM) {                                                                       \
-                if (BW_PECACHE) outer16<3>(af, pec[c], ACCE); else outer16<3>(af, pf, ACCE); \
+            if (PEM) {       /* PEM > 0: evaluate the operand (1 = E, 2 = eps); PEM < 0: the one of the previous step again */ \
+                if (PEM > 0) pe_frags<((PEM) > 0 ? (PEM) : 1)>(lds + BW_PTS + c * 16 * 8, i, kg, symmetric, pec[c]); \
+                outer16<3>(af, pec[c], ACCE);                                                \
             }                                                                                \
             if (RS >= 0) {                                                                   \
                 const float v = (af.x + af.y) + (af.z + af.w);                               \
@@ -606,24 +572,22 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
                 cur_img = img0 == img3 ? img0 : -2;
             }
             BW_STEP_BEGIN
-            if (!BW_FLAGS) gss += kg == 0 ? ptsw[i * 8 + 7] : 0.f;  // db5[0] = sum of Gs (point i of chain tile w; stash written in step 0)
-            BW_CONSUME(d3, d0e, false, 2, -1, 1)                   // 0: q0 x eps
-            BW_STEP_BEGIN BW_CONSUME(d1h, d1e, true, -2, -1, 0)       // 1: q1 x (Gp0 | eps)     (PEM < 0: the operand of the previous step again)
-            BW_STEP_BEGIN BW_CONSUME(d2h, d2e, true, -2, -1, 0)       // 2: q2 x (Gp1 | eps)
-            BW_STEP_BEGIN BW_CONSUME(d3, d0e, true, 0, -1, 0)         // 3: q3 x Gp2
-            BW_STEP_BEGIN BW_CONSUME(d4, d0e, true, 0, -1, 0)         // 4: q4 x Gp3
-            BW_STEP_BEGIN BW_CONSUME(d5, d0e, true, 0, 5, 0)          // 5: Gf x h4
-            BW_STEP_BEGIN BW_CONSUME(d4, d0e, true, 0, 4, 0)          // 6: Ga4 x h3
-            BW_STEP_BEGIN BW_CONSUME(d3, d0e, true, 0, 3, 0)          // 7: Ga3 x h2
-            BW_STEP_BEGIN BW_CONSUME(d2h, d2e, true, 1, 2, 0)         // 8: Ga2 x (h1 | E)
-            BW_STEP_BEGIN BW_CONSUME(d1h, d1e, true, -1, 1, 0)        // 9: Ga1 x (h0 | E)
-            BW_STEP_BEGIN BW_CONSUME(d3, d0e, false, -1, 0, 2)        // 10: Ga0 x E
-            if (!BW_FLAGS) {
+            gss += kg == 0 ? ptsw[i * 8 + 7] : 0.f;                 // db5[0] = sum of Gs (point i of chain tile w; stash written in step 0)
+            BW_CONSUME(d3, d0e, false, 2, -1)                   // 0: q0 x eps
+            BW_STEP_BEGIN BW_CONSUME(d1h, d1e, true, -2, -1)       // 1: q1 x (Gp0 | eps)     (PEM < 0: the operand of the previous step again)
+            BW_STEP_BEGIN BW_CONSUME(d2h, d2e, true, -2, -1)       // 2: q2 x (Gp1 | eps)
+            BW_STEP_BEGIN BW_CONSUME(d3, d0e, true, 0, -1)         // 3: q3 x Gp2
+            BW_STEP_BEGIN BW_CONSUME(d4, d0e, true, 0, -1)         // 4: q4 x Gp3
+            BW_STEP_BEGIN BW_CONSUME(d5, d0e, true, 0, 5)          // 5: Gf x h4
+            BW_STEP_BEGIN BW_CONSUME(d4, d0e, true, 0, 4)          // 6: Ga4 x h3
+            BW_STEP_BEGIN BW_CONSUME(d3, d0e, true, 0, 3)          // 7: Ga3 x h2
+            BW_STEP_BEGIN BW_CONSUME(d2h, d2e, true, 1, 2)         // 8: Ga2 x (h1 | E)
+            BW_STEP_BEGIN BW_CONSUME(d1h, d1e, true, -1, 1)        // 9: Ga1 x (h0 | E)
+            BW_STEP_BEGIN BW_CONSUME(d3, d0e, false, -1, 0)        // 10: Ga0 x E
 #pragma unroll
-                for (int c = 0; c < BW_CHAIN; ++c) {                //     slot B of step 10 carries r0: its row sums are dW5 row 0
-                    const float4 rf = xch_frag(lds + BW_XCH + (c * 2 + 1) * 1024, rd, w);
-                    rs0 += (rf.x + rf.y) + (rf.z + rf.w);
-                }
+            for (int c = 0; c < BW_CHAIN; ++c) {                    //     slot B of step 10 carries r0: its row sums are dW5 row 0
+                const float4 rf = xch_frag(lds + BW_XCH + (c * 2 + 1) * 1024, rd, w);
+                rs0 += (rf.x + rf.y) + (rf.z + rf.w);
             }
             BW_STAMP(prof_k)
         }
