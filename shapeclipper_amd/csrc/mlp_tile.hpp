@@ -52,12 +52,111 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 
 // ---- products ------------------------------------------------------------------------------------
+// Two arithmetics with the same operand layouts, selected at compile time by SC_MLP_SPLIT.  The product is built with 0.  1 is the round-5
+// go / no-go experiment (VERDICT r04 next #2 ii): correct at every existing parity bar (44 render / SDF / full-step tests), but SLOWER in
+// the real kernels -- training render 6.4 -> 7.6 ms, evaluation render 11.9 -> 14.9 ms, sdf_bwdw 2.58 -> 3.25 ms on one box
+// (profiles/r05_mlp_split_ab.txt; tools/build_mlp_variant.sh split -DSC_MLP_SPLIT=1) although the isolated layer is 1.6-1.9x faster
+// (profiles/r05_chain_split_micro.txt): per 16-point tile the split adds ~5,900 vector instructions (weights AND activations, every
+// product) to kernels whose vector work is already on the critical path, about what the 18 k saved matrix cycles are worth, plus 21-38
+// spilled registers.  Pre-split weights would remove 80 % of the added instructions but need 6 instead of 4 bytes per weight in LDS:
+// 177 KiB for the SDF image, over the 160 KiB of a CU (sdf_bwdw has 7 KiB to spare).  No-go in this form; a go needs weights streamed
+// through LDS per layer, i.e. a different kernel structure.
+//   0  v_mfma_f32_16x16x4_f32: an exact fp32 fma chain at the fp32 peak rate (157 TFLOP/s);
+//   1  (round 5) every product evaluated from EXACT three-piece bf16 splits of both operands, x = p0 + p1 + p2 (round to nearest,
+//      residuals exact), as the six piece products a_p b_q with p + q <= 2 on v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- the
+//      arithmetic of the trunk convolutions (conv3x3.hip, VERDICT r02 ruling): what is dropped is below 2^-24 of a product, the error
+//      against float64 is that of the fp32 form.  A lane's own eight registers in[8 ks .. 8 ks + 7] ARE its B fragment of K-step ks
+//      when K index 8 g + j of that step stands for channel 16 (2 ks + j / 4) + 4 g + j % 4 -- the weights are read from the SAME fp32
+//      LDS image in that order and split in registers (tools/micro/chain_split_micro.hip: 1.6-1.9x per 64 x 64 layer, and the split of
+//      the weights costs nothing measurable beside pre-split ones: these vector instructions run in the shadow of the matrix pipe).
+#ifndef SC_MLP_SPLIT
+#define SC_MLP_SPLIT 0
+#endif
+typedef __bf16 mlp_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short mlp_s16x4 __attribute__((ext_vector_type(4)));
+typedef short mlp_s16x8 __attribute__((ext_vector_type(8)));
+
+template <int N>
+struct MlpPieces {          // three bf16 pieces of N (4 or 8) fp32 values, packed as MFMA fragments
+    mlp_bf16x8 p[3];        // (N == 4: the low halves)
+};
+template <int N>
+__device__ __forceinline__ void mlp_split(const float (&v)[N], MlpPieces<N>& o) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const __bf16 h0 = (__bf16)v[j];
+        const float r1 = v[j] - (float)h0;
+        const __bf16 h1 = (__bf16)r1;
+        const float r2 = r1 - (float)h1;
+        o.p[0][j] = h0, o.p[1][j] = h1, o.p[2][j] = (__bf16)r2;
+    }
+}
+// acc += sum over the 32 (N = 8) or 16 (N = 4) K indices of the step of a * b: six exact piece products, small terms first
+template <int N>
+__device__ __forceinline__ f32x4 mlp_six(const MlpPieces<N>& a, const MlpPieces<N>& b, f32x4 acc) {
+    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+    // Every piece stays live until the last of the six MFMAs has issued (the empty asm statements below).  Without them hipcc 7.2 lets the
+    // register allocator put the DESTINATION of an MFMA on the registers of a piece whose last use it is (seen in rgb_composite_bwd:
+    // `v_mfma_f32_16x16x32_bf16 v[18:21], v[48:51], v[18:21], v[22:25]`, D on B): legal for the 16x16 shapes LLVM knows, but the gfx950
+    // K = 32 shape still reads its operands after the first pass -- the product came out wrong and different from run to run (round 5,
+    // tools/dbg_render_ops.py).  The statements take the accumulator as an in / out operand so that they cannot move above the MFMAs.
+    if constexpr (N == 8) {
+#pragma unroll
+        for (int t = 0; t < 6; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[PA[t]], b.p[PB[t]], acc, 0, 0, 0);
+        asm volatile("" : "+v"(acc) : "v"(__builtin_bit_cast(f32x4, a.p[0])), "v"(__builtin_bit_cast(f32x4, a.p[1])), "v"(__builtin_bit_cast(f32x4, a.p[2])),
+                     "v"(__builtin_bit_cast(f32x4, b.p[0])), "v"(__builtin_bit_cast(f32x4, b.p[1])), "v"(__builtin_bit_cast(f32x4, b.p[2])));
+    } else {
+        mlp_s16x4 a4[3], b4[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const mlp_s16x8 a8 = __builtin_bit_cast(mlp_s16x8, a.p[q]), b8 = __builtin_bit_cast(mlp_s16x8, b.p[q]);
+            a4[q] = mlp_s16x4{a8[0], a8[1], a8[2], a8[3]};
+            b4[q] = mlp_s16x4{b8[0], b8[1], b8[2], b8[3]};
+        }
+#pragma unroll
+        for (int t = 0; t < 6; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a4[PA[t]], b4[PB[t]], acc, 0, 0, 0);
+        typedef float f32x2_ __attribute__((ext_vector_type(2)));
+        asm volatile("" : "+v"(acc) : "v"(__builtin_bit_cast(f32x2_, a4[0])), "v"(__builtin_bit_cast(f32x2_, a4[1])), "v"(__builtin_bit_cast(f32x2_, a4[2])),
+                     "v"(__builtin_bit_cast(f32x2_, b4[0])), "v"(__builtin_bit_cast(f32x2_, b4[1])), "v"(__builtin_bit_cast(f32x2_, b4[2])));
+    }
+    return acc;
+}
+// hipcc 7.2 under-counts the wait states between v_mfma_f32_16x16x32_bf16 and a VMEM instruction that READS its result (measured round 5:
+// rgb_composite_bwd stored d L / d feature straight out of the last MFMA of a product -- one s_nop 0 and seven unrelated instructions
+// after it -- and HBM received the accumulator's previous contents, different from run to run).  Every split product therefore ends
+// with explicit wait states; 2 x s_nop 7 = 16 states cover the longest pass count the ISA documents for this hazard class.
+#ifndef SC_MLP_SPLIT_NOPS
+#define SC_MLP_SPLIT_NOPS 0
+#endif
+__device__ __forceinline__ void mlp_split_settle() {
+#pragma unroll
+    for (int i = 0; i < SC_MLP_SPLIT_NOPS; ++i) asm volatile("s_nop 7");
+}
+
 // acc[mt] += W[row0 + 16*mt + i][col0 + kp(s) + 4*g] * in[s]       wl = W + (row0+i)*LD + col0 + 4*g
 // Row strides are multiples of 4 floats: the weights of the four K-steps 4T..4T+3 of a lane (columns 16T+4g .. +3 of its row)
 // are one aligned ds_read_b128 -- a quarter of the LDS instructions (and of their address adds) of the per-MFMA ds_read_b32.
 template <int LD, int MT>
 __device__ __forceinline__ void mm_act(const float* wl, const float (&in)[ACT_STEPS], f32x4 (&acc)[MT]) {
     static_assert(LD % 4 == 0, "row stride must keep the float4 weight reads aligned");
+#if SC_MLP_SPLIT
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        MlpPieces<8> b;
+        const float bv[8] = {in[8 * ks], in[8 * ks + 1], in[8 * ks + 2], in[8 * ks + 3], in[8 * ks + 4], in[8 * ks + 5], in[8 * ks + 6], in[8 * ks + 7]};
+        mlp_split<8>(bv, b);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const float4 w0 = *reinterpret_cast<const float4*>(wl + mt * 16 * LD + 32 * ks);
+            const float4 w1 = *reinterpret_cast<const float4*>(wl + mt * 16 * LD + 32 * ks + 16);
+            const float av[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+            MlpPieces<8> a;
+            mlp_split<8>(av, a);
+            acc[mt] = mlp_six<8>(a, b, acc[mt]);
+        }
+    }
+    mlp_split_settle();
+#else
 #pragma unroll
     for (int T = 0; T < NT; ++T) {
         float4 w[MT];
@@ -71,16 +170,36 @@ __device__ __forceinline__ void mm_act(const float* wl, const float (&in)[ACT_ST
                 acc[mt] = mfma16(wv, in[4 * T + r], acc[mt]);
             }
     }
+#endif
     __builtin_amdgcn_sched_barrier(0);
 }
 
 // acc[mt] += W[row0 + kp(s) + 4*g][col0 + 16*mt + i] * in[s]       wl = W + (row0+4*g)*LD + col0 + i
 template <int LD, int MT>
 __device__ __forceinline__ void mm_act_t(const float* wl, const float (&in)[ACT_STEPS], f32x4 (&acc)[MT]) {
+#if SC_MLP_SPLIT
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        MlpPieces<8> b;
+        const float bv[8] = {in[8 * ks], in[8 * ks + 1], in[8 * ks + 2], in[8 * ks + 3], in[8 * ks + 4], in[8 * ks + 5], in[8 * ks + 6], in[8 * ks + 7]};
+        mlp_split<8>(bv, b);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float av[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) av[j] = wl[kp(8 * ks + j) * LD + 16 * mt];
+            MlpPieces<8> a;
+            mlp_split<8>(av, a);
+            acc[mt] = mlp_six<8>(a, b, acc[mt]);
+        }
+    }
+    mlp_split_settle();
+#else
 #pragma unroll
     for (int s = 0; s < ACT_STEPS; ++s)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(wl[kp(s) * LD + 16 * mt], in[s], acc[mt]);
+#endif
     __builtin_amdgcn_sched_barrier(0);
 }
 // The same product with the column-wise weight reads software-pipelined one block of 4 K-steps (16 ds_read_b32, merged into 8
@@ -91,6 +210,34 @@ __device__ __forceinline__ void mm_act_t(const float* wl, const float (&in)[ACT_
 // hides the latency and the 32 extra live registers cost more.
 template <int LD, int MT>
 __device__ __forceinline__ void mm_act_t_pipe(const float* wl, const float (&in)[ACT_STEPS], f32x4 (&acc)[MT]) {
+#if SC_MLP_SPLIT
+    // split arithmetic: the eight column-wise reads of the NEXT (K-step, channel tile) are issued before the split + MFMAs of this one
+    float cur[8], nxt[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cur[j] = wl[kp(j) * LD];
+    MlpPieces<8> b;
+#pragma unroll
+    for (int u = 0; u < 2 * MT; ++u) {
+        const int ks = u / MT, mt = u % MT;
+        if (mt == 0) {
+            const float bv[8] = {in[8 * ks], in[8 * ks + 1], in[8 * ks + 2], in[8 * ks + 3], in[8 * ks + 4], in[8 * ks + 5], in[8 * ks + 6], in[8 * ks + 7]};
+            mlp_split<8>(bv, b);
+        }
+        if (u + 1 < 2 * MT) {
+            const int ks1 = (u + 1) / MT, mt1 = (u + 1) % MT;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) nxt[j] = wl[kp(8 * ks1 + j) * LD + 16 * mt1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        MlpPieces<8> a;
+        mlp_split<8>(cur, a);
+        acc[mt] = mlp_six<8>(a, b, acc[mt]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cur[j] = nxt[j];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mlp_split_settle();
+#else
     float wa[4 * MT], wb[4 * MT];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -113,15 +260,50 @@ __device__ __forceinline__ void mm_act_t_pipe(const float* wl, const float (&in)
             for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(cur[r * MT + mt], in[4 * T + r], acc[mt]);
         __builtin_amdgcn_sched_barrier(0);
     }
+#endif
 }
 
 // acc[mt] += W[row0 + 16*mt + i][col0 + 4*(S0+s) + g] * in[s]      wl = W + (row0+i)*LD + col0 + g
 template <int LD, int MT, int S0, int NS>
 __device__ __forceinline__ void mm_pe(const float* wl, const float* in, f32x4 (&acc)[MT]) {
+#if SC_MLP_SPLIT
+    static_assert(NS == 4 || NS == 12, "one coordinate (16 slots: one 16x16x16 step) or the whole encoding (32 + 16 slots)");
+    if constexpr (NS == 12) {
+        MlpPieces<8> b;
+        const float bv[8] = {in[0], in[1], in[2], in[3], in[4], in[5], in[6], in[7]};
+        mlp_split<8>(bv, b);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float av[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) av[j] = wl[mt * 16 * LD + 4 * (S0 + j)];
+            MlpPieces<8> a;
+            mlp_split<8>(av, a);
+            acc[mt] = mlp_six<8>(a, b, acc[mt]);
+        }
+    }
+    {
+        constexpr int S1 = NS == 12 ? 8 : 0;
+        MlpPieces<4> b;
+        const float bv[4] = {in[S1], in[S1 + 1], in[S1 + 2], in[S1 + 3]};
+        mlp_split<4>(bv, b);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float av[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) av[j] = wl[mt * 16 * LD + 4 * (S0 + S1 + j)];
+            MlpPieces<4> a;
+            mlp_split<4>(av, a);
+            acc[mt] = mlp_six<4>(a, b, acc[mt]);
+        }
+    }
+    mlp_split_settle();
+#else
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma16(wl[mt * 16 * LD + 4 * (S0 + s)], in[s], acc[mt]);
+#endif
     __builtin_amdgcn_sched_barrier(0);
 }
 
