@@ -14,6 +14,7 @@ import torch.nn as nn
 
 from .. import packing
 from ..functional import SdfFunction
+from . import eager_path
 
 
 class Embedder:
@@ -87,8 +88,12 @@ class SDFNetwork(nn.Module):
 
     def __init__(self, opt):
         super().__init__()
-        packing.check_arch(opt)
+        # outside the compiled family (packing.check_arch): stock device operators, model/eager_path.py (round 5; raised before)
+        self.eager = not packing.arch_supported(opt)
+        if self.eager:
+            eager_path.warn_once(packing.arch_summary(opt))
         a = opt.arch.impl_sdf
+        self.posenc_res = a.pos_enc
         self.force_symmetry = opt.arch.force_symmetry
         self.proj_latent_dim = a.proj_latent_dim
         self.n_hidden = a.n_hidden_layers
@@ -132,6 +137,8 @@ class SDFNetwork(nn.Module):
         """(w_pack, cbias [B,5,64]) for the HIP kernels; differentiable w.r.t. parameters and latent.
         The weight image does not depend on the latent: inside one Graph.forward (between begin_step() calls) it is
         built once and shared by the main render, the NN-view render and the eikonal calls (4 uses per step)."""
+        if self.eager:
+            raise NotImplementedError("no packed weight image for this architecture (%d x %d): it runs on model/eager_path.py" % (self.n_hidden, self.n_channel))
         cache = getattr(self, "_pack_cache", None)
         if cache is not None and cache[0] == torch.is_grad_enabled():
             return cache[1], packing.sdf_cbias(None, proj_latent, gathered=cache[2], arch=self._arch(proj_latent.shape[1]))
@@ -149,6 +156,9 @@ class SDFNetwork(nn.Module):
 
     def forward(self, points_raw, proj_latent):
         """Per-point latent form of the reference ([N,3], [N,Z] -> [N,1+C]); every point is its own 'image'."""
+        if self.eager:
+            eager_path.require_device(points_raw)
+            return eager_path.sdf_mlp(self, points_raw.unsqueeze(1), proj_latent).squeeze(1)
         w_pack, cbias = self.packed(proj_latent)
         sdf, _, feat = SdfFunction.apply(points_raw, w_pack, cbias, 1, bool(self.force_symmetry), False, True)
         return torch.cat([sdf[:, None], packing.tbl_to_rows(feat, points_raw.shape[0])[:, :self.n_channel]], dim=1)
@@ -158,6 +168,8 @@ class SDFNetwork(nn.Module):
         With compute_grad the latent is detached (reference :168-169) and `gradients` stays differentiable."""
         n = points_flat.shape[0]
         assert n % batch_size == 0 and proj_latent.shape[1] == opt.arch.impl_sdf.proj_latent_dim
+        if self.eager:
+            return eager_path.sdf_conditional_output(self, batch_size, points_flat, proj_latent, compute_grad)
         if compute_grad:
             proj_latent = proj_latent.detach()
         w_pack, cbias = self.packed(proj_latent)
@@ -173,7 +185,7 @@ class RGBNetwork(nn.Module):
 
     def __init__(self, opt):
         super().__init__()
-        packing.check_arch(opt)
+        self.eager = not packing.arch_supported(opt)
         a = opt.arch.impl_rgb
         self.force_symmetry = opt.arch.force_symmetry
         self.proj_latent_dim = a.proj_latent_dim

@@ -65,8 +65,13 @@ class Renderer(nn.Module):
             raise NotImplementedError("only render.normal_model=volume is implemented (the shipped setting)")
         self.ray_sampler = UniformSampler(opt)
         self.N_samples = opt.render.n_samples_uniform
-        if self.N_samples != 64:
-            raise NotImplementedError("the compositing kernel maps the 64 samples of a ray onto one 64-lane wavefront")
+        # The compositing kernel maps the 64 samples of a ray onto one 64-lane wavefront and the chain kernels hold one architecture family
+        # in LDS: any other render.n_samples_uniform / arch.impl_* runs on stock device operators (model/eager_path.py, round 5).
+        self.eager = bool(getattr(sdf_network, "eager", False) or getattr(rgb_network, "eager", False) or self.N_samples != 64)
+        if self.eager:
+            from . import eager_path
+            eager_path.warn_once("render.n_samples_uniform = %d" % self.N_samples if self.N_samples != 64 else "implicit networks")
+            sdf_network.eager = rgb_network.eager = True          # one path for the whole render (the HIP kernels hand TBL64 features to each other)
 
     def forward(self, opt, pose, intr, scale_dist, proj_latent_sdf, proj_latent_rgb, ray_idx=None, training=True,
                 visualize=False):
@@ -97,6 +102,9 @@ class Renderer(nn.Module):
         up = lambda x: x.to(ray_dirs.device, non_blocking=True)
         t_rand = up(torch.rand(B * R, S, device=rdev, pin_memory=pin)) if training else None
         eik_idx = up(torch.randint(S, (B * R,), device=rdev, pin_memory=pin))
+        if self.eager:
+            return self._forward_eager(opt, cam_loc, ray_dirs, depth_fac, scale_dist, t_rand, eik_idx, B, R, proj_latent_sdf, proj_latent_rgb,
+                                       training, visualize, up, rdev, pin)
         z_vals, points_flat = RaySampleFunction.apply(cam_loc, ray_dirs, scale_dist, t_rand, R, float(opt.camera.dist))
         z_eik = torch.gather(z_vals, 1, eik_idx.unsqueeze(-1))
         assert proj_latent_rgb.shape[1] == opt.arch.impl_rgb.proj_latent_dim
@@ -136,6 +144,34 @@ class Renderer(nn.Module):
             return (rgb_output, mask_output, mask_hard_output, depth_output, normal_output, grad_eikonal,
                     pick(points_flat.detach()), pick(transp), pick(rgba))
         return rgb_output, mask_output, mask_hard_output, depth_output, normal_output, grad_eikonal
+
+    def _forward_eager(self, opt, cam_loc, ray_dirs, depth_fac, scale_dist, t_rand, eik_idx, B, R, latent_sdf, latent_rgb, training, visualize,
+                       up, rdev, pin):
+        """The render on stock device operators (other architectures / sample counts): same random draws in the same order, same outputs."""
+        from . import eager_path
+        S = self.N_samples
+        cam_loc, ray_dirs, depth_fac = cam_loc.reshape(-1, 3), ray_dirs.reshape(-1, 3), depth_fac.reshape(-1)
+        centre = (opt.camera.dist * scale_dist).repeat_interleave(R).view(B * R, 1)
+        t = torch.linspace(0.0, 1.0, steps=S, device=ray_dirs.device)
+        z_vals = (centre - 0.7) * (1.0 - t) + (centre + 0.7) * t                      # reference renderer.py:17-24
+        if training:
+            mids = 0.5 * (z_vals[..., 1:] + z_vals[..., :-1])
+            upper, lower = torch.cat([mids, z_vals[..., -1:]], -1), torch.cat([z_vals[..., :1], mids], -1)
+            z_vals = lower + (upper - lower) * t_rand
+        z_eik = torch.gather(z_vals, 1, eik_idx.unsqueeze(-1))
+        eik = None
+        if training:
+            eik = up(torch.empty(B * R, 3, device=rdev, pin_memory=pin).uniform_(self.eik_range[0], self.eik_range[1])).reshape(B, R, 3)
+        out = eager_path.render(self, opt, cam_loc, ray_dirs, depth_fac, z_vals, z_eik, eik, B, R, latent_sdf, latent_rgb, training)
+        if not visualize:
+            return out[:6]
+        points_flat, alphas, rgb_flat = out[6]
+        opacity = alphas.reshape(B, -1, 1)
+        transp = torch.cat([opacity, 1 - opacity, torch.zeros_like(opacity)], dim=-1)
+        rgba = torch.cat([rgb_flat.reshape(B, -1, 3), opacity], dim=-1)
+        idx = torch.randperm(R)[:200].to(opacity.device)
+        pick = lambda x: self.sample_rays_visualize(idx, x.reshape(B, R, S, -1))
+        return out[:6] + (pick(points_flat.detach()), pick(transp), pick(rgba))
 
     def volume_rendering(self, z_vals, sdf):
         """Standalone torch form of reference renderer.py:187-209 for external callers (small tensors)."""

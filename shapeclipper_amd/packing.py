@@ -52,6 +52,21 @@ def _slots(w_pe: torch.Tensor) -> torch.Tensor:
     return ext[:, _SLOT_IDX_DEV[key]]
 
 
+def arch_supported(opt) -> bool:
+    """True when the HIP chain kernels take opt.arch (see check_arch); otherwise the networks run on model/eager_path.py."""
+    a = opt.arch
+    return (a.impl_sdf.n_hidden_layers == 5 and 1 <= a.impl_sdf.n_channels <= 64 and 0 <= a.impl_sdf.pos_enc <= 6
+            and set(a.impl_sdf.skip_connection) <= {1, 2}
+            and a.impl_rgb.n_hidden_layers == 3 and 1 <= a.impl_rgb.n_channels <= 64 and 0 <= a.impl_rgb.pos_enc <= 6)
+
+
+def arch_summary(opt) -> str:
+    a = opt.arch
+    return "impl_sdf %d x %d, pos_enc %d, skip %s; impl_rgb %d x %d, pos_enc %d" % (
+        a.impl_sdf.n_hidden_layers, a.impl_sdf.n_channels, a.impl_sdf.pos_enc, list(a.impl_sdf.skip_connection),
+        a.impl_rgb.n_hidden_layers, a.impl_rgb.n_channels, a.impl_rgb.pos_enc)
+
+
 def check_arch(opt) -> None:
     """What the HIP chain kernels take.  They are compiled for 5 hidden SDF layers / 3 hidden RGB layers of 64 channels with the positional
     encoding in 48 slots (6 octaves) and optional skip inputs at SDF layers 1 and 2; every SMALLER member of the reference's config family

@@ -43,6 +43,11 @@ def get_dense_3D_grid(opt, var, N=None):
 def compute_level_grid(opt, sdf_network, proj_latent_sdf, points_3D):
     B, N = points_3D.shape[0], points_3D.shape[1]
     flat = points_3D.reshape(-1, 3).contiguous()
+    if getattr(sdf_network, "eager", False):        # architectures outside the HIP family: one x-slab at a time, as the reference (:21-38)
+        from ..model import eager_path
+        with torch.no_grad():
+            slabs = [eager_path.sdf_mlp(sdf_network, points_3D[:, i].reshape(B, -1, 3), proj_latent_sdf)[..., 0].view(B, N, N) for i in range(N)]
+        return torch.stack(slabs, dim=1)
     w_pack, cbias = sdf_network.packed(proj_latent_sdf)
     sdf, _, _ = ops.sdf_forward(flat, w_pack, cbias, N * N * N, symmetric=bool(sdf_network.force_symmetry),
                                 want_grad=False, want_feat=False)

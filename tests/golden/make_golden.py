@@ -504,6 +504,60 @@ def main():
              **{"cot." + k: v for k, v in cot15.items()}, **{"w." + k: v for k, v in sd_np(sdf15, "sdf.").items()},
              **{"w." + k: v for k, v in sd_np(rgb15, "rgb.").items()}, **{"grad." + n: g_ for n, g_ in zip(names15, grads15)})
 
+    # ---------------- G16: an architecture OUTSIDE the HIP kernels' family, rendered by the reference's own Renderer ------------------------
+    # VERDICT r04 missing #2 (model/implicit.py:93-113,199-214; model/renderer.py:13-37): deeper / wider networks, more octaves, another skip
+    # layer, another sample count.  The product runs these on stock device operators (shapeclipper_amd/model/eager_path.py); this fixture is
+    # what the reference computes for one: SDF 6 x 128, 8 octaves, skip [3], latent 48; RGB 2 x 96, 7 octaves, latent 32; 32 samples per ray.
+    gen16 = torch.Generator().manual_seed(1616)
+    opt16 = ref_opt(8, 8)
+    opt16.arch.impl_sdf.n_hidden_layers, opt16.arch.impl_sdf.n_channels, opt16.arch.impl_sdf.pos_enc = 6, 128, 8
+    opt16.arch.impl_sdf.skip_connection, opt16.arch.impl_sdf.proj_latent_dim = [3], 48
+    opt16.arch.impl_rgb.n_hidden_layers, opt16.arch.impl_rgb.n_channels, opt16.arch.impl_rgb.pos_enc, opt16.arch.impl_rgb.proj_latent_dim = 2, 96, 7, 32
+    opt16.render.n_samples_uniform = 32
+    cfg16 = R.Cfg(H=8, W=8, n_samples=32, hidden_sdf=128, n_hidden_sdf=6, posenc_sdf=8, skip_in=(3,), latent_sdf=48,
+                  hidden_rgb=96, n_hidden_rgb=2, posenc_rgb=7, latent_rgb=32)
+    torch.manual_seed(16)
+    sdf16, rgb16 = ref_implicit.SDFNetwork(opt16), ref_implicit.RGBNetwork(opt16)
+    perturb_(sdf16, 0.01, gen16)
+    perturb_(rgb16, 0.05, gen16)
+    ren16 = ref_renderer.Renderer(opt16, sdf16, rgb16)
+    with torch.no_grad():
+        ren16.density.beta.fill_(0.07)
+    R16 = 24
+    ridx16 = torch.stack([torch.randperm(64, generator=gen16)[:R16] for _ in range(2)], 0)
+    lv16 = dict(pose=pose.clone().requires_grad_(True), intr=intr.clone().requires_grad_(True), scale_dist=sdist.clone().requires_grad_(True),
+                z_sdf=(torch.randn(2, 48, generator=gen16) * 0.3).requires_grad_(True), z_rgb=torch.randn(2, 32, generator=gen16).requires_grad_(True))
+    cot16 = dict(rgb=torch.randn(2, R16, 3, generator=gen16), mask=torch.randn(2, R16, 1, generator=gen16), depth=torch.randn(2, R16, 1, generator=gen16),
+                 normal=torch.randn(2, R16, 3, generator=gen16), eik=torch.randn(2 * 2 * R16, generator=gen16))
+    fun16 = lambda o_: ((o_[0] * cot16["rgb"]).sum() + (o_[1] * cot16["mask"]).sum() + (o_[3] * cot16["depth"]).sum()
+                        + (o_[4] * cot16["normal"]).sum() + (o_[5] * cot16["eik"]).sum())
+    torch.manual_seed(1617)
+    state16 = torch.get_rng_state()
+    outs16 = ren16(opt16, lv16["pose"], lv16["intr"], lv16["scale_dist"], lv16["z_sdf"], lv16["z_rgb"], ray_idx=ridx16, training=True)
+    par16 = dict(ren16.named_parameters())
+    tens16 = list(par16.values()) + list(lv16.values())
+    names16 = list(par16.keys()) + list(lv16.keys())
+    g16 = torch.autograd.grad(fun16(outs16), tens16, allow_unused=True)
+    g16 = {n: (g_ if g_ is not None else torch.zeros_like(t_)) for n, g_, t_ in zip(names16, g16, tens16)}
+    torch.set_rng_state(state16)
+    t16, ei16, ep16 = R.draw_render_randoms(2 * R16, 32, True)
+    o16 = R.render(cfg16, weights_from(sdf16), weights_from(rgb16), ren16.density.beta.detach().clone(), lv16["pose"].detach(), lv16["intr"].detach(),
+                   lv16["scale_dist"].detach(), lv16["z_sdf"].detach(), lv16["z_rgb"].detach(), ridx16, True, t16, ei16, ep16)
+    for k, v in zip(("rgb", "mask", "mask_hard", "depth", "normal", "grad_eikonal"), outs16[:6]):
+        close(o16[k], v, 0, "G16 render " + k)
+    # evaluation render of the same networks (all 64 pixels, no jitter) and a level grid slab
+    with torch.no_grad():
+        ev16 = ren16(opt16, pose, intr, sdist, lv16["z_sdf"].detach(), lv16["z_rgb"].detach(), ray_idx=None, training=False)
+    gp16 = (torch.rand(2 * 50, 3, generator=gen16) * 2 - 1) * 0.6
+    s16, f16, gr16 = sdf16.get_conditional_output(opt16, 2, gp16.clone(), lv16["z_sdf"].detach(), compute_grad=True)
+    save("g16_other_architecture", ray_idx=ridx16, t_rand=t16, eik_idx=ei16, eik_pts=ep16, pose=pose, intr=intr, scale_dist=sdist,
+         z_sdf=lv16["z_sdf"].detach(), z_rgb=lv16["z_rgb"].detach(), beta=np.float32(0.07),
+         rgb=outs16[0], mask=outs16[1], mask_hard=outs16[2], depth=outs16[3], normal=outs16[4], grad_eikonal=outs16[5],
+         eval_rgb=ev16[0], eval_mask=ev16[1], eval_depth=ev16[3], eval_normal=ev16[4],
+         pts=gp16, pts_sdf=s16, pts_feat=f16, pts_grad=gr16,
+         **{"cot." + k: v for k, v in cot16.items()}, **{"grad." + k: v for k, v in g16.items()},
+         **{"w." + k: v for k, v in sd_np(sdf16, "sdf.").items()}, **{"w." + k: v for k, v in sd_np(rgb16, "rgb.").items()})
+
     print("all oracle-vs-reference checks passed; fixtures written to", OUT)
 
 

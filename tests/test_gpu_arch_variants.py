@@ -113,15 +113,22 @@ def test_variant_training_render_matches_the_oracle(tag):
     assert (zr_d.grad.cpu() - zr_c.grad).abs().max() <= 5e-4 * max(float(zr_c.grad.abs().max()), 1e-6)
 
 
-def test_unsupported_architectures_still_raise():
+def test_architectures_outside_the_family_take_the_stock_operator_path():
+    """Round 5: wider / deeper networks, more octaves, other skip layers no longer raise -- they are flagged `eager` and run on
+    model/eager_path.py (parity: tests/test_gpu_other_architectures.py); the packed-image entry point still refuses them."""
+    import warnings
     from shapeclipper_amd.model.implicit import SDFNetwork
     for extra in (["--arch.impl_sdf.n_channels=128"], ["--arch.impl_sdf.pos_enc=10"], ["--arch.impl_sdf.n_hidden_layers=8"],
                   ["--arch.impl_sdf.skip_connection=[3]"]):
         from shapeclipper_amd.utils import options
         opt = options.set(options.parse_arguments(["--yaml=options/pix3d/config.yaml", "--name=pytest_arch", "--output_root=/tmp/sc_pytest"] + extra),
                           verbose=False)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            net = SDFNetwork(opt)
+        assert net.eager
         with pytest.raises(NotImplementedError):
-            SDFNetwork(opt)
+            net.packed(torch.zeros(1, 64))
 
 
 def test_variant_architecture_trains_through_the_runner():

@@ -173,7 +173,7 @@ def test_golden_recipe_reproduces_committed_fixtures(tmp_path):
     r = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     made = sorted(p.name for p in tmp_path.glob("*.npz"))
-    assert len(made) == 14, made
+    assert len(made) == 15, made
     for name in made:
         a, b = np.load(tmp_path / name), np.load(os.path.join(GOLDEN_DIR, name))
         assert set(a.files) == set(b.files), name

@@ -25,8 +25,9 @@ rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print("operators with device time: %d kinds, %.2f ms of device time, %d calls" % (len(rows), tot / 1e3, sum(r[1] for r in rows)))
 rows2 = sorted([r for r in rows if r[2].startswith("aten::")], key=lambda r: -r[1])
+print("stock aten operators: %d kinds, %d calls, %.2f ms of device time" % (len(rows2), sum(r[1] for r in rows2), sum(r[0] for r in rows2) / 1e3))
 print("--- stock operators by call count")
-for dev, n, k, sh in rows2[:45]:
+for dev, n, k, sh in rows2[:int(os.environ.get('TOP', '45'))]:
     print("%8.1f us %4d x  %-28s %s" % (dev, n, k, sh))
 print("--- by device time")
 for dev, n, k, sh in rows[:25]:
