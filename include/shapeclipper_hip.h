@@ -536,6 +536,29 @@ int sc_basic_block_forward(const sc_block_args* args, void* stream);
 int sc_basic_block_backward(const sc_block_args* args, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * 1x1 "Bottleneck_Linear" blocks (csrc/bottleneck.hip): a linear layer WITHOUT bias on row vectors followed by BatchNorm over the rows,
+ * optional residual and ReLU, one launch per linear each way.  Replaces, per block, the reference's two nn.Conv2d(C, C, 1) + two
+ * nn.BatchNorm2d on 1x1 maps (model/view_estimator.py:6-33 heads, model/graph.py:16-44 latent projectors): rocBLAS products + separate
+ * BatchNorm launches before.  x [N][Cin], w [Cout][Cin] (torch layout), y / out / res [N][Cout]; `groups` stacked sub-batches of N / groups
+ * rows with their own statistics (save_mean / save_rstd [groups][Cout]); running statistics (may be NULL when training) are updated
+ * once per group in order, *n_tracked += groups.  Limits: N <= 128, groups <= 4, Cin % 64 == 0, Cout % 16 == 0
+ * (sc_linear_bn_supported says whether a shape is taken).  Fixed summation orders: bit-reproducible.
+ *   forward:   y = x w^T;  out = [relu]( gamma (y - mean) rstd + beta [+ res] )
+ *   backward:  g = (g_out, or gy_next [N][Cnext] x w_next [Cnext][Cout] when g_out is NULL) [+ g_add]; ReLU mask from `out`;
+ *              g_res (may be NULL) receives the masked gradient (= gradient of `res`); BatchNorm backward -> gy [N][Cout];
+ *              dw [Cout][Cin] = gy^T x; dgamma, dbeta [Cout]
+ *   data:      dx [N][Cin] = gy [N][Cout] w [Cout][Cin] [+ g_add]                                                                  */
+int sc_linear_bn_supported(int N, int Cin, int Cout, int groups);
+int sc_linear_bn_forward(const float* x, const float* w, const float* gamma, const float* beta, const float* res, float* y, float* out,
+                         float* save_mean, float* save_rstd, float* run_mean, float* run_var, int64_t* n_tracked, int N, int Cin,
+                         int Cout, int groups, int training, int relu, float eps, float momentum, void* stream);
+int sc_linear_bn_backward(const float* g_out, const float* gy_next, const float* w_next, const float* g_add, int Cnext, const float* out,
+                          const float* y, const float* save_mean, const float* save_rstd, const float* gamma, const float* x, float* gy,
+                          float* g_res, float* dw, float* dgamma, float* dbeta, int N, int Cin, int Cout, int groups, int training, int relu,
+                          void* stream);
+int sc_linear_backward_data(const float* gy, const float* w, const float* g_add, float* dx, int N, int Cin, int Cout, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Launch policy (csrc/device.hip) -- the one process-level setting of the library.  The persistent one-workgroup-per-CU grids
  * (stream-K 3x3 convolutions and their weight gradients, stem / 1x1 / stride-2 gradients) are sized for
  * sc_grid_cus() = device CUs - reserved.  Reserve CUs when another stream must make progress beside them: RCCL's

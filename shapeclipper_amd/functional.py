@@ -162,6 +162,32 @@ class BnActFunction(torch.autograd.Function):
         return dx, dres, dg, db, None, None, None, None, None, None, None, None
 
 
+class BottleneckLinearFunction(torch.autograd.Function):
+    """out = relu(bn2(relu(bn1(x W1^T)) W2^T) + x): a 1x1 Bottleneck_Linear block (reference view_estimator.py:6-33, graph.py:16-40) as two
+    launches forward and three backward (csrc/bottleneck.hip) instead of ~14 stock launches.  bn* = (running_mean, running_var,
+    num_batches_tracked, training, momentum, eps) as BnActFunction takes them."""
+
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, bn1, bn2, groups):
+        x, w1, w2 = ops._aligned(x), ops._aligned(w1), ops._aligned(w2)
+        rm1, rv1, nt1, training, mom1, eps1 = bn1
+        rm2, rv2, nt2, _, mom2, eps2 = bn2
+        a1, y1, st1 = ops.linear_bn_forward(x, w1, g1, b1, None, rm1, rv1, nt1, training, mom1, eps1, True, groups)
+        out, y2, st2 = ops.linear_bn_forward(a1, w2, g2, b2, x, rm2, rv2, nt2, training, mom2, eps2, True, groups)
+        ctx.meta = (training, groups)
+        ctx.save_for_backward(x, w1, g1, w2, g2, y1, a1, st1, y2, out, st2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        training, groups = ctx.meta
+        x, w1, g1, w2, g2, y1, a1, st1, y2, out, st2 = ctx.saved_tensors
+        gy2, g_res, dw2, dg2, db2 = ops.linear_bn_backward(ops._aligned(g_out), None, None, None, out, y2, st2, g2, a1, True, training, True, groups)
+        gy1, _, dw1, dg1, db1 = ops.linear_bn_backward(None, gy2, w2, None, a1, y1, st1, g1, x, False, training, True, groups)
+        dx = ops.linear_backward_data(gy1, w1, g_res) if ctx.needs_input_grad[0] else None
+        return dx, dw1, dg1, db1, dw2, dg2, db2, None, None, None
+
+
 class BnReluPoolFunction(torch.autograd.Function):
     """ResNet stem tail: maxpool3x3/2( relu( batch_norm(x) ) ) without materialising the full-resolution BN output."""
 
@@ -202,6 +228,25 @@ def bn_act(bn, x, residual=None, relu=True, groups=1):
                                bn.running_var if track else None,
                                bn.num_batches_tracked if (track and training) else None,
                                training, float(bn.momentum), float(bn.eps), relu, groups)
+
+
+def _bn_state(bn):
+    training = bn.training or not bn.track_running_stats
+    track = bn.track_running_stats
+    return (bn.running_mean if track else None, bn.running_var if track else None,
+            bn.num_batches_tracked if (track and training) else None, training, float(bn.momentum), float(bn.eps))
+
+
+def bottleneck_linear(x, conv1, bn1, conv2, bn2, groups=1):
+    """relu(bn2(conv2(relu(bn1(conv1(v))))) + v) for a feature VECTOR x [N, C] (1x1 map), conv* = nn.Conv2d(C, C, 1, bias=False): the
+    fused HIP block when the shape is taken (N <= 128, groups <= 4, C % 64 == 0), else None (the caller keeps its operator-by-operator form)."""
+    C = x.shape[1]
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and _bn_fusable(bn1, x[..., None, None]) and _bn_fusable(bn2, x[..., None, None])
+            and conv1.bias is None and conv2.bias is None and conv1.weight.shape == (C, C, 1, 1) and conv2.weight.shape == (C, C, 1, 1)
+            and x.shape[0] % groups == 0 and ops.linear_bn_supported(x.shape[0], C, C, groups)):
+        return None
+    return BottleneckLinearFunction.apply(x, conv1.weight.view(C, C), bn1.weight, bn1.bias, conv2.weight.view(C, C), bn2.weight, bn2.bias,
+                                          _bn_state(bn1), _bn_state(bn2), groups)
 
 
 def bn_relu_maxpool(bn, x, groups=1):

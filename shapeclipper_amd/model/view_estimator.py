@@ -7,8 +7,10 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as torch_F
 
-from ..functional import bn_act
+from ..functional import bn_act, bottleneck_linear
 from . import resnet
+
+HIP_BOTTLENECK = True      # `--hip.fused_bottleneck!`: the operator-by-operator form (rocBLAS products + separate BatchNorm launches)
 
 
 class Bottleneck_Linear(nn.Module):
@@ -34,6 +36,10 @@ class Bottleneck_Linear(nn.Module):
         return torch_F.linear(x, conv.weight.view(conv.out_channels, conv.in_channels))
 
     def forward(self, x, groups=1):
+        if HIP_BOTTLENECK and x.is_cuda:
+            out = bottleneck_linear(x, self.linear1, self.bn1, self.linear2, self.bn2, groups=groups)      # 2 launches forward, 3 backward
+            if out is not None:
+                return out
         v = x[..., None, None]
         out = bn_act(self.bn1, self._linear(self.linear1, x)[..., None, None], groups=groups)        # conv1x1 -> BN -> ReLU
         out = self._linear(self.linear2, out.flatten(1))[..., None, None]

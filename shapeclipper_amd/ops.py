@@ -1086,3 +1086,51 @@ class Conv3x3PackSet:
     def get(self, w, flip):
         off, n = self.where[(self.index[id(w)], int(flip))]
         return self.buf[off:off + n]
+
+
+# ---- fused 1x1 bottleneck blocks (csrc/bottleneck.hip) ----------------------------------------------------------------------------------
+def linear_bn_supported(N, Cin, Cout, groups) -> bool:
+    return bool(_lib.load().sc_linear_bn_supported(c_int(N), c_int(Cin), c_int(Cout), c_int(groups)))
+
+
+def linear_bn_forward(x, w, gamma, beta, res, running_mean, running_var, n_tracked, training, momentum, eps, relu, groups):
+    """out = [relu](bn(x w^T) [+ res]) in one launch -> (out, y, stats [2, G, Cout]).  x [N, Cin], w [Cout, Cin]."""
+    N, Cin = x.shape
+    Cout = w.shape[0]
+    y, out = torch.empty(N, Cout, device=x.device, dtype=torch.float32), torch.empty(N, Cout, device=x.device, dtype=torch.float32)
+    stats = torch.empty(2, groups, Cout, device=x.device, dtype=torch.float32)
+    code = _lib.load().sc_linear_bn_forward(_lib.ptr(x), _lib.ptr(w), _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(res), _lib.ptr(y), _lib.ptr(out),
+                                            _lib.ptr(stats[0]), _lib.ptr(stats[1]), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(n_tracked),
+                                            c_int(N), c_int(Cin), c_int(Cout), c_int(groups), c_int(1 if training else 0), c_int(1 if relu else 0),
+                                            ctypes.c_float(eps), ctypes.c_float(momentum), _lib.stream())
+    _lib.check(code, "sc_linear_bn_forward")
+    return out, y, stats
+
+
+def linear_bn_backward(g_out, gy_next, w_next, g_add, out, y, stats, gamma, x, want_res, training, relu, groups):
+    """Reverse of linear_bn_forward -> (gy [N, Cout], g_res | None, dw [Cout, Cin], dgamma, dbeta).  The incoming gradient is g_out, or
+    gy_next @ w_next when g_out is None, plus g_add."""
+    N, Cin = x.shape
+    Cout = y.shape[1]
+    f32 = dict(device=x.device, dtype=torch.float32)
+    gy = torch.empty(N, Cout, **f32)
+    g_res = torch.empty(N, Cout, **f32) if want_res else None
+    dw = torch.empty(Cout, Cin, **f32)
+    dgb = torch.empty(2, Cout, **f32)
+    code = _lib.load().sc_linear_bn_backward(_lib.ptr(g_out), _lib.ptr(gy_next), _lib.ptr(w_next), _lib.ptr(g_add),
+                                             c_int(gy_next.shape[1] if gy_next is not None else 0), _lib.ptr(out), _lib.ptr(y), _lib.ptr(stats[0]),
+                                             _lib.ptr(stats[1]), _lib.ptr(gamma), _lib.ptr(x), _lib.ptr(gy), _lib.ptr(g_res), _lib.ptr(dw),
+                                             _lib.ptr(dgb[0]), _lib.ptr(dgb[1]), c_int(N), c_int(Cin), c_int(Cout), c_int(groups),
+                                             c_int(1 if training else 0), c_int(1 if relu else 0), _lib.stream())
+    _lib.check(code, "sc_linear_bn_backward")
+    return gy, g_res, dw, dgb[0], dgb[1]
+
+
+def linear_backward_data(gy, w, g_add):
+    """dx [N, Cin] = gy [N, Cout] @ w [Cout, Cin] (+ g_add)."""
+    N, Cout = gy.shape
+    Cin = w.shape[1]
+    dx = torch.empty(N, Cin, device=gy.device, dtype=torch.float32)
+    _lib.check(_lib.load().sc_linear_backward_data(_lib.ptr(gy), _lib.ptr(w), _lib.ptr(g_add), _lib.ptr(dx), c_int(N), c_int(Cin), c_int(Cout),
+                                                   _lib.stream()), "sc_linear_backward_data")
+    return dx

@@ -22,7 +22,7 @@ torch.backends.cudnn.benchmark = False
 # defaults for keys this build adds (a reference YAML without them still loads)
 # deterministic_conv: the reference sets cudnn.deterministic=True globally (utils/options.py:14); on ROCm that
 # restricts MIOpen to GEMM-based backward solvers (measured 437 ms of 640 ms per bs32 step), so it is opt-in here.
-HIP_DEFAULTS = dict(hip=dict(device_rng=False, device_choice=True, fused_backward=True, deterministic_conv=False, fused_loss=True, fused_adam=True, guarded_step=True, batched_encoders=True, two_streams=True, overlap_allreduce=False, reserve_cus=0, fused_block=True, rocblas=True, conv3x3=True, conv3x3_split=True, conv_stem=True, conv1x1=True, conv3x3s2=True, conv3x3s2_grads=True))
+HIP_DEFAULTS = dict(hip=dict(device_rng=False, device_choice=True, fused_backward=True, deterministic_conv=False, fused_loss=True, fused_adam=True, guarded_step=True, batched_encoders=True, two_streams=True, overlap_allreduce=False, reserve_cus=0, fused_block=True, fused_bottleneck=True, rocblas=True, conv3x3=True, conv3x3_split=True, conv_stem=True, conv1x1=True, conv3x3s2=True, conv3x3s2_grads=True))
 
 
 def parse_arguments(args):
@@ -118,6 +118,8 @@ def process_options(opt):
     resnet.HIP_CONV3X3_S2 = bool(opt.get("hip", {}).get("conv3x3s2", True))
     resnet.HIP_CONV3X3_S2_GRADS = bool(opt.get("hip", {}).get("conv3x3s2_grads", True))
     resnet.FUSED_BLOCK = bool(opt.get("hip", {}).get("fused_block", True))
+    from ..model import view_estimator
+    view_estimator.HIP_BOTTLENECK = bool(opt.get("hip", {}).get("fused_bottleneck", True))
     # The ~83 small fp32 GEMMs of a step (estimator heads, latent projectors: [B..3B, 256..512] x [C, C]) through rocBLAS instead of torch's
     # default hipBLASLt: 7 instead of 18 us of host time per call (tools/attic/probe_blas.py: a host-paced B=8 step 16.3 -> 14.9 ms); process-global
     # like cudnn.deterministic above, `--hip.rocblas!` leaves torch's choice alone.
