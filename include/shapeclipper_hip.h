@@ -559,6 +559,17 @@ int sc_linear_bn_backward(const float* g_out, const float* gy_next, const float*
 int sc_linear_backward_data(const float* gy, const float* w, const float* g_add, float* dx, int N, int Cin, int Cout, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Per-image biases of the conditioned MLP layers (csrc/latent_bias.hip): the latent columns of a layer act on the [B][Z] latent once per
+ * image -- the reference repeats the latent per sample point (model/implicit.py:166, model/renderer.py:89).
+ *   out [B][NL][64] = bias [NL][64] + (l < L ? post[l] : 0) * z [B][Z] lat[l * 64 + ch][Z]^T      (post may be NULL = 1)
+ *   backward: g [B][NL][64] -> g_z [B][Z] (may be NULL), g_lat [L * 64][Z], g_bias [NL][64].  Every element is one fixed-order sum:
+ *   results do not depend on the batch size.                                                                                          */
+int sc_latent_bias_forward(const float* z, const float* lat, const float* bias, const float* post, float* out, int B, int Z, int L, int NL,
+                           void* stream);
+int sc_latent_bias_backward(const float* g, const float* z, const float* lat, const float* post, float* g_z, float* g_lat, float* g_bias,
+                            int B, int Z, int L, int NL, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Launch policy (csrc/device.hip) -- the one process-level setting of the library.  The persistent one-workgroup-per-CU grids
  * (stream-K 3x3 convolutions and their weight gradients, stem / 1x1 / stride-2 gradients) are sized for
  * sc_grid_cus() = device CUs - reserved.  Reserve CUs when another stream must make progress beside them: RCCL's

@@ -114,7 +114,19 @@ class Graph(nn.Module):
         var.latent_shape = var.latent_raw[:, :opt.arch.latent_dim_shape]
         var.latent_rgb = var.latent_raw[:, opt.arch.latent_dim_shape:]
         var.proj_latent_sdf = self.latent_proj_shape(var.latent_shape)
-        var.proj_latent_rgb = self.latent_proj_rgb(var.latent_rgb)
+        # The colour projector runs on the input view here and on every neighbour view in forward_NN (reference graph.py:78, :198): when the
+        # neighbours' latents are already known (batched encoders) all of them go through it ONCE, stacked, with per-set BatchNorm
+        # statistics updated in the reference's call order -- one set of launches and one gradient per shared weight instead of one per view.
+        nn_lat = [nn_in.latent_raw[:, opt.arch.latent_dim_shape:] for nn_in in views if "latent_raw" in nn_in] if use_NN else []
+        if nn_lat and len(nn_lat) == len(views) and var.latent_rgb.is_cuda and opt.get("hip", {}).get("batched_encoders", True):
+            G = 1 + len(nn_lat)
+            proj = self._project_stacked(self.latent_proj_rgb, torch.cat([var.latent_rgb] + nn_lat, 0), G)
+            pieces = proj.reshape(G, B, proj.shape[1]).unbind(0)
+            var.proj_latent_rgb = pieces[0]
+            for nn_in, piece in zip(views, pieces[1:]):
+                nn_in.proj_latent_rgb = piece
+        else:
+            var.proj_latent_rgb = self.latent_proj_rgb(var.latent_rgb)
 
         var.pose, var.intr, var.scale_dist = self.pred_pose(opt, var)
         var.normal_transformed = self.transform_normal(var.normal_gt if "normal_gt" in var else var.normal_input, var.pose)
@@ -244,6 +256,13 @@ class Graph(nn.Module):
             var._estim_flip = est[len(images)]
 
     @staticmethod
+    def _project_stacked(projector, x, groups):
+        """A latent projector (Bottleneck_Linear, Bottleneck_Linear, Linear) on `groups` stacked sub-batches: the result of `groups` calls."""
+        for m in projector:
+            x = m(x, groups=groups) if isinstance(m, _EstimatorBottleneck) else m(x)
+        return x
+
+    @staticmethod
     def _side_stream(device):
         """Second HIP stream of a device (process-wide: module attributes must stay deep-copyable / picklable)."""
         key = str(device)
@@ -261,7 +280,8 @@ class Graph(nn.Module):
         for v, nn_in in enumerate(views):
             ray_idx = nn_in.ray_idx if sampled else None
             latent_NN = nn_in.latent_raw if "latent_raw" in nn_in else self.encoder(nn_in.rgb_input_map)
-            proj_latent_rgb_NN = self.latent_proj_rgb(latent_NN[:, opt.arch.latent_dim_shape:])
+            proj_latent_rgb_NN = (nn_in.proj_latent_rgb if "proj_latent_rgb" in nn_in
+                                  else self.latent_proj_rgb(latent_NN[:, opt.arch.latent_dim_shape:]))
             var.proj_latent_rgb_NN = proj_latent_rgb_NN
             pose_NN, intr_NN, scale_NN = self.pred_pose(opt, var, pred_NN=True, given_input=nn_in.rgb_input_map,
                                                         estim=nn_in.get("estim"))

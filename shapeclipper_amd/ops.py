@@ -1134,3 +1134,24 @@ def linear_backward_data(gy, w, g_add):
     _lib.check(_lib.load().sc_linear_backward_data(_lib.ptr(gy), _lib.ptr(w), _lib.ptr(g_add), _lib.ptr(dx), c_int(N), c_int(Cin), c_int(Cout),
                                                    _lib.stream()), "sc_linear_backward_data")
     return dx
+
+
+# ---- per-image latent biases (csrc/latent_bias.hip) --------------------------------------------------------------------------------------
+def latent_bias_forward(z, lat, bias, post):
+    B, Z = z.shape
+    L, NL = lat.shape[0] // 64, bias.shape[0]
+    out = torch.empty(B, NL, 64, device=z.device, dtype=torch.float32)
+    _lib.check(_lib.load().sc_latent_bias_forward(_lib.ptr(z), _lib.ptr(lat), _lib.ptr(bias), _lib.ptr(post), _lib.ptr(out), c_int(B), c_int(Z), c_int(L),
+                                                  c_int(NL), _lib.stream()), "sc_latent_bias_forward")
+    return out
+
+
+def latent_bias_backward(g, z, lat, post, NL, want_z=True):
+    B, Z = z.shape
+    L = lat.shape[0] // 64
+    f32 = dict(device=z.device, dtype=torch.float32)
+    g_z = torch.empty(B, Z, **f32) if want_z else None
+    g_lat, g_bias = torch.empty(L * 64, Z, **f32), torch.empty(NL, 64, **f32)
+    _lib.check(_lib.load().sc_latent_bias_backward(_lib.ptr(g), _lib.ptr(z), _lib.ptr(lat), _lib.ptr(post), _lib.ptr(g_z), _lib.ptr(g_lat), _lib.ptr(g_bias),
+                                                   c_int(B), c_int(Z), c_int(L), c_int(NL), _lib.stream()), "sc_latent_bias_backward")
+    return g_z, g_lat, g_bias

@@ -207,63 +207,115 @@ def _names(kind):
     return [k for l in range(n) for k in ("lin%d.weight" % l, "lin%d.bias" % l)]
 
 
-def gather_params(kind: str, W: Dict[str, torch.Tensor], Z: int, arch=None) -> torch.Tensor:
-    """[ packed image | latent block | bias rows ] of a network in one gather (differentiable w.r.t. every parameter)."""
+class _PackParams(torch.autograd.Function):
+    """(packed weight image, latent block [L*64, Z], bias rows [NL, 64]) of a network from its raw parameters: ONE gather forward, ONE
+    scatter-add backward.  Three separate outputs instead of slices of one vector: a slice node's backward is a full-size zero fill + a copy,
+    and the pieces have 3-6 consumers per step (round 5: 7 fills + 6 adds of the 42,433-element vector per step went away)."""
+
+    @staticmethod
+    def forward(ctx, kind, Z, arch, *params):
+        plan = _plan(kind, Z, params[0].device, arch)
+        src = torch.cat([p.reshape(-1) for p in params] + [params[0].new_zeros(1)])
+        out = torch.index_select(src, 0, plan["idx"])
+        if plan["scale"] is not None:
+            out = out * plan["scale"]
+        ctx.plan, ctx.shapes = plan, [tuple(p.shape) for p in params]
+        n_pack, n_lat = plan["n_pack"], plan["n_lat"]
+        return out[:n_pack], out[n_pack:n_pack + n_lat].view(n_lat // Z, Z), out[n_pack + n_lat:].view(-1, 64)
+
+    @staticmethod
+    def backward(ctx, g_w, g_lat, g_bias):
+        plan = ctx.plan
+        ref = next(t for t in (g_w, g_lat, g_bias) if t is not None)
+        z = lambda n: ref.new_zeros(n)
+        g = torch.cat([g_w.reshape(-1) if g_w is not None else z(plan["n_pack"]), g_lat.reshape(-1) if g_lat is not None else z(plan["n_lat"]),
+                       g_bias.reshape(-1) if g_bias is not None else z(plan["n_bias"])])
+        if plan["scale"] is not None:
+            g = g * plan["scale"]
+        flat = ref.new_zeros(plan["total"] + 1).index_add_(0, plan["idx"], g)     # (every source element is gathered at most once besides the zero pad)
+        outs, o = [], 0
+        for sh in ctx.shapes:
+            n = int(torch.Size(sh).numel())
+            outs.append(flat[o:o + n].view(sh))
+            o += n
+        return (None, None, None) + tuple(outs)
+
+
+class _LatentBias(torch.autograd.Function):
+    """c = bias + post * (z @ lat^T) per image in one HIP launch each way (csrc/latent_bias.hip); batch-size invariant."""
+
+    @staticmethod
+    def forward(ctx, z, lat, bias, post):
+        from . import ops
+        z, lat, bias = ops._aligned(z), ops._aligned(lat), ops._aligned(bias)
+        out = ops.latent_bias_forward(z, lat, bias, post)
+        ctx.save_for_backward(z, lat, post)
+        ctx.nl = bias.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops
+        z, lat, post = ctx.saved_tensors
+        g_z, g_lat, g_bias = ops.latent_bias_backward(ops._aligned(g), z, lat, post, ctx.nl, ctx.needs_input_grad[0])
+        return g_z, g_lat, g_bias, None
+
+
+def gather_params(kind: str, W: Dict[str, torch.Tensor], Z: int, arch=None):
+    """(packed image, latent block [L*64, Z], bias rows [NL, 64]) of a network in one gather (differentiable w.r.t. every parameter)."""
     names = _names(kind)
-    dev = W[names[0]].device
-    plan = _plan(kind, Z, dev, arch)
+    plan = _plan(kind, Z, W[names[0]].device, arch)
     for n, sh in zip(names, plan["shapes"]):
         assert tuple(W[n].shape) == tuple(sh), (n, tuple(W[n].shape), sh)
-    src = torch.cat([W[n].reshape(-1) for n in names] + [W[names[0]].new_zeros(1)])
-    out = torch.index_select(src, 0, plan["idx"])
-    return out * plan["scale"] if plan["scale"] is not None else out
+    return _PackParams.apply(kind, Z, arch, *[W[n] for n in names])
 
 
-def _bias_from(kind: str, g: torch.Tensor, z: torch.Tensor, arch=None) -> torch.Tensor:
+def _bias_from(kind: str, parts, z: torch.Tensor, arch=None) -> torch.Tensor:
+    lat, bias = parts
     B, Z = z.shape
-    plan = _plan(kind, Z, g.device, arch)
-    n_pack, n_lat = plan["n_pack"], plan["n_lat"]
-    L = n_lat // (64 * Z)                               # conditioned layers: 3 (sdf) / 1 (rgb)
-    lat = g[n_pack:n_pack + n_lat].view(L * 64, Z)
-    bias = g[n_pack + n_lat:].view(1, -1, 64)
-    zw = (z @ lat.t()).view(B, L, 64)
-    if plan["post"] is not None:
-        zw = zw * plan["post"]
-    NL = bias.shape[1]
-    return torch.nn.functional.pad(zw, (0, 0, 0, NL - L)) + bias                 # = bias + z-term (fp32 addition commutes)
+    plan = _plan(kind, Z, lat.device, arch)
+    L, NL = lat.shape[0] // 64, bias.shape[0]
+    post = plan["post"]
+    if z.is_cuda:                                       # one launch each way; no CPU fallback on the device path (raises if the library is missing)
+        return _LatentBias.apply(z, lat, bias, post.reshape(-1) if post is not None else None)
+    zw = (z @ lat.t()).view(B, L, 64)                   # host tensors (config[0] plumbing, CPU tests of the packing): stock operators
+    if post is not None:
+        zw = zw * post
+    return torch.nn.functional.pad(zw, (0, 0, 0, NL - L)) + bias.unsqueeze(0)
 
 
-def sdf_cbias(W: Dict[str, torch.Tensor], z: torch.Tensor, gathered: torch.Tensor = None, arch=None) -> torch.Tensor:
-    """Per-image biases c_l = b_l + W_l[:, latent] @ z (skip layers scaled by 1/sqrt2) -> [B, 5, 64]."""
+def sdf_cbias(W: Dict[str, torch.Tensor], z: torch.Tensor, gathered=None, arch=None) -> torch.Tensor:
+    """Per-image biases c_l = b_l + W_l[:, latent] @ z (skip layers scaled by 1/sqrt2) -> [B, 5, 64].  gathered: the (latent block, bias rows)
+    pair pack_sdf(..., return_gathered=True) handed out (shared by the renders of a step)."""
     if arch is None and W is not None:
         arch = arch_of("sdf", W, z.shape[1])
-    g = gathered if gathered is not None else gather_params("sdf", W, z.shape[1], arch)
-    return _bias_from("sdf", g, z, arch)
+    parts = gathered if gathered is not None else gather_params("sdf", W, z.shape[1], arch)[1:]
+    return _bias_from("sdf", parts, z, arch)
 
 
 def pack_sdf(W: Dict[str, torch.Tensor], z: torch.Tensor, return_gathered: bool = False):
     """SDFNetwork parameters (state-dict names lin{l}.weight/.bias) + latent z [B, Z]
     -> (w_pack [SDF_PACK_FLOATS], cbias [B, 5, 64]).  The architecture (channels, octaves, skip inputs) is read off the shapes."""
     arch = arch_of("sdf", W, z.shape[1])
-    g = gather_params("sdf", W, z.shape[1], arch)
-    out = (g[:SDF_PACK_FLOATS], _bias_from("sdf", g, z, arch))
-    return out + (g,) if return_gathered else out
+    w_pack, lat, bias = gather_params("sdf", W, z.shape[1], arch)
+    out = (w_pack, _bias_from("sdf", (lat, bias), z, arch))
+    return out + ((lat, bias),) if return_gathered else out
 
 
-def rgb_dbias(W: Dict[str, torch.Tensor], z: torch.Tensor, gathered: torch.Tensor = None, arch=None, n_sdf: int = 64) -> torch.Tensor:
+def rgb_dbias(W: Dict[str, torch.Tensor], z: torch.Tensor, gathered=None, arch=None, n_sdf: int = 64) -> torch.Tensor:
     if arch is None and W is not None:
         arch = arch_of("rgb", W, z.shape[1], n_sdf)
-    g = gathered if gathered is not None else gather_params("rgb", W, z.shape[1], arch)
-    return _bias_from("rgb", g, z, arch)
+    parts = gathered if gathered is not None else gather_params("rgb", W, z.shape[1], arch)[1:]
+    return _bias_from("rgb", parts, z, arch)
 
 
 def pack_rgb(W: Dict[str, torch.Tensor], z: torch.Tensor, return_gathered: bool = False, n_sdf: int = 64):
     """RGBNetwork parameters + latent z_rgb [B, Z] -> (v_pack [RGB_PACK_FLOATS], dbias [B, 3, 64]).
     lin0 input order is [PE(39), z_rgb(Z), sdf_feature(64)] (model/implicit.py:231)."""
     arch = arch_of("rgb", W, z.shape[1], n_sdf)
-    g = gather_params("rgb", W, z.shape[1], arch)
-    out = (g[:RGB_PACK_FLOATS], _bias_from("rgb", g, z, arch))
-    return out + (g,) if return_gathered else out
+    v_pack, lat, bias = gather_params("rgb", W, z.shape[1], arch)
+    out = (v_pack, _bias_from("rgb", (lat, bias), z, arch))
+    return out + ((lat, bias),) if return_gathered else out
 
 
 def n_tiles(n_points: int) -> int:

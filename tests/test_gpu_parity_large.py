@@ -283,9 +283,9 @@ def test_config2_render_128_b32_rows_equal_single_image_renders(golden):
             assert torch.equal(full[2][item], one[2][0]) or float((full[1][item] - 0.5).abs().min()) < 1e-5
     hit = float(full[2].mean())
     print("128x128 render B=32: rows vs single-image renders max abs diff %.2e, hit fraction %.2f" % (worst, hit))
-    # the per-image latent biases are one [B, 64] x [64, 192] GEMM: its summation order depends on B in rocBLAS (the default BLAS since round 4,
-    # `--hip.rocblas`), so the batched and the single-image renders differ by the rounding of a 64-term fp32 sum (2.2e-6 measured; hipBLASLt: 1e-6)
-    assert worst < 5e-6 and 0.1 < hit < 0.9
+    # Round 5: the per-image latent biases come from csrc/latent_bias.hip -- one fixed-order sum per element, whatever the batch
+    # size -- so a row of the batched render IS the single-image render, bit for bit (with the rocBLAS product of round 4: 2.2e-6).
+    assert worst == 0.0 and 0.1 < hit < 0.9
 
 
 def test_chamfer_backward_20000_vs_oracle():
