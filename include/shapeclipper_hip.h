@@ -127,6 +127,22 @@ int sc_rgb_composite_backward_v3(
     float* g_sdf, float* g_grad, float* g_feat, float* g_points, float* g_z, float* g_depth_fac, float* g_beta,
     float* gy, float* rr, float* gy3, float* v3_part, void* stream);
 
+/* The same reverse pass with the weight gradients of V0, V1, V2 and the per-image bias gradients formed INSIDE the kernel (round 5: four
+ * weight-gradient waves beside the four chain waves, operands handed over through LDS -- the scheme of sc_sdf_backward_fused) instead of
+ * the gy / rr hand-off tensors and three sc_wgrad launches.  partial: [sc_rgb_composite_backward_fused_parts(n_rays)]
+ * [sc_rgb_composite_backward_fused_partial_floats(n_images)] floats, one image per workgroup = d/d(V0 | V1 | V2) (RgbPack order, 15,360
+ * floats) then [n_images][3][64] bias gradients, fully written; sum them in index order (sc_partial_reduce).  v3_part as above.
+ * n_images <= 256.                                                                                                             */
+int sc_rgb_composite_backward_fused_parts(int n_rays);
+int sc_rgb_composite_backward_fused_partial_floats(int n_images);
+int sc_rgb_composite_backward_fused(
+    const float* points, const float* z_vals, const float* depth_fac, const float* sdf, const float* grad,
+    const float* feat, const float* v_pack, const float* dbias, const float* beta_param, const float* rgb_flat,
+    int n_rays, int rays_per_image, int n_images, int symmetric, float beta_min, float bgcolor, float normal_pow,
+    const float* G_rgb, const float* G_mask, const float* G_depth, const float* G_normal,
+    float* g_sdf, float* g_grad, float* g_feat, float* g_points, float* g_z, float* g_depth_fac, float* g_beta,
+    float* partial, float* v3_part, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Weight-gradient GEMM  dW[64][nb0+nb1] = sum_points A(p) (x) [B0(p) | B1(p)]  over one or two terms.
  * Operand transform codes: 1 plain TBL64, 2 softplus(a), 3 p*softplus'(a), 4 w5row*softplus'(a),

@@ -12,6 +12,7 @@
 //   (Gy2 -> V2^T -> Gy1 -> V1^T -> Gy0 -> V0f^T -> G feature, PE Jacobian -> G point) and leave
 //   Gy_l / r_l in HBM (TBL64) for the weight-gradient GEMMs (wgrad.hip).
 #include "rgb_common.hpp"
+#include "mlp_xch.hpp"
 
 namespace sc {
 
@@ -35,18 +36,120 @@ struct RgbBwdArgs {
     float* gy;           // 3 x TBL64: pre-activation gradients Gy0, Gy1, Gy2
     float* rr;           // 3 x TBL64: post-ReLU activations r0, r1, r2
     float* gy3;          // [P][3]: gradient at the pre-sigmoid output
+    float* partial;      // FUSED kernel only: [gridDim.x][partial_stride]: per workgroup the gradient of V0 | V1 | V2 (RgbPack::V3 floats) followed
+                         // by the per-image bias gradients [n_images][3][64]; fully written; summed in index order by sc_partial_reduce
+    int partial_stride;
     float* v3_part;      // null, or [SC_RGB_BWD_BETA_PARTS][196]: per wave of the grid the sums over its points of gy3_j * r2[ch] (= dV3 [3][64]),
                          // of gy3_j (= db3 [3]) and one zero -- fully written; their sum in index order (sc_partial_reduce) is the gradient of
                          // the output layer.  With it rr[2] and gy3 are NOT written (nobody else reads them): 280 MB less per launch.
 };
 
-__global__ __launch_bounds__(256, 2) void rgb_composite_bwd_kernel(RgbBwdArgs a) {
+// FUSED (round 5): the weight gradients of V0, V1, V2 and the per-image bias gradients are formed INSIDE this kernel by
+// four more waves (the scheme of sdf_bwdw.hip: the chain waves drop each layer's operand pair -- Gy_l and the layer's input -- into a
+// 4 KiB LDS slot pair, two workgroup barriers bracket the write, wave 4 + w accumulates rows 16 w .. 16 w + 15 of every matrix with fp32
+// MFMAs whose K index is the point) instead of writing Gy_0..2 and r_0..1 to HBM (1.6 GB per bs32 render) for three sc_wgrad launches.
+constexpr int RB_XCH = (RgbLds::TOTAL + 3) & ~3;          // exchange slots [chain wave][A | B][1024]
+constexpr int RB_PTS = RB_XCH + 4 * 2 * 1024;             // point stash [chain wave][16 points][8]: x0 x1 x2 - | - - valid -
+constexpr int RB_LDS_FLOATS = RB_PTS + 4 * 16 * 8;
+
+template <bool FUSED>
+__global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? 1 : 2) void rgb_composite_bwd_kernel(RgbBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    stage_rgb_weights(lds, a.v, threadIdx.x, 256);
+    stage_rgb_weights(lds, a.v, threadIdx.x, FUSED ? 512 : 256);
+    if (FUSED) {
+        for (int e = threadIdx.x; e < RB_LDS_FLOATS - RB_XCH; e += 512) lds[RB_XCH + e] = 0.f;
+        float* cbz = a.partial + (size_t)blockIdx.x * a.partial_stride + RgbPack::V3;
+        for (int e = threadIdx.x; e < a.n_images * 192; e += 512) cbz[e] = 0.f;
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_iter = (a.n_rays + (int)gridDim.x * 4 - 1) / ((int)gridDim.x * 4);       // ray of (iteration, wave): (it * grid + block) * 4 + wave
+    if (FUSED && wave >= 4) {
+        // ================= weight-gradient role: wave 4 + w owns rows 16 w .. 16 w + 15 of dV0 [64][48 | 64], dV1, dV2 [64][64] =================
+        const int w = wave - 4, i = lane & 15, kg = lane >> 4;
+        const int rd = (kg * 64 + (i ^ kg)) << 2;
+        const bool symmetric = a.symmetric != 0;
+        f32x4 d0e[3], d0f[4], d1[4], d2[4];
+        acc_zero(d0e); acc_zero(d0f); acc_zero(d1); acc_zero(d2);
+        float* cbp = a.partial + (size_t)blockIdx.x * a.partial_stride + RgbPack::V3;
+        float rs[3] = {0.f, 0.f, 0.f};
+        int cur_img = -1;                                    // >= 0: rs[] belongs to this image; -2: the four rays of the iteration straddle images
+        auto flush = [&]() {
+            if (cur_img >= 0) {
+#pragma unroll
+                for (int l = 0; l < 3; ++l) {
+                    float v = rs[l];
+                    v += __shfl_xor(v, 16);
+                    v += __shfl_xor(v, 32);
+                    if (kg == 0) cbp[((size_t)cur_img * 3 + l) * 64 + 16 * w + i] += v;      // one writer per address: plain read-modify-write
+                    rs[l] = 0.f;
+                }
+            }
+        };
+#define RB_CONSUME(ACC, PEACC, WITH_PE, RS)                                                 \
+        lds_barrier(); lds_barrier();                                                        \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                      \
+            const float* sA = lds + RB_XCH + (c * 2 + 0) * 1024;                             \
+            const float* sB = lds + RB_XCH + (c * 2 + 1) * 1024;                             \
+            const float4 af = xch_frag(sA, rd, w);                                           \
+            float4 bf[4];                                                                    \
+            _Pragma("unroll") for (int n = 0; n < 4; ++n) bf[n] = xch_frag(sB, rd, n);       \
+            outer16<4>(af, bf, ACC);                                                         \
+            if (WITH_PE) {                                                                   \
+                float4 pf[3];                                                                \
+                pe_frags<1>(lds + RB_PTS + c * 16 * 8, i, kg, symmetric, pf);                \
+                outer16<3>(af, pf, PEACC);                                                   \
+            }                                                                                \
+            const float v = (af.x + af.y) + (af.z + af.w);                                   \
+            if (cur_img >= 0) rs[RS] += v;                                                   \
+            else {                                                                           \
+                float t = v;                                                                 \
+                t += __shfl_xor(t, 16);                                                      \
+                t += __shfl_xor(t, 32);                                                      \
+                const int ray_c = (it * (int)gridDim.x + (int)blockIdx.x) * 4 + c;           \
+                if (kg == 0 && ray_c < a.n_rays)                                             \
+                    cbp[((size_t)min(ray_c / a.rays_per_image, a.n_images - 1) * 3 + RS) * 64 + 16 * w + i] += t; \
+            }                                                                                \
+        }
+#pragma unroll 1
+        for (int it = 0; it < n_iter; ++it) {
+            const int ray0 = (it * (int)gridDim.x + (int)blockIdx.x) * 4, ray3 = min(ray0 + 3, a.n_rays - 1);
+            const int img0 = min(min(ray0, a.n_rays - 1) / a.rays_per_image, a.n_images - 1), img3 = min(ray3 / a.rays_per_image, a.n_images - 1);
+            if (img0 != cur_img || img3 != img0) {
+                flush();
+                cur_img = img0 == img3 ? img0 : -2;
+            }
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k) {
+                RB_CONSUME(d2, d0e, false, 2)               // Gy2 x r1
+                RB_CONSUME(d1, d0e, false, 1)               // Gy1 x r0
+                RB_CONSUME(d0f, d0e, true, 0)               // Gy0 x (feature | E)
+            }
+        }
+#undef RB_CONSUME
+        flush();
+        float* out = a.partial + (size_t)blockIdx.x * a.partial_stride;
+        auto put = [&](const f32x4* acc, int ntile, int off, int ld, int col0) {
+            for (int n = 0; n < ntile; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[off + (16 * w + 4 * kg + r) * ld + col0 + 16 * n + i] = acc[n][r];
+        };
+        put(d0e, 3, RgbPack::V0, 112, 0);
+        put(d0f, 4, RgbPack::V0, 112, 48);
+        put(d1, 4, RgbPack::V1, 64, 0);
+        put(d2, 4, RgbPack::V2, 64, 0);
+        return;
+    }
     const int p = lane & 15, g = lane >> 4;
     RgbLanePtrs L(lds, p, g);
+    [[maybe_unused]] float* slotA = lds + RB_XCH + (wave * 2 + 0) * 1024;
+    [[maybe_unused]] float* slotB = lds + RB_XCH + (wave * 2 + 1) * 1024;
+    [[maybe_unused]] float* ptsw = lds + RB_PTS + wave * 16 * 8;
+    [[maybe_unused]] int wr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wr[r] = (((p >> 2) * 64 + 4 * g + (r ^ (p >> 2))) << 2) + (p & 3);
+// hand one operand pair to the weight-gradient waves: B1 (they have finished the previous pair), write, B2 (visible)
+#define RB_EXCHANGE(WRITES) if (FUSED) { lds_barrier(); WRITES lds_barrier(); }
     const float bp = a.beta_param[0];
     const float beta = fabsf(bp) + a.beta_min;
     const float dbeta_dbp = bp > 0.f ? 1.f : (bp < 0.f ? -1.f : 0.f);
@@ -58,7 +161,21 @@ __global__ __launch_bounds__(256, 2) void rgb_composite_bwd_kernel(RgbBwdArgs a)
 #pragma unroll
         for (int s2 = 0; s2 < ACT_STEPS; ++s2) v3acc[j][s2] = 0.f;
 
-    for (int ray = blockIdx.x * 4 + wave; ray < a.n_rays; ray += gridDim.x * 4) {
+#pragma unroll 1
+    for (int it = 0; it < n_iter; ++it) {
+        const int ray = (it * (int)gridDim.x + (int)blockIdx.x) * 4 + wave;
+        if (ray >= a.n_rays) {
+            if (!FUSED) break;
+            for (int st = 0; st < 12; ++st) {               // tail: keep the barrier count of an iteration (4 tiles x 3 steps), feed zeros
+                lds_barrier();
+                if (st == 0) {
+                    xch_zero(slotA, lane); xch_zero(slotB, lane);
+                    if (lane < 32) reinterpret_cast<float4*>(ptsw)[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                lds_barrier();
+            }
+            continue;
+        }
         const int img = min(ray / a.rays_per_image, a.n_images - 1);
         const float* db = a.dbias + (size_t)img * 192 + 4 * g;
         const size_t sp = (size_t)ray * 64 + lane;   // this lane's sample
@@ -153,8 +270,10 @@ __global__ __launch_bounds__(256, 2) void rgb_composite_bwd_kernel(RgbBwdArgs a)
             float r[3][ACT_STEPS];
             float col[3];
             rgb_chain(L, db, e, f, r, col);
-            tbl_store(a.rr + 0 * tbl, tile, p, g, r[0]);
-            tbl_store(a.rr + 1 * tbl, tile, p, g, r[1]);
+            if (!FUSED) {
+                tbl_store(a.rr + 0 * tbl, tile, p, g, r[0]);
+                tbl_store(a.rr + 1 * tbl, tile, p, g, r[1]);
+            }
             const float y0 = gc0 * col[0] * (1.f - col[0]);
             const float y1 = gc1 * col[1] * (1.f - col[1]);
             const float y2 = gc2 * col[2] * (1.f - col[2]);
@@ -176,18 +295,25 @@ __global__ __launch_bounds__(256, 2) void rgb_composite_bwd_kernel(RgbBwdArgs a)
                 const float gr = L.v3[kp(s2)] * y0 + L.v3[64 + kp(s2)] * y1 + L.v3[128 + kp(s2)] * y2;
                 gyv[s2] = r[2][s2] > 0.f ? gr : 0.f;
             }
-            tbl_store(a.gy + 2 * tbl, tile, p, g, gyv);
+            if (!FUSED) tbl_store(a.gy + 2 * tbl, tile, p, g, gyv);
+            RB_EXCHANGE(xch_write(slotA, wr, gyv, 1.f); xch_write(slotB, wr, r[1], 1.f);
+                        if (g == 0) {
+                            *reinterpret_cast<float4*>(ptsw + p * 8) = make_float4(x0, x1, x2, 0.f);
+                            *reinterpret_cast<float4*>(ptsw + p * 8 + 4) = make_float4(0.f, 0.f, 1.f, 0.f);
+                        })
             f32x4 acc[NT];
             acc_zero(acc);
             mm_act_t<RgbLds::LD1, NT>(L.v2t, gyv, acc);
 #pragma unroll
             for (int s2 = 0; s2 < ACT_STEPS; ++s2) gyv[s2] = r[1][s2] > 0.f ? acc[s2 >> 2][s2 & 3] : 0.f;
-            tbl_store(a.gy + 1 * tbl, tile, p, g, gyv);
+            if (!FUSED) tbl_store(a.gy + 1 * tbl, tile, p, g, gyv);
+            RB_EXCHANGE(xch_write(slotA, wr, gyv, 1.f); xch_write(slotB, wr, r[0], 1.f);)
             acc_zero(acc);
             mm_act_t<RgbLds::LD1, NT>(L.v1t, gyv, acc);
 #pragma unroll
             for (int s2 = 0; s2 < ACT_STEPS; ++s2) gyv[s2] = r[0][s2] > 0.f ? acc[s2 >> 2][s2 & 3] : 0.f;
-            tbl_store(a.gy + 0 * tbl, tile, p, g, gyv);
+            if (!FUSED) tbl_store(a.gy + 0 * tbl, tile, p, g, gyv);
+            RB_EXCHANGE(xch_write(slotA, wr, gyv, 1.f); xch_write(slotB, wr, f, 1.f);)
             acc_zero(acc);
             mm_act_t<RgbLds::LD0, NT>(L.v0ft, gyv, acc);
             float gf[ACT_STEPS];
@@ -248,11 +374,40 @@ extern "C" int sc_rgb_composite_backward_v3(
     sc::RgbBwdArgs a{points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta_param, rgb_flat,
                      n_rays, rays_per_image, n_images, symmetric, beta_min, bgcolor, normal_pow,
                      G_rgb, G_mask, G_depth, G_normal, g_sdf, g_grad, g_feat, g_points, g_z, g_depth_fac, g_beta,
-                     gy, rr, gy3, v3_part};
+                     gy, rr, gy3, nullptr, 0, v3_part};
     int blocks = (n_rays + 3) / 4;
     if (blocks > 512) blocks = 512;
     const size_t lds_bytes = sc::RgbLds::TOTAL * sizeof(float);
-    hipLaunchKernelGGL(sc::rgb_composite_bwd_kernel, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream_, a);
+    hipLaunchKernelGGL(sc::rgb_composite_bwd_kernel<false>, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream_, a);
+    return (int)hipGetLastError();
+}
+
+// Workgroups (= partial images) of sc_rgb_composite_backward_fused for n_rays, and floats per partial image.
+extern "C" int sc_rgb_composite_backward_fused_parts(int n_rays) {
+    const int blocks = (n_rays + 3) / 4;
+    return blocks > 256 ? 256 : (blocks < 1 ? 1 : blocks);
+}
+extern "C" int sc_rgb_composite_backward_fused_partial_floats(int n_images) { return sc::RgbPack::V3 + n_images * 192; }
+
+// The same reverse pass with the gradients of V0, V1, V2 and of the per-image biases formed in the kernel (no gy / rr hand-off tensors):
+// partial [parts][partial_floats(n_images)] receives one image per workgroup, fully written; v3_part as in the _v3 form (required).
+extern "C" int sc_rgb_composite_backward_fused(
+    const float* points, const float* z_vals, const float* depth_fac, const float* sdf, const float* grad,
+    const float* feat, const float* v_pack, const float* dbias, const float* beta_param, const float* rgb_flat,
+    int n_rays, int rays_per_image, int n_images, int symmetric, float beta_min, float bgcolor, float normal_pow,
+    const float* G_rgb, const float* G_mask, const float* G_depth, const float* G_normal,
+    float* g_sdf, float* g_grad, float* g_feat, float* g_points, float* g_z, float* g_depth_fac, float* g_beta,
+    float* partial, float* v3_part, void* stream_) {
+    if (n_rays <= 0) return 0;
+    if (!partial || !v3_part || n_images <= 0 || n_images > 256) return (int)hipErrorInvalidValue;
+    sc::RgbBwdArgs a{points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta_param, rgb_flat,
+                     n_rays, rays_per_image, n_images, symmetric, beta_min, bgcolor, normal_pow,
+                     G_rgb, G_mask, G_depth, G_normal, g_sdf, g_grad, g_feat, g_points, g_z, g_depth_fac, g_beta,
+                     nullptr, nullptr, nullptr, partial, sc_rgb_composite_backward_fused_partial_floats(n_images), v3_part};
+    const int blocks = sc_rgb_composite_backward_fused_parts(n_rays);
+    const size_t lds_bytes = (size_t)sc::RB_LDS_FLOATS * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)sc::rgb_composite_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL(sc::rgb_composite_bwd_kernel<true>, dim3(blocks), dim3(512), lds_bytes, (hipStream_t)stream_, a);
     return (int)hipGetLastError();
 }
 

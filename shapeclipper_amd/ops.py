@@ -268,6 +268,9 @@ def sdf_backward(points, w_pack, n_per_image, n_images, symmetric, stash_a, stas
     return g_points, g_w, g_c
 
 
+FUSED_RGB_WGRAD = True      # `--hip.fused_rgb_wgrad!`: Gy_l / r_l through HBM and three sc_wgrad launches (the round-4 path)
+
+
 def rgb_composite_backward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta_param, rgb_flat,
                            rays_per_image, symmetric, beta_min, bgcolor, normal_pow,
                            G_rgb, G_mask, G_depth, G_normal):
@@ -284,9 +287,32 @@ def rgb_composite_backward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, d
     g = dict(sdf=torch.empty(P, **f32), grad=torch.empty(P, 3, **f32), feat=torch.empty(T, **f32),
              points=torch.empty(P, 3, **f32), z_vals=torch.empty(n_rays, 64, **f32),
              depth_fac=torch.empty(n_rays, **f32), beta=torch.empty(RGB_BWD_BETA_PARTS, **f32))
+    v3_part = torch.empty(RGB_BWD_BETA_PARTS * 196, **f32)     # per-wave partial sums of dV3 [3][64] | db3 [3] | 0
+    if FUSED_RGB_WGRAD and n_images <= 256:
+        # round 5: the gradients of V0, V1, V2 and of the per-image biases are formed inside the kernel by four weight-gradient waves (the scheme
+        # of sc_sdf_backward_fused): no Gy_l / r_l hand-off tensors (1.6 GB per bs32 render) and no sc_wgrad launches
+        parts = int(lib.sc_rgb_composite_backward_fused_parts(c_int(n_rays)))
+        stride = int(lib.sc_rgb_composite_backward_fused_partial_floats(c_int(n_images)))
+        partial = torch.empty(parts * stride, **f32)
+        code = lib.sc_rgb_composite_backward_fused(
+            _lib.ptr(points), _lib.ptr(z_vals), _lib.ptr(depth_fac), _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(feat),
+            _lib.ptr(v_pack), _lib.ptr(dbias), _lib.ptr(beta_param), _lib.ptr(rgb_flat), c_int(n_rays),
+            c_int(rays_per_image), c_int(n_images), c_int(1 if symmetric else 0), ctypes.c_float(beta_min),
+            ctypes.c_float(bgcolor), ctypes.c_float(normal_pow), _lib.ptr(G_rgb), _lib.ptr(G_mask), _lib.ptr(G_depth),
+            _lib.ptr(G_normal), _lib.ptr(g["sdf"]), _lib.ptr(g["grad"]), _lib.ptr(g["feat"]), _lib.ptr(g["points"]),
+            _lib.ptr(g["z_vals"]), _lib.ptr(g["depth_fac"]), _lib.ptr(g["beta"]), _lib.ptr(partial), _lib.ptr(v3_part), _lib.stream())
+        _lib.check(code, "sc_rgb_composite_backward_fused")
+        g_all = _partial_reduce(lib, partial, parts, stride, stride, torch.empty(stride, **f32))
+        g_v = torch.empty(RGB_PACK_FLOATS, **f32)
+        g_v[:RGB_OFF["V3"]] = g_all[:RGB_OFF["V3"]]
+        g["beta"] = _partial_reduce(lib, g["beta"], RGB_BWD_BETA_PARTS, 1, 1, torch.empty(1, **f32))
+        assert RGB_OFF["B3"] == RGB_OFF["V3"] + 192 and RGB_PACK_FLOATS == RGB_OFF["B3"] + 4
+        _partial_reduce(lib, v3_part, RGB_BWD_BETA_PARTS, 196, 196, g_v[RGB_OFF["V3"]:])
+        g["v_pack"] = g_v
+        g["dbias"] = g_all[RGB_OFF["V3"]:].view(n_images, 3, 64)
+        return g
     gy = torch.empty(3 * T, **f32)
     rr = torch.empty(2 * T, **f32)         # r0, r1 (operands of dV1 / dV2); r2 and gy3 only feed the output layer's gradient, formed in the kernel:
-    v3_part = torch.empty(RGB_BWD_BETA_PARTS * 196, **f32)     # per-wave partial sums of dV3 [3][64] | db3 [3] | 0
     code = lib.sc_rgb_composite_backward_v3(
         _lib.ptr(points), _lib.ptr(z_vals), _lib.ptr(depth_fac), _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(feat),
         _lib.ptr(v_pack), _lib.ptr(dbias), _lib.ptr(beta_param), _lib.ptr(rgb_flat), c_int(n_rays),

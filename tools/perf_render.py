@@ -13,10 +13,11 @@ ap.add_argument("--R", type=int, default=512)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--eval", action="store_true")
 ap.add_argument("--yaml", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "options/pix3d/config.yaml"))
+ap.add_argument("--opt", action="append", default=[], help="extra option overrides, e.g. --opt=--hip.fused_rgb_wgrad!")
 ap.add_argument("--full", type=int, default=0, help="full-frame evaluation render of FULL x FULL pixels (BASELINE config[2]: 128)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
-opt = options.set(options.parse_arguments(["--yaml=" + a.yaml, "--name=perf", "--output_root=/tmp/sc_perf"]), verbose=False)
+opt = options.set(options.parse_arguments(["--yaml=" + a.yaml, "--name=perf", "--output_root=/tmp/sc_perf"] + a.opt), verbose=False)
 torch.manual_seed(0)
 sdf, rgb = SDFNetwork(opt), RGBNetwork(opt)
 r = Renderer(opt, sdf, rgb).to(dev)
@@ -56,4 +57,4 @@ for _ in range(a.iters):
     step()
 torch.cuda.synchronize()
 dt = (time.time() - t0) / a.iters
-print("B=%d R=%d  %s: %.2f ms per render call  -> %.1f img/s  (%.2f Mrays/s)" % (B, R, "eval fwd" if a.eval else "train fwd+bwd", dt * 1e3, B / dt, B * R / dt / 1e6))
+print(" ".join(a.opt) + " B=%d R=%d  %s: %.2f ms per render call  -> %.1f img/s  (%.2f Mrays/s)" % (B, R, "eval fwd" if a.eval else "train fwd+bwd", dt * 1e3, B / dt, B * R / dt / 1e6))
