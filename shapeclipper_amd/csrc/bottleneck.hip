@@ -28,34 +28,75 @@ constexpr int TPW = MAXT / WAVES;      // row tiles per wave
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ float f4e(const float4& v, int r) { return r == 0 ? v.x : (r == 1 ? v.y : (r == 2 ? v.z : v.w)); }
 
-// acc[t][r] (lane: channel n = lane & 15, row 16 tile + 4 kg + r) += sum_k A[row][k] * B[k][n], A = a [N][K] row-major,
-// B[k][n] = bT ? b[k * ldb + n0 + n] : b[(n0 + n) * ldb + k].  K % 16 == 0.  The K index a lane group contributes to an MFMA is arbitrary
-// as long as both operands agree: element r of the float4 at k = 16 t + 4 kg is K index 16 t + 4 kg + r.
+// acc[u][r] (lane: channel n = lane & 15, row 16 (wave + 4 u) + 4 kg + r) = sum_k A[row][k] * B[k][n], A = a [N][K] row-major,
+// B[k][n] = BT ? b[k * ldb + n0 + n] : b[(n0 + n) * ldb + k].  K % 64 == 0.
+// The four waves split K: wave w multiplies ALL row tiles by its quarter of K (operands double-buffered in registers: the loads of the
+// next 16 K values are in flight under the MFMAs of the current ones -- these products are latency-bound, 32 workgroups on 256 CUs),
+// the quarters are added in wave order through LDS (fixed order), and wave w leaves with the tiles w and w + 4 it owns in the epilogue.
+// The K index a lane group contributes to an MFMA is arbitrary as long as both operands agree: element r of the float4 at
+// k = 16 t + 4 kg is K index 16 t + 4 kg + r.
 template <bool BT>
 __device__ __forceinline__ void gemm_rows(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, int n0, int K, int N,
-                                          int wave, int lane, f32x4 (&acc)[TPW]) {
-    const int i = lane & 15, kg = lane >> 4;
-    int row[TPW];
+                                          int wave, int lane, float* __restrict__ red, f32x4 (&acc)[TPW]) {
+    const int i = lane & 15, kg = lane >> 4, ntile = (N + 15) >> 4;
+    const int kq = K / WAVES, k0 = wave * kq + 4 * kg;
+    const float* ap[MAXT];
 #pragma unroll
-    for (int u = 0; u < TPW; ++u) row[u] = min(16 * (wave + WAVES * u) + i, N - 1);
-#pragma unroll 4
-    for (int t = 0; t < K / 16; ++t) {
-        const int k = 16 * t + 4 * kg;
-        float4 bv;
+    for (int t = 0; t < MAXT; ++t) ap[t] = a + (size_t)min(16 * t + i, N - 1) * lda + k0;
+    const float* bp = BT ? b + (size_t)k0 * ldb + n0 + i : b + (size_t)(n0 + i) * ldb + k0;
+    auto load_b = [&](int kk) {
+        float4 v;
         if (BT) {
-            bv.x = b[(size_t)(k + 0) * ldb + n0 + i]; bv.y = b[(size_t)(k + 1) * ldb + n0 + i];
-            bv.z = b[(size_t)(k + 2) * ldb + n0 + i]; bv.w = b[(size_t)(k + 3) * ldb + n0 + i];
+            v.x = bp[(size_t)(kk + 0) * ldb]; v.y = bp[(size_t)(kk + 1) * ldb]; v.z = bp[(size_t)(kk + 2) * ldb]; v.w = bp[(size_t)(kk + 3) * ldb];
         } else {
-            bv = *reinterpret_cast<const float4*>(b + (size_t)(n0 + i) * ldb + k);
+            v = *reinterpret_cast<const float4*>(bp + kk);
         }
+        return v;
+    };
+    f32x4 part[MAXT];
 #pragma unroll
-        for (int u = 0; u < TPW; ++u) {
-            if (16 * (wave + WAVES * u) >= N) continue;                // wave-uniform
-            const float4 av = *reinterpret_cast<const float4*>(a + (size_t)row[u] * lda + k);
+    for (int t = 0; t < MAXT; ++t) part[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 av[MAXT], an[MAXT], bv = load_b(0), bn = bv;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[u] = mfma(f4e(av, r), f4e(bv, r), acc[u]);
-        }
+    for (int t = 0; t < MAXT; ++t) {
+        av[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < ntile) av[t] = *reinterpret_cast<const float4*>(ap[t]);
+        an[t] = av[t];
     }
+#pragma unroll 1
+    for (int kk = 0; kk < kq; kk += 16) {
+        if (kk + 16 < kq) {
+            bn = load_b(kk + 16);
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t)
+                if (t < ntile) an[t] = *reinterpret_cast<const float4*>(ap[t] + kk + 16);
+        }
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t)
+            if (t < ntile) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[t] = mfma(f4e(av[t], r), f4e(bv, r), part[t]);
+            }
+        bv = bn;
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) av[t] = an[t];
+    }
+    __syncthreads();                                               // (`red` may still be read by the previous phase)
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t)
+        if (t < ntile) *reinterpret_cast<f32x4*>(red + ((wave * MAXT + t) * 64 + lane) * 4) = part[t];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        const int t = wave + WAVES * u;
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t < ntile) {
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) s += *reinterpret_cast<const f32x4*>(red + ((w * MAXT + t) * 64 + lane) * 4);
+        }
+        acc[u] = s;
+    }
+    __syncthreads();
 }
 
 // per-group sums of v[u][r] over the rows of the workgroup, for this lane's channel: lane groups by shuffle, waves through LDS in index
@@ -102,12 +143,11 @@ struct FwdArgs {
 
 __global__ __launch_bounds__(64 * WAVES) void linear_bn_fwd_kernel(FwdArgs a) {
     __shared__ float red[WAVES * MAXG * 16];
+    __shared__ __attribute__((aligned(16))) float gred[WAVES * MAXT * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, kg = lane >> 4;
     const int c0 = blockIdx.x * 16, c = c0 + i, N = a.N, G = a.G, Ng = N / G;
     f32x4 acc[TPW];
-#pragma unroll
-    for (int u = 0; u < TPW; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    gemm_rows<false>(a.x, a.Cin, a.w, a.Cin, c0, a.Cin, N, wave, lane, acc);
+    gemm_rows<false>(a.x, a.Cin, a.w, a.Cin, c0, a.Cin, N, wave, lane, gred, acc);
     float v[TPW][4];
     int grp[TPW][4], rowi[TPW][4];
 #pragma unroll
@@ -193,12 +233,13 @@ struct BwdArgs {
 __global__ __launch_bounds__(64 * WAVES) void linear_bn_bwd_kernel(BwdArgs a) {
     __shared__ float red[WAVES * MAXG * 16];
     __shared__ float gys[MAXT * 16 * 16];                          // gy of this workgroup's 16 channels: [row][channel]
+    __shared__ __attribute__((aligned(16))) float gred[WAVES * MAXT * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, kg = lane >> 4;
     const int c0 = blockIdx.x * 16, c = c0 + i, N = a.N, G = a.G, Ng = N / G;
     f32x4 acc[TPW];
 #pragma unroll
     for (int u = 0; u < TPW; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!a.g_out) gemm_rows<true>(a.gy_next, a.Cnext, a.w_next, a.Cout, c0, a.Cnext, N, wave, lane, acc);
+    if (!a.g_out) gemm_rows<true>(a.gy_next, a.Cnext, a.w_next, a.Cout, c0, a.Cnext, N, wave, lane, gred, acc);
     float g[TPW][4], xh[TPW][4], gx[TPW][4];
     int grp[TPW][4], rowi[TPW][4];
     float mean[MAXG], rstd[MAXG];
@@ -259,20 +300,39 @@ __global__ __launch_bounds__(64 * WAVES) void linear_bn_bwd_kernel(BwdArgs a) {
     __syncthreads();
     // dW[c0 + m][:] = sum_rows gy[row][m] x[row][:]: wave w takes the 64-column groups w, w + 4, ...; a lane's float4 of x (columns
     // 4 n .. 4 n + 3 of the group) feeds four MFMAs whose accumulators are those four columns
-    const int ntile = (N + 15) / 16;
+    const int ntile = (N + 15) / 16, nstep = 4 * ntile;            // K steps of the row sum: step s = (tile s >> 2, r = s & 3) <-> rows 16 t + 4 kg + r
     for (int cg = wave; cg < a.Cin / 64; cg += WAVES) {
         f32x4 d[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) d[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int t = 0; t < ntile; ++t)
+        const float* xc = a.x + 64 * cg + 4 * i;
+        auto load_x = [&](int st) {
+            const int row = 16 * (st >> 2) + 4 * kg + (st & 3);
+            return *reinterpret_cast<const float4*>(xc + (size_t)min(row, N - 1) * a.Cin);
+        };
+        constexpr int PF = 8;                                      // loads in flight per lane (the products are latency-bound)
+        float4 xb[PF];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * t + 4 * kg + r;
-                const float av = gys[row * 16 + i];
-                const float4 xv = *reinterpret_cast<const float4*>(a.x + (size_t)min(row, N - 1) * a.Cin + 64 * cg + 4 * i);
+        for (int q = 0; q < PF; ++q) xb[q] = load_x(min(q, nstep - 1));
+#pragma unroll 1
+        for (int s0 = 0; s0 < nstep; s0 += PF) {
+            float4 xc_[PF];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) d[j] = mfma(av, f4e(xv, j), d[j]);
+            for (int q = 0; q < PF; ++q) xc_[q] = xb[q];
+            if (s0 + PF < nstep) {
+#pragma unroll
+                for (int q = 0; q < PF; ++q) xb[q] = load_x(min(s0 + PF + q, nstep - 1));
             }
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                const int st = s0 + q;
+                if (st < nstep) {
+                    const float av = gys[(16 * (st >> 2) + 4 * kg + (st & 3)) * 16 + i];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) d[j] = mfma(av, f4e(xc_[q], j), d[j]);
+                }
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             *reinterpret_cast<float4*>(a.dw + (size_t)(c0 + 4 * kg + r) * a.Cin + 64 * cg + 4 * i) = make_float4(d[0][r], d[1][r], d[2][r], d[3][r]);
@@ -284,11 +344,10 @@ __global__ __launch_bounds__(64 * WAVES) void linear_bwd_data_kernel(const float
                                                                       const float* __restrict__ g_add, float* __restrict__ dx, int N, int Cin,
                                                                       int Cout) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, kg = lane >> 4;
+    __shared__ __attribute__((aligned(16))) float gred[WAVES * MAXT * 256];
     const int c0 = blockIdx.x * 16;
     f32x4 acc[TPW];
-#pragma unroll
-    for (int u = 0; u < TPW; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    gemm_rows<true>(gy, Cout, w, Cin, c0, Cout, N, wave, lane, acc);
+    gemm_rows<true>(gy, Cout, w, Cin, c0, Cout, N, wave, lane, gred, acc);
 #pragma unroll
     for (int u = 0; u < TPW; ++u)
 #pragma unroll

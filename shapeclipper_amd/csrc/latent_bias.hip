@@ -24,7 +24,9 @@ __global__ __launch_bounds__(64) void latent_bias_fwd_kernel(const float* __rest
     out[((size_t)b * NL + l) * 64 + ch] = bias[l * 64 + ch] + v;
 }
 
-// blocks [0, B): g_z[b][:];  blocks [B, B + NL): layer l = block - B: g_bias[l][:] and (l < L) g_lat[l * 64 .. + 63][:]
+// blocks [0, B): g_z[b][:];  blocks [B, B + 4 NL): layer l = (block - B) / 4, channels 16 q .. 16 q + 15 (q = (block - B) % 4):
+// g_bias[l][those] and (l < L) g_lat[l * 64 + those][:].  Loops over the batch / the channels are unrolled with independent loads in flight
+// (these kernels are latency-bound: a few KB of work on one workgroup each); the summation ORDER stays the index order.
 __global__ __launch_bounds__(256) void latent_bias_bwd_kernel(const float* __restrict__ g, const float* __restrict__ z, const float* __restrict__ lat,
                                                                const float* __restrict__ post, float* __restrict__ g_z, float* __restrict__ g_lat,
                                                                float* __restrict__ g_bias, int B, int Z, int L, int NL) {
@@ -32,29 +34,37 @@ __global__ __launch_bounds__(256) void latent_bias_bwd_kernel(const float* __res
     if ((int)blockIdx.x < B) {
         const int b = blockIdx.x;
         if (!g_z) return;
+        __shared__ float gs[8 * 64];                               // this image's gradient rows of the conditioned layers (L <= 8)
+        for (int e = t; e < L * 64; e += 256) gs[e] = g[(size_t)b * NL * 64 + e];
+        __syncthreads();
         for (int k = t; k < Z; k += 256) {
             float s = 0.f;
             for (int l = 0; l < L; ++l) {
                 const float p = post ? post[l] : 1.f;
+                const float* lp = lat + (size_t)l * 64 * Z + k;
                 float sl = 0.f;
-                for (int ch = 0; ch < 64; ++ch) sl = __builtin_fmaf(g[((size_t)b * NL + l) * 64 + ch], lat[(size_t)(l * 64 + ch) * Z + k], sl);
+#pragma unroll 16
+                for (int ch = 0; ch < 64; ++ch) sl = __builtin_fmaf(gs[l * 64 + ch], lp[(size_t)ch * Z], sl);
                 s += p * sl;
             }
             g_z[(size_t)b * Z + k] = s;
         }
         return;
     }
-    const int l = blockIdx.x - B;
-    if (t < 64) {
+    const int l = (blockIdx.x - B) >> 2, q = (blockIdx.x - B) & 3;
+    if (t < 16) {
+        const int ch = 16 * q + t;
         float s = 0.f;
-        for (int b = 0; b < B; ++b) s += g[((size_t)b * NL + l) * 64 + t];
-        g_bias[l * 64 + t] = s;
+#pragma unroll 8
+        for (int b = 0; b < B; ++b) s += g[((size_t)b * NL + l) * 64 + ch];
+        g_bias[l * 64 + ch] = s;
     }
     if (l < L) {
         const float p = post ? post[l] : 1.f;
-        for (int e = t; e < 64 * Z; e += 256) {
-            const int ch = e / Z, k = e - ch * Z;
+        for (int e = t; e < 16 * Z; e += 256) {
+            const int ch = 16 * q + e / Z, k = e % Z;
             float s = 0.f;
+#pragma unroll 8
             for (int b = 0; b < B; ++b) s = __builtin_fmaf(g[((size_t)b * NL + l) * 64 + ch], z[(size_t)b * Z + k], s);
             g_lat[(size_t)(l * 64 + ch) * Z + k] = p * s;
         }
@@ -73,7 +83,7 @@ extern "C" int sc_latent_bias_forward(const float* z, const float* lat, const fl
 
 extern "C" int sc_latent_bias_backward(const float* g, const float* z, const float* lat, const float* post, float* g_z, float* g_lat, float* g_bias,
                                        int B, int Z, int L, int NL, void* stream) {
-    if (B <= 0 || Z <= 0 || L < 0 || NL < L || NL <= 0) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(sc::latent_bias_bwd_kernel, dim3(B + NL), dim3(256), 0, (hipStream_t)stream, g, z, lat, post, g_z, g_lat, g_bias, B, Z, L, NL);
+    if (B <= 0 || Z <= 0 || L < 0 || L > 8 || NL < L || NL <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(sc::latent_bias_bwd_kernel, dim3(B + 4 * NL), dim3(256), 0, (hipStream_t)stream, g, z, lat, post, g_z, g_lat, g_bias, B, Z, L, NL);
     return (int)hipGetLastError();
 }
