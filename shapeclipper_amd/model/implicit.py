@@ -140,11 +140,17 @@ class SDFNetwork(nn.Module):
         if self.eager:
             raise NotImplementedError("no packed weight image for this architecture (%d x %d): it runs on model/eager_path.py" % (self.n_hidden, self.n_channel))
         cache = getattr(self, "_pack_cache", None)
+        # the per-image biases too are shared inside a forward pass: the main and the neighbour-view render condition the SDF on the SAME
+        # latent tensor, their two eikonal calls on the same detached one (round 5: 4 -> 2 bias launches each way per step, one gradient each)
+        zkey = (proj_latent.data_ptr(), proj_latent._version, tuple(proj_latent.shape), bool(proj_latent.requires_grad))
         if cache is not None and cache[0] == torch.is_grad_enabled():
-            return cache[1], packing.sdf_cbias(None, proj_latent, gathered=cache[2], arch=self._arch(proj_latent.shape[1]))
+            hit = cache[3].get(zkey)
+            if hit is None:
+                hit = cache[3][zkey] = (packing.sdf_cbias(None, proj_latent, gathered=cache[2], arch=self._arch(proj_latent.shape[1])), proj_latent)
+            return cache[1], hit[0]
         w_pack, cbias, gathered = packing.pack_sdf(self.weight_dict(), proj_latent, return_gathered=True)
         if getattr(self, "_pack_cache_on", False):
-            self._pack_cache = (torch.is_grad_enabled(), w_pack, gathered)
+            self._pack_cache = (torch.is_grad_enabled(), w_pack, gathered, {zkey: (cbias, proj_latent)})     # (the latent is kept alive: its address is the key)
         return w_pack, cbias
 
     def _arch(self, Z):
