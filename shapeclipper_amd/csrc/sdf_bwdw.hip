@@ -57,21 +57,12 @@ struct SdfBwdwArgs {
 #define BW_STAMP(ID)
 #endif
 
-#ifndef SC_BWDW_GXW
-#define SC_BWDW_GXW 1
-#endif
-// Round 5: d L / d point is formed by the WEIGHT-GRADIENT waves.  All of it is six terms  gx_c += sum_ch V[ch] (W_le DV_c)[ch]  with
-// V = q_l (steps 0-2) or Ga_l (steps 8-10) -- exactly the A operands the chain waves hand over anyway -- and DV a positional-encoding
-// derivative of the point: 48 MFMAs + ~150 vector instructions per term and tile that sat on the chain waves' critical path (288 of their
-// 1,008 MFMAs) while the weight-gradient waves waited half of the time (profiles/r05_bwdw_phase_profile_pecache.txt: 53 k of 107 k cycles).
-constexpr bool BW_GXW = SC_BWDW_GXW != 0;
 constexpr int BW_CHAIN = 4;                          // chain waves (= wgrad waves) per workgroup
 constexpr int BW_WLDS = (SdfLds::TOTAL + 3) & ~3;    // weight image, floats
 constexpr int BW_XCH = BW_WLDS;                      // exchange slots: [chain wave][A|B][1024]
 constexpr int BW_PTS = BW_XCH + BW_CHAIN * 2 * 1024; // point stash: [chain wave][16 points][8] = x0 x1 x2 gam0 gam1 gam2 valid -
 constexpr int BW_RED = BW_PTS + BW_CHAIN * 16 * 8;   // [0..63] sum r0 (dW5 row 0), [64] sum Gs (db5[0])
-constexpr int BW_GXS = BW_RED + 68;                  // BW_GXW: [wgrad wave][chain tile][coordinate][point] partial point gradients of one iteration
-constexpr int BW_LDS_FLOATS = BW_GXS + (BW_GXW ? BW_CHAIN * BW_CHAIN * 3 * 16 : 0);
+constexpr int BW_LDS_FLOATS = BW_RED + 68;
 static_assert(BW_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 
 __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
@@ -130,6 +121,10 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
 
 // the write phase of one step: B1 (the wgrad waves have finished reading the previous pair), write, B2 (visible).
 // VM is the validity mask of the lane's point: a compile-time 1 for full tiles (all but the last tile of a launch)
+// (Round 5 experiment, commit c7425e8: the six point-gradient terms -- 288 of the chain waves' 1,008 MFMAs per tile, all of d L / d point --
+// moved to the weight-gradient waves, which wait half of the time and already receive the terms' V operands (q_l, Ga_l) in slot A.  Correct,
+// 17 % SLOWER: 3.03 vs 2.59 ms, profiles/r05_bwdw_gxw_experiment.txt -- with the PE derivatives of four tiles and the extra accumulators the
+// weight-gradient role spills 89 registers inside its loops; the role is register-bound, not time-bound.)
 // (Round 5 experiment, commit 2093f09: the two barriers replaced by per-slot LDS counters -- each chain wave hands over at its own pace, the
 // wgrad waves walk the four slots as a queue.  Correct, 4 % SLOWER: 2.69 vs 2.59 ms; profiles/r05_bwdw_phase_profile_flags_experiment.txt:
 // the wgrad waves then wait for each slot's flag and fragments in front of its MFMAs instead of reading ahead across the four tiles.)
@@ -202,7 +197,7 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
 //   gx_c += sum_ch V[ch] * (W_le * DV[4c..4c+3])[ch]     V = q_l, DV = Gg_c d2E/dx_c^2 (steps 0-2);  V = Ga_l, DV = dE/dx_c (layers 2-0)
 // They sit where this wave would otherwise wait for the wgrad waves (which carry the PE outer products of the same steps).
 #define BW_PE_DOT2(WE, LD, V)                                                               \
-            if (!BW_GXW && a.g_points) {                                                                \
+            if (a.g_points) {                                                                \
                 _Pragma("unroll") for (int c = 0; c < 3; ++c) {                               \
                     f32x4 tacc[NT];                                                          \
                     acc_zero(tacc);                                                          \
@@ -217,7 +212,7 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
                 }                                                                            \
             }
 #define BW_PE_DOT(WE, LD, V, DV)                                                            \
-            if (!BW_GXW && a.g_points) {                                                                \
+            if (a.g_points) {                                                                \
                 _Pragma("unroll") for (int c = 0; c < 3; ++c) {                               \
                     f32x4 tacc[NT];                                                          \
                     acc_zero(tacc);                                                          \
@@ -382,7 +377,7 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
                 BW_V_ELEM(av, pv, gaB)                                                              // Ga1, h1
                 BW_EXCHANGE(8, xch_write(slotA, wr, gaA, VM); xch_write(slotB, wr, hv, VM);)       // step 8: (Ga2, h1)
                 float e[PE_STEPS], d1[PE_STEPS], d2[PE_STEPS];
-                if (!BW_GXW) pe_slots<true, false, true>(x0, x1, x2, g, symmetric, e, d1, d2);
+                pe_slots<true, false, true>(x0, x1, x2, g, symmetric, e, d1, d2);
                 BW_PE_DOT(w2e, SdfLds::LD1, gaA, d1)                                                // Ga2 (gaA is overwritten below)
                 acc_zero(acc);
                 mm_act_t_pipe<SdfLds::LD1, NT>(w1t, gaB, acc);
@@ -392,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
                 BW_EXCHANGE(9, xch_write(slotA, wr, gaB, VM); xch_write(slotB, wr, hv, VM);)       // step 9: (Ga1, h0)
                 BW_PE_DOT(w1e, SdfLds::LD1, gaB, d1)                                                // Ga1
                 BW_PE_DOT(w0, SdfLds::LD0, gaA, d1)                                                 // Ga0
-                if (!BW_GXW && a.g_points) {
+                if (a.g_points) {
                     const float o0 = group_sum(gx[0]), o1 = group_sum(gx[1]), o2 = group_sum(gx[2]);
                     if (valid && g == 0) {
                         a.g_points[(size_t)pt * 3 + 0] = o0;
@@ -431,26 +426,6 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
         // launch on one box, profiles/r05_bwdw_variants_ab.txt -- these ~50 vector instructions per tile and step were issue time of the
         // SIMD the chain wave shares, and they sat in exactly the steps where the chain waves waited for this role).
         float4 pec[BW_CHAIN][3];
-        // BW_GXW: this lane's share of d L / d point of point i of the four chain tiles (channels 16 w + 4 kg .. + 3), and the lane's views of
-        // the positional-encoding columns of W0 / W1 / W2 (A operand of W_le DV: row 16 w + i, lane group kg's slot of a K-step)
-        float gxp[BW_CHAIN][3];
-#pragma unroll
-        for (int c = 0; c < BW_CHAIN; ++c) gxp[c][0] = gxp[c][1] = gxp[c][2] = 0.f;
-        const float* we0 = lds + SdfLds::W0 + (16 * w + i) * SdfLds::LD0 + kg;
-        const float* we1 = lds + SdfLds::W1 + 64 + (16 * w + i) * SdfLds::LD1 + kg;
-        const float* we2 = lds + SdfLds::W2 + 64 + (16 * w + i) * SdfLds::LD1 + kg;
-        float* gxs = lds + BW_GXS;
-        int gx_base = -1;                                    // first tile of the iteration whose partial point gradients sit in gxs
-        // cross-wave sum (wave order) of an iteration's partials and the store: wave w takes chain tile w, lane = (coordinate, point)
-        auto gx_store = [&]() {
-            if (gx_base >= 0 && lane < 48) {
-                const int c3 = lane >> 4, pt = (gx_base + w) * TP + (lane & 15);
-                float v = 0.f;
-#pragma unroll
-                for (int ww = 0; ww < BW_CHAIN; ++ww) v += gxs[((ww * BW_CHAIN + w) * 3 + c3) * 16 + (lane & 15)];
-                if (gx_base + w < t_end && pt < a.n_points) a.g_points[(size_t)pt * 3 + c3] = v;
-            }
-        };
         int cur_img = -1;                                    // >= 0: rs[] belongs to this image; -2: mixed iteration (direct atomics)
         auto flush = [&]() {
             if (cur_img >= 0) {
@@ -473,7 +448,7 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
 #define BW_STEP_BEGIN lds_barrier(); lds_barrier();
 #endif
 // one step over the four chain tiles.  HP: 64-wide B operand in slot B; PEM: 0 none, 1 E, 2 eps; RS: bias layer (-1 none, 5 = Gf)
-#define BW_CONSUME(ACCH, ACCE, HP, PEM, RS, GXM, WEP)                                                 \
+#define BW_CONSUME(ACCH, ACCE, HP, PEM, RS)                                                 \
         _Pragma("unroll") for (int c = 0; c < BW_CHAIN; ++c) {                               \
             const float* sA = lds + BW_XCH + (c * 2 + 0) * 1024;                             \
             const float* sB = lds + BW_XCH + (c * 2 + 1) * 1024;                             \
@@ -486,41 +461,6 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
             if (PEM) {       /* PEM > 0: evaluate the operand (1 = E, 2 = eps); PEM < 0: the one of the previous step again */ \
                 if (PEM > 0) pe_frags<((PEM) > 0 ? (PEM) : 1)>(lds + BW_PTS + c * 16 * 8, i, kg, symmetric, pec[c]); \
                 outer16<3>(af, pec[c], ACCE);                                                \
-            }                                                                                \
-            if (BW_GXW && GXM && a.g_points) {     /* point-gradient term of this step: V = slot A, DV = dE/dx (GXM 1) or Gg d2E/dx2 (GXM 2) */ \
-                const float* st_ = lds + BW_PTS + c * 16 * 8 + i * 8;                        \
-                const float4 xa = *reinterpret_cast<const float4*>(st_);                     \
-                const float4 xb = *reinterpret_cast<const float4*>(st_ + 4);                 \
-                float V_[4];                                                                 \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r)                                 \
-                    V_[r] = sA[((((i >> 2) * 64 + ((16 * w + 4 * kg + r) ^ (i >> 2))) << 2)) + (i & 3)]; \
-                const float gam_[3] = {xa.w, xb.x, xb.y};                                    \
-                const float xs_[3] = {symmetric ? fabsf(xa.x) : xa.x, xa.y, xa.z};           \
-                const float fb_ = kg == 0 ? 1.f : (kg == 1 ? 4.f : 16.f);                    \
-                const float sg_ = symmetric ? (xa.x > 0.f ? 1.f : (xa.x < 0.f ? -1.f : 0.f)) : 1.f; \
-                _Pragma("unroll") for (int c3 = 0; c3 < 3; ++c3) {                            \
-                    /* the four slots of coordinate c3 this lane group owns (pe_slots order): sin, cos of f0 = 4^kg, of f1 = 2 f0; group 3: x, 0, 0, 0 */ \
-                    const float sgc_ = c3 == 0 ? sg_ : 1.f;                                  \
-                    float s0_, c0_, s1_, c1_;                                                \
-                    __sincosf(xs_[c3] * fb_, &s0_, &c0_);                                    \
-                    __sincosf(xs_[c3] * (2.f * fb_), &s1_, &c1_);                            \
-                    float dv_[4];      /* d1: f cos sg, -f sin sg;  Gg d2 = gam * (-f^2 sin sg^2, -f^2 cos sg^2) */ \
-                    if (kg == 3) {                                                           \
-                        dv_[0] = GXM == 1 ? sgc_ : 0.f; dv_[1] = dv_[2] = dv_[3] = 0.f;      \
-                    } else if (GXM == 1) {                                                   \
-                        dv_[0] = fb_ * c0_ * sgc_; dv_[1] = -fb_ * s0_ * sgc_;               \
-                        dv_[2] = 2.f * fb_ * c1_ * sgc_; dv_[3] = -2.f * fb_ * s1_ * sgc_;   \
-                    } else {                                                                 \
-                        const float q_ = gam_[c3] * sgc_ * sgc_;                             \
-                        dv_[0] = -fb_ * fb_ * s0_ * q_; dv_[1] = -fb_ * fb_ * c0_ * q_;      \
-                        dv_[2] = -4.f * fb_ * fb_ * s1_ * q_; dv_[3] = -4.f * fb_ * fb_ * c1_ * q_; \
-                    }                                                                        \
-                    f32x4 t_ = {0.f, 0.f, 0.f, 0.f};                                         \
-                    _Pragma("unroll") for (int j = 0; j < 4; ++j) t_ = mfma16((WEP)[4 * (4 * c3 + j)], dv_[j], t_); \
-                    float ds_ = 0.f;                                                         \
-                    _Pragma("unroll") for (int r = 0; r < 4; ++r) ds_ = __builtin_fmaf(V_[r], t_[r], ds_); \
-                    gxp[c][c3] += ds_;                                                       \
-                }                                                                            \
             }                                                                                \
             if (RS >= 0) {                                                                   \
                 const float v = (af.x + af.y) + (af.z + af.w);                               \
@@ -555,35 +495,22 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
                 cur_img = img0 == img3 ? img0 : -2;
             }
             BW_STEP_BEGIN
-            if (BW_GXW && a.g_points) { gx_store(); gx_base = base; }       // (the partials of the previous iteration: visible since the barriers above)
             gss += kg == 0 ? ptsw[i * 8 + 7] : 0.f;                 // db5[0] = sum of Gs (point i of chain tile w; stash written in step 0)
-            BW_CONSUME(d3, d0e, false, 2, -1, 2, we0)           // 0: q0 x eps
-            BW_STEP_BEGIN BW_CONSUME(d1h, d1e, true, -2, -1, 2, we1)      // 1: q1 x (Gp0 | eps)     (PEM < 0: the operand of the previous step again)
-            BW_STEP_BEGIN BW_CONSUME(d2h, d2e, true, -2, -1, 2, we2)      // 2: q2 x (Gp1 | eps)
-            BW_STEP_BEGIN BW_CONSUME(d3, d0e, true, 0, -1, 0, we0)        // 3: q3 x Gp2
-            BW_STEP_BEGIN BW_CONSUME(d4, d0e, true, 0, -1, 0, we0)        // 4: q4 x Gp3
-            BW_STEP_BEGIN BW_CONSUME(d5, d0e, true, 0, 5, 0, we0)         // 5: Gf x h4
-            BW_STEP_BEGIN BW_CONSUME(d4, d0e, true, 0, 4, 0, we0)         // 6: Ga4 x h3
-            BW_STEP_BEGIN BW_CONSUME(d3, d0e, true, 0, 3, 0, we0)         // 7: Ga3 x h2
-            BW_STEP_BEGIN BW_CONSUME(d2h, d2e, true, 1, 2, 1, we2)        // 8: Ga2 x (h1 | E)
-            BW_STEP_BEGIN BW_CONSUME(d1h, d1e, true, -1, 1, 1, we1)       // 9: Ga1 x (h0 | E)
-            BW_STEP_BEGIN BW_CONSUME(d3, d0e, false, -1, 0, 1, we0)       // 10: Ga0 x E
+            BW_CONSUME(d3, d0e, false, 2, -1)                   // 0: q0 x eps
+            BW_STEP_BEGIN BW_CONSUME(d1h, d1e, true, -2, -1)       // 1: q1 x (Gp0 | eps)     (PEM < 0: the operand of the previous step again)
+            BW_STEP_BEGIN BW_CONSUME(d2h, d2e, true, -2, -1)       // 2: q2 x (Gp1 | eps)
+            BW_STEP_BEGIN BW_CONSUME(d3, d0e, true, 0, -1)         // 3: q3 x Gp2
+            BW_STEP_BEGIN BW_CONSUME(d4, d0e, true, 0, -1)         // 4: q4 x Gp3
+            BW_STEP_BEGIN BW_CONSUME(d5, d0e, true, 0, 5)          // 5: Gf x h4
+            BW_STEP_BEGIN BW_CONSUME(d4, d0e, true, 0, 4)          // 6: Ga4 x h3
+            BW_STEP_BEGIN BW_CONSUME(d3, d0e, true, 0, 3)          // 7: Ga3 x h2
+            BW_STEP_BEGIN BW_CONSUME(d2h, d2e, true, 1, 2)         // 8: Ga2 x (h1 | E)
+            BW_STEP_BEGIN BW_CONSUME(d1h, d1e, true, -1, 1)        // 9: Ga1 x (h0 | E)
+            BW_STEP_BEGIN BW_CONSUME(d3, d0e, false, -1, 0)        // 10: Ga0 x E
 #pragma unroll
             for (int c = 0; c < BW_CHAIN; ++c) {                    //     slot B of step 10 carries r0: its row sums are dW5 row 0
                 const float4 rf = xch_frag(lds + BW_XCH + (c * 2 + 1) * 1024, rd, w);
                 rs0 += (rf.x + rf.y) + (rf.z + rf.w);
-            }
-            if (BW_GXW && a.g_points) {       // this iteration's partial point gradients: lane groups summed, one row per (tile, coordinate)
-#pragma unroll
-                for (int c = 0; c < BW_CHAIN; ++c)
-#pragma unroll
-                    for (int c3 = 0; c3 < 3; ++c3) {
-                        float v = gxp[c][c3];
-                        v += __shfl_xor(v, 16);
-                        v += __shfl_xor(v, 32);
-                        if (kg == 0) gxs[((w * BW_CHAIN + c) * 3 + c3) * 16 + i] = v;
-                        gxp[c][c3] = 0.f;
-                    }
             }
             BW_STAMP(prof_k)
         }
@@ -595,7 +522,6 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
             if (lane == 0) lds[BW_RED + 64 + w] = gs;
         }
         __syncthreads();
-        if (BW_GXW && a.g_points) gx_store();                   // the last iteration's point gradients
         // ---- this workgroup's partial image: rows 16w + 4kg + r, columns 16n + i of every matrix ----
         float* out = a.partial + (size_t)blockIdx.x * a.partial_stride;
         {
