@@ -378,7 +378,7 @@ def main():
         mean_big = sum(big) / len(big)
         achieved = FLOPS_PER_POINT[dom] * n_pts_main / (mean_big * 1e-3) / 1e12
         traffic, traffic_source = None, None
-        for prof in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        for prof in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             try:   # HBM-side bytes per launch measured with rocprofv3 --pmc on this workload (profiles/, see its _comment)
                 with open(os.path.join(ROOT, "profiles", prof)) as f:
                     traffic = json.load(f)["kernels"][dom]["traffic_bytes"] if a.batch == 32 else None
