@@ -473,6 +473,11 @@ long long sc_conv3x3_workspace_floats_split(int hw);
 int sc_conv3x3_tile_channels_split(int hw);
 int sc_conv3x3_forward_split(const float* x, const float* w_pack, float* out, float* workspace, int batch, int cin, int cout, int hw,
                              void* stream);
+/* out = conv(x, w) + addend, the sum formed in the store epilogue (addend: a tensor of the output's shape; split != 0: w_pack is a split image).
+ * Used for d L / d x of a residual block: backward-data of conv1 + the gradient of the skip branch (model/graph.py's torchvision BasicBlock:
+ * autograd's accumulation of the two uses of the block input).                                                                      */
+int sc_conv3x3_forward_add(const float* x, const float* w_pack, const float* addend, float* out, float* workspace, int batch, int cin,
+                           int cout, int hw, int split, void* stream);
 
 /* 3x3 / stride 2 / pad 1 (BasicBlock.conv1 of layer2-4; torchvision layer{2,3,4}.0.conv1 behind model/graph.py:50-54 and
  * model/view_estimator.py:40-42), same kernel family: hw = side of the INPUT map (56, 28 or 14), out [batch][cout][hw/2][hw/2].

@@ -10,20 +10,6 @@
 
 #include "shapeclipper_hip.h"
 
-namespace sc {
-// dx += dres: the sum autograd formed for the two uses of the block input (convolution operand and residual branch)
-__global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, long long n4, long long n) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n4) {
-        float4 u = reinterpret_cast<float4*>(a)[i];
-        const float4 v = reinterpret_cast<const float4*>(b)[i];
-        u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w;
-        reinterpret_cast<float4*>(a)[i] = u;
-    }
-    if (i == 0)
-        for (long long k = n4 * 4; k < n; ++k) a[k] += b[k];
-}
-}  // namespace sc
 
 extern "C" int sc_basic_block_forward(const sc_block_args* a, void* stream) {
     if (!a || a->batch <= 0 || a->channels <= 0) return (int)hipErrorInvalidValue;
@@ -57,13 +43,8 @@ extern "C" int sc_basic_block_backward(const sc_block_args* a, void* stream) {
     rc = sc_bn_act_backward(a->da1, a->y1, nullptr, a->g1, a->b1, a->st1, a->st1 + (size_t)G * C, a->bn_ws, a->dy1, nullptr, a->dgb1, a->dgb1 + C, B,
                             C, HW, 1, a->training, G, stream);
     if (rc) return rc;
-    if (a->need_dx) {
-        rc = conv(a->dy1, a->pb1, a->dx, a->conv_ws, B, C, C, hw, stream);
-        if (rc) return rc;
-        const long long n = (long long)B * C * HW, n4 = n / 4;
-        hipLaunchKernelGGL(sc::add_inplace_kernel, dim3((unsigned)((n4 + 255) / 256 > 0 ? (n4 + 255) / 256 : 1)), dim3(256), 0, (hipStream_t)stream,
-                           a->dx, a->dres, n4, n);
-        rc = (int)hipGetLastError();
+    if (a->need_dx) {       // dx = conv1^T(dy1) + dres: the residual-branch gradient joins in the convolution's store epilogue (round 5)
+        rc = sc_conv3x3_forward_add(a->dy1, a->pb1, a->dres, a->dx, a->conv_ws, B, C, C, hw, a->split, stream);
         if (rc) return rc;
     }
     if (a->gw1) rc = wgrad(a->dy1, a->x, a->gw1, a->wgrad_ws, B, C, C, hw, stream);

@@ -183,7 +183,7 @@ __device__ __forceinline__ float* conv_out_pixel(float* __restrict__ out, int p,
 
 template <class C>
 __device__ __forceinline__ void conv_store_tile(float* __restrict__ out, const f32x16 (&acc)[C::WM][C::WN], int tile, int nct, int npix,
-                                                int cout, int wm, int wn, int lane) {
+                                                int cout, int wm, int wn, int lane, const float* __restrict__ addend) {
     int phase, pt, ct;
     conv_tile_decode<C>(tile, nct, phase, pt, ct);
 #pragma unroll
@@ -197,7 +197,9 @@ __device__ __forceinline__ void conv_store_tile(float* __restrict__ out, const f
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = ct * C::CT + (wm * C::WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (co < cout) ob[(size_t)co * cs] = acc[i][j][r];
+                // addend (round 5): a tensor of the output's shape added in the epilogue -- the residual-branch gradient joining the
+                // backward-data result of a BasicBlock's conv1 (was a separate read-read-write launch per block and step)
+                if (co < cout) ob[(size_t)co * cs] = addend ? acc[i][j][r] + addend[(ob - out) + (size_t)co * cs] : acc[i][j][r];
             }
     }
 }
@@ -248,7 +250,7 @@ __device__ __forceinline__ void conv_bd2_step(const float* Ws, const float* Xs, 
 template <class C>
 __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const float* __restrict__ x, const float* __restrict__ wpack,
                                                              float* __restrict__ out, float* __restrict__ partial, int batch, int cin,
-                                                             int cout, const int* __restrict__ spans) {
+                                                             int cout, const int* __restrict__ spans, const float* __restrict__ addend) {
     constexpr int W = C::W, Wp = C::Wp, HW = C::HW, Sp = C::Sp, CT = C::CT, PT = C::PT, CB = C::CB, NT = C::NT;
     constexpr int WM = C::WM, WN = C::WN, LX = C::LX, NXE = C::NXE;
     extern __shared__ float4 conv_smem[];
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const flo
 
         CV_STAMP(sid + 2)
         if (kb0 == 0 && kb1 == nk) {
-            conv_store_tile<C>(out, acc, tile, nct, npix, cout, wm, wn, lane);
+            conv_store_tile<C>(out, acc, tile, nct, npix, cout, wm, wn, lane, addend);
         } else {                                            // partial tile, in register order: [wave][i][j][r / 4][lane][4], 16-byte stores
             float4* dst = reinterpret_cast<float4*>(partial + ((size_t)g * 2 + (item - sp.rounds)) * C::TILE);
 #pragma unroll
@@ -527,7 +529,8 @@ __global__ __launch_bounds__(C::NT, C::WGS_PER_CU) void conv3x3_kernel(const flo
 // workgroups whose spans cover it, in K order, and store the result.
 template <class C>
 __global__ __launch_bounds__(C::NT) void conv3x3_fixup_kernel(const float* __restrict__ partial, float* __restrict__ out, int batch,
-                                                              int cin, int cout, int G, const int* __restrict__ spans) {
+                                                              int cin, int cout, int G, const int* __restrict__ spans,
+                                                              const float* __restrict__ addend) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / C::WGN, wn = wave % C::WGN;
     const int npix = batch * C::HWO, nct = (cout + C::CT - 1) / C::CT, tiles = ((npix + C::PT - 1) / C::PT) * nct * (C::BD2 ? 4 : 1);
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(C::NT) void conv3x3_fixup_kernel(const float* __res
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = ct * C::CT + (wm * C::WM + i) * 32 + r + 2 * r0 + 4 * (lane >> 5);      // row of acc[r0 + r]: r + 8 (r0 / 4)
-                if (co < cout) ob[(size_t)co * cs] = acc[i][j][r];
+                if (co < cout) ob[(size_t)co * cs] = addend ? acc[i][j][r] + addend[(ob - out) + (size_t)co * cs] : acc[i][j][r];
             }
     }
 #ifdef SC_CONV_PROFILE
@@ -852,7 +855,8 @@ static const int* conv_spans(int tail_tiles, int nk, int G, int ov2, hipStream_t
 }
 
 template <class C>
-static int launch_conv(const float* x, const float* wpack, float* out, float* workspace, int batch, int cin, int cout, hipStream_t st) {
+static int launch_conv(const float* x, const float* wpack, float* out, float* workspace, int batch, int cin, int cout, hipStream_t st,
+                       const float* addend = nullptr) {
     if (cin % C::CB || batch <= 0) return (int)hipErrorInvalidValue;
     const int tiles = ((batch * C::HWO + C::PT - 1) / C::PT) * ((cout + C::CT - 1) / C::CT) * (C::BD2 ? 4 : 1), nk = conv_nk<C>(cin);
     const int G = conv_grid() * C::WGS_PER_CU;
@@ -863,9 +867,9 @@ static int launch_conv(const float* x, const float* wpack, float* out, float* wo
     const ConvSplit sp = conv_split(tiles, nk, G);
     // overhead of a touched tile in half K-steps: a K-step of the 512-pixel tiles takes ~5.3 us, of the 256-pixel tiles ~3.2
     const int* spans = (SC_CONV_SPANS && sp.tail_tiles > 0 && sp.per_wg <= nk) ? conv_spans(sp.tail_tiles, nk, G, C::PT >= 512 ? 2 : 3, st) : nullptr;
-    hipLaunchKernelGGL((conv3x3_kernel<C>), dim3(G), dim3(C::NT), C::LDS_BYTES, st, x, wpack, out, workspace, batch, cin, cout, spans);
+    hipLaunchKernelGGL((conv3x3_kernel<C>), dim3(G), dim3(C::NT), C::LDS_BYTES, st, x, wpack, out, workspace, batch, cin, cout, spans, addend);
     if (sp.tail_tiles > 0)
-        hipLaunchKernelGGL((conv3x3_fixup_kernel<C>), dim3(sp.tail_tiles, 4), dim3(C::NT), 0, st, workspace, out, batch, cin, cout, G, spans);
+        hipLaunchKernelGGL((conv3x3_fixup_kernel<C>), dim3(sp.tail_tiles, 4), dim3(C::NT), 0, st, workspace, out, batch, cin, cout, G, spans, addend);
     return (int)hipGetLastError();
 }
 
@@ -1046,6 +1050,19 @@ extern "C" int sc_conv3x3_pack(const float* w, float* w_pack, int cin, int cout,
 #undef CALL
     }
 #define CALL(C) sc::launch_pack<C>(w, w_pack, cin, cout, transpose_flip & 1, (hipStream_t)stream)
+    SC_CONV_DISPATCH(hw, CALL)
+#undef CALL
+}
+
+// out = conv(x, w) + addend (addend [batch][cout][hw][hw], may alias nothing else): the sum is formed in the store epilogue
+extern "C" int sc_conv3x3_forward_add(const float* x, const float* w_pack, const float* addend, float* out, float* workspace, int batch, int cin,
+                                      int cout, int hw, int split, void* stream) {
+    if (split) {
+#define CALL(C) sc::launch_conv<C>(x, w_pack, out, workspace, batch, cin, cout, (hipStream_t)stream, addend)
+        SC_CONV_DISPATCH_SPLIT(hw, CALL)
+#undef CALL
+    }
+#define CALL(C) sc::launch_conv<C>(x, w_pack, out, workspace, batch, cin, cout, (hipStream_t)stream, addend)
     SC_CONV_DISPATCH(hw, CALL)
 #undef CALL
 }
