@@ -68,7 +68,9 @@ int sc_chamfer3d_backward(const float* xyz1, const float* xyz2, float* gradxyz1,
  * Outputs (any may be NULL):  sdf [n_points];  grad [n_points][3] = d sdf / d point (its presence
  * selects the gradient kernel);  feat / stash_a / stash_p: tile-blocked 64-channel tensors
  * (TBL64: [ceil(n/16)][16][16][4] floats), stash_a holds 5 and stash_p 4 such tensors back to back
- * (pre-activations a_0..a_4 and adjoints p_0..p_3 kept for sc_sdf_backward).
+ * (since round 5 the ACTIVATIONS h_0..h_4 = softplus(a_l) -- a_l before -- and the adjoints p_0..p_3, kept for sc_sdf_backward[_fused]: with
+ * u = exp(-100 h) the reverse passes get sp'(a) = 1 - u and sp''(a) = 100 (1 - u) u from ONE transcendental and sp(a) = h from none; the buffer
+ * is opaque to callers: whatever sc_sdf_forward wrote is what the backward entry points of the SAME library build read).
  * scratch: required when grad != NULL and stash_a == NULL: 256*8*5*1024 floats of per-wave scratch.  */
 #define SC_SDF_PACK_FLOATS (64*48 + 2*64*112 + 2*64*64 + 65*64 + 65)
 #define SC_RGB_PACK_FLOATS (64*112 + 2*64*64 + 3*64 + 4)

@@ -346,6 +346,29 @@ __device__ __forceinline__ float softplus_val(float a, float t) {
 __device__ __forceinline__ float softplus_d1(float a, float t, float r) { return (a >= 0.f ? 1.f : t) * r; }
 __device__ __forceinline__ float softplus_d2(float t, float r) { return 100.f * t * r * r; }
 
+// ---- what the kernels park between their sweeps (training stash `stash_a`, per-wave scratch) -----------------------------------------------
+// SC_STASH_H = 0: the pre-activation a_l; every reader re-evaluates softplus and its derivatives from it (exp2 + rcp, + log for the value).
+// SC_STASH_H = 1 (round 5): the ACTIVATION h_l = softplus(a_l).  With u = exp(-100 h):  exp(100 h) = 1 + exp(100 a), so
+//     sp'(a) = sigmoid(100 a) = 1 - u,      sp''(a) = 100 sp' (1 - sp') = 100 (1 - u) u,      sp(a) = h (no evaluation at all):
+// ONE transcendental per element and sweep instead of two or three.  1 - u carries an absolute error of one fp32 ulp of 1 (6e-8): for
+// strongly negative a (sp' < 1e-4) that is a large RELATIVE error of a factor that multiplies a negligible term -- the parity bars
+// (2e-4 of the largest gradient) do not move (tests/test_gpu_parity_large.py, test_gpu_full_step_parity.py).
+#ifndef SC_STASH_H
+#define SC_STASH_H 1
+#endif
+__device__ __forceinline__ float stash_of(float a, float h) { return SC_STASH_H ? h : a; }
+__device__ __forceinline__ void stash_parts(float v, float& t, float& r) {
+#if SC_STASH_H
+    t = __builtin_amdgcn_exp2f(-144.26950408889634f * v);          // u = exp(-100 h)  (h >= 0)
+    r = 1.f - t;                                                   // sp'(a)
+#else
+    softplus_parts(v, t, r);
+#endif
+}
+__device__ __forceinline__ float stash_d1(float v, float t, float r) { return SC_STASH_H ? r : softplus_d1(v, t, r); }
+__device__ __forceinline__ float stash_d2(float t, float r) { return SC_STASH_H ? 100.f * t * r : softplus_d2(t, r); }
+__device__ __forceinline__ float stash_val(float v, float t) { return SC_STASH_H ? v : softplus_val(v, t); }
+
 // ---- positional encoding in slot order ---------------------------------------------------------------
 // e[4c+j]: value, d1[4c+j]: d/dx_c, d2[4c+j]: d2/dx_c^2 of the slot this lane (group g) owns.
 // Symmetry (implicit.py:139-145): coordinate 0 enters as |x0|; chain-rule factor sign(x0) with
@@ -370,8 +393,12 @@ __device__ __forceinline__ void pe_slots(float x0, float x1, float x2, int g, bo
 #ifdef SC_NO_FAST_TRIG                       // experiment switch: accurate sincosf everywhere (tools/ab_fast_trig.sh)
             sincosf(xs[c] * f, &sn, &cs);
 #else
+#ifdef SC_FORCE_FAST_TRIG                    // timing experiment: what the accurate sincosf of the forward kernels costs
+            __sincosf(xs[c] * f, &sn, &cs);
+#else
             if (FAST) __sincosf(xs[c] * f, &sn, &cs);
             else sincosf(xs[c] * f, &sn, &cs);
+#endif
 #endif
             e[4 * c + 2 * m] = raw ? (m == 0 ? xs[c] : 0.f) : sn;
             e[4 * c + 2 * m + 1] = raw ? 0.f : cs;

@@ -116,10 +116,10 @@ __global__ __launch_bounds__(64 * SDFB_WAVES) void sdf_bwd_kernel(SdfBwdArgs a) 
                 float pn[ACT_STEPS];                                                         \
                 _Pragma("unroll") for (int s = 0; s < ACT_STEPS; ++s) {                       \
                     float t, r;                                                              \
-                    softplus_parts(av[s], t, r);                                             \
-                    const float ds = softplus_d1(av[s], t, r);                               \
+                    stash_parts(av[s], t, r);                                             \
+                    const float ds = stash_d1(av[s], t, r);                               \
                     gpv[s] = gq[s] * ds;                                                     \
-                    pn[s] = gq[s] * pv[s] * softplus_d2(t, r);                               \
+                    pn[s] = gq[s] * pv[s] * stash_d2(t, r);                               \
                     pv[s] = pv[s] * ds;                      /* q_l, for the second-order point term */ \
                 }                                                                            \
                 tbl_store(a.gp + (size_t)(L) * tbl, tile, p, g, gpv);                        \
@@ -154,9 +154,9 @@ __global__ __launch_bounds__(64 * SDFB_WAVES) void sdf_bwd_kernel(SdfBwdArgs a) 
 #pragma unroll
             for (int s = 0; s < ACT_STEPS; ++s) {
                 float t, r;
-                softplus_parts(j_av[s], t, r);
-                j_pend[s] = gq[s] * w5s[kp(s)] * softplus_d2(t, r);
-                j_u[s] = gq[s] * softplus_d1(j_av[s], t, r);
+                stash_parts(j_av[s], t, r);
+                j_pend[s] = gq[s] * w5s[kp(s)] * stash_d2(t, r);
+                j_u[s] = gq[s] * stash_d1(j_av[s], t, r);
             }
             // gx now holds the second-order part of G point (Gx_c = Gg_c * sum_l q_l . (W_le d2E/dx_c^2)); the V sweep adds the rest
         }
@@ -194,10 +194,10 @@ __global__ __launch_bounds__(64 * SDFB_WAVES) void sdf_bwd_kernel(SdfBwdArgs a) 
             for (int s = 0; s < ACT_STEPS; ++s) {
                 const float a4 = HAS_GG ? j_av[s] : av[s];      /* (av is free again after this block) */
                 float t, r;
-                softplus_parts(a4, t, r);
+                stash_parts(a4, t, r);
                 const float gh = acc[s >> 2][s & 3] + w5s[kp(s)] * Gs;
-                r0v[s] = Gs * softplus_val(a4, t) + (HAS_GG ? j_u[s] : 0.f);
-                gav[s] = gh * softplus_d1(a4, t, r) + (HAS_GG ? j_pend[s] : 0.f);
+                r0v[s] = Gs * stash_val(a4, t) + (HAS_GG ? j_u[s] : 0.f);
+                gav[s] = gh * stash_d1(a4, t, r) + (HAS_GG ? j_pend[s] : 0.f);
             }
             tbl_store(a.r0, tile, p, g, r0v);
             tbl_store(a.ga + 4 * tbl, tile, p, g, gav);
@@ -207,8 +207,8 @@ __global__ __launch_bounds__(64 * SDFB_WAVES) void sdf_bwd_kernel(SdfBwdArgs a) 
         mm_act_t<LD, NT>(WT, gav, acc);                                                      \
         _Pragma("unroll") for (int s = 0; s < ACT_STEPS; ++s) {                               \
             float t, r;                                                                      \
-            softplus_parts(av[s], t, r);                                                     \
-            gav[s] = acc[s >> 2][s & 3] * softplus_d1(av[s], t, r) + (HAS_GG ? pv[s] : 0.f); \
+            stash_parts(av[s], t, r);                                                     \
+            gav[s] = acc[s >> 2][s & 3] * stash_d1(av[s], t, r) + (HAS_GG ? pv[s] : 0.f); \
         }                                                                                    \
         tbl_store(a.ga + (size_t)(L) * tbl, tile, p, g, gav);
         SC_V_LOAD(3, av, pv)

@@ -251,11 +251,11 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
                     float pn[ACT_STEPS];                                                     \
                     _Pragma("unroll") for (int s = 0; s < ACT_STEPS; ++s) {                   \
                         float t, r;                                                          \
-                        softplus_parts(av[s], t, r);                                         \
-                        const float ds = softplus_d1(av[s], t, r);                           \
+                        stash_parts(av[s], t, r);                                         \
+                        const float ds = stash_d1(av[s], t, r);                           \
                         const float gq = acc[s >> 2][s & 3];                                 \
                         gpn[s] = gq * ds;                                                    \
-                        pn[s] = gq * pv[s] * softplus_d2(t, r);                              \
+                        pn[s] = gq * pv[s] * stash_d2(t, r);                              \
                         pv[s] = pv[s] * ds;                                                  \
                     }                                                                        \
                     tbl_store(park + (size_t)(L) * 1024, 0, p, g, pn);                       \
@@ -304,9 +304,9 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
 #pragma unroll
                     for (int s = 0; s < ACT_STEPS; ++s) {
                         float t, r;
-                        softplus_parts(j_av[s], t, r);
-                        const float ds = softplus_d1(j_av[s], t, r), gq = acc[s >> 2][s & 3], w5 = w5s[kp(s)];
-                        j_pend[s] = gq * w5 * softplus_d2(t, r);
+                        stash_parts(j_av[s], t, r);
+                        const float ds = stash_d1(j_av[s], t, r), gq = acc[s >> 2][s & 3], w5 = w5s[kp(s)];
+                        j_pend[s] = gq * w5 * stash_d2(t, r);
                         j_u[s] = gq * ds;
                         q4[s] = w5 * ds;
                     }
@@ -328,9 +328,9 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
 #define BW_V_ELEM(av, pv, gan)                                                              \
                 _Pragma("unroll") for (int s = 0; s < ACT_STEPS; ++s) {                       \
                     float t, r;                                                              \
-                    softplus_parts(av[s], t, r);                                             \
-                    gan[s] = acc[s >> 2][s & 3] * softplus_d1(av[s], t, r) + pv[s];          \
-                    hv[s] = softplus_val(av[s], t);                                          \
+                    stash_parts(av[s], t, r);                                             \
+                    gan[s] = acc[s >> 2][s & 3] * stash_d1(av[s], t, r) + pv[s];          \
+                    hv[s] = stash_val(av[s], t);                                          \
                 }
                 acc_zero(acc);
                 float gf[ACT_STEPS];
@@ -347,11 +347,11 @@ __global__ __launch_bounds__(512, 2) void sdf_bwdw_kernel(SdfBwdwArgs a) {
 #pragma unroll
                     for (int s = 0; s < ACT_STEPS; ++s) {
                         float t, r;
-                        softplus_parts(j_av[s], t, r);
+                        stash_parts(j_av[s], t, r);
                         const float gh = acc[s >> 2][s & 3] + w5s[kp(s)] * Gs;
-                        hv[s] = softplus_val(j_av[s], t);
+                        hv[s] = stash_val(j_av[s], t);
                         r0v[s] = (Gs * hv[s] + j_u[s]) * vmask;
-                        gaA[s] = gh * softplus_d1(j_av[s], t, r) + j_pend[s];
+                        gaA[s] = gh * stash_d1(j_av[s], t, r) + j_pend[s];
                     }
                     // dW5 row 0 = sum over points of r0 and db5[0] = sum Gs are row sums the wgrad waves take on the way: r0 rides in
                     // the idle slot B of step 10, Gs in the point stash.  (They used to be reduced here with DPP adds and 16 LDS

@@ -88,12 +88,13 @@ __global__ __launch_bounds__(64 * SDF_WAVES) void sdf_fwd_kernel(SdfFwdArgs a) {
         {                                                                                  \
             float av[ACT_STEPS];                                                           \
             acc_to_regs(acc, av);                                                          \
-            if (park) tbl_store(park + (size_t)(L) * park_stride, ptile, p, g, av);        \
+            if (!SC_STASH_H && park) tbl_store(park + (size_t)(L) * park_stride, ptile, p, g, av); \
             _Pragma("unroll") for (int s = 0; s < ACT_STEPS; ++s) {                         \
                 float t, r;                                                                \
                 softplus_parts(av[s], t, r);                                               \
                 h[s] = softplus_val(av[s], t);                                             \
             }                                                                              \
+            if (SC_STASH_H && park) tbl_store(park + (size_t)(L) * park_stride, ptile, p, g, h);   /* the ACTIVATION is parked (mlp_tile.hpp) */ \
         }
 
         // ---- value chain ----
@@ -156,8 +157,8 @@ __global__ __launch_bounds__(64 * SDF_WAVES) void sdf_fwd_kernel(SdfFwdArgs a) {
             {                                                                              \
                 _Pragma("unroll") for (int s = 0; s < ACT_STEPS; ++s) {                     \
                     float t, r;                                                            \
-                    softplus_parts(av[s], t, r);                                           \
-                    const float ds = softplus_d1(av[s], t, r);                             \
+                    stash_parts(av[s], t, r);                                              \
+                    const float ds = stash_d1(av[s], t, r);                                \
                     q[s] = (EXPR) * ds;                                                    \
                 }                                                                          \
             }

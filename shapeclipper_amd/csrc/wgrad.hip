@@ -50,8 +50,14 @@ constexpr int WG_MAXNB = 112;
 __device__ __forceinline__ float4 wg_load4(const float* base, int tile, int grp, int pt) {
     return reinterpret_cast<const float4*>(base)[((size_t)tile * 16 + grp) * 16 + pt];
 }
-__device__ __forceinline__ float sp_d1(float a) { float t, r; softplus_parts(a, t, r); return softplus_d1(a, t, r); }
-__device__ __forceinline__ float sp_val(float a) { float t, r; softplus_parts(a, t, r); return softplus_val(a, t); }
+__device__ __forceinline__ float sp_d1(float a) { float t, r; stash_parts(a, t, r); return stash_d1(a, t, r); }       // (a: the stashed value, mlp_tile.hpp SC_STASH_H)
+__device__ __forceinline__ float sp_val(float a) {
+#if SC_STASH_H
+    return a;
+#else
+    float t, r; softplus_parts(a, t, r); return softplus_val(a, t);
+#endif
+}
 
 // ---- fragment loads straight from the TBL64 image --------------------------------------------------
 // MFMA 16x16x4 wants  A[i = channel][k = point]: lane (i = l&15, g = l>>4) supplies channel i of point
