@@ -237,6 +237,17 @@ int sc_ray_sample_forward(const float* cam_loc, const float* ray_dirs, const flo
 int sc_ray_sample_backward(const float* ray_dirs, const float* z_vals, const float* g_points,
                            const float* g_z_extra, int n_rays, int rays_per_image, int n_images, float cam_dist,
                            float* g_cam_loc, float* g_ray_dirs, float* g_scale_dist, void* stream);
+/* The same pair with the eikonal sample points of a training render (model/renderer.py:154-165) produced / differentiated on the way:
+ * eik_points [n_images][2 rays_per_image][3] = per image the rays_per_image uniform points (eik_uniform [n_rays][3], copied) followed by the
+ * near-surface point of every ray = its sample eik_idx[ray] (int64 [n_rays]; cam_loc + z_eik ray_dir, bit-identical to that entry of
+ * `points`).  backward: g_eik_points (may be NULL) adds the near points' gradients to the samples they are; g_points may be NULL (zeros).
+ * n_rays == n_images * rays_per_image.                                                                                              */
+int sc_ray_sample_forward_eik(const float* cam_loc, const float* ray_dirs, const float* scale_dist, const float* u, const long long* eik_idx,
+                              const float* eik_uniform, int n_rays, int rays_per_image, int n_images, float cam_dist, float* z_vals,
+                              float* points, float* eik_points, void* stream);
+int sc_ray_sample_backward_eik(const float* ray_dirs, const float* z_vals, const float* g_points, const float* g_z_extra, const long long* eik_idx,
+                               const float* g_eik_points, int n_rays, int rays_per_image, int n_images, float cam_dist, float* g_cam_loc,
+                               float* g_ray_dirs, float* g_scale_dist, void* stream);
 
 /* One render in a single call (Renderer.forward, model/renderer.py:57-152):
  * sc_ray_sample_forward -> sc_sdf_forward -> sc_rgb_composite_forward.  z_vals, points, sdf, grad, feat and

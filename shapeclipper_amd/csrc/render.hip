@@ -23,7 +23,9 @@ __device__ __forceinline__ float linspace01(int i, int steps) {
 __global__ __launch_bounds__(256) void ray_sample_kernel(const float* __restrict__ cam_loc, const float* __restrict__ ray_dirs,
                                                          const float* __restrict__ scale_dist, const float* __restrict__ u,
                                                          int n_rays, int rays_per_image, int n_images, float cam_dist,
-                                                         float* __restrict__ z_vals, float* __restrict__ points) {
+                                                         float* __restrict__ z_vals, float* __restrict__ points,
+                                                         const long long* __restrict__ eik_idx, const float* __restrict__ eik_uniform,
+                                                         float* __restrict__ eik_points) {
 #pragma clang fp contract(off)   // keep torch's separate mul / add roundings (HIP's __fmul_rn is a plain '*' and would be fused)
     const int lane = threadIdx.x & 63;
     for (int ray = blockIdx.x * 4 + (threadIdx.x >> 6); ray < n_rays; ray += gridDim.x * 4) {
@@ -41,8 +43,15 @@ __global__ __launch_bounds__(256) void ray_sample_kernel(const float* __restrict
         z_vals[(size_t)ray * 64 + lane] = z;
         const size_t p = (size_t)ray * 64 + lane;
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-            points[p * 3 + k] = __fadd_rn(cam_loc[(size_t)ray * 3 + k], __fmul_rn(z, ray_dirs[(size_t)ray * 3 + k]));
+        for (int k = 0; k < 3; ++k) {
+            const float v = __fadd_rn(cam_loc[(size_t)ray * 3 + k], __fmul_rn(z, ray_dirs[(size_t)ray * 3 + k]));
+            points[p * 3 + k] = v;
+            // eikonal points of the image (renderer.py:154-165): [uniform block R | near-surface block R]; the near point of a ray IS its
+            // sample eik_idx -- cam_loc + z_eik * ray_dir, the same two roundings -- so it is copied, not re-derived from a gather of z
+            if (eik_points && lane == (int)eik_idx[ray]) eik_points[((size_t)(img * 2 + 1) * rays_per_image + (ray - img * rays_per_image)) * 3 + k] = v;
+        }
+        if (eik_points && lane < 3)
+            eik_points[((size_t)(img * 2) * rays_per_image + (ray - img * rays_per_image)) * 3 + lane] = eik_uniform[(size_t)ray * 3 + lane];
     }
 }
 
@@ -52,12 +61,18 @@ __global__ __launch_bounds__(256) void ray_sample_bwd_kernel(const float* __rest
                                                              const float* __restrict__ g_points, const float* __restrict__ g_z_extra,
                                                              int n_rays, int rays_per_image, int n_images, float cam_dist,
                                                              float* __restrict__ g_cam_loc, float* __restrict__ g_ray_dirs,
-                                                             float* __restrict__ g_scale_dist) {
+                                                             float* __restrict__ g_scale_dist, const long long* __restrict__ eik_idx,
+                                                             const float* __restrict__ g_eik_points) {
     const int lane = threadIdx.x & 63;
     for (int ray = blockIdx.x * 4 + (threadIdx.x >> 6); ray < n_rays; ray += gridDim.x * 4) {
         const size_t p = (size_t)ray * 64 + lane;
         const float z = z_vals[p];
-        const float g0 = g_points[p * 3], g1 = g_points[p * 3 + 1], g2 = g_points[p * 3 + 2];
+        float g0 = g_points ? g_points[p * 3] : 0.f, g1 = g_points ? g_points[p * 3 + 1] : 0.f, g2 = g_points ? g_points[p * 3 + 2] : 0.f;
+        if (g_eik_points && lane == (int)eik_idx[ray]) {        // the near-surface eikonal point of this ray is this sample
+            const int img = min(ray / rays_per_image, n_images - 1);
+            const float* ge = g_eik_points + ((size_t)(img * 2 + 1) * rays_per_image + (ray - img * rays_per_image)) * 3;
+            g0 += ge[0]; g1 += ge[1]; g2 += ge[2];
+        }
         const float d0 = ray_dirs[(size_t)ray * 3], d1 = ray_dirs[(size_t)ray * 3 + 1], d2 = ray_dirs[(size_t)ray * 3 + 2];
         float gz = g0 * d0 + g1 * d1 + g2 * d2 + (g_z_extra ? g_z_extra[p] : 0.f);
         float s0 = g0, s1 = g1, s2 = g2, t0 = z * g0, t1 = z * g1, t2 = z * g2;
@@ -108,7 +123,31 @@ int sc_ray_sample_forward(const float* cam_loc, const float* ray_dirs, const flo
     int blocks = (n_rays + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(sc::ray_sample_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, cam_loc, ray_dirs, scale_dist, u,
-                       n_rays, rays_per_image, n_images, cam_dist, z_vals, points);
+                       n_rays, rays_per_image, n_images, cam_dist, z_vals, points, (const long long*)nullptr, (const float*)nullptr, (float*)nullptr);
+    return (int)hipGetLastError();
+}
+
+int sc_ray_sample_forward_eik(const float* cam_loc, const float* ray_dirs, const float* scale_dist, const float* u, const long long* eik_idx,
+                              const float* eik_uniform, int n_rays, int rays_per_image, int n_images, float cam_dist, float* z_vals,
+                              float* points, float* eik_points, void* stream_) {
+    if (n_rays <= 0) return 0;
+    if (!eik_idx || !eik_uniform || !eik_points || n_rays != rays_per_image * n_images) return (int)hipErrorInvalidValue;
+    int blocks = (n_rays + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sc::ray_sample_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, cam_loc, ray_dirs, scale_dist, u,
+                       n_rays, rays_per_image, n_images, cam_dist, z_vals, points, eik_idx, eik_uniform, eik_points);
+    return (int)hipGetLastError();
+}
+
+int sc_ray_sample_backward_eik(const float* ray_dirs, const float* z_vals, const float* g_points, const float* g_z_extra, const long long* eik_idx,
+                               const float* g_eik_points, int n_rays, int rays_per_image, int n_images, float cam_dist, float* g_cam_loc,
+                               float* g_ray_dirs, float* g_scale_dist, void* stream_) {
+    if (n_rays <= 0) return 0;
+    if (g_eik_points && (!eik_idx || n_rays != rays_per_image * n_images)) return (int)hipErrorInvalidValue;
+    int blocks = (n_rays + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sc::ray_sample_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, ray_dirs, z_vals, g_points,
+                       g_z_extra, n_rays, rays_per_image, n_images, cam_dist, g_cam_loc, g_ray_dirs, g_scale_dist, eik_idx, g_eik_points);
     return (int)hipGetLastError();
 }
 
@@ -119,7 +158,8 @@ int sc_ray_sample_backward(const float* ray_dirs, const float* z_vals, const flo
     int blocks = (n_rays + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(sc::ray_sample_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, ray_dirs, z_vals, g_points,
-                       g_z_extra, n_rays, rays_per_image, n_images, cam_dist, g_cam_loc, g_ray_dirs, g_scale_dist);
+                       g_z_extra, n_rays, rays_per_image, n_images, cam_dist, g_cam_loc, g_ray_dirs, g_scale_dist, (const long long*)nullptr,
+                       (const float*)nullptr);
     return (int)hipGetLastError();
 }
 

@@ -138,6 +138,32 @@ class RaySampleFunction(torch.autograd.Function):
         return g_o, g_d, g_sd, None, None, None
 
 
+class RaySampleEikFunction(torch.autograd.Function):
+    """RaySampleFunction + the eikonal sample points of a training render (reference model/renderer.py:154-165) in the same two launches:
+    -> z_vals [n_rays,64], points [n_rays*64,3], eik_points [B, 2 R, 3] (uniform block | near-surface block).  The near point of a ray is its
+    sample eik_idx -- no gather of z, no second evaluation of cam_loc + z * ray_dir, and in backward no scatter into a dense z gradient
+    (round 5: ~15 stock launches per render)."""
+
+    @staticmethod
+    def forward(ctx, cam_loc, ray_dirs, scale_dist, u, eik_idx, eik_uniform, rays_per_image, cam_dist):
+        ctx.set_materialize_grads(False)
+        cam_loc, ray_dirs, scale_dist = cam_loc.contiguous(), ray_dirs.contiguous(), scale_dist.contiguous()
+        eik_idx, eik_uniform = eik_idx.contiguous(), eik_uniform.contiguous()
+        z, pts, eik = ops.ray_sample_forward_eik(cam_loc, ray_dirs, scale_dist, u, eik_idx, eik_uniform, rays_per_image, cam_dist)
+        ctx.save_for_backward(ray_dirs, z, eik_idx)
+        ctx.meta = (rays_per_image, scale_dist.shape[0], cam_dist)
+        return z, pts, eik
+
+    @staticmethod
+    def backward(ctx, g_z, g_points, g_eik):
+        ray_dirs, z, eik_idx = ctx.saved_tensors
+        rpi, n_images, cam_dist = ctx.meta
+        g_o, g_d, g_sd = ops.ray_sample_backward_eik(ray_dirs, z, g_points.contiguous() if g_points is not None else None,
+                                                     g_z.contiguous() if g_z is not None else None, eik_idx,
+                                                     g_eik.contiguous() if g_eik is not None else None, rpi, n_images, cam_dist)
+        return g_o, g_d, g_sd, None, None, None, None, None
+
+
 class BnActFunction(torch.autograd.Function):
     """y = [relu]( batch_norm(x) [+ res] ) in two HIP launches (csrc/bn_act.hip); nn.BatchNorm2d semantics for the
     running statistics (updated in place; num_batches_tracked incremented by the kernel)."""

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as torch_F
 
-from ..functional import CameraRaysFunction, RaySampleFunction, RgbCompositeFunction, SdfFunction
+from ..functional import CameraRaysFunction, RaySampleEikFunction, RaySampleFunction, RgbCompositeFunction, SdfFunction
 from ..utils import camera
 from .implicit import LaplaceDensity
 
@@ -105,8 +105,15 @@ class Renderer(nn.Module):
         if self.eager:
             return self._forward_eager(opt, cam_loc, ray_dirs, depth_fac, scale_dist, t_rand, eik_idx, B, R, proj_latent_sdf, proj_latent_rgb,
                                        training, visualize, up, rdev, pin)
-        z_vals, points_flat = RaySampleFunction.apply(cam_loc, ray_dirs, scale_dist, t_rand, R, float(opt.camera.dist))
-        z_eik = torch.gather(z_vals, 1, eik_idx.unsqueeze(-1))
+        eik_points = None
+        if training and ray_dirs.is_cuda:
+            # the eikonal points come out of the sampling launch: the uniform draw (CPU generator, the reference's third draw of a render,
+            # renderer.py:158 -- nothing else touches the generator in between) and, per ray, the sample eik_idx as its near-surface point
+            eik_u = up(torch.empty(B * R, 3, device=rdev, pin_memory=pin).uniform_(self.eik_range[0], self.eik_range[1]))
+            z_vals, points_flat, eik_points = RaySampleEikFunction.apply(cam_loc, ray_dirs, scale_dist, t_rand, eik_idx, eik_u, R, float(opt.camera.dist))
+        else:
+            z_vals, points_flat = RaySampleFunction.apply(cam_loc, ray_dirs, scale_dist, t_rand, R, float(opt.camera.dist))
+            z_eik = torch.gather(z_vals, 1, eik_idx.unsqueeze(-1))
         assert proj_latent_rgb.shape[1] == opt.arch.impl_rgb.proj_latent_dim
 
         # fused SDF value + feature + d(sdf)/dx, then RGB MLP + density + compositing
@@ -127,10 +134,12 @@ class Renderer(nn.Module):
         grad_eikonal = None
         if training:
             # uniform points (CPU generator, as the reference) + one near-surface point per ray
-            n_eik = B * R
-            eik = up(torch.empty(n_eik, 3, device=rdev, pin_memory=pin).uniform_(self.eik_range[0], self.eik_range[1])).reshape(B, R, 3)
-            near = (cam_loc + z_eik * ray_dirs).reshape(B, R, 3)
-            eik_points = torch.cat([eik, near], 1).reshape(-1, 3)
+            if eik_points is None:
+                n_eik = B * R
+                eik = up(torch.empty(n_eik, 3, device=rdev, pin_memory=pin).uniform_(self.eik_range[0], self.eik_range[1])).reshape(B, R, 3)
+                near = (cam_loc + z_eik * ray_dirs).reshape(B, R, 3)
+                eik_points = torch.cat([eik, near], 1)
+            eik_points = eik_points.reshape(-1, 3)
             _, _, g_eik = self.sdf_network.get_conditional_output(opt, B, eik_points, proj_latent_sdf, compute_grad=True)
             grad_eikonal = g_eik.norm(2, dim=1)
 

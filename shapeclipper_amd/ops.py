@@ -386,6 +386,34 @@ def ray_sample_forward(cam_loc, ray_dirs, scale_dist, u, rays_per_image, cam_dis
     return z, pts
 
 
+def ray_sample_forward_eik(cam_loc, ray_dirs, scale_dist, u, eik_idx, eik_uniform, rays_per_image, cam_dist):
+    """ray_sample_forward + the eikonal sample points of the render [B, 2 R, 3] (uniform block | near-surface block) in the same launch."""
+    lib = _lib.load()
+    n_rays, B = ray_dirs.shape[0], scale_dist.shape[0]
+    z = torch.empty(n_rays, 64, device=ray_dirs.device, dtype=torch.float32)
+    pts = torch.empty(n_rays * 64, 3, device=ray_dirs.device, dtype=torch.float32)
+    eik = torch.empty(B, 2 * rays_per_image, 3, device=ray_dirs.device, dtype=torch.float32)
+    code = lib.sc_ray_sample_forward_eik(_lib.ptr(cam_loc), _lib.ptr(ray_dirs), _lib.ptr(scale_dist), _lib.ptr(u), _lib.ptr(eik_idx), _lib.ptr(eik_uniform),
+                                         c_int(n_rays), c_int(rays_per_image), c_int(B), ctypes.c_float(cam_dist), _lib.ptr(z), _lib.ptr(pts),
+                                         _lib.ptr(eik), _lib.stream())
+    _lib.check(code, "sc_ray_sample_forward_eik")
+    return z, pts, eik
+
+
+def ray_sample_backward_eik(ray_dirs, z_vals, g_points, g_z, eik_idx, g_eik, rays_per_image, n_images, cam_dist):
+    lib = _lib.load()
+    n_rays = ray_dirs.shape[0]
+    dev = ray_dirs.device
+    g_o = torch.empty(n_rays, 3, device=dev, dtype=torch.float32)
+    g_d = torch.empty(n_rays, 3, device=dev, dtype=torch.float32)
+    g_sd = torch.empty(n_rays, device=dev, dtype=torch.float32)
+    code = lib.sc_ray_sample_backward_eik(_lib.ptr(ray_dirs), _lib.ptr(z_vals), _lib.ptr(g_points), _lib.ptr(g_z), _lib.ptr(eik_idx), _lib.ptr(g_eik),
+                                          c_int(n_rays), c_int(rays_per_image), c_int(n_images), ctypes.c_float(cam_dist), _lib.ptr(g_o),
+                                          _lib.ptr(g_d), _lib.ptr(g_sd), _lib.stream())
+    _lib.check(code, "sc_ray_sample_backward_eik")
+    return g_o, g_d, g_sd.view(n_images, rays_per_image).sum(dim=1)
+
+
 def ray_sample_backward(ray_dirs, z_vals, g_points, g_z, rays_per_image, n_images, cam_dist):
     lib = _lib.load()
     n_rays = ray_dirs.shape[0]
