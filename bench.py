@@ -398,10 +398,9 @@ def main():
         bound = "hbm" if (hbm_rate and hbm_rate >= 0.75 * 6300.0) else "mfma"
         roofline = dict(kernel=dom, bound=bound, achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS,
                         unit="TFLOP/s", frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic, traffic_source=traffic_source,
-                        limiter="issue, on the chain waves' own path: 99 k of the 107 k cycles per 4 tiles are the chain wave's instruction stream (32 k MFMA, "
-                                "~25 k vector instructions, 14 k slot writes + barriers) while the weight-gradient waves wait 53 k "
-                                "(profiles/r05_bwdw_phase_profile_pecache.txt); two restructurings that shift work to the waiting role were built and are "
-                                "slower (DESIGN.md 4.1)",
+                        limiter="issue: 87 k cycles per 4 tiles against 60 k of MFMAs; both roles of the workgroup are busy (chain waves wait 11 k, weight-gradient "
+                                "waves 23 k: profiles/r05_bwdw_phase_profile_final.txt); restructurings that shift work between the roles were built and are slower "
+                                "(DESIGN.md 4.1)",
                         launch_ms=round(mean_big, 4), points_per_launch=n_pts_main,
                         flops_per_point=FLOPS_PER_POINT[dom],
                         hbm_GBps_of_measured_traffic=round(hbm_rate, 1) if hbm_rate else None)
