@@ -112,18 +112,29 @@ __global__ __launch_bounds__(1024) void loss_fused_kernel(LossArgs a) {
         return;
     }
     // ---------------- block B: robust masked normal loss over the whole batch ----------------
+    // (round 5) The first LOSS_VR elements of a thread (i = tid + j nt: all of them at the training size, 16,384 rays on 1,024 threads) stay in
+    // registers through the four selection passes and the final pass -- they used to be re-read from the workspace in each -- and the
+    // 256-bin scan of a pass is a wave-wide prefix sum instead of one thread walking the bins (100 -> ~35 us per launch, two launches per step).
     const int N = a.B * a.R;
+    constexpr int LOSS_VR = 16;
+    float vreg[LOSS_VR];
     unsigned int n_local = 0;
-    for (int i = tid; i < N; i += nt) {
+    auto angle = [&](int i) {
         const bool m = a.mask_t[i] > 0.5f && a.mask[i] > 0.5f;
-        float ang = 0.f;
+        float ang = __builtin_nanf("");                 // NaN marks "not in the mask"
         if (m) {
             ang = 1.f - (a.normal[i * 3] * a.normal_t[i * 3] + a.normal[i * 3 + 1] * a.normal_t[i * 3 + 1]
                          + a.normal[i * 3 + 2] * a.normal_t[i * 3 + 2]);
             ++n_local;
         }
-        a.ang_ws[i] = m ? ang : __builtin_nanf("");    // NaN marks "not in the mask"
+        return ang;
+    };
+#pragma unroll
+    for (int j = 0; j < LOSS_VR; ++j) {
+        const int i = tid + j * nt;
+        vreg[j] = i < N ? angle(i) : __builtin_nanf("");
     }
+    for (int i = tid + LOSS_VR * nt; i < N; i += nt) a.ang_ws[i] = angle(i);
     if (tid == 0) sh_n = 0;
     __syncthreads();
     atomicAdd(&sh_n, n_local);
@@ -138,23 +149,36 @@ __global__ __launch_bounds__(1024) void loss_fused_kernel(LossArgs a) {
             for (int k = tid; k < 256; k += nt) hist[k] = 0;
             __syncthreads();
             const uint32_t hi_mask = pass == 3 ? 0u : (0xFFFFFFFFu << (8 * (pass + 1)));
-            for (int i = tid; i < N; i += nt) {
-                const float v = a.ang_ws[i];
+            auto count = [&](float v) {
                 if (v == v) {
                     const uint32_t key = order_key(v);
                     if ((key & hi_mask) == (prefix & hi_mask)) atomicAdd(&hist[(key >> (8 * pass)) & 255u], 1u);
                 }
-            }
+            };
+#pragma unroll
+            for (int j = 0; j < LOSS_VR; ++j) count(vreg[j]);
+            for (int i = tid + LOSS_VR * nt; i < N; i += nt) count(a.ang_ws[i]);
             __syncthreads();
-            if (tid == 0) {
-                unsigned int acc = 0, r = remaining;
-                int d = 0;
-                for (; d < 256; ++d) {
-                    if (acc + hist[d] >= r) break;
-                    acc += hist[d];
+            if (tid < 64) {       // first bin d with (bins before d) + hist[d] >= remaining: lane = 4 bins, wave-wide inclusive prefix sum
+                const unsigned int r = remaining;
+                unsigned int h[4], sum = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { h[q] = hist[4 * tid + q]; sum += h[q]; }
+                unsigned int incl = sum;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const unsigned int t = __shfl_up(incl, d);
+                    if (tid >= d) incl += t;
                 }
-                sh_prefix = prefix | ((uint32_t)d << (8 * pass));
-                sh_remaining = r - acc;
+                unsigned int acc = incl - sum;
+                if (acc < r && r <= incl) {             // exactly one lane (the total is >= remaining)
+                    int d = 4 * tid;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        if (d == 4 * tid + q && acc + h[q] < r) { acc += h[q]; ++d; }
+                    sh_prefix = prefix | ((uint32_t)d << (8 * pass));
+                    sh_remaining = r - acc;
+                }
             }
             __syncthreads();
             prefix = sh_prefix;
@@ -170,12 +194,20 @@ __global__ __launch_bounds__(1024) void loss_fused_kernel(LossArgs a) {
     float s_loss = 0.f;
     const float inv_keep = n_keep > 0 ? 1.f / (float)n_keep : 0.f;
     // ties: process in index order with a serialised counter only when needed (rare)
-    for (int base = 0; base < N; base += nt) {
+#pragma unroll 1
+    for (int base = 0, jj = 0; base < N; base += nt, ++jj) {
         const int i = base + tid;
         bool keep = false, tie = false;
         float v = 0.f;
         if (i < N) {
-            v = a.ang_ws[i];
+            v = 0.f;
+            if (jj < LOSS_VR) {
+#pragma unroll
+                for (int j = 0; j < LOSS_VR; ++j)
+                    if (j == jj) v = vreg[j];
+            } else {
+                v = a.ang_ws[i];
+            }
             if (v == v && n_keep > 0) {
                 const uint32_t key = order_key(v);
                 keep = key < kth_key;
