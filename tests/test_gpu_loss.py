@@ -55,3 +55,32 @@ def test_empty_mask_gives_nan_like_torch():
     m = torch.zeros(2, 16, 1, device=dev)
     out = FusedRenderLoss.apply(z, z, m, m, z, z, None, 5.0, 0.0, 0.8)
     assert torch.isnan(out[2]) and out[0].item() == 0.0
+
+
+@pytest.mark.parametrize("B,Rr", [(32, 512), (40, 512), (33, 500)])
+def test_robust_normal_selection_at_and_past_the_register_resident_size(B, Rr):
+    """Round 5: the selection keeps the first 16 elements of each of its 1,024 threads in registers (all 16,384 at the training size) and
+    reads the rest from the workspace: the training size, a larger batch that uses both paths, and a ragged size -- values and the
+    gradient of the normal loss against the oracle, with exact ties across the register / workspace boundary."""
+    from oracle import reference_ops as R
+    from shapeclipper_amd.functional import FusedRenderLoss
+    dev = torch.device("cuda:0")
+    torch.manual_seed(B + Rr)
+    rgb, tgt = torch.rand(B, Rr, 3), torch.rand(B, Rr, 3)
+    pm, tm = torch.rand(B, Rr, 1), (torch.rand(B, Rr, 1) > 0.4).float()
+    npred = torch.nn.functional.normalize(torch.randn(B, Rr, 3), dim=-1)
+    ngt = torch.nn.functional.normalize(torch.randn(B, Rr, 3), dim=-1)
+    npred[0, :60] = npred[0, 0]; ngt[0, :60] = ngt[0, 0]                      # exact duplicates at the start ...
+    npred[-1, -60:] = npred[0, 0]; ngt[-1, -60:] = ngt[0, 0]                  # ... and at the very end (past element 16,384 when B*R is larger)
+    cfg = R.Cfg()
+    mask = (tm > 0.5) & (pm > 0.5)
+    np_c = npred.clone().requires_grad_(True)
+    ref = R.normal_loss(cfg, np_c, ngt, mask, tolerance=0.2)
+    ref.backward()
+    np_d = npred.to(dev).requires_grad_(True)
+    out = FusedRenderLoss.apply(rgb.to(dev), tgt.to(dev), pm.to(dev), tm.to(dev), np_d, ngt.to(dev), None, 5.0, 0.0, 0.8)
+    assert abs(out[2].item() - ref.item()) < 2e-5 * max(1.0, abs(ref.item()))
+    out[2].backward()
+    # ties are exact duplicates: which of them are kept does not change the value, but it does change WHICH rows get a gradient; the
+    # reference keeps the first ones of a stable sort, i.e. the lowest indices -- as the kernel does
+    assert (np_d.grad.cpu() - np_c.grad).abs().max() < 1e-6
