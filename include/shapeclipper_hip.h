@@ -222,6 +222,22 @@ int sc_clip_vit_forward_f16(const float* image, int B, int C, int H, int W, int 
                             float* out, void* workspace, long long workspace_bytes, void* stream);
 int sc_gemm_f16(int epi, const uint16_t* A, const uint16_t* Wt, const float* bias, void* out, int M, int N, int K, void* stream);
 int sc_f32_to_f16(const float* x, uint16_t* y, long long n, void* stream);
+/* Small-batch form of the ViT-B layers (csrc/clip_cluster.hpp; same call site, CLIP_anno.py:166-167, at the batch the annotator
+ * uses): all transformer layers in ONE launch, an image per cluster of 8 CUs of one XCD, four bounded cluster barriers per layer, no
+ * chip-wide synchronisation.  It reads the layer matrices from a RE-PACKED image (same values, the order its waves consume them in: every
+ * MFMA fragment one contiguous KB) that sc_clip_cluster_pack builds once per model from the row-major image above.
+ * sc_clip_cluster_supported: 1 for width 768 / MLP 3072 / 12 heads / at most 64 tokens per image, else 0.
+ * sc_clip_cluster_pack_elems: 16-bit values of the re-packed image (layers * 12 * 768 * 768).
+ * sc_clip_cluster_pack: w16 = the tower's 16-bit image (bf16 or fp16 alike), Kp as above, out = the re-packed layers.
+ * sc_clip_vit_forward_packed: sc_clip_vit_forward (fp16 == 0) / sc_clip_vit_forward_f16 (fp16 != 0) with w_cluster beside w16; batches of at
+ * most 64 images (SC_CLIP_CLUSTER_MAX_B) on a device with >= 256 CUs take the cluster form, everything else the launch-per-operation form
+ * (w_cluster may be NULL then).  A device that cannot hold the grid at once ends every wait after 0.2 s and returns NaN embeddings.       */
+int sc_clip_cluster_supported(int D, int mlp, int heads, int tokens);
+long long sc_clip_cluster_pack_elems(int layers);
+int sc_clip_cluster_pack(const uint16_t* w16, int Kp, int layers, uint16_t* out, void* stream);
+int sc_clip_vit_forward_packed(const float* image, int B, int C, int H, int W, int patch, int D, int mlp, int layers, int heads,
+                               int proj_dim, const uint16_t* w16, const float* w_f32, const uint16_t* w_cluster, int fp16,
+                               float ln_eps, float* out, void* workspace, long long workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Ray sampling (UniformSampler.get_z_vals + point generation, model/renderer.py:13-37,84-86).

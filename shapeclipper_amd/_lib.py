@@ -21,6 +21,7 @@ SYMBOLS = (
     "sc_chamfer3d_forward", "sc_chamfer3d_forward_split", "sc_chamfer3d_forward_grid", "sc_chamfer3d_backward", "sc_sdf_forward", "sc_rgb_composite_forward",
     "sc_rgb_composite_backward", "sc_sdf_backward", "sc_wgrad", "sc_partial_reduce", "sc_tbl_sum", "sc_loss_fused_forward",
     "sc_clip_vit_forward", "sc_gemm_bf16", "sc_f32_to_bf16", "sc_clip_vit_forward_f16", "sc_gemm_f16", "sc_f32_to_f16",
+    "sc_clip_cluster_supported", "sc_clip_cluster_pack", "sc_clip_vit_forward_packed",
     "sc_ray_sample_forward", "sc_ray_sample_backward", "sc_ray_sample_forward_eik", "sc_ray_sample_backward_eik", "sc_render_forward", "sc_sdf_grid_forward", "sc_loss_fused_backward",
     "sc_bn_splits", "sc_bn_act_forward", "sc_bn_act_backward", "sc_bn_relu_pool_forward", "sc_bn_relu_pool_backward",
     "sc_isosurface_count", "sc_isosurface_emit", "sc_marching_cubes_count", "sc_marching_cubes_emit",
@@ -37,7 +38,7 @@ SYMBOLS = (
     "sc_rgb_composite_backward_fused_partial_floats",
 )
 # entry points that do not return an int status
-SYMBOLS_OTHER = ("sc_render_backward_workspace_bytes", "sc_chamfer3d_grid_workspace_bytes", "sc_clip_vit_workspace_bytes", "sc_conv3x3_pack_floats", "sc_conv3x3_workspace_floats", "sc_conv3x3_wgrad_workspace_floats", "sc_conv3x3_pack_floats_split", "sc_conv3x3_workspace_floats_split", "sc_conv_stem_wgrad_workspace_floats", "sc_conv1x1s2_wgrad_workspace_floats", "sc_conv3x3s2_pack_floats", "sc_conv3x3s2_workspace_floats", "sc_conv3x3s2_bd_pack_floats", "sc_conv3x3s2_bd_workspace_floats")
+SYMBOLS_OTHER = ("sc_clip_cluster_pack_elems", "sc_render_backward_workspace_bytes", "sc_chamfer3d_grid_workspace_bytes", "sc_clip_vit_workspace_bytes", "sc_conv3x3_pack_floats", "sc_conv3x3_workspace_floats", "sc_conv3x3_wgrad_workspace_floats", "sc_conv3x3_pack_floats_split", "sc_conv3x3_workspace_floats_split", "sc_conv_stem_wgrad_workspace_floats", "sc_conv1x1s2_wgrad_workspace_floats", "sc_conv3x3s2_pack_floats", "sc_conv3x3s2_workspace_floats", "sc_conv3x3s2_bd_pack_floats", "sc_conv3x3s2_bd_workspace_floats")
 
 _lib: Optional[ctypes.CDLL] = None
 

@@ -1,0 +1,591 @@
+// clip_cluster.hpp -- the transformer layers of the CLIP ViT-B image tower at SMALL batch as ONE launch (included by clip_vit.hip).
+//
+// Replaces, for B <= 64 images of T <= 64 tokens (ViT-B/32 at 224 x 224: T = 50), the 7 dependent launches per layer of clip_vit_forward
+// (LayerNorm, qkv GEMM, attention, out-projection, LayerNorm, fc1, fc2: 84 launches per tower, ~4.6 us of cold start each whatever the
+// shape, profiles/r04_clip_gaps_32_B_32.txt) behind `clip_encoder.encode_image(image)` (/root/reference/CLIP_anno.py:166).
+//
+// Decomposition BY IMAGE.  A transformer layer is row-local except attention, and attention is image-local: nothing in the tower needs a
+// chip-wide synchronisation.  An image's 50 rows (one padded 64-row MFMA band) are owned by a CLUSTER of 8 workgroups = 8 CUs of ONE XCD
+// (workgroup b is dispatched to XCD b % 8; 256 CUs = 32 clusters = 32 images in flight); member c of a cluster computes, for its image,
+//   qkv      the 192 columns (q | k | v) of head c and, for c < 4, of head c + 8     -> attention of those heads inside the same CU
+//   out-proj columns [96 c, 96 c + 96) of x +=                                        (A = the attention rows of all 8 members)
+//   fc1      columns [384 c, 384 c + 384) of quick_gelu(.)
+//   fc2      columns [96 c, 96 c + 96) of x +=                                        (A = the hidden rows of all 8 members)
+// and the members meet at FOUR cluster barriers per layer (one counter per cluster, release / acquire at agent scope: correct wherever the
+// workgroups land; the XCD placement only makes the exchanged rows L2 hits).  Every weight byte is read by exactly one member of a cluster, the
+// four clusters of an XCD walk the same weight stream (L2 hits for three of them).
+//
+// GEMM core (slice_gemm below): the activation band is SMALL (64 x 768 16-bit = 96 KB) and every wave needs all of it, the weight slice is
+// LARGE and each element is needed once -- so neither goes through LDS: the four waves split K (wave q owns K-quarter q: its 64 x 192 piece of
+// the band lives in 96 registers for the whole phase), weight fragments go global -> registers (one 16-byte load per lane and 16 x 32 fragment,
+// three 32-column chunks in flight) and feed v_mfma_f32_16x16x32 directly (W fragment as the first operand: a lane ends up with 4 consecutive
+// output columns of one row).  The four K-partials of a 64 x 32 block are added in wave order through LDS (fixed order; wave w finishes row
+// block w) and leave through the epilogue (bias, fp16 / quick_gelu / x +=).  LayerNorm is recomputed by every member straight into the
+// operand registers (row statistics exactly as layernorm_kernel: two-pass, same summation order).
+//
+// A lost workgroup (a device that cannot hold the whole grid at once) would leave the others spinning: every wait is bounded (0.2 s), the
+// first time-out raises the error word, every later wait returns at once and the images of the launch are poisoned with NaN -- loud, no hang.
+#pragma once
+
+namespace sc {
+namespace cl {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#ifndef SC_CL_ABLATE
+#define SC_CL_ABLATE 0                // experiments of tools/prof_clip_cluster.py (never set in the product build): 1 = no weight loads
+#endif
+#ifndef SC_CL_PROF
+#define SC_CL_PROF 0                  // 1 (tools/build_variants.sh clip_vit.hip SC_CL_PROF 1): workgroup 0 stamps the 100 MHz clock at every phase boundary
+#endif
+#if SC_CL_PROF
+__device__ long long g_prof[16 * 16];
+#define SC_CL_STAMP(I) if (blockIdx.x == 0 && threadIdx.x == 0 && l < 16) g_prof[l * 16 + (I)] = wall_clock64();
+#else
+#define SC_CL_STAMP(I)
+#endif
+
+constexpr int CL = 8;                 // workgroups (CUs) per image
+constexpr int CD = 768, CMLP = 3072, CHEADS = 12;
+constexpr int KQ = 192, KS = KQ / 32; // K-quarter of a 768-wide operand band per wave, 32-wide MFMA sub-steps in it
+constexpr int RED_FLOATS = 4 * 2 * 4 * 64 * 4;          // [wave][column block][row block][lane] float4 = 32 KB per buffer
+constexpr int VT_LD = 64 + 4;
+constexpr int BAND_BYTES = 64 * (CD * 2 + 16);            // LayerNorm operand band (97 KB); the two K-partial buffers (64 KB) alias its start
+constexpr int LDS_BYTES = BAND_BYTES + 2 * 64 * VT_LD * 2 + 384 * 4;      // 97 KB + 17 KB + 1.5 KB: one workgroup per CU
+constexpr long long SPIN_TICKS = 20000000LL;             // 0.2 s of the 100 MHz wall clock
+
+template <bool H>
+__device__ __forceinline__ f32x4 mma(const uint4& w, const uint4& a, const f32x4& c) {
+    if (H) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
+}
+template <bool H>
+__device__ __forceinline__ uint32_t pk2(float lo, float hi) { return (uint32_t)cvt16<H>(lo) | ((uint32_t)cvt16<H>(hi) << 16); }
+
+struct WChunk { uint4 v[2][KS]; };          // 32 weight rows (two 16-row MFMA blocks) x this wave's K-quarter
+
+// The fp32 vectors of one layer inside the tower's weight image (clip_vit_forward: same order)
+struct Layer { const float *ln1_g, *ln1_b, *b_qkv, *b_o, *ln2_g, *ln2_b, *b_fc1, *b_fc2; };
+__device__ __forceinline__ Layer layer_at(const float* wf, int l) {
+    Layer L;
+    wf += (size_t)l * (9 * CD + CMLP);
+    L.ln1_g = wf; L.ln1_b = wf + CD; L.b_qkv = wf + 2 * CD; L.b_o = wf + 5 * CD; L.ln2_g = wf + 6 * CD; L.ln2_b = wf + 7 * CD;
+    L.b_fc1 = wf + 8 * CD; L.b_fc2 = wf + 8 * CD + CMLP;
+    return L;
+}
+
+// The weight stream of a member: per layer n1 = 6 (one head) or 12 (two heads) chunks of qkv, 3 of the out-projection, 12 of fc1, 12 of fc2
+// (4 K-passes x 3 column pairs), the layers one after the other.  A chunk = 32 weight rows x one 768-wide K band; wave q needs its K-quarter
+// of it as 12 MFMA fragments (2 row blocks x 6 sub-steps; lane = 16 (k / 8 % 4) + row % 16 holds 8 consecutive k of one row).  Read from the
+// row-major matrices that is 64 scattered 16-byte accesses per wave instruction (every lane another row, 1.5 KB apart): measured 1.5 us per
+// chunk step, 30 GB/s per CU.  The layers are therefore RE-PACKED once per model (sc_clip_cluster_pack) in consumption order
+//     [layer][member][chunk][wave q][row block][sub-step][lane][8 values]
+// so that a fragment is one contiguous KB, a wave's chunk 12 consecutive KB and a member's layer one contiguous stream.
+constexpr int FRAG_ELEMS = 512, WAVE_CHUNK_ELEMS = 12 * FRAG_ELEMS, CHUNK_ELEMS = 4 * WAVE_CHUNK_ELEMS;     // 1 KB, 12 KB, 48 KB
+constexpr int LAYER_CHUNKS = 288;                                  // 12 * 768 * 768 values = 4 x 39 + 4 x 33 chunks
+constexpr size_t LAYER_ELEMS = (size_t)LAYER_CHUNKS * CHUNK_ELEMS;
+__host__ __device__ __forceinline__ int member_chunks(int c) { return (c + 8 < CHEADS ? 12 : 6) + 27; }
+__host__ __device__ __forceinline__ int member_first_chunk(int c) { return c <= 4 ? 39 * c : 156 + 33 * (c - 4); }
+// source of chunk `idx` of member c: matrix offset inside the layer (row-major image of clip_vit_forward), first row, row pitch, K offset
+__host__ __device__ __forceinline__ void chunk_source(int c, int idx, size_t& mat, int& n0, int& ld, int& koff) {
+    const int n1 = c + 8 < CHEADS ? 12 : 6;
+    koff = 0;
+    if (idx < n1) {
+        const int hs = idx >= 6, j = idx - 6 * hs, head = hs ? c + 8 : c;
+        mat = 0; n0 = (j >> 1) * CD + head * 64 + (j & 1) * 32; ld = CD;
+    } else if (idx < n1 + 3) {
+        mat = (size_t)3 * CD * CD; n0 = 96 * c + 32 * (idx - n1); ld = CD;
+    } else if (idx < n1 + 15) {
+        mat = (size_t)4 * CD * CD; n0 = 384 * c + 32 * (idx - n1 - 3); ld = CD;
+    } else {
+        const int j = idx - n1 - 15, pass = j / 3, pair = j - 3 * pass;
+        mat = (size_t)4 * CD * CD + (size_t)CMLP * CD; n0 = 96 * c + 32 * pair; ld = CMLP; koff = pass * CD;
+    }
+}
+// one thread per 16-byte piece of the packed image
+__global__ __launch_bounds__(256) void cluster_pack_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ out, int layers) {
+    const size_t pieces = (size_t)layers * LAYER_ELEMS / 8;
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < pieces; p += (size_t)gridDim.x * 256) {
+        const int lane = (int)(p & 63);
+        size_t r = p >> 6;
+        const int s = (int)(r % 6); r /= 6;
+        const int cb = (int)(r & 1); r >>= 1;
+        const int kq = (int)(r & 3); r >>= 2;
+        const int chunk = (int)(r % LAYER_CHUNKS), l = (int)(r / LAYER_CHUNKS);
+        int c = 0;
+        while (c < 7 && chunk >= member_first_chunk(c + 1)) ++c;
+        size_t mat; int n0, ld, koff;
+        chunk_source(c, chunk - member_first_chunk(c), mat, n0, ld, koff);
+        const bf16_t* src = w + (size_t)l * (12 * CD * CD) + mat + (size_t)(n0 + 16 * cb + (lane & 15)) * ld + koff + kq * KQ + 32 * s + 8 * (lane >> 4);
+        reinterpret_cast<uint4*>(out)[p] = *reinterpret_cast<const uint4*>(src);
+    }
+}
+
+struct Stream {
+    const bf16_t* wc; int layers, first, per, kq, lane;
+    __device__ __forceinline__ void load(WChunk& q, int l, int idx) const {
+        if (SC_CL_ABLATE & 1) { if (l >= 0) return; }             // experiment: no weight loads (the registers keep what they held)
+        if (idx >= per) { idx -= per; ++l; }
+        if (l >= layers) { l = layers - 1; idx = per - 1; }          // past the end: a valid chunk again (never consumed) -- the prefetch
+                                                                     // stays unconditional, so the memory counter arithmetic never forks
+        const uint4* p = reinterpret_cast<const uint4*>(wc + (size_t)l * LAYER_ELEMS + (size_t)(first + idx) * CHUNK_ELEMS + kq * WAVE_CHUNK_ELEMS) + lane;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) q.v[cb][s] = p[(cb * KS + s) * 64];
+    }
+};
+
+template <bool H16>
+__device__ __forceinline__ void mma_chunk(f32x4 (&acc)[2][4], const WChunk& q, const uint4 (&act)[4][KS]) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) acc[cb][rb] = mma<H16>(q.v[cb][s], act[rb][s], acc[cb][rb]);
+}
+
+// K-partials of a 64 x 32 block: every wave parks its four row blocks (lane-linear float4: conflict-free), the barrier, wave w adds row
+// block w in wave order.  (Branch-free on purpose: keeping the wave's own partial in registers cost a branch per row block.)
+__device__ __forceinline__ void put_partials(float* red, const f32x4 (&acc)[2][4], int wave, int lane) {
+    f32x4* dst = reinterpret_cast<f32x4*>(red) + wave * 8 * 64 + lane;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) dst[(cb * 4 + rb) * 64] = acc[cb][rb];
+}
+__device__ __forceinline__ void get_sums(const float* red, int wave, int lane, f32x4 (&out)[2]) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(red) + wave * 64 + lane;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        f32x4 t = src[(0 * 8 + cb * 4) * 64];
+#pragma unroll
+        for (int p = 1; p < 4; ++p) t = t + src[(p * 8 + cb * 4) * 64];
+        out[cb] = t;
+    }
+}
+
+// LayerNorm of the image's T rows -> the 16-bit operand band in LDS (row pitch BAND_PITCH bytes).  layernorm_kernel's arithmetic and
+// summation order exactly (a row in the registers of one wave: three float4 per lane, mean first, then the centred squares, butterfly sums).
+// Wave w takes rows w, w + 4, ..., seven at a time: their loads leave in one round trip.  (First form of this phase: every wave normalised
+// its own MFMA-layout piece of x straight into the operand registers -- 48 float4 loads per lane with their arithmetic on 96 + 96 registers;
+// under that pressure the compiler issued the loads two at a time, ~24 dependent round trips per LayerNorm.)
+constexpr int BAND_PITCH = CD * 2 + 16;
+template <bool H16>
+__device__ __forceinline__ void ln_to_band(char* band, const float* xi, int T, float eps, const float* g, const float* b, int wave, int lane) {
+    constexpr int RB = 7;
+    float4 gg[3], bb[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        gg[k] = reinterpret_cast<const float4*>(g)[k * 64 + lane];
+        bb[k] = reinterpret_cast<const float4*>(b)[k * 64 + lane];
+    }
+    for (int r0 = wave; r0 < T; r0 += 4 * RB) {
+        float4 v[RB][3];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const float4* xr = reinterpret_cast<const float4*>(xi + (size_t)min(r0 + 4 * i, T - 1) * CD);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[i][k] = (SC_CL_ABLATE & 4) ? make_float4(lane, i, k, 1.f) : xr[k * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // the seven rows side by side: their butterflies are independent chains (one row after the other, the 2 x 6 dependent cross-lane
+        // steps per row -- 13 rows per wave -- were most of this phase: 9.7 us)
+        float sm[RB], ss[RB];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            sm[i] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) sm[i] += (v[i][k].x + v[i][k].y) + (v[i][k].z + v[i][k].w);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1)
+#pragma unroll
+            for (int i = 0; i < RB; ++i) sm[i] += (SC_CL_ABLATE & 2) ? sm[i] : __shfl_xor(sm[i], o);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const float mean = sm[i] / CD;
+            ss[i] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                v[i][k].x -= mean; v[i][k].y -= mean; v[i][k].z -= mean; v[i][k].w -= mean;
+                ss[i] += (v[i][k].x * v[i][k].x + v[i][k].y * v[i][k].y) + (v[i][k].z * v[i][k].z + v[i][k].w * v[i][k].w);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1)
+#pragma unroll
+            for (int i = 0; i < RB; ++i) ss[i] += (SC_CL_ABLATE & 2) ? ss[i] : __shfl_xor(ss[i], o);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const float inv = rsqrtf(ss[i] / CD + eps);
+            const int row = r0 + 4 * i;
+            if (row < T && !((SC_CL_ABLATE & 8) && lane != 0)) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float o0 = v[i][k].x * inv * gg[k].x + bb[k].x, o1 = v[i][k].y * inv * gg[k].y + bb[k].y;
+                    const float o2 = v[i][k].z * inv * gg[k].z + bb[k].z, o3 = v[i][k].w * inv * gg[k].w + bb[k].w;
+                    *reinterpret_cast<uint2*>(band + row * BAND_PITCH + (k * 64 + lane) * 8) = make_uint2(pk2<H16>(o0, o1), pk2<H16>(o2, o3));
+                }
+            }
+        }
+    }
+}
+// Operand registers of this wave = its K-quarter of the band: rows 16 rb + (lane & 15), 8 consecutive K values per lane and sub-step.  Rows
+// past T - 1 hold whatever the LDS held: their products are never stored and never enter another row's result.
+__device__ __forceinline__ void act_from_band(uint4 (&act)[4][KS], const char* band, int kq, int lane) {
+    const char* p = band + (lane & 15) * BAND_PITCH + (kq * KQ + 8 * (lane >> 4)) * 2;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) act[rb][s] = *reinterpret_cast<const uint4*>(p + rb * 16 * BAND_PITCH + 64 * s);
+}
+// ... = 16-bit rows src[row][koff + ...] (row pitch ld); rows past T - 1 repeat row T - 1
+__device__ __forceinline__ void act_from_rows(uint4 (&act)[4][KS], const bf16_t* src, int ld, int koff, int T, int kq, int lane) {
+    const int m16 = lane & 15, k8 = koff + kq * KQ + 8 * (lane >> 4);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+        const bf16_t* p = src + (size_t)min(16 * rb + m16, T - 1) * ld + k8;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) act[rb][s] = *reinterpret_cast<const uint4*>(p + 32 * s);
+    }
+}
+
+// Bounded wait of a cluster: all CL members have arrived `target / CL` times.  Thread 0 publishes and acquires for the workgroup; the two
+// workgroup barriers order the other waves' accesses around it (their stores are acknowledged by L2 before the first: s_waitcnt vmcnt(0)).
+//   local = false  release / acquire fences at agent scope (L2 write-back + invalidate: buffer_wbl2 sc1 / buffer_inv sc1) -- correct wherever
+//                  the members run; measured ~4 us per barrier inside this kernel
+//   local = true   the members share one XCD, i.e. one L2 (checked at kernel start from the hardware XCC id): what a member wrote is in that
+//                  L2 once its stores are acknowledged, so publishing is the counter increment alone and acquiring is the invalidation of
+//                  this CU's vector L1 (buffer_inv sc0: the workgroup-scope invalidate of the threadgroup-split memory model)
+#ifndef SC_CL_BARRIER
+#define SC_CL_BARRIER 1               // 0: never take the local form (A/B)
+#endif
+__device__ __forceinline__ void cluster_barrier(unsigned* cnt, unsigned target, unsigned* err, bool local) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (!local) __threadfence();
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long t0 = wall_clock64();
+        int spins = 0;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 63) == 0) {
+                if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                if (wall_clock64() - t0 > SPIN_TICKS) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+        if (local) asm volatile("buffer_inv sc0" ::: "memory");
+        else __threadfence();
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ unsigned xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 15u;
+}
+
+// Attention of one (image, head) by the two waves of a pair -- attention_small_kernel's arithmetic (one pass, both 32-key score tiles in
+// registers, V^T in LDS).  `active` = false: the pair only keeps the workgroup barrier company.
+template <bool H16>
+__device__ __forceinline__ void attention_pair(const bf16_t* qkv_i, bf16_t* att_i, int T, int hd, bool active, bf16_t* Vt, int ptid) {
+    constexpr int D = CD, ldv = VT_LD;
+    const size_t rs = (size_t)3 * D;
+    const bf16_t* base = qkv_i + (size_t)hd * 64;
+    const int lane = ptid & 63, pw = ptid >> 6, n = lane & 31, h = lane >> 5;
+    auto frag = [&](int row, int col_off) -> bf16x8 {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (active && row < T) v = *reinterpret_cast<const uint4*>(base + (size_t)row * rs + col_off + 8 * h);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    const int q = pw * 32 + n;
+    bf16x8 qf[4], kf[2][4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        qf[s4] = frag(q, 16 * s4);
+        kf[0][s4] = frag(n, D + 16 * s4);
+        kf[1][s4] = frag(32 + n, D + 16 * s4);
+    }
+    if (active)
+        for (int e = ptid; e < 64 * 8; e += 128) {
+            const int key = e >> 3, dc = (e & 7) * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (key < T) v = *reinterpret_cast<const uint4*>(base + (size_t)key * rs + 2 * D + dc);
+            const bf16_t* pv = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) Vt[(dc + j) * ldv + key] = pv[j];
+        }
+    const float NEG = -3.0e38f, scale = 0.125f;
+    float v[2][16];
+    float m = NEG;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) S = mfma16<H16>(kf[c][s4], qf[s4], S);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = 32 * c + (r & 3) + 8 * (r >> 2) + 4 * h;
+            v[c][r] = key < T ? S[r] * scale : NEG;
+            m = fmaxf(m, v[c][r]);
+        }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            v[c][r] = v[c][r] > NEG ? __expf(v[c][r] - m) : 0.f;
+            l += v[c][r];
+        }
+    l += __shfl_xor(l, 32);
+    const float inv = 1.f / l;
+    __syncthreads();                                   // both V^T images are complete
+    if (!active) return;
+    f32x16 O[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[t][r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bf16_t tmp[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tmp[e] = cvt16<H16>(v[c][8 * j + e] * inv);
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, tmp);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const bf16_t* vp = Vt + (32 * t + n) * ldv + 32 * c + 16 * j + 4 * h;
+                const uint2 lo = *reinterpret_cast<const uint2*>(vp), hi = *reinterpret_cast<const uint2*>(vp + 8);
+                const uint4 pk = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                O[t] = mfma16<H16>(__builtin_bit_cast(bf16x8, pk), pf, O[t]);
+            }
+        }
+    if (q < T) {
+        bf16_t* orow = att_i + (size_t)q * D + hd * 64 + 4 * h;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                *reinterpret_cast<uint2*>(orow + 32 * t + 8 * r4) =
+                    make_uint2(pk2<H16>(O[t][4 * r4], O[t][4 * r4 + 1]), pk2<H16>(O[t][4 * r4 + 2], O[t][4 * r4 + 3]));
+    }
+}
+
+enum { E_QKV = 0, E_RESID = 1, E_GELU = 2 };
+
+// Epilogue of a 64 x 32 block [rows of this image] x [n0, n0 + 32): wave w owns rows 16 w + (lane & 15), a lane 4 consecutive columns per
+// column block.  It issues NO vector-memory load: the memory counter retires in issue order, so a load issued behind the weight prefetch makes
+// its wait drain the whole ring (the first builds did exactly that -- the compiler sinks such loads to their use).  The phase's bias slice is
+// staged in LDS when the phase starts (`bias_l`: chunk ci at floats [32 ci, 32 ci + 32)), the residual values of x += are requested with
+// the phase's operand loads.
+template <bool H16, int EPI>
+__device__ __forceinline__ void epilogue(const f32x4 (&sum)[2], const float* bias_l, const float4 (&res)[2], int n0, void* out_i, int ldo,
+                                         int T, int wave, int lane) {
+    const int row = 16 * wave + (lane & 15);
+    float4 bv[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) bv[cb] = *reinterpret_cast<const float4*>(bias_l + 16 * cb + 4 * (lane >> 4));
+    if (row >= T) return;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const unsigned n = (unsigned)(n0 + 16 * cb + 4 * (lane >> 4)), o = (unsigned)row * (unsigned)ldo + n;
+        float v0 = sum[cb][0] + bv[cb].x, v1 = sum[cb][1] + bv[cb].y, v2 = sum[cb][2] + bv[cb].z, v3 = sum[cb][3] + bv[cb].w;
+        if (EPI == E_RESID) {
+            *reinterpret_cast<float4*>(reinterpret_cast<char*>(out_i) + o * 4u) =
+                make_float4(v0 + res[cb].x, v1 + res[cb].y, v2 + res[cb].z, v3 + res[cb].w);
+        } else {
+            if (EPI == E_GELU) {
+                v0 = v0 / (1.f + __expf(-1.702f * v0)); v1 = v1 / (1.f + __expf(-1.702f * v1));
+                v2 = v2 / (1.f + __expf(-1.702f * v2)); v3 = v3 / (1.f + __expf(-1.702f * v3));
+            }
+            *reinterpret_cast<uint2*>(reinterpret_cast<char*>(out_i) + o * 2u) = make_uint2(pk2<H16>(v0, v1), pk2<H16>(v2, v3));
+        }
+    }
+}
+// this lane's residual values of the member's 96 columns of x (three chunks): only this member ever writes them
+__device__ __forceinline__ void resid_request(float4 (&res)[3][2], const float* xi, int c, int T, int wave, int lane) {
+    const unsigned row = (unsigned)min(16 * wave + (lane & 15), T - 1);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+            res[p][cb] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(xi) +
+                                                          (row * (unsigned)CD + (unsigned)(96 * c + 32 * p + 16 * cb + 4 * (lane >> 4))) * 4u);
+}
+
+// One chunk of a single-pass phase: the ring two chunks ahead, 48 MFMAs, add the K-partials, epilogue
+#define SC_CL_STEP(CUR, NXT, CI, N0, EPI, RES, OUT, LDO)                                        \
+    {                                                                                          \
+        st.load(NXT, l, gbase + (CI) + 2);                                                     \
+        f32x4 acc[2][4];                                                                       \
+        _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) _Pragma("unroll") for (int rb = 0; rb < 4; ++rb) acc[cb][rb] = f32x4{0.f, 0.f, 0.f, 0.f}; \
+        mma_chunk<H16>(acc, CUR, act);                                                         \
+        float* rbuf = red + ((CI) & 1) * RED_FLOATS;                                           \
+        f32x4 sum[2];                                                                          \
+        put_partials(rbuf, acc, wave, lane);                                                   \
+        __syncthreads();                                                                       \
+        get_sums(rbuf, wave, lane, sum);                                                       \
+        epilogue<H16, EPI>(sum, bias_l + 32 * (CI), RES, N0, OUT, LDO, T, wave, lane);         \
+    }
+
+template <bool H16>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void clip_layers_cluster_kernel(
+    float* x, bf16_t* qkv, bf16_t* att, bf16_t* hbuf, const bf16_t* __restrict__ wc, const float* __restrict__ wf, int layers, int img0, int B,
+    int T, float eps, unsigned* sync) {
+    extern __shared__ float lds_f[];
+    float* red = lds_f;
+    char* band = reinterpret_cast<char*>(lds_f);
+    bf16_t* Vt = reinterpret_cast<bf16_t*>(band + BAND_BYTES);
+    float* bias_l = reinterpret_cast<float*>(Vt + 2 * 64 * VT_LD);      // 384 floats: the running phase's bias slice, chunk-major
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x, xcd = b & 7, r8 = b >> 3, c = r8 & 7, grp = r8 >> 3;
+    const int slot = grp * 8 + xcd, img = img0 + slot;
+    if (img >= B) return;                                  // the whole cluster leaves
+    unsigned* cnt = sync + 32 * (1 + slot);                // one 128-byte line per cluster; sync[0] = error word
+    unsigned* err = sync;
+    unsigned arrivals = 0;
+    float* xi = x + (size_t)img * T * CD;
+    bf16_t* qkv_i = qkv + (size_t)img * T * 3 * CD;
+    bf16_t* att_i = att + (size_t)img * T * CD;
+    bf16_t* h_i = hbuf + (size_t)img * T * CMLP;
+    const int nh = c + 8 < CHEADS ? 2 : 1, n1 = 6 * nh;
+    const float4 no_res[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+
+    // do the members of this cluster share an XCD?  (every member sets the bit of its XCC id; one agent-scope barrier; one bit = yes)
+    if (tid == 0) __hip_atomic_fetch_or(cnt + 1, 1u << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    arrivals += CL;
+    cluster_barrier(cnt, arrivals, err, false);
+    const bool local = SC_CL_BARRIER != 0 && __popc(__hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 1;
+
+    Stream st{wc, layers, member_first_chunk(c), n1 + 27, wave, lane};
+    WChunk q0, q1, q2;
+    st.load(q0, 0, 0);
+    st.load(q1, 0, 1);
+    uint4 act[4][KS];
+    float4 res[3][2];
+    for (int l = 0; l < layers; ++l) {
+        const Layer L = layer_at(wf, l);
+        SC_CL_STAMP(0)
+#define SC_CL_QKV_N0(CI) ((((CI) % 6) >> 1) * CD + ((CI) >= 6 ? c + 8 : c) * 64 + (((CI) % 6) & 1) * 32)
+        // ---- ln_1 -> q | k | v of this member's heads -------------------------------------------------------------------------------
+        if (tid < n1 * 8) reinterpret_cast<float4*>(bias_l)[tid] = *reinterpret_cast<const float4*>(L.b_qkv + SC_CL_QKV_N0(tid >> 3) + 4 * (tid & 7));
+        ln_to_band<H16>(band, xi, T, eps, L.ln1_g, L.ln1_b, wave, lane);
+        __syncthreads();
+        act_from_band(act, band, wave, lane);
+        __syncthreads();                                   // the K-partial buffers alias the band
+        SC_CL_STAMP(1)
+        int gbase = 0;
+        for (int ci = 0; ci < n1; ci += 3) {
+            SC_CL_STEP(q0, q2, ci, SC_CL_QKV_N0(ci), E_QKV, no_res, qkv_i, 3 * CD)
+            SC_CL_STEP(q1, q0, ci + 1, SC_CL_QKV_N0(ci + 1), E_QKV, no_res, qkv_i, 3 * CD)
+            SC_CL_STEP(q2, q1, ci + 2, SC_CL_QKV_N0(ci + 2), E_QKV, no_res, qkv_i, 3 * CD)
+        }
+#undef SC_CL_QKV_N0
+        __syncthreads();                                   // this member's q | k | v rows are in memory for all four waves
+        SC_CL_STAMP(2)
+        // ---- attention of those heads (waves 0, 1: head c; waves 2, 3: head c + 8) ---------------------------------------------------
+        attention_pair<H16>(qkv_i, att_i, T, wave < 2 ? c : c + 8, wave < 2 || nh == 2, Vt + (wave >> 1) * 64 * VT_LD, tid & 127);
+        if (tid < 24) reinterpret_cast<float4*>(bias_l)[tid] = *reinterpret_cast<const float4*>(L.b_o + 96 * c + 4 * tid);
+        resid_request(res, xi, c, T, wave, lane);
+        SC_CL_STAMP(3)
+        arrivals += CL;
+        cluster_barrier(cnt, arrivals, err, local);
+        SC_CL_STAMP(4)
+        // ---- x += out-projection ---------------------------------------------------------------------------------------------------
+        act_from_rows(act, att_i, CD, 0, T, wave, lane);
+        gbase = n1;
+        SC_CL_STEP(q0, q2, 0, 96 * c, E_RESID, res[0], xi, CD)
+        SC_CL_STEP(q1, q0, 1, 96 * c + 32, E_RESID, res[1], xi, CD)
+        SC_CL_STEP(q2, q1, 2, 96 * c + 64, E_RESID, res[2], xi, CD)
+        SC_CL_STAMP(5)
+        arrivals += CL;
+        cluster_barrier(cnt, arrivals, err, local);
+        SC_CL_STAMP(6)
+        // ---- ln_2 -> quick_gelu(fc1) -------------------------------------------------------------------------------------------------
+        if (tid < 96) reinterpret_cast<float4*>(bias_l)[tid] = *reinterpret_cast<const float4*>(L.b_fc1 + 384 * c + 4 * tid);
+        ln_to_band<H16>(band, xi, T, eps, L.ln2_g, L.ln2_b, wave, lane);
+        __syncthreads();
+        act_from_band(act, band, wave, lane);
+        __syncthreads();
+        SC_CL_STAMP(7)
+        gbase = n1 + 3;
+        for (int ci = 0; ci < 12; ci += 3) {
+            SC_CL_STEP(q0, q2, ci, 384 * c + 32 * ci, E_GELU, no_res, h_i, CMLP)
+            SC_CL_STEP(q1, q0, ci + 1, 384 * c + 32 * (ci + 1), E_GELU, no_res, h_i, CMLP)
+            SC_CL_STEP(q2, q1, ci + 2, 384 * c + 32 * (ci + 2), E_GELU, no_res, h_i, CMLP)
+        }
+        SC_CL_STAMP(8)
+        arrivals += CL;
+        cluster_barrier(cnt, arrivals, err, local);
+        SC_CL_STAMP(9)
+        // ---- x += fc2: four K-passes of 768 over the hidden rows, the three column pairs accumulate across the passes -----------------
+        if (tid < 24) reinterpret_cast<float4*>(bias_l)[tid] = *reinterpret_cast<const float4*>(L.b_fc2 + 96 * c + 4 * tid);
+        resid_request(res, xi, c, T, wave, lane);
+        gbase = n1 + 15;
+        {
+            f32x4 acc2[3][2][4];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb) acc2[p][cb][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int pass = 0; pass < 4; ++pass) {
+                act_from_rows(act, h_i, CMLP, pass * CD, T, wave, lane);
+                st.load(q2, l, gbase + 3 * pass + 2);
+                mma_chunk<H16>(acc2[0], q0, act);
+                st.load(q0, l, gbase + 3 * pass + 3);
+                mma_chunk<H16>(acc2[1], q1, act);
+                st.load(q1, l, gbase + 3 * pass + 4);
+                mma_chunk<H16>(acc2[2], q2, act);
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                float* rbuf = red + (p & 1) * RED_FLOATS;
+                f32x4 sum[2];
+                put_partials(rbuf, acc2[p], wave, lane);
+                __syncthreads();
+                get_sums(rbuf, wave, lane, sum);
+                epilogue<H16, E_RESID>(sum, bias_l + 32 * p, res[p], 96 * c + 32 * p, xi, CD, T, wave, lane);
+            }
+        }
+        SC_CL_STAMP(10)
+        arrivals += CL;
+        cluster_barrier(cnt, arrivals, err, local);
+        SC_CL_STAMP(11)
+    }
+    // a time-out anywhere in the launch: poison this image's class-token row (ln_post reads it), the caller sees NaN
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u && c == 0)
+        for (int d = tid; d < CD; d += 256) xi[d] = __builtin_nanf("");
+}
+#undef SC_CL_STEP
+
+static int launch_cluster_pack(const bf16_t* w, bf16_t* out, int layers, hipStream_t st) {
+    hipLaunchKernelGGL(cluster_pack_kernel, dim3(4096), dim3(256), 0, st, w, out, layers);
+    return (int)hipGetLastError();
+}
+
+// grid of one launch: 64 workgroups per 8 images (workgroup b -> XCD b % 8, member (b / 8) % 8, image group b / 64)
+template <bool H16>
+static int launch_layers_cluster(float* x, bf16_t* qkv, bf16_t* att, bf16_t* hbuf, const bf16_t* wc, const float* wf, int layers, int B, int T,
+                                 float eps, unsigned* sync, hipStream_t st) {
+    (void)hipFuncSetAttribute((const void*)clip_layers_cluster_kernel<H16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    for (int img0 = 0; img0 < B; img0 += 32) {
+        const int nb = B - img0 < 32 ? B - img0 : 32;
+        if (hipMemsetAsync(sync, 0, 33 * 128, st) != hipSuccess) return (int)hipGetLastError();
+        hipLaunchKernelGGL(clip_layers_cluster_kernel<H16>, dim3(64 * ((nb + 7) / 8)), dim3(256), LDS_BYTES, st, x, qkv, att, hbuf, wc, wf, layers,
+                           img0, B, T, eps, sync);
+    }
+    return (int)hipGetLastError();
+}
+
+}  // namespace cl
+}  // namespace sc

@@ -1029,6 +1029,10 @@ __global__ __launch_bounds__(128) void attention_small_kernel(const bf16_t* __re
     }
 }
 
+}  // namespace sc
+#include "clip_cluster.hpp"
+namespace sc {
+
 template <bool H16>
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = cvt16<H16>(x[i]);
@@ -1202,7 +1206,7 @@ static int launch_gemm(int epi, const bf16_t* A, const bf16_t* Wt, const float* 
 // Full image tower (H16: fp16 instead of bf16 operands).  See include/shapeclipper_hip.h for the weight image layout.
 template <bool H16>
 static int clip_vit_forward(const float* image, int B, int C, int H, int W, int patch, int D, int mlp, int layers, int heads,
-                            int proj_dim, const uint16_t* w_bf16, const float* w_f32, float ln_eps, float* out,
+                            int proj_dim, const uint16_t* w_bf16, const float* w_f32, const uint16_t* w_cluster, float ln_eps, float* out,
                             void* workspace, long long workspace_bytes, void* stream_) {
     hipStream_t st = (hipStream_t)stream_;
     if (D % 64 || D / heads != 64 || mlp % 64) return (int)hipErrorInvalidValue;
@@ -1220,6 +1224,7 @@ static int clip_vit_forward(const float* image, int B, int C, int H, int W, int 
     bf16_t* att = (bf16_t*)carve((size_t)M * D * 2);
     bf16_t* hbuf = (bf16_t*)carve((size_t)M * mlp * 2);
     bf16_t* pooled = (bf16_t*)carve((size_t)B * D * 2);
+    unsigned* cl_sync = (unsigned*)carve(33 * 128);       // clip_cluster.hpp: error word + one counter line per cluster
     if ((long long)off > workspace_bytes) return (int)hipErrorInvalidValue;
     // weight images: bf16 matrices then fp32 vectors, in this fixed order
     const bf16_t* wb = w_bf16;
@@ -1242,7 +1247,21 @@ static int clip_vit_forward(const float* image, int B, int C, int H, int W, int 
     if (rc) return rc;
     hipLaunchKernelGGL(embed_kernel, dim3(1024), dim3(256), 0, st, patch_out, cls, pos, x, B, T, D);
     hipLaunchKernelGGL((layernorm_kernel<false, H16>), dim3((M + 3) / 4), dim3(256), 0, st, x, D, lnpre_g, lnpre_b, (void*)x, M, D, ln_eps);
-    for (int l = 0; l < layers; ++l) {
+    // Small batch of the ViT-B geometry: all layers in one launch, an image per cluster of 8 CUs (clip_cluster.hpp)
+    static const int cl_max_b = [] { const char* e = getenv("SC_CLIP_CLUSTER_MAX_B"); return e ? atoi(e) : 0; }();   // 0 while the cluster form is slower than the launches (profiles/r05_clip_cluster_*)
+    int layers_left = layers;
+    if (w_cluster != nullptr && D == cl::CD && mlp == cl::CMLP && heads == cl::CHEADS && T <= 64 && B <= cl_max_b) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return (int)hipGetLastError();
+        if (cus >= 256) {                                   // 32 clusters resident at once: one workgroup per CU
+            if ((rc = cl::launch_layers_cluster<H16>(x, qkv, att, hbuf, w_cluster, wf, layers, B, T, ln_eps, cl_sync, st))) return rc;
+            wb += (size_t)layers * 12 * D * D;
+            wf += (size_t)layers * (9 * D + mlp);
+            layers_left = 0;
+        }
+    }
+    for (int l = 0; l < layers_left; ++l) {
         const bf16_t* w_qkv = wb; wb += (size_t)3 * D * D;
         const bf16_t* w_o = wb; wb += (size_t)D * D;
         const bf16_t* w_fc1 = wb; wb += (size_t)mlp * D;
@@ -1302,12 +1321,19 @@ int sc_gemm_f16(int epi, const uint16_t* A, const uint16_t* Wt, const float* bia
     return sc::launch_gemm<true>(epi, A, Wt, bias, out, M, N, K, (hipStream_t)stream_);
 }
 
+#if SC_CL_PROF
+// profiling build only: the phase stamps of workgroup 0 (12 per layer, 16 layers x 16 slots of 100 MHz ticks)
+int sc_clip_cluster_prof_read(long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sc::cl::g_prof), sizeof(long long) * 256);
+}
+#endif
+
 // Bytes of device workspace sc_clip_vit_forward carves for this geometry (same carve order and 256-byte alignment).
 long long sc_clip_vit_workspace_bytes(int B, int C, int H, int W, int patch, int D, int mlp) {
     const long long np = (long long)(H / patch) * (W / patch), T = np + 1, M = (long long)B * T;
     const long long Kp = ((long long)C * patch * patch + 63) & ~63LL;
-    const long long sizes[8] = {B * np * Kp * 2, B * np * D * 4, M * D * 4, M * D * 2, M * 3 * D * 2, M * D * 2, M * mlp * 2,
-                                (long long)B * D * 2};
+    const long long sizes[9] = {B * np * Kp * 2, B * np * D * 4, M * D * 4, M * D * 2, M * 3 * D * 2, M * D * 2, M * mlp * 2,
+                                (long long)B * D * 2, 33 * 128};
     long long total = 0;
     for (long long s : sizes) total += (s + 255) & ~255LL;
     return total;
@@ -1317,7 +1343,7 @@ long long sc_clip_vit_workspace_bytes(int B, int C, int H, int W, int patch, int
 int sc_clip_vit_forward(const float* image, int B, int C, int H, int W, int patch, int D, int mlp, int layers, int heads,
                         int proj_dim, const uint16_t* w_bf16, const float* w_f32, float ln_eps, float* out,
                         void* workspace, long long workspace_bytes, void* stream_) {
-    return sc::clip_vit_forward<false>(image, B, C, H, W, patch, D, mlp, layers, heads, proj_dim, w_bf16, w_f32, ln_eps, out, workspace,
+    return sc::clip_vit_forward<false>(image, B, C, H, W, patch, D, mlp, layers, heads, proj_dim, w_bf16, w_f32, nullptr, ln_eps, out, workspace,
                                        workspace_bytes, stream_);
 }
 // The same tower with IEEE fp16 operands (`w_f16`: the 16-bit weight image as fp16 bit patterns, same order) -- the arithmetic
@@ -1325,8 +1351,33 @@ int sc_clip_vit_forward(const float* image, int B, int C, int H, int W, int patc
 int sc_clip_vit_forward_f16(const float* image, int B, int C, int H, int W, int patch, int D, int mlp, int layers, int heads,
                             int proj_dim, const uint16_t* w_f16, const float* w_f32, float ln_eps, float* out,
                             void* workspace, long long workspace_bytes, void* stream_) {
-    return sc::clip_vit_forward<true>(image, B, C, H, W, patch, D, mlp, layers, heads, proj_dim, w_f16, w_f32, ln_eps, out, workspace,
+    return sc::clip_vit_forward<true>(image, B, C, H, W, patch, D, mlp, layers, heads, proj_dim, w_f16, w_f32, nullptr, ln_eps, out, workspace,
                                       workspace_bytes, stream_);
+}
+
+
+// ---- small-batch form of the ViT-B layers (clip_cluster.hpp): one launch for all layers, an image per cluster of 8 CUs ----------------
+// 1 if the cluster form takes this geometry (width 768, MLP 3072, 12 heads, at most 64 tokens per image), else 0
+int sc_clip_cluster_supported(int D, int mlp, int heads, int tokens) {
+    return D == sc::cl::CD && mlp == sc::cl::CMLP && heads == sc::cl::CHEADS && tokens >= 1 && tokens <= 64 ? 1 : 0;
+}
+// 16-bit values of the re-packed layer image: layers x 12 x 768 x 768 (the same values as the row-major layer matrices, other order)
+long long sc_clip_cluster_pack_elems(int layers) { return (long long)layers * (long long)sc::cl::LAYER_ELEMS; }
+// w16: the tower's 16-bit weight image (layout of sc_clip_vit_forward); Kp = patch-embedding K padded to 64 (the layers start at D * Kp)
+int sc_clip_cluster_pack(const uint16_t* w16, int Kp, int layers, uint16_t* out, void* stream_) {
+    if (layers <= 0 || Kp <= 0) return (int)hipErrorInvalidValue;
+    return sc::cl::launch_cluster_pack(w16 + (size_t)sc::cl::CD * Kp, out, layers, (hipStream_t)stream_);
+}
+// sc_clip_vit_forward / _f16 with the re-packed layer image beside the row-major one (`fp16` != 0: IEEE fp16 operands, else bf16): batches
+// of at most SC_CLIP_CLUSTER_MAX_B (default 64) images run their layers in the cluster form, larger ones exactly as sc_clip_vit_forward.
+int sc_clip_vit_forward_packed(const float* image, int B, int C, int H, int W, int patch, int D, int mlp, int layers, int heads, int proj_dim,
+                               const uint16_t* w16, const float* w_f32, const uint16_t* w_cluster, int fp16, float ln_eps, float* out,
+                               void* workspace, long long workspace_bytes, void* stream_) {
+    if (fp16)
+        return sc::clip_vit_forward<true>(image, B, C, H, W, patch, D, mlp, layers, heads, proj_dim, w16, w_f32, w_cluster, ln_eps, out, workspace,
+                                          workspace_bytes, stream_);
+    return sc::clip_vit_forward<false>(image, B, C, H, W, patch, D, mlp, layers, heads, proj_dim, w16, w_f32, w_cluster, ln_eps, out, workspace,
+                                       workspace_bytes, stream_);
 }
 
 }  // extern "C"

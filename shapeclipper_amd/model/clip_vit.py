@@ -89,7 +89,18 @@ class ClipVisionTower(nn.Module):
         vecs += [g(vm + "post_layernorm.weight"), g(vm + "post_layernorm.bias")]
         w_bf16 = torch.cat([m.reshape(-1) for m in mats]).to(torch.float16 if self.dtype16 == "fp16" else torch.bfloat16).contiguous()
         w_f32 = torch.cat([v.reshape(-1).float() for v in vecs]).contiguous()
-        return w_bf16, w_f32
+        # ViT-B geometry at <= 64 tokens: the layer matrices once more in the order the small-batch kernel consumes them (csrc/clip_cluster.hpp)
+        w_cluster = None
+        lib = _lib.load()
+        T = (c["image_size"] // c["patch"]) ** 2 + 1
+        if w_bf16.is_cuda and lib.sc_clip_cluster_supported(ctypes.c_int(c["width"]), ctypes.c_int(c["mlp"]), ctypes.c_int(c["heads"]), ctypes.c_int(T)):
+            lib.sc_clip_cluster_pack_elems.restype = ctypes.c_longlong
+            n = int(lib.sc_clip_cluster_pack_elems(ctypes.c_int(c["layers"])))
+            w_cluster = torch.empty(n, device=w_bf16.device, dtype=w_bf16.dtype)
+            with torch.cuda.device(w_bf16.device):
+                _lib.check(lib.sc_clip_cluster_pack(_lib.ptr(w_bf16), ctypes.c_int(mats[0].shape[1]), ctypes.c_int(c["layers"]), _lib.ptr(w_cluster),
+                                                    _lib.stream()), "sc_clip_cluster_pack")
+        return w_bf16, w_f32, w_cluster
 
     def workspace_bytes(self, B):
         c = self.cfg
@@ -107,16 +118,17 @@ class ClipVisionTower(nn.Module):
         assert image.shape[1:] == (c["channels"], c["image_size"], c["image_size"])
         if self._packed is None or self._packed[0].device != image.device:
             self._packed = self._pack()
-        w_bf16, w_f32 = self._packed
+        w_bf16, w_f32, w_cluster = self._packed
         out = torch.empty(B, c["proj"], device=image.device, dtype=torch.float32)
         nbytes = self.workspace_bytes(B)
         ws = torch.empty(nbytes, device=image.device, dtype=torch.uint8)
-        fwd = lib.sc_clip_vit_forward_f16 if self.dtype16 == "fp16" else lib.sc_clip_vit_forward
-        code = fwd(_lib.ptr(image), ctypes.c_int(B), ctypes.c_int(c["channels"]),
-                                       ctypes.c_int(c["image_size"]), ctypes.c_int(c["image_size"]), ctypes.c_int(c["patch"]),
-                                       ctypes.c_int(c["width"]), ctypes.c_int(c["mlp"]), ctypes.c_int(c["layers"]),
-                                       ctypes.c_int(c["heads"]), ctypes.c_int(c["proj"]), _lib.ptr(w_bf16), _lib.ptr(w_f32),
-                                       ctypes.c_float(1e-5), _lib.ptr(out), _lib.ptr(ws), ctypes.c_longlong(nbytes), _lib.stream())
+        code = lib.sc_clip_vit_forward_packed(_lib.ptr(image), ctypes.c_int(B), ctypes.c_int(c["channels"]),
+                                              ctypes.c_int(c["image_size"]), ctypes.c_int(c["image_size"]), ctypes.c_int(c["patch"]),
+                                              ctypes.c_int(c["width"]), ctypes.c_int(c["mlp"]), ctypes.c_int(c["layers"]),
+                                              ctypes.c_int(c["heads"]), ctypes.c_int(c["proj"]), _lib.ptr(w_bf16), _lib.ptr(w_f32),
+                                              _lib.ptr(w_cluster) if w_cluster is not None else ctypes.c_void_p(0),
+                                              ctypes.c_int(1 if self.dtype16 == "fp16" else 0),
+                                              ctypes.c_float(1e-5), _lib.ptr(out), _lib.ptr(ws), ctypes.c_longlong(nbytes), _lib.stream())
         _lib.check(code, "sc_clip_vit_forward")
         return out
 
