@@ -48,6 +48,15 @@ __device__ long long g_prof[16 * 16];
 constexpr int CL = 8;                 // workgroups (CUs) per image
 constexpr int CD = 768, CMLP = 3072, CHEADS = 12;
 constexpr int KQ = 192, KS = KQ / 32; // K-quarter of a 768-wide operand band per wave, 32-wide MFMA sub-steps in it
+#ifndef SC_CL_FC2_UNROLL
+#define SC_CL_FC2_UNROLL 0
+#endif
+#ifndef SC_CL_RING
+#define SC_CL_RING 3
+#endif
+constexpr int NR = SC_CL_RING;        // weight chunks of a wave's ring (NR - 1 in flight)
+constexpr int pad_to_ring(int n) { return (n + NR - 1) / NR * NR; }
+constexpr int P3 = pad_to_ring(3), P12 = pad_to_ring(12);
 constexpr int RED_FLOATS = 4 * 2 * 4 * 64 * 4;          // [wave][column block][row block][lane] float4 = 32 KB per buffer
 constexpr int VT_LD = 64 + 4;
 constexpr int BAND_BYTES = 64 * (CD * 2 + 16);            // LayerNorm operand band (97 KB); the two K-partial buffers (64 KB) alias its start
@@ -121,18 +130,27 @@ __global__ __launch_bounds__(256) void cluster_pack_kernel(const bf16_t* __restr
     }
 }
 
+// Entries of a member's layer as the ring sees them: every phase (n1 qkv chunks, 3 out-projection, 12 fc1, 12 fc2) is padded with BUBBLES to a
+// multiple of the ring length, so that each phase starts at ring slot 0 and every slot index is a compile-time constant.  A bubble is a
+// prefetch and nothing else; its own load repeats the phase's last chunk (a cache hit, never consumed).
 struct Stream {
-    const bf16_t* wc; int layers, first, per, kq, lane;
-    __device__ __forceinline__ void load(WChunk& q, int l, int idx) const {
+    const bf16_t* wc; int layers, first, n1, n1p, kq, lane;
+    __device__ __forceinline__ void load(WChunk& q, int l, int e) const {
         if (SC_CL_ABLATE & 1) { if (l >= 0) return; }             // experiment: no weight loads (the registers keep what they held)
-        if (idx >= per) { idx -= per; ++l; }
-        if (l >= layers) { l = layers - 1; idx = per - 1; }          // past the end: a valid chunk again (never consumed) -- the prefetch
+        const int per = n1p + P3 + 2 * P12;
+        if (e >= per) { e -= per; ++l; }
+        if (l >= layers) { l = layers - 1; e = per - 1; }            // past the end: a valid chunk again (never consumed) -- the prefetch
                                                                      // stays unconditional, so the memory counter arithmetic never forks
-        const uint4* p = reinterpret_cast<const uint4*>(wc + (size_t)l * LAYER_ELEMS + (size_t)(first + idx) * CHUNK_ELEMS + kq * WAVE_CHUNK_ELEMS) + lane;
+        int chunk;
+        if (e < n1p) chunk = min(e, n1 - 1);
+        else if (e < n1p + P3) chunk = n1 + min(e - n1p, 2);
+        else if (e < n1p + P3 + P12) chunk = n1 + 3 + min(e - n1p - P3, 11);
+        else chunk = n1 + 15 + min(e - n1p - P3 - P12, 11);
+        const char* base = reinterpret_cast<const char*>(wc + (size_t)l * LAYER_ELEMS + (size_t)(first + chunk) * CHUNK_ELEMS + kq * WAVE_CHUNK_ELEMS);
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int s = 0; s < KS; ++s) q.v[cb][s] = p[(cb * KS + s) * 64];
+            for (int s = 0; s < KS; ++s) q.v[cb][s] = *reinterpret_cast<const uint4*>(base + (unsigned)(lane * 16 + (cb * KS + s) * 1024));
     }
 };
 
@@ -167,11 +185,26 @@ __device__ __forceinline__ void get_sums(const float* red, int wave, int lane, f
 }
 
 // LayerNorm of the image's T rows -> the 16-bit operand band in LDS (row pitch BAND_PITCH bytes).  layernorm_kernel's arithmetic and
-// summation order exactly (a row in the registers of one wave: three float4 per lane, mean first, then the centred squares, butterfly sums).
+// two-pass form (a row in the registers of one wave: three float4 per lane, mean first, then the centred squares; sums by wave_sum).
 // Wave w takes rows w, w + 4, ..., seven at a time: their loads leave in one round trip.  (First form of this phase: every wave normalised
 // its own MFMA-layout piece of x straight into the operand registers -- 48 float4 loads per lane with their arithmetic on 96 + 96 registers;
 // under that pressure the compiler issued the loads two at a time, ~24 dependent round trips per LayerNorm.)
 constexpr int BAND_PITCH = CD * 2 + 16;
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// sum over the 64 lanes, every lane gets it: four DPP steps inside each row of 16 lanes, the four row totals through scalar registers (no
+// LDS traffic; the 2 x 6 ds_bpermute butterflies per row of the first form cost 5-8 us per LayerNorm at 13 rows per wave)
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);     // row_half_mirror
+    v += dpp_mov<0x140>(v);     // row_mirror
+    const int b = __builtin_bit_cast(int, v);
+    return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))) +
+           (__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48)));
+}
 template <bool H16>
 __device__ __forceinline__ void ln_to_band(char* band, const float* xi, int T, float eps, const float* g, const float* b, int wave, int lane) {
     constexpr int RB = 7;
@@ -200,9 +233,7 @@ __device__ __forceinline__ void ln_to_band(char* band, const float* xi, int T, f
             for (int k = 0; k < 3; ++k) sm[i] += (v[i][k].x + v[i][k].y) + (v[i][k].z + v[i][k].w);
         }
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1)
-#pragma unroll
-            for (int i = 0; i < RB; ++i) sm[i] += (SC_CL_ABLATE & 2) ? sm[i] : __shfl_xor(sm[i], o);
+        for (int i = 0; i < RB; ++i) sm[i] = wave_sum(sm[i]);
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             const float mean = sm[i] / CD;
@@ -214,9 +245,7 @@ __device__ __forceinline__ void ln_to_band(char* band, const float* xi, int T, f
             }
         }
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1)
-#pragma unroll
-            for (int i = 0; i < RB; ++i) ss[i] += (SC_CL_ABLATE & 2) ? ss[i] : __shfl_xor(ss[i], o);
+        for (int i = 0; i < RB; ++i) ss[i] = wave_sum(ss[i]);
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             const float inv = rsqrtf(ss[i] / CD + eps);
@@ -379,32 +408,44 @@ __device__ __forceinline__ void attention_pair(const bf16_t* qkv_i, bf16_t* att_
     }
 }
 
-enum { E_QKV = 0, E_RESID = 1, E_GELU = 2 };
+enum { E_QKV = 0, E_RESID = 1, E_GELU = 2, E_ACC = 3 };
 
 // Epilogue of a 64 x 32 block [rows of this image] x [n0, n0 + 32): wave w owns rows 16 w + (lane & 15), a lane 4 consecutive columns per
 // column block.  It issues NO vector-memory load: the memory counter retires in issue order, so a load issued behind the weight prefetch makes
 // its wait drain the whole ring (the first builds did exactly that -- the compiler sinks such loads to their use).  The phase's bias slice is
-// staged in LDS when the phase starts (`bias_l`: chunk ci at floats [32 ci, 32 ci + 32)), the residual values of x += are requested with
-// the phase's operand loads.
+// staged in LDS when the phase starts (`bias_l`: the chunk's 32 floats), the residual values of x += are requested with the phase's operand
+// loads.  `t_store` = T, or 0 for a block that is not to be stored (the step in front of a phase's first one; an fc2 pass that is not the last).
+//   E_QKV   16-bit(sum + bias)                 E_GELU  16-bit(quick_gelu(sum + bias))
+//   E_RESID x = res + (sum + bias)             E_ACC   res += sum (valid blocks); x = res + bias where stored (fc2: four K-passes)
 template <bool H16, int EPI>
-__device__ __forceinline__ void epilogue(const f32x4 (&sum)[2], const float* bias_l, const float4 (&res)[2], int n0, void* out_i, int ldo,
-                                         int T, int wave, int lane) {
+__device__ __forceinline__ void epilogue(const f32x4 (&sum)[2], const float* bias_l, float4 (&res)[2], int n0, void* out_i, int ldo,
+                                         int t_store, bool valid, int wave, int lane) {
     const int row = 16 * wave + (lane & 15);
     float4 bv[2];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) bv[cb] = *reinterpret_cast<const float4*>(bias_l + 16 * cb + 4 * (lane >> 4));
-    if (row >= T) return;
+    if (EPI == E_ACC) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            res[cb].x += valid ? sum[cb][0] : 0.f; res[cb].y += valid ? sum[cb][1] : 0.f;
+            res[cb].z += valid ? sum[cb][2] : 0.f; res[cb].w += valid ? sum[cb][3] : 0.f;
+        }
+    }
+    if (row >= t_store) return;
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
         const unsigned n = (unsigned)(n0 + 16 * cb + 4 * (lane >> 4)), o = (unsigned)row * (unsigned)ldo + n;
         float v0 = sum[cb][0] + bv[cb].x, v1 = sum[cb][1] + bv[cb].y, v2 = sum[cb][2] + bv[cb].z, v3 = sum[cb][3] + bv[cb].w;
-        if (EPI == E_RESID) {
+        if (EPI == E_ACC) {
+            *reinterpret_cast<float4*>(reinterpret_cast<char*>(out_i) + o * 4u) =
+                make_float4(res[cb].x + bv[cb].x, res[cb].y + bv[cb].y, res[cb].z + bv[cb].z, res[cb].w + bv[cb].w);
+        } else if (EPI == E_RESID) {
             *reinterpret_cast<float4*>(reinterpret_cast<char*>(out_i) + o * 4u) =
                 make_float4(v0 + res[cb].x, v1 + res[cb].y, v2 + res[cb].z, v3 + res[cb].w);
         } else {
-            if (EPI == E_GELU) {
-                v0 = v0 / (1.f + __expf(-1.702f * v0)); v1 = v1 / (1.f + __expf(-1.702f * v1));
-                v2 = v2 / (1.f + __expf(-1.702f * v2)); v3 = v3 / (1.f + __expf(-1.702f * v3));
+            if (EPI == E_GELU) {          // x * sigmoid(1.702 x); the quotient by v_rcp_f32 (1 ulp) -- the result is rounded to 16 bits
+                v0 *= __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v0)); v1 *= __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v1));
+                v2 *= __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v2)); v3 *= __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v3));
             }
             *reinterpret_cast<uint2*>(reinterpret_cast<char*>(out_i) + o * 2u) = make_uint2(pk2<H16>(v0, v1), pk2<H16>(v2, v3));
         }
@@ -421,19 +462,29 @@ __device__ __forceinline__ void resid_request(float4 (&res)[3][2], const float* 
                                                           (row * (unsigned)CD + (unsigned)(96 * c + 32 * p + 16 * cb + 4 * (lane >> 4))) * 4u);
 }
 
-// One chunk of a single-pass phase: the ring two chunks ahead, 48 MFMAs, add the K-partials, epilogue
-#define SC_CL_STEP(CUR, NXT, CI, N0, EPI, RES, OUT, LDO)                                        \
+// One step of a phase (entry E of the layer, ring slot J): the ring NR - 1 entries ahead; the K-partials of the PREVIOUS step are fetched
+// from LDS, added and sent through its epilogue while this step's 48 MFMAs run (one after the other the two cost 0.7 us per step with the
+// matrix pipe idle for more than half of it); this step's partials go to the other LDS buffer; one workgroup barrier.
+#define SC_CL_STEP(J, E, EPI, BIASPREV, RESPREV, N0PREV, OUT, LDO, TPREV, VALIDPREV)             \
     {                                                                                          \
-        st.load(NXT, l, gbase + (CI) + 2);                                                     \
+        st.load(ring[((J) + NR - 1) % NR], l, (E) + NR - 1);                                   \
+        f32x4 psum[2];                                                                         \
+        if (!(SC_CL_ABLATE & 32)) get_sums(red + (((E) + 1) & 1) * RED_FLOATS, wave, lane, psum); else { psum[0] = f32x4{0.f, 0.f, 0.f, 0.f}; psum[1] = psum[0]; } \
         f32x4 acc[2][4];                                                                       \
         _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) _Pragma("unroll") for (int rb = 0; rb < 4; ++rb) acc[cb][rb] = f32x4{0.f, 0.f, 0.f, 0.f}; \
-        mma_chunk<H16>(acc, CUR, act);                                                         \
-        float* rbuf = red + ((CI) & 1) * RED_FLOATS;                                           \
-        f32x4 sum[2];                                                                          \
-        put_partials(rbuf, acc, wave, lane);                                                   \
-        __syncthreads();                                                                       \
-        get_sums(rbuf, wave, lane, sum);                                                       \
-        epilogue<H16, EPI>(sum, bias_l + 32 * (CI), RES, N0, OUT, LDO, T, wave, lane);         \
+        if (!(SC_CL_ABLATE & 16)) mma_chunk<H16>(acc, ring[J], act);                           \
+        else acc[0][0][0] = __uint_as_float(ring[J].v[0][0].x ^ ring[J].v[1][5].w ^ act[0][0].x ^ act[3][5].w);  \
+        epilogue<H16, EPI>(psum, BIASPREV, RESPREV, N0PREV, OUT, LDO, TPREV, VALIDPREV, wave, lane); \
+        if (!(SC_CL_ABLATE & 32)) { put_partials(red + ((E) & 1) * RED_FLOATS, acc, wave, lane); __syncthreads(); } \
+        else if (__float_as_uint(acc[0][0][0] + acc[1][3][3] + acc[0][2][1]) == 0x12345u) red[lane] = acc[1][1][1]; \
+        __builtin_amdgcn_sched_barrier(0);     /* nothing of the next step moves up here (hoisted operand loads cost registers) */ \
+    }
+// the last step of a phase has nobody behind it
+#define SC_CL_TAIL(E, EPI, BIAS, RES, N0, OUT, LDO, TST)                                        \
+    {                                                                                          \
+        f32x4 psum[2];                                                                         \
+        get_sums(red + ((E) & 1) * RED_FLOATS, wave, lane, psum);                              \
+        epilogue<H16, EPI>(psum, BIAS, RES, N0, OUT, LDO, TST, true, wave, lane);              \
     }
 
 template <bool H16>
@@ -445,7 +496,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     char* band = reinterpret_cast<char*>(lds_f);
     bf16_t* Vt = reinterpret_cast<bf16_t*>(band + BAND_BYTES);
     float* bias_l = reinterpret_cast<float*>(Vt + 2 * 64 * VT_LD);      // 384 floats: the running phase's bias slice, chunk-major
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane0 = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave: a scalar for the compiler too
     const int b = blockIdx.x, xcd = b & 7, r8 = b >> 3, c = r8 & 7, grp = r8 >> 3;
     const int slot = grp * 8 + xcd, img = img0 + slot;
     if (img >= B) return;                                  // the whole cluster leaves
@@ -457,7 +508,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     bf16_t* att_i = att + (size_t)img * T * CD;
     bf16_t* h_i = hbuf + (size_t)img * T * CMLP;
     const int nh = c + 8 < CHEADS ? 2 : 1, n1 = 6 * nh;
-    const float4 no_res[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    float4 no_res[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
 
     // do the members of this cluster share an XCD?  (every member sets the bit of its XCC id; one agent-scope barrier; one bit = yes)
     if (tid == 0) __hip_atomic_fetch_or(cnt + 1, 1u << xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -465,14 +516,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     cluster_barrier(cnt, arrivals, err, false);
     const bool local = SC_CL_BARRIER != 0 && __popc(__hip_atomic_load(cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 1;
 
-    Stream st{wc, layers, member_first_chunk(c), n1 + 27, wave, lane};
-    WChunk q0, q1, q2;
-    st.load(q0, 0, 0);
-    st.load(q1, 0, 1);
+    const int n1p = pad_to_ring(n1);
+    Stream st{wc, layers, member_first_chunk(c), n1, n1p, wave, lane0};
+    WChunk ring[NR];
+#pragma unroll
+    for (int j = 0; j < NR - 1; ++j) st.load(ring[j], 0, j);
     uint4 act[4][KS];
     float4 res[3][2];
+#define SC_CL_BUBBLE(J, E) st.load(ring[((J) + NR - 1) % NR], l, (E) + NR - 1);
     for (int l = 0; l < layers; ++l) {
         const Layer L = layer_at(wf, l);
+        // the lane index, opaque once per layer: everything addressed through it is recomputed here instead of being hoisted out of the layer
+        // loop as dozens of loop-invariant 64-bit per-lane addresses -- which the register allocator then spilled, and a scratch reload in a
+        // step is a vector-memory load behind the weight prefetch (its wait drains the ring)
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
         SC_CL_STAMP(0)
 #define SC_CL_QKV_N0(CI) ((((CI) % 6) >> 1) * CD + ((CI) >= 6 ? c + 8 : c) * 64 + (((CI) % 6) & 1) * 32)
         // ---- ln_1 -> q | k | v of this member's heads -------------------------------------------------------------------------------
@@ -482,12 +540,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         act_from_band(act, band, wave, lane);
         __syncthreads();                                   // the K-partial buffers alias the band
         SC_CL_STAMP(1)
-        int gbase = 0;
-        for (int ci = 0; ci < n1; ci += 3) {
-            SC_CL_STEP(q0, q2, ci, SC_CL_QKV_N0(ci), E_QKV, no_res, qkv_i, 3 * CD)
-            SC_CL_STEP(q1, q0, ci + 1, SC_CL_QKV_N0(ci + 1), E_QKV, no_res, qkv_i, 3 * CD)
-            SC_CL_STEP(q2, q1, ci + 2, SC_CL_QKV_N0(ci + 2), E_QKV, no_res, qkv_i, 3 * CD)
+        for (int ci = 0; ci < n1p; ci += NR) {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const int e = ci + j;
+                if (e < n1) SC_CL_STEP(j, e, E_QKV, bias_l + 32 * (e - 1), no_res, SC_CL_QKV_N0(e - 1), qkv_i, 3 * CD, e > 0 ? T : 0, true)
+                else SC_CL_BUBBLE(j, e)
+            }
         }
+        SC_CL_TAIL(n1 - 1, E_QKV, bias_l + 32 * (n1 - 1), no_res, SC_CL_QKV_N0(n1 - 1), qkv_i, 3 * CD, T)
 #undef SC_CL_QKV_N0
         __syncthreads();                                   // this member's q | k | v rows are in memory for all four waves
         SC_CL_STAMP(2)
@@ -499,12 +560,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         arrivals += CL;
         cluster_barrier(cnt, arrivals, err, local);
         SC_CL_STAMP(4)
-        // ---- x += out-projection ---------------------------------------------------------------------------------------------------
+        // ---- x += out-projection: three steps (+ bubbles) ------------------------------------------------------------------------------
         act_from_rows(act, att_i, CD, 0, T, wave, lane);
-        gbase = n1;
-        SC_CL_STEP(q0, q2, 0, 96 * c, E_RESID, res[0], xi, CD)
-        SC_CL_STEP(q1, q0, 1, 96 * c + 32, E_RESID, res[1], xi, CD)
-        SC_CL_STEP(q2, q1, 2, 96 * c + 64, E_RESID, res[2], xi, CD)
+        {
+            const int e0 = n1p;
+            static_assert(NR >= 3, "the out-projection is written for a ring of at least three chunks");
+            SC_CL_STEP(0, e0, E_RESID, bias_l, no_res, 0, xi, CD, 0, false)
+            SC_CL_STEP(1, e0 + 1, E_RESID, bias_l, res[0], 96 * c, xi, CD, T, true)
+            SC_CL_STEP(2, e0 + 2, E_RESID, bias_l + 32, res[1], 96 * c + 32, xi, CD, T, true)
+#pragma unroll
+            for (int j = 3; j < P3; ++j) SC_CL_BUBBLE(j % NR, e0 + j)
+            SC_CL_TAIL(e0 + 2, E_RESID, bias_l + 64, res[2], 96 * c + 64, xi, CD, T)
+        }
         SC_CL_STAMP(5)
         arrivals += CL;
         cluster_barrier(cnt, arrivals, err, local);
@@ -516,57 +583,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         act_from_band(act, band, wave, lane);
         __syncthreads();
         SC_CL_STAMP(7)
-        gbase = n1 + 3;
-        for (int ci = 0; ci < 12; ci += 3) {
-            SC_CL_STEP(q0, q2, ci, 384 * c + 32 * ci, E_GELU, no_res, h_i, CMLP)
-            SC_CL_STEP(q1, q0, ci + 1, 384 * c + 32 * (ci + 1), E_GELU, no_res, h_i, CMLP)
-            SC_CL_STEP(q2, q1, ci + 2, 384 * c + 32 * (ci + 2), E_GELU, no_res, h_i, CMLP)
+        for (int ci = 0; ci < P12; ci += NR) {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const int k = ci + j, e = n1p + P3 + k;
+                if (P12 == 12 || k < 12) SC_CL_STEP(j, e, E_GELU, bias_l + 32 * (k - 1), no_res, 384 * c + 32 * (k - 1), h_i, CMLP, k > 0 ? T : 0, true)
+                else SC_CL_BUBBLE(j, e)
+            }
         }
+        SC_CL_TAIL(n1p + P3 + 11, E_GELU, bias_l + 32 * 11, no_res, 384 * c + 32 * 11, h_i, CMLP, T)
         SC_CL_STAMP(8)
         arrivals += CL;
         cluster_barrier(cnt, arrivals, err, local);
         SC_CL_STAMP(9)
-        // ---- x += fc2: four K-passes of 768 over the hidden rows, the three column pairs accumulate across the passes -----------------
+        // ---- x += fc2: four K-passes of 768 over the hidden rows; the member's three column pairs accumulate in `res` across the passes --
         if (tid < 24) reinterpret_cast<float4*>(bias_l)[tid] = *reinterpret_cast<const float4*>(L.b_fc2 + 96 * c + 4 * tid);
         resid_request(res, xi, c, T, wave, lane);
-        gbase = n1 + 15;
-        {
-            f32x4 acc2[3][2][4];
+        static_assert(12 % NR == 0, "fc2 below is written for a ring length that divides its 12 steps");
+#if SC_CL_FC2_UNROLL
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+#else
+#pragma unroll 1
+#endif
+        for (int k0 = 0; k0 < 12; k0 += SC_CL_FC2_UNROLL ? 12 : 0 + (NR % 3 == 0 ? NR : 12))
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                    for (int rb = 0; rb < 4; ++rb) acc2[p][cb][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int pass = 0; pass < 4; ++pass) {
-                act_from_rows(act, h_i, CMLP, pass * CD, T, wave, lane);
-                st.load(q2, l, gbase + 3 * pass + 2);
-                mma_chunk<H16>(acc2[0], q0, act);
-                st.load(q0, l, gbase + 3 * pass + 3);
-                mma_chunk<H16>(acc2[1], q1, act);
-                st.load(q1, l, gbase + 3 * pass + 4);
-                mma_chunk<H16>(acc2[2], q2, act);
-            }
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                float* rbuf = red + (p & 1) * RED_FLOATS;
-                f32x4 sum[2];
-                put_partials(rbuf, acc2[p], wave, lane);
-                __syncthreads();
-                get_sums(rbuf, wave, lane, sum);
-                epilogue<H16, E_RESID>(sum, bias_l + 32 * p, res[p], 96 * c + 32 * p, xi, CD, T, wave, lane);
-            }
+        for (int kk = 0; kk < (NR % 3 == 0 ? NR : 12); ++kk) {     // ring slot k % NR and column pair k % 3 are constants (pass k / 3 too if unrolled)
+            const int k = k0 + kk;
+            const int e = n1p + P3 + P12 + k;
+            if (kk % 3 == 0) act_from_rows(act, h_i, CMLP, (k / 3) * CD, T, wave, lane);
+            // the step behind: k - 1 = pass (k - 1) / 3, pair (k - 1) % 3; its block leaves after the last pass
+            SC_CL_STEP(kk % NR, e, E_ACC, bias_l + 32 * ((kk + 2) % 3), res[(kk + 2) % 3], 96 * c + 32 * ((kk + 2) % 3), xi, CD, k - 1 >= 9 ? T : 0, k > 0)
         }
+        SC_CL_TAIL(n1p + P3 + P12 + 11, E_ACC, bias_l + 64, res[2], 96 * c + 64, xi, CD, T)
         SC_CL_STAMP(10)
         arrivals += CL;
         cluster_barrier(cnt, arrivals, err, local);
         SC_CL_STAMP(11)
     }
+#undef SC_CL_BUBBLE
     // a time-out anywhere in the launch: poison this image's class-token row (ln_post reads it), the caller sees NaN
     if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u && c == 0)
         for (int d = tid; d < CD; d += 256) xi[d] = __builtin_nanf("");
 }
 #undef SC_CL_STEP
+#undef SC_CL_TAIL
 
 static int launch_cluster_pack(const bf16_t* w, bf16_t* out, int layers, hipStream_t st) {
     hipLaunchKernelGGL(cluster_pack_kernel, dim3(4096), dim3(256), 0, st, w, out, layers);

@@ -1,6 +1,7 @@
 """Phase profile of the cluster form of the CLIP layers (library built with SC_CL_PROF=1: tools/build_variants.sh clip_vit.hip SC_CL_PROF 1,
 SHAPECLIPPER_HIP_LIB=shapeclipper_amd/lib/variants/lib_SC_CL_PROF_1.so).  python tools/prof_clip_cluster.py [batch=32]"""
 import ctypes, os, sys
+os.environ.setdefault("SC_CLIP_CLUSTER_MAX_B", "64")
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import torch
 from shapeclipper_amd import _lib
