@@ -229,10 +229,12 @@ int sc_f32_to_f16(const float* x, uint16_t* y, long long n, void* stream);
  * sc_clip_cluster_supported: 1 for width 768 / MLP 3072 / 12 heads / at most 64 tokens per image, else 0.
  * sc_clip_cluster_pack_elems: 16-bit values of the re-packed image (layers * 12 * 768 * 768).
  * sc_clip_cluster_pack: w16 = the tower's 16-bit image (bf16 or fp16 alike), Kp as above, out = the re-packed layers.
- * sc_clip_vit_forward_packed: sc_clip_vit_forward (fp16 == 0) / sc_clip_vit_forward_f16 (fp16 != 0) with w_cluster beside w16; batches of at
- * most 64 images (SC_CLIP_CLUSTER_MAX_B) on a device with >= 256 CUs take the cluster form, everything else the launch-per-operation form
+ * sc_clip_vit_forward_packed: sc_clip_vit_forward (fp16 == 0) / sc_clip_vit_forward_f16 (fp16 != 0) with w_cluster beside w16; batches of
+ * min_b <= B <= max_b images (default 26..32, where it is the faster form; sc_clip_cluster_set_batch_range, or SC_CLIP_CLUSTER_MIN_B / _MAX_B
+ * in the environment at load time) on a device with >= 256 CUs take the cluster form, everything else the launch-per-operation form
  * (w_cluster may be NULL then).  A device that cannot hold the grid at once ends every wait after 0.2 s and returns NaN embeddings.       */
 int sc_clip_cluster_supported(int D, int mlp, int heads, int tokens);
+int sc_clip_cluster_set_batch_range(int min_b, int max_b);
 long long sc_clip_cluster_pack_elems(int layers);
 int sc_clip_cluster_pack(const uint16_t* w16, int Kp, int layers, uint16_t* out, void* stream);
 int sc_clip_vit_forward_packed(const float* image, int B, int C, int H, int W, int patch, int D, int mlp, int layers, int heads,

@@ -48,8 +48,8 @@ __device__ long long g_prof[16 * 16];
 constexpr int CL = 8;                 // workgroups (CUs) per image
 constexpr int CD = 768, CMLP = 3072, CHEADS = 12;
 constexpr int KQ = 192, KS = KQ / 32; // K-quarter of a 768-wide operand band per wave, 32-wide MFMA sub-steps in it
-#ifndef SC_CL_FC2_UNROLL
-#define SC_CL_FC2_UNROLL 0
+#ifndef SC_CL_LN_ROWS
+#define SC_CL_LN_ROWS 7          // rows of a wave normalised per round trip (7: two round trips at 50 tokens; 13 / 16: one)
 #endif
 #ifndef SC_CL_RING
 #define SC_CL_RING 3
@@ -57,7 +57,6 @@ constexpr int KQ = 192, KS = KQ / 32; // K-quarter of a 768-wide operand band pe
 constexpr int NR = SC_CL_RING;        // weight chunks of a wave's ring (NR - 1 in flight)
 constexpr int pad_to_ring(int n) { return (n + NR - 1) / NR * NR; }
 constexpr int P3 = pad_to_ring(3), P12 = pad_to_ring(12);
-constexpr int RED_FLOATS = 4 * 2 * 4 * 64 * 4;          // [wave][column block][row block][lane] float4 = 32 KB per buffer
 constexpr int VT_LD = 64 + 4;
 constexpr int BAND_BYTES = 64 * (CD * 2 + 16);            // LayerNorm operand band (97 KB); the two K-partial buffers (64 KB) alias its start
 constexpr int LDS_BYTES = BAND_BYTES + 2 * 64 * VT_LD * 2 + 384 * 4;      // 97 KB + 17 KB + 1.5 KB: one workgroup per CU
@@ -131,55 +130,62 @@ __global__ __launch_bounds__(256) void cluster_pack_kernel(const bf16_t* __restr
 }
 
 // Entries of a member's layer as the ring sees them: every phase (n1 qkv chunks, 3 out-projection, 12 fc1, 12 fc2) is padded with BUBBLES to a
-// multiple of the ring length, so that each phase starts at ring slot 0 and every slot index is a compile-time constant.  A bubble is a
-// prefetch and nothing else; its own load repeats the phase's last chunk (a cache hit, never consumed).
+// multiple of the ring length (fc2: each of its four K-passes of 3 chunks), so that each phase starts at ring slot 0 and every slot index is a compile-time constant.  A bubble is a
+// prefetch and nothing else.
 struct Stream {
     const bf16_t* wc; int layers, first, n1, n1p, kq, lane;
     __device__ __forceinline__ void load(WChunk& q, int l, int e) const {
         if (SC_CL_ABLATE & 1) { if (l >= 0) return; }             // experiment: no weight loads (the registers keep what they held)
-        const int per = n1p + P3 + 2 * P12;
+        const int per = n1p + P3 + P12 + 4 * P3;
         if (e >= per) { e -= per; ++l; }
         if (l >= layers) { l = layers - 1; e = per - 1; }            // past the end: a valid chunk again (never consumed) -- the prefetch
                                                                      // stays unconditional, so the memory counter arithmetic never forks
-        int chunk;
-        if (e < n1p) chunk = min(e, n1 - 1);
-        else if (e < n1p + P3) chunk = n1 + min(e - n1p, 2);
-        else if (e < n1p + P3 + P12) chunk = n1 + 3 + min(e - n1p - P3, 11);
-        else chunk = n1 + 15 + min(e - n1p - P3 - P12, 11);
+        int chunk, r;
+        bool real;
+        if (e < n1p) { real = e < n1; chunk = min(e, n1 - 1); }
+        else if ((r = e - n1p) < P3) { real = r < 3; chunk = n1 + min(r, 2); }
+        else if ((r -= P3) < P12) { real = r < 12; chunk = n1 + 3 + min(r, 11); }
+        else { r -= P12; const int pass = r / P3, k = r - pass * P3; real = k < 3; chunk = n1 + 15 + 3 * pass + min(k, 2); }
+        // a bubble asks for ONE fragment of its phase's last chunk twelve times (a first-level cache hit after the first): the number of
+        // loads per step stays the same, the traffic does not grow
+        const unsigned stride = real ? 1024u : 0u;
         const char* base = reinterpret_cast<const char*>(wc + (size_t)l * LAYER_ELEMS + (size_t)(first + chunk) * CHUNK_ELEMS + kq * WAVE_CHUNK_ELEMS);
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int s = 0; s < KS; ++s) q.v[cb][s] = *reinterpret_cast<const uint4*>(base + (unsigned)(lane * 16 + (cb * KS + s) * 1024));
+            for (int s = 0; s < KS; ++s) q.v[cb][s] = *reinterpret_cast<const uint4*>(base + (size_t)((cb * KS + s) * stride) + (unsigned)(lane * 16));
     }
 };
 
+// Row blocks are ROTATED per wave: operand / accumulator index i of wave w is row block (w + i) & 3, so that the block a wave finishes
+// (row block w) is always its index 0 -- a compile-time register, not a run-time choice.
 template <bool H16>
-__device__ __forceinline__ void mma_chunk(f32x4 (&acc)[2][4], const WChunk& q, const uint4 (&act)[4][KS]) {
+__device__ __forceinline__ void mma_half(f32x4 (&acc)[4], const uint4 (&w)[KS], const uint4 (&act)[4][KS]) {
 #pragma unroll
     for (int s = 0; s < KS; ++s)
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int rb = 0; rb < 4; ++rb) acc[cb][rb] = mma<H16>(q.v[cb][s], act[rb][s], acc[cb][rb]);
+        for (int i = 0; i < 4; ++i) acc[i] = mma<H16>(w[s], act[i][s], acc[i]);
 }
 
-// K-partials of a 64 x 32 block: every wave parks its four row blocks (lane-linear float4: conflict-free), the barrier, wave w adds row
-// block w in wave order.  (Branch-free on purpose: keeping the wave's own partial in registers cost a branch per row block.)
-__device__ __forceinline__ void put_partials(float* red, const f32x4 (&acc)[2][4], int wave, int lane) {
-    f32x4* dst = reinterpret_cast<f32x4*>(red) + wave * 8 * 64 + lane;
+// K-partials of a 64 x 32 block.  Wave p parks the three row blocks it does not finish (index i = 1..3 = row block (p + i) & 3; lane-linear
+// float4: conflict-free) and keeps its own; after the barrier wave w adds, to its own partial of row block w, those of waves w + 1, w + 2,
+// w + 3 (mod 4) -- a fixed order per row block.  24 KB written + 24 KB read per step and CU (the first form parked and re-read all four: the
+// LDS time of a step, 0.2 us, was as long as two thirds of its MFMAs and did not run under them).
+constexpr int RED_FLOATS = 4 * 2 * 3 * 64 * 4;          // [wave][column block][i - 1][lane] float4 = 24 KB per buffer
+__device__ __forceinline__ void put_half(float* red, int cb, const f32x4 (&acc)[4], int wave, int lane) {
+    f32x4* dst = reinterpret_cast<f32x4*>(red) + ((wave * 2 + cb) * 3) * 64 + lane;
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) dst[(cb * 4 + rb) * 64] = acc[cb][rb];
+    for (int i = 1; i < 4; ++i) dst[(i - 1) * 64] = acc[i];
 }
-__device__ __forceinline__ void get_sums(const float* red, int wave, int lane, f32x4 (&out)[2]) {
-    const f32x4* src = reinterpret_cast<const f32x4*>(red) + wave * 64 + lane;
+__device__ __forceinline__ void get_sums(const float* red, const f32x4 (&own)[2], int wave, int lane, f32x4 (&out)[2]) {
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
-        f32x4 t = src[(0 * 8 + cb * 4) * 64];
+        f32x4 t = own[cb];
 #pragma unroll
-        for (int p = 1; p < 4; ++p) t = t + src[(p * 8 + cb * 4) * 64];
+        for (int d = 1; d < 4; ++d) {            // source wave p = (wave + d) & 3 holds row block `wave` at its index (wave - p) & 3 = 4 - d
+            const int p = (wave + d) & 3;
+            t = t + reinterpret_cast<const f32x4*>(red)[((p * 2 + cb) * 3 + (3 - d)) * 64 + lane];
+        }
         out[cb] = t;
     }
 }
@@ -197,6 +203,7 @@ __device__ __forceinline__ float dpp_mov(float v) {
 // sum over the 64 lanes, every lane gets it: four DPP steps inside each row of 16 lanes, the four row totals through scalar registers (no
 // LDS traffic; the 2 x 6 ds_bpermute butterflies per row of the first form cost 5-8 us per LayerNorm at 13 rows per wave)
 __device__ __forceinline__ float wave_sum(float v) {
+    if (SC_CL_ABLATE & 2) return v;
     v += dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]
     v += dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]
     v += dpp_mov<0x141>(v);     // row_half_mirror
@@ -207,7 +214,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 template <bool H16>
 __device__ __forceinline__ void ln_to_band(char* band, const float* xi, int T, float eps, const float* g, const float* b, int wave, int lane) {
-    constexpr int RB = 7;
+    constexpr int RB = SC_CL_LN_ROWS;
     float4 gg[3], bb[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -261,24 +268,28 @@ __device__ __forceinline__ void ln_to_band(char* band, const float* xi, int T, f
         }
     }
 }
-// Operand registers of this wave = its K-quarter of the band: rows 16 rb + (lane & 15), 8 consecutive K values per lane and sub-step.  Rows
+// Operand registers of this wave = its K-quarter of the band: index i = rows 16 ((w + i) & 3) + (lane & 15) (the wave index IS the K-quarter),
+// 8 consecutive K values per lane and sub-step.  Rows
 // past T - 1 hold whatever the LDS held: their products are never stored and never enter another row's result.
 __device__ __forceinline__ void act_from_band(uint4 (&act)[4][KS], const char* band, int kq, int lane) {
     const char* p = band + (lane & 15) * BAND_PITCH + (kq * KQ + 8 * (lane >> 4)) * 2;
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int s = 0; s < KS; ++s) act[rb][s] = *reinterpret_cast<const uint4*>(p + rb * 16 * BAND_PITCH + 64 * s);
+        for (int s = 0; s < KS; ++s) act[i][s] = *reinterpret_cast<const uint4*>(p + ((kq + i) & 3) * 16 * BAND_PITCH + 64 * s);
 }
 // ... = 16-bit rows src[row][koff + ...] (row pitch ld); rows past T - 1 repeat row T - 1
 __device__ __forceinline__ void act_from_rows(uint4 (&act)[4][KS], const bf16_t* src, int ld, int koff, int T, int kq, int lane) {
     const int m16 = lane & 15, k8 = koff + kq * KQ + 8 * (lane >> 4);
+    const bf16_t* p[4];
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
-        const bf16_t* p = src + (size_t)min(16 * rb + m16, T - 1) * ld + k8;
+    for (int i = 0; i < 4; ++i) p[i] = src + (size_t)min(16 * ((kq + i) & 3) + m16, T - 1) * ld + k8;
+    // requested in the order the MFMAs consume them (sub-step major): loads retire in issue order, so the first products wait for 4 of
+    // the 24 fragments instead of 19, and the rest of the transfer (24 KB per wave) runs under them
 #pragma unroll
-        for (int s = 0; s < KS; ++s) act[rb][s] = *reinterpret_cast<const uint4*>(p + 32 * s);
-    }
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) act[i][s] = *reinterpret_cast<const uint4*>(p[i] + 32 * s);
 }
 
 // Bounded wait of a cluster: all CL members have arrived `target / CL` times.  Thread 0 publishes and acquires for the workgroup; the two
@@ -469,21 +480,26 @@ __device__ __forceinline__ void resid_request(float4 (&res)[3][2], const float* 
     {                                                                                          \
         st.load(ring[((J) + NR - 1) % NR], l, (E) + NR - 1);                                   \
         f32x4 psum[2];                                                                         \
-        if (!(SC_CL_ABLATE & 32)) get_sums(red + (((E) + 1) & 1) * RED_FLOATS, wave, lane, psum); else { psum[0] = f32x4{0.f, 0.f, 0.f, 0.f}; psum[1] = psum[0]; } \
-        f32x4 acc[2][4];                                                                       \
-        _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) _Pragma("unroll") for (int rb = 0; rb < 4; ++rb) acc[cb][rb] = f32x4{0.f, 0.f, 0.f, 0.f}; \
-        if (!(SC_CL_ABLATE & 16)) mma_chunk<H16>(acc, ring[J], act);                           \
-        else acc[0][0][0] = __uint_as_float(ring[J].v[0][0].x ^ ring[J].v[1][5].w ^ act[0][0].x ^ act[3][5].w);  \
+        if (!(SC_CL_ABLATE & 32)) get_sums(red + (par ^ 1) * RED_FLOATS, own, wave, lane, psum); else { psum[0] = own[0]; psum[1] = own[1]; } \
+        float* rbuf = red + par * RED_FLOATS;                                                  \
+        f32x4 a0[4], a1[4];                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) { a0[i] = f32x4{0.f, 0.f, 0.f, 0.f}; a1[i] = a0[i]; } \
+        if (!(SC_CL_ABLATE & 16)) mma_half<H16>(a0, ring[J].v[0], act);                        \
+        else a0[0][0] = __uint_as_float(ring[J].v[0][0].x ^ ring[J].v[0][5].w ^ act[0][0].x ^ act[3][5].w);  \
+        if (!(SC_CL_ABLATE & 32)) put_half(rbuf, 0, a0, wave, lane);                           \
+        if (!(SC_CL_ABLATE & 16)) mma_half<H16>(a1, ring[J].v[1], act);                        \
+        else a1[0][0] = __uint_as_float(ring[J].v[1][0].x ^ ring[J].v[1][5].w ^ act[1][0].x ^ act[2][5].w);  \
         epilogue<H16, EPI>(psum, BIASPREV, RESPREV, N0PREV, OUT, LDO, TPREV, VALIDPREV, wave, lane); \
-        if (!(SC_CL_ABLATE & 32)) { put_partials(red + ((E) & 1) * RED_FLOATS, acc, wave, lane); __syncthreads(); } \
-        else if (__float_as_uint(acc[0][0][0] + acc[1][3][3] + acc[0][2][1]) == 0x12345u) red[lane] = acc[1][1][1]; \
+        if (!(SC_CL_ABLATE & 32)) { put_half(rbuf, 1, a1, wave, lane); __syncthreads(); }      \
+        own[0] = a0[0]; own[1] = a1[0];                                                        \
+        par ^= 1;                                                                              \
         __builtin_amdgcn_sched_barrier(0);     /* nothing of the next step moves up here (hoisted operand loads cost registers) */ \
     }
 // the last step of a phase has nobody behind it
 #define SC_CL_TAIL(E, EPI, BIAS, RES, N0, OUT, LDO, TST)                                        \
     {                                                                                          \
         f32x4 psum[2];                                                                         \
-        get_sums(red + ((E) & 1) * RED_FLOATS, wave, lane, psum);                              \
+        get_sums(red + (par ^ 1) * RED_FLOATS, own, wave, lane, psum);                         \
         epilogue<H16, EPI>(psum, BIAS, RES, N0, OUT, LDO, TST, true, wave, lane);              \
     }
 
@@ -523,7 +539,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int j = 0; j < NR - 1; ++j) st.load(ring[j], 0, j);
     uint4 act[4][KS];
     float4 res[3][2];
+    f32x4 own[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};      // this wave's partial of the row block it finishes, kept across the barrier
+    int par = 0;                                          // K-partial buffer of the running step (the step behind it used the other)
 #define SC_CL_BUBBLE(J, E) st.load(ring[((J) + NR - 1) % NR], l, (E) + NR - 1);
+#pragma unroll 1
     for (int l = 0; l < layers; ++l) {
         const Layer L = layer_at(wf, l);
         // the lane index, opaque once per layer: everything addressed through it is recomputed here instead of being hoisted out of the layer
@@ -540,6 +559,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         act_from_band(act, band, wave, lane);
         __syncthreads();                                   // the K-partial buffers alias the band
         SC_CL_STAMP(1)
+#pragma unroll 1
         for (int ci = 0; ci < n1p; ci += NR) {
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
@@ -583,6 +603,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         act_from_band(act, band, wave, lane);
         __syncthreads();
         SC_CL_STAMP(7)
+#pragma unroll 1
         for (int ci = 0; ci < P12; ci += NR) {
 #pragma unroll
             for (int j = 0; j < NR; ++j) {
@@ -599,22 +620,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // ---- x += fc2: four K-passes of 768 over the hidden rows; the member's three column pairs accumulate in `res` across the passes --
         if (tid < 24) reinterpret_cast<float4*>(bias_l)[tid] = *reinterpret_cast<const float4*>(L.b_fc2 + 96 * c + 4 * tid);
         resid_request(res, xi, c, T, wave, lane);
-        static_assert(12 % NR == 0, "fc2 below is written for a ring length that divides its 12 steps");
-#if SC_CL_FC2_UNROLL
-#pragma unroll
-#else
 #pragma unroll 1
-#endif
-        for (int k0 = 0; k0 < 12; k0 += SC_CL_FC2_UNROLL ? 12 : 0 + (NR % 3 == 0 ? NR : 12))
+        for (int pass = 0; pass < 4; ++pass) {
+            act_from_rows(act, h_i, CMLP, pass * CD, T, wave, lane);
 #pragma unroll
-        for (int kk = 0; kk < (NR % 3 == 0 ? NR : 12); ++kk) {     // ring slot k % NR and column pair k % 3 are constants (pass k / 3 too if unrolled)
-            const int k = k0 + kk;
-            const int e = n1p + P3 + P12 + k;
-            if (kk % 3 == 0) act_from_rows(act, h_i, CMLP, (k / 3) * CD, T, wave, lane);
-            // the step behind: k - 1 = pass (k - 1) / 3, pair (k - 1) % 3; its block leaves after the last pass
-            SC_CL_STEP(kk % NR, e, E_ACC, bias_l + 32 * ((kk + 2) % 3), res[(kk + 2) % 3], 96 * c + 32 * ((kk + 2) % 3), xi, CD, k - 1 >= 9 ? T : 0, k > 0)
+            for (int kk = 0; kk < P3; ++kk) {
+                const int e = n1p + P3 + P12 + pass * P3 + kk;
+                // the step behind: column pair (kk + 2) % 3 (of the pass before for kk = 0); its block leaves after the last pass
+                if (kk < 3) SC_CL_STEP(kk % NR, e, E_ACC, bias_l + 32 * ((kk + 2) % 3), res[(kk + 2) % 3], 96 * c + 32 * ((kk + 2) % 3), xi, CD,
+                                       pass == 3 && kk > 0 ? T : 0, pass > 0 || kk > 0)
+                else SC_CL_BUBBLE(kk % NR, e)
+            }
         }
-        SC_CL_TAIL(n1p + P3 + P12 + 11, E_ACC, bias_l + 64, res[2], 96 * c + 64, xi, CD, T)
+        SC_CL_TAIL(0, E_ACC, bias_l + 64, res[2], 96 * c + 64, xi, CD, T)
         SC_CL_STAMP(10)
         arrivals += CL;
         cluster_barrier(cnt, arrivals, err, local);

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <atomic>
 #include "gemm8p.hpp"
 
 namespace sc {
@@ -1203,6 +1204,10 @@ static int launch_gemm(int epi, const bf16_t* A, const bf16_t* Wt, const float* 
     return (int)hipGetLastError();
 }
 
+// batch range of the cluster form (sc_clip_cluster_set_batch_range; environment SC_CLIP_CLUSTER_MIN_B / _MAX_B at load time)
+static std::atomic<int> g_cluster_min_b{[] { const char* e = getenv("SC_CLIP_CLUSTER_MIN_B"); return e ? atoi(e) : 26; }()};
+static std::atomic<int> g_cluster_max_b{[] { const char* e = getenv("SC_CLIP_CLUSTER_MAX_B"); return e ? atoi(e) : 32; }()};
+
 // Full image tower (H16: fp16 instead of bf16 operands).  See include/shapeclipper_hip.h for the weight image layout.
 template <bool H16>
 static int clip_vit_forward(const float* image, int B, int C, int H, int W, int patch, int D, int mlp, int layers, int heads,
@@ -1247,10 +1252,12 @@ static int clip_vit_forward(const float* image, int B, int C, int H, int W, int 
     if (rc) return rc;
     hipLaunchKernelGGL(embed_kernel, dim3(1024), dim3(256), 0, st, patch_out, cls, pos, x, B, T, D);
     hipLaunchKernelGGL((layernorm_kernel<false, H16>), dim3((M + 3) / 4), dim3(256), 0, st, x, D, lnpre_g, lnpre_b, (void*)x, M, D, ln_eps);
-    // Small batch of the ViT-B geometry: all layers in one launch, an image per cluster of 8 CUs (clip_cluster.hpp)
-    static const int cl_max_b = [] { const char* e = getenv("SC_CLIP_CLUSTER_MAX_B"); return e ? atoi(e) : 0; }();   // 0 while the cluster form is slower than the launches (profiles/r05_clip_cluster_*)
+    // One batch range of the ViT-B geometry runs all its layers in one launch, an image per cluster of 8 CUs (clip_cluster.hpp).  Measured
+    // (profiles/r05_clip_cluster_ab.txt): below ~26 images the launch-per-operation form is faster (its GEMMs are small), above 32 the
+    // cluster form needs a second round of the chip.
+    const int cl_min_b = g_cluster_min_b.load(), cl_max_b = g_cluster_max_b.load();
     int layers_left = layers;
-    if (w_cluster != nullptr && D == cl::CD && mlp == cl::CMLP && heads == cl::CHEADS && T <= 64 && B <= cl_max_b) {
+    if (w_cluster != nullptr && D == cl::CD && mlp == cl::CMLP && heads == cl::CHEADS && T <= 64 && B >= cl_min_b && B <= cl_max_b) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return (int)hipGetLastError();
@@ -1360,6 +1367,12 @@ int sc_clip_vit_forward_f16(const float* image, int B, int C, int H, int W, int 
 // 1 if the cluster form takes this geometry (width 768, MLP 3072, 12 heads, at most 64 tokens per image), else 0
 int sc_clip_cluster_supported(int D, int mlp, int heads, int tokens) {
     return D == sc::cl::CD && mlp == sc::cl::CMLP && heads == sc::cl::CHEADS && tokens >= 1 && tokens <= 64 ? 1 : 0;
+}
+// Batches of min_b <= B <= max_b images take the cluster form (max_b < min_b: never).  Returns 0.
+int sc_clip_cluster_set_batch_range(int min_b, int max_b) {
+    sc::g_cluster_min_b.store(min_b);
+    sc::g_cluster_max_b.store(max_b);
+    return 0;
 }
 // 16-bit values of the re-packed layer image: layers x 12 x 768 x 768 (the same values as the row-major layer matrices, other order)
 long long sc_clip_cluster_pack_elems(int layers) { return (long long)layers * (long long)sc::cl::LAYER_ELEMS; }

@@ -221,3 +221,60 @@ def test_clip_tower_from_openai_state_dict(res, patch, width, layers, proj, B):
     tower = ClipVisionTower.from_openai_state_dict(sd16).cuda()
     assert tower.cfg["heads"] == width // 64 and tower.cfg["layers"] == layers and tower.cfg["proj"] == proj
     _check(tower.encode_image(x.cuda()).cpu(), ref, "fp16", "from openai names, %d x %d layers, patch %d" % (width, layers, patch))
+
+
+# ---- the small-batch cluster form of the ViT-B layers (csrc/clip_cluster.hpp) -----------------------------------------------------------
+def _cluster_range(lo, hi):
+    import ctypes
+    from shapeclipper_amd import _lib
+    _lib.check(_lib.load().sc_clip_cluster_set_batch_range(ctypes.c_int(lo), ctypes.c_int(hi)), "sc_clip_cluster_set_batch_range")
+
+
+@pytest.fixture
+def cluster_range():
+    """Tests move the batch range of the cluster form; the default (26..32) is restored afterwards."""
+    yield _cluster_range
+    _cluster_range(26, 32)
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("B", [1, 7, 32, 41])            # one image; a ragged last group of 8; the BASELINE batch; a second round of the chip
+def test_clip_cluster_form_vs_transformers_and_launch_form(B, dtype, cluster_range):
+    """Both forms of the tower against the fp32 architecture oracle at the bars above, and against each other: they differ only in the
+    summation order of the K-partials and of the LayerNorm sums (cos > 0.999999 between them; bf16: 0.9999)."""
+    from shapeclipper_amd.model.clip_vit import ClipVisionTower, VIT_B32
+    c = VIT_B32
+    hf = _hf(c["width"], c["layers"], c["heads"], c["mlp"], c["patch"], c["image_size"], c["proj"], seed=11)
+    x = torch.randn(B, 3, 224, 224)
+    with torch.no_grad():
+        ref = hf(pixel_values=x).image_embeds
+    tower = ClipVisionTower(**c, dtype=dtype)
+    tower.load_state_dict(hf.state_dict())
+    tower = tower.cuda()
+    cluster_range(1, 64)
+    got_c = tower.encode_image(x.cuda()).cpu()
+    again = tower.encode_image(x.cuda()).cpu()
+    cluster_range(1, 0)                                   # never
+    got_l = tower.encode_image(x.cuda()).cpu()
+    _check(got_c, ref, dtype, "ViT-B/32 cluster form, B=%d" % B)
+    _check(got_l, ref, dtype, "ViT-B/32 launch form, B=%d" % B)
+    assert torch.equal(got_c, again), "the cluster form is deterministic (fixed summation order, no atomics in the data path)"
+    assert not torch.equal(got_c, got_l), "both calls ran the same form: the batch range did not take effect"
+    cos = torch.nn.functional.cosine_similarity(got_c, got_l, dim=-1).min().item()
+    print("cluster form vs launch form, %s, B=%d: min cosine %.8f, max |diff| %.2e" % (dtype, B, cos, (got_c - got_l).abs().max().item()))
+    assert cos > (0.999999 if dtype == "fp16" else 0.9999)
+
+
+def test_clip_cluster_form_is_batch_invariant(cluster_range):
+    """An image is owned by one cluster whatever else is in the batch: row i of a batch of 32 is bit-identical to the image run alone."""
+    from shapeclipper_amd.model.clip_vit import ClipVisionTower, VIT_B32
+    torch.manual_seed(5)
+    tower = ClipVisionTower(**VIT_B32).cuda()
+    x = torch.randn(32, 3, 224, 224, device="cuda")
+    cluster_range(1, 64)
+    full = tower.encode_image(x)
+    for i in (0, 13, 31):
+        assert torch.equal(tower.encode_image(x[i:i + 1])[0], full[i]), i
+    # ... and the default range takes the BASELINE batch through the cluster form
+    cluster_range(26, 32)
+    assert torch.equal(tower.encode_image(x), full)

@@ -33,7 +33,7 @@ if __name__ == "__main__":
         child(sys.argv[1], [int(b) for b in sys.argv[2:]])
         sys.exit(0)
     batches = sys.argv[1:] or ["1", "5", "8", "32", "33", "64"]
-    for tag, env in (("launches", {"SC_CLIP_CLUSTER_MAX_B": "0"}), ("cluster", {"SC_CLIP_CLUSTER_MAX_B": "64"})):
+    for tag, env in (("launches", {"SC_CLIP_CLUSTER_MAX_B": "0"}), ("cluster", {"SC_CLIP_CLUSTER_MIN_B": "1", "SC_CLIP_CLUSTER_MAX_B": "64"})):
         e = dict(os.environ); e.update(env)
         rc = subprocess.call(["timeout", "300", sys.executable, os.path.abspath(__file__), tag] + batches, env=e)
         if rc: print("%s: exit code %d" % (tag, rc))

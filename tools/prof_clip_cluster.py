@@ -2,6 +2,7 @@
 SHAPECLIPPER_HIP_LIB=shapeclipper_amd/lib/variants/lib_SC_CL_PROF_1.so).  python tools/prof_clip_cluster.py [batch=32]"""
 import ctypes, os, sys
 os.environ.setdefault("SC_CLIP_CLUSTER_MAX_B", "64")
+os.environ.setdefault("SC_CLIP_CLUSTER_MIN_B", "1")
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import torch
 from shapeclipper_amd import _lib

@@ -1,6 +1,6 @@
 mkdir -p gpurun_out/cl
-for v in ab17 ab33 ab49; do
-  echo "== $v"
-  SHAPECLIPPER_HIP_LIB=$PWD/shapeclipper_amd/lib/variants/lib_clip_$v.so timeout 300 python tools/prof_clip_cluster.py 32 > gpurun_out/cl/prof_${v}_32.log 2>&1
-  tail -1 gpurun_out/cl/prof_${v}_32.log
-done
+export SC_DBG_OUT=gpurun_out/cl
+timeout 1500 python -m pytest tests/test_gpu_clip.py -x -q -s 2>&1 | grep -v amdgpu.ids > gpurun_out/cl/test_clip.log
+grep -i "cluster form\|passed\|failed\|error" gpurun_out/cl/test_clip.log | tail -30
+timeout 900 python tools/dbg_clip_cluster.py 12 16 20 24 28 32 > gpurun_out/cl/dbg_sweep.log 2>&1
+grep -v amdgpu.ids gpurun_out/cl/dbg_sweep.log | grep "ms"
