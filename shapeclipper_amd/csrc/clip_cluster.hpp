@@ -1,8 +1,9 @@
 // clip_cluster.hpp -- the transformer layers of the CLIP ViT-B image tower at SMALL batch as ONE launch (included by clip_vit.hip).
 //
-// Replaces, for B <= 64 images of T <= 64 tokens (ViT-B/32 at 224 x 224: T = 50), the 7 dependent launches per layer of clip_vit_forward
-// (LayerNorm, qkv GEMM, attention, out-projection, LayerNorm, fc1, fc2: 84 launches per tower, ~4.6 us of cold start each whatever the
-// shape, profiles/r04_clip_gaps_32_B_32.txt) behind `clip_encoder.encode_image(image)` (/root/reference/CLIP_anno.py:166).
+// Replaces, for 26 <= B <= 32 images of T <= 64 tokens (ViT-B/32 at 224 x 224: T = 50; the annotator's batch), the 7 dependent launches per
+// layer of clip_vit_forward (LayerNorm, qkv GEMM, attention, out-projection, LayerNorm, fc1, fc2: 84 launches per tower, ~4.6 us of cold
+// start each whatever the shape, profiles/r04_clip_gaps_32_B_32.txt) behind `clip_encoder.encode_image(image)`
+// (/root/reference/CLIP_anno.py:166).  DESIGN.md 4.3.1 has the measurements (0.99 -> 0.86 ms per batch-32 tower) and what bounds it.
 //
 // Decomposition BY IMAGE.  A transformer layer is row-local except attention, and attention is image-local: nothing in the tower needs a
 // chip-wide synchronisation.  An image's 50 rows (one padded 64-row MFMA band) are owned by a CLUSTER of 8 workgroups = 8 CUs of ONE XCD
@@ -11,17 +12,17 @@
 //   out-proj columns [96 c, 96 c + 96) of x +=                                        (A = the attention rows of all 8 members)
 //   fc1      columns [384 c, 384 c + 384) of quick_gelu(.)
 //   fc2      columns [96 c, 96 c + 96) of x +=                                        (A = the hidden rows of all 8 members)
-// and the members meet at FOUR cluster barriers per layer (one counter per cluster, release / acquire at agent scope: correct wherever the
-// workgroups land; the XCD placement only makes the exchanged rows L2 hits).  Every weight byte is read by exactly one member of a cluster, the
-// four clusters of an XCD walk the same weight stream (L2 hits for three of them).
+// and the members meet at FOUR cluster barriers per layer (one counter per cluster; XCD-local when the members share an XCD -- checked from
+// the hardware XCC id -- and at agent scope otherwise: correct wherever the workgroups land).  Every weight byte is read by exactly one
+// member of a cluster; the four clusters of an XCD walk the same weight stream (L2 hits for three of them).
 //
-// GEMM core (slice_gemm below): the activation band is SMALL (64 x 768 16-bit = 96 KB) and every wave needs all of it, the weight slice is
-// LARGE and each element is needed once -- so neither goes through LDS: the four waves split K (wave q owns K-quarter q: its 64 x 192 piece of
-// the band lives in 96 registers for the whole phase), weight fragments go global -> registers (one 16-byte load per lane and 16 x 32 fragment,
-// three 32-column chunks in flight) and feed v_mfma_f32_16x16x32 directly (W fragment as the first operand: a lane ends up with 4 consecutive
-// output columns of one row).  The four K-partials of a 64 x 32 block are added in wave order through LDS (fixed order; wave w finishes row
-// block w) and leave through the epilogue (bias, fp16 / quick_gelu / x +=).  LayerNorm is recomputed by every member straight into the
-// operand registers (row statistics exactly as layernorm_kernel: two-pass, same summation order).
+// GEMM core: the activation band is SMALL (64 x 768 16-bit = 96 KB) and every wave needs all of it, the weight slice is LARGE and each
+// element is needed once -- so neither goes through LDS: the four waves split K (wave q owns K-quarter q: its 64 x 192 piece of the band
+// lives in 96 registers for the whole phase), weight fragments go global -> registers from a RE-PACKED image (a fragment = one contiguous
+// KB; a ring of chunks per wave) and feed v_mfma_f32_16x16x32 directly (W fragment as the first operand: a lane ends up with 4 consecutive
+// output columns of one row).  The four K-partials of a 64 x 32 block are added in a fixed order through LDS (wave w finishes row block w)
+// and leave through the epilogue (bias, 16-bit / quick_gelu / x +=) under the next step's MFMAs.  LayerNorm is recomputed by every member
+// (two-pass, fp32) into an LDS band the waves read their operand registers from.
 //
 // A lost workgroup (a device that cannot hold the whole grid at once) would leave the others spinning: every wait is bounded (0.2 s), the
 // first time-out raises the error word, every later wait returns at once and the images of the launch are poisoned with NaN -- loud, no hang.
