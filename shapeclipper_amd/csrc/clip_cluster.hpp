@@ -155,6 +155,7 @@ struct Stream {
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int s = 0; s < KS; ++s) q.v[cb][s] = *reinterpret_cast<const uint4*>(base + (size_t)((cb * KS + s) * stride) + (unsigned)(lane * 16));
+        // (non-temporal loads here -- global_load ... nt -- were 12 % slower and, once in four processes, not reproducible run to run: dropped)
     }
 };
 

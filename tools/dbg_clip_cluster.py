@@ -28,7 +28,27 @@ def child(tag, batches):
     torch.save(res, os.path.join(OUT, "clip_%s.pt" % tag))
 
 
+def stress(n=300, B=32):
+    """n calls of the cluster form on one input: every result bit-identical to the first (python tools/dbg_clip_cluster.py stress)."""
+    import torch
+    from shapeclipper_amd.model.clip_vit import ClipVisionTower, VIT_B32
+    torch.manual_seed(0)
+    t = ClipVisionTower(**VIT_B32).cuda()
+    x = torch.randn(B, 3, 224, 224, device="cuda")
+    first = t.encode_image(x)
+    bad = 0
+    for i in range(n):
+        if i % 50 == 0:
+            junk = torch.randn(64, 1024, 1024, device="cuda").sum()       # something else on the chip in between: other cache contents, other clocks
+        bad += int(not torch.equal(t.encode_image(x), first))
+    print("stress: %d calls at B=%d, %d differ from the first" % (n, B, bad))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "stress":
+        os.environ.setdefault("SC_CLIP_CLUSTER_MIN_B", "1"); os.environ.setdefault("SC_CLIP_CLUSTER_MAX_B", "64")
+        globals()["stress"]()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] in ("cluster", "launches"):
         child(sys.argv[1], [int(b) for b in sys.argv[2:]])
         sys.exit(0)
@@ -43,3 +63,4 @@ if __name__ == "__main__":
         d = (a[B] - b[B]).abs().max().item(); s = a[B].abs().max().item()
         cos = torch.nn.functional.cosine_similarity(a[B], b[B], dim=1).min().item()
         print("B=%d: max |diff| %.3e (scale %.3e)  min cos %.7f  identical=%s" % (B, d, s, cos, bool((a[B] == b[B]).all())))
+
