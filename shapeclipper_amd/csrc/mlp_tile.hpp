@@ -327,17 +327,13 @@ __device__ __forceinline__ void acc_zero(f32x4 (&acc)[MT]) {
 // softplus(beta=100) and derivatives (model/implicit.py:136; torch threshold=20 is reproduced to
 // well below fp32 resolution: beyond it log1p(t) < 2.1e-9*0.01).  t = exp(-|100a|), r = 1/(1+t):
 //   sp = max(a,0) + log(1+t)/100,  sp' = (a>=0 ? 1 : t) * r,  sp'' = 100 * t * r^2
-// (one multiply by -100 log2(e) with the |.| source modifier + v_exp_f32; max(a, 0) as ONE v_med3_f32: fmaxf() costs a second
+// (one multiply by -100 log2(e) with the |.| source modifier + v_exp_f32; max(a, 0) as ONE instruction (relu_f below): fmaxf() costs a second
 //  v_max for sNaN quieting -- every vector instruction of these kernels is on the critical path, see below.  NOT inline asm:
 //  the hazard recogniser does not see an asm statement reading an MFMA result and omits the wait states -- measured: wrong
 //  colours at 1e-2.)
 // Round 5: as ONE v_max_i32 on the bit pattern (negative floats are negative integers; -0.0 -> +0.0).  hipcc 7.2 expands the
 // v_med3_f32 form into a canonicalising v_max_f32 x, x + v_max_f32 0, x (read from the ISA: two instructions per element).
-#ifdef SC_AB_OLD
-__device__ __forceinline__ float relu_f(float a) { return __builtin_amdgcn_fmed3f(a, 0.f, __builtin_inff()); }
-#else
 __device__ __forceinline__ float relu_f(float a) { return __builtin_bit_cast(float, max(__builtin_bit_cast(int, a), 0)); }
-#endif
 __device__ __forceinline__ void softplus_parts(float a, float& t, float& r) {
     t = __builtin_amdgcn_exp2f(-144.26950408889634f * fabsf(a));
     r = __builtin_amdgcn_rcpf(1.f + t);

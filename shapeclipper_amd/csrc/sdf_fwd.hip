@@ -44,11 +44,7 @@ __global__ __launch_bounds__(64 * SDF_WAVES) void sdf_fwd_kernel(SdfFwdArgs a) {
 
     // wave index as a SCALAR: the per-wave scratch base below depends on it, and with a vector-register wave index hipcc wrapped each
     // of the 40 park stores / loads of a tile in a waterfall loop (4 v_readfirstlane + 2 v_cmp + exec save / restore + branch).
-#ifdef SC_AB_OLD
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#else
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#endif
     const int p = lane & 15, g = lane >> 4;
     const int ntiles = (a.n_points + TP - 1) / TP;
     const size_t tbl = (size_t)ntiles * 1024;
