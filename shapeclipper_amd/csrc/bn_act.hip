@@ -18,6 +18,7 @@
 // sequential forward calls would apply them; dgamma/dbeta are summed over the groups (shared parameters).
 // Bound: HBM (8 TB/s).  Algorithmic bytes per element: forward 12-16 B, backward 20-28 B.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <type_traits>
 
@@ -386,6 +387,75 @@ __global__ __launch_bounds__(BN_T) void bn_relu_pool_fwd2_kernel(PoolFwdArgs a) 
     }
 }
 
+// Round 5: the same pass with R consecutive output rows per thread.  The 2 R + 1 input rows of the strip are requested together
+// (2 R + 1 eight-byte loads in flight per lane instead of 3), a shared row (2 ho + 1 is the last row of window ho and the first of ho + 1) is
+// loaded, normalised and rectified ONCE, and the index arithmetic is paid per strip.  Same fma, same comparisons in the same scan order per
+// output: identical values and indices.
+template <int R>
+__global__ __launch_bounds__(BN_T) void bn_relu_pool_fwd_rows_kernel(PoolFwdArgs a) {
+    const int c = blockIdx.x;
+    const BnShare sh = bn_share(a.st.N, a.st.G);
+    const int HW = a.H * a.W, C = a.st.C, W = a.W;
+    float mean, rstd;
+    bn_forward_stats(a.st, c, sh, mean, rstd);
+    const float scale = a.gamma[c] * rstd, shift = a.beta[c] - mean * scale;
+    const int HoWo = a.Ho * a.Wo;
+    const int RG = (a.Ho + R - 1) / R, per = RG * a.Wo;            // strips per plane
+    const int cnt = (sh.Ng - sh.s + sh.S - 1) / sh.S, total = cnt * per;
+    const int lane = threadIdx.x & 63;
+    for (int t0 = 0; t0 < total; t0 += BN_T) {
+        const int t = t0 + threadIdx.x;
+        const bool on = t < total;
+        const int tt = on ? t : total - 1;
+        const int nl = tt / per, o = tt - nl * per;
+        const int rg = o / a.Wo, wo = o - rg * a.Wo;
+        const int ho0 = rg * R;
+        const size_t plane = ((size_t)(sh.n0 + sh.s + nl * sh.S) * C + c);
+        const float* xp = a.st.x + plane * HW;
+        float2 v[2 * R + 1];
+        float lf[2 * R + 1];
+#pragma unroll
+        for (int k = 0; k < 2 * R + 1; ++k) {
+            const int h = 2 * ho0 - 1 + k;
+            const bool hv = h >= 0 && h < a.H;
+            v[k] = make_float2(0.f, 0.f);
+            lf[k] = 0.f;
+            if (hv) v[k] = *reinterpret_cast<const float2*>(xp + h * W + 2 * wo);
+            if (lane == 0 && wo > 0 && hv) lf[k] = xp[h * W + 2 * wo - 1];
+        }
+        float r0[2 * R + 1], r1[2 * R + 1], left[2 * R + 1];
+#pragma unroll
+        for (int k = 0; k < 2 * R + 1; ++k) {
+            const float u0 = fmaf(v[k].x, scale, shift), u1 = fmaf(v[k].y, scale, shift);
+            r0[k] = u0 < 0.f ? 0.f : u0;                                                  // relu(NaN) = NaN
+            r1[k] = u1 < 0.f ? 0.f : u1;
+            left[k] = __shfl_up(r1[k], 1);                                                // the left neighbour's column 2 wo - 1 (same strip when wo > 0)
+            if (lane == 0) {
+                const float ul = fmaf(lf[k], scale, shift);
+                left[k] = ul < 0.f ? 0.f : ul;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int ho = ho0 + r;
+            float best = -__builtin_inff();
+            int bi = -1;
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh) {
+                const int k = 2 * r + dh, h = 2 * ho - 1 + dh;
+                if (h < 0 || h >= a.H) continue;
+                if (wo > 0 && (left[k] > best || bi < 0 || left[k] != left[k])) { best = left[k]; bi = h * W + 2 * wo - 1; }
+                if (r0[k] > best || bi < 0 || r0[k] != r0[k]) { best = r0[k]; bi = h * W + 2 * wo; }      // strict >: first maximum in scan order; a NaN wins
+                if (r1[k] > best || bi < 0 || r1[k] != r1[k]) { best = r1[k]; bi = h * W + 2 * wo + 1; }
+            }
+            if (on && ho < a.Ho) {
+                a.y[plane * HoWo + ho * a.Wo + wo] = best;
+                a.idx[plane * HoWo + ho * a.Wo + wo] = bi;
+            }
+        }
+    }
+}
+
 struct PoolBwdArgs {
     const float* dy; const int* idx; const float* x; const float* gamma; const float* beta; const float* mean;
     const float* rstd; float* partial; float* dx;
@@ -474,6 +544,114 @@ __global__ __launch_bounds__(BN_T) void bn_relu_pool_bwd_gather_kernel(PoolBwdAr
                 sgx += g * ((xv - mean) * rstd);
             }
             if (V2 && MODE != 1) *reinterpret_cast<float2*>(a.dx + plane * HW + h * a.W + 2 * j) = grow;
+        }
+    }
+    if (MODE == 2) return;
+    block_sum2(sg, sgx, red);
+    if (threadIdx.x == 0) store_partial(a.partial, c, sh, a.G, sg, sgx);
+}
+
+// Round 5, even W: the same two gather passes with a strip of R vertically adjacent 2 x 2 blocks per thread.  The windows of block row i are
+// rows i and i + 1, so a strip needs R + 1 window rows instead of 2 R; window column j + 1 comes from the lane to the right (consecutive
+// lanes = consecutive j of one strip; only a wave's last lane loads it itself): 2 (R + 1) four-byte loads of idx / dy per strip instead of
+// 8 R, all of them and the 2 R eight-byte loads of x requested before the first use.  Per position the same expressions in the same order
+// as the kernel above.  R = 1 (the default) keeps every thread's set of positions, i.e. results identical to that kernel bit for bit
+// (206 -> 188 us at 64 images, 328 -> 276 at 96); with R = 2 / 4 (180 / 272, 178 / 270 us) a thread's share of the per-channel sums is a
+// different set of positions and dgamma / dbeta / dx agree to rounding only (tools/perf_stem_pool_ab.py, profiles/r05_stem_pool_ab.txt).
+template <int MODE, int R>
+__global__ __launch_bounds__(BN_T) void bn_relu_pool_bwd_rows_kernel(PoolBwdArgs a) {
+    __shared__ float red[2 * BN_T / 64];
+    const int c = blockIdx.x;
+    const BnShare sh = bn_share(a.N, a.G);
+    const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
+    const int Hq = (a.H + 1) >> 1, Wq = a.W >> 1, RG = (Hq + R - 1) / R, Q = RG * Wq;
+    const float mean = a.mean[(size_t)sh.g * a.C + c], rstd = a.rstd[(size_t)sh.g * a.C + c];
+    const float scale = a.gamma[c] * rstd, shift = a.beta[c] - mean * scale;
+    float sg = 0.f, sgx = 0.f;
+    float mg = 0.f, mgx = 0.f;
+    if (MODE == 2) {
+        float tsg, tsgx;
+        combine_partials(a.partial, c, sh.g, sh.S, a.G, tsg, tsgx);
+        if (blockIdx.y == 0 && threadIdx.x == 0) {      // parameters are shared by the groups: sum over all of them
+            float tg = 0.f, tgx = 0.f;
+            for (int g = 0; g < a.G; ++g) {
+                float u, v;
+                combine_partials(a.partial, c, g, sh.S, a.G, u, v);
+                tg += u;
+                tgx += v;
+            }
+            a.dgamma[c] = tgx;
+            a.dbeta[c] = tg;
+        }
+        const float n = (float)sh.Ng * (float)HW;
+        mg = a.training ? tsg / n : 0.f;
+        mgx = a.training ? tsgx / n : 0.f;
+    }
+    const int cnt = (sh.Ng - sh.s + sh.S - 1) / sh.S, total = cnt * Q;
+    const int lane = threadIdx.x & 63;
+    for (int t0 = 0; t0 < total; t0 += BN_T) {
+        const int t = t0 + threadIdx.x;
+        const bool on = t < total;
+        const int tt = on ? t : total - 1;
+        const int nl = tt / Q, q = tt - nl * Q;
+        const int rg = q / Wq, j = q - rg * Wq, i0 = rg * R;
+        const size_t plane = ((size_t)(sh.n0 + sh.s + nl * sh.S) * a.C + c);
+        int wi[R + 1][2];
+        float wd[R + 1][2];
+        float2 xrow[2 * R];
+        const bool own_right = lane == 63 && (j + 1) < a.Wo;            // nobody to the right in this wave
+#pragma unroll
+        for (int di = 0; di <= R; ++di) {
+            const bool okr = (i0 + di) < a.Ho;
+            const size_t o = plane * HoWo + (size_t)(i0 + di) * a.Wo + j;
+            wi[di][0] = okr && j < a.Wo ? a.idx[o] : -1;
+            wd[di][0] = okr && j < a.Wo ? a.dy[o] : 0.f;
+            wi[di][1] = okr && own_right ? a.idx[o + 1] : -1;
+            wd[di][1] = okr && own_right ? a.dy[o + 1] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 2 * R; ++k) {
+            const int h = 2 * i0 + k;
+            xrow[k] = h < a.H ? *reinterpret_cast<const float2*>(a.x + plane * HW + h * a.W + 2 * j) : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int di = 0; di <= R; ++di) {
+            const int ri = __shfl_down(wi[di][0], 1);
+            const float rd = __shfl_down(wd[di][0], 1);
+            if (lane != 63) {                                           // the right neighbour holds (strip, j + 1) when j + 1 < Wq
+                const bool okc = (j + 1) < a.Wo;
+                wi[di][1] = okc ? ri : -1;
+                wd[di][1] = okc ? rd : 0.f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (int eh = 0; eh < 2; ++eh) {
+                const int h = 2 * (i0 + r) + eh;
+                if (h >= a.H) continue;
+                float2 grow;
+#pragma unroll
+                for (int ew = 0; ew < 2; ++ew) {
+                    const int pos = h * a.W + 2 * j + ew;
+                    const float xv = ew ? xrow[2 * r + eh].y : xrow[2 * r + eh].x;
+                    float g = 0.f;
+                    // even row/col: covered only by window i (j); odd: by windows i and i+1 (j and j+1)
+#pragma unroll
+                    for (int di = 0; di <= eh; ++di)
+#pragma unroll
+                        for (int dj = 0; dj <= ew; ++dj)
+                            if (wi[r + di][dj] == pos) g += wd[r + di][dj];
+                    if (!(fmaf(xv, scale, shift) > 0.f)) g = 0.f;        // ReLU gate (a max of 0 carries no gradient)
+                    const float o = MODE == 2 ? scale * (g - mg - (xv - mean) * rstd * mgx) : g;
+                    if (ew) grow.y = o; else grow.x = o;
+                    if (on) {
+                        sg += g;
+                        sgx += g * ((xv - mean) * rstd);
+                    }
+                }
+                if (MODE == 2 && on) *reinterpret_cast<float2*>(a.dx + plane * HW + h * a.W + 2 * j) = grow;
+            }
         }
     }
     if (MODE == 2) return;
@@ -686,7 +864,11 @@ static inline bool bn_fused_takes(int N, int C, int HW, int G) {
     return C >= 256 && G <= BNF_G && vecs <= (long long)BNF_T * BNF_V;
 }
 
-static inline int bn_splits(int Ng, int C, int G) {      // blocks per (channel, group); C * G * S ~ 2048 blocks
+// Blocks per (channel, group); C * G * S ~ 2048 blocks (8 resident blocks of 256 threads per CU).  Round 5: a rule that minimises
+// rounds(C G S) x ceil(Ng / S) instead (one image per block for the three-group passes of the view estimator: exactly three rounds) was
+// measured and is NOT faster -- 44 -> 46 us, 24 -> 28 us per forward at 96 images: these passes already move 5-6 TB/s, the smaller blocks
+// only add prologues.
+static inline int bn_splits(int Ng, int C, int G) {
     int S = (2048 + C * G - 1) / (C * G);
     if (S > Ng) S = Ng;
     if (S > 32) S = 32;
@@ -750,7 +932,11 @@ extern "C" int sc_bn_relu_pool_forward(const float* x, const float* gamma, const
     if (training) hipLaunchKernelGGL(sc::bn_stats_kernel, grid, dim3(sc::BN_T), 0, st, x, N, C, H * W, groups, partial);
     sc::PoolFwdArgs a{{x, partial, save_mean, save_rstd, run_mean, run_var, n_tracked, N, C, H * W, groups, training, eps, momentum},
                       gamma, beta, y, idx, H, W, (H + 2 - 3) / 2 + 1, (W + 2 - 3) / 2 + 1};
-    if ((W & 1) == 0) hipLaunchKernelGGL(sc::bn_relu_pool_fwd2_kernel, grid, dim3(sc::BN_T), 0, st, a);
+#ifndef SC_POOL_ROWS
+#define SC_POOL_ROWS 4
+#endif
+    if ((W & 1) == 0 && SC_POOL_ROWS > 0) hipLaunchKernelGGL(sc::bn_relu_pool_fwd_rows_kernel<(SC_POOL_ROWS > 0 ? SC_POOL_ROWS : 1)>, grid, dim3(sc::BN_T), 0, st, a);
+    else if ((W & 1) == 0) hipLaunchKernelGGL(sc::bn_relu_pool_fwd2_kernel, grid, dim3(sc::BN_T), 0, st, a);
     else hipLaunchKernelGGL(sc::bn_relu_pool_fwd_kernel, grid, dim3(sc::BN_T), 0, st, a);
     return (int)hipGetLastError();
 }
@@ -764,6 +950,14 @@ extern "C" int sc_bn_relu_pool_backward(const float* dy, const int* idx, const f
     hipStream_t st = (hipStream_t)stream_;
     const dim3 grid(C, groups * sc::bn_splits(N / groups, C, groups));
     sc::PoolBwdArgs a{dy, idx, x, gamma, beta, mean, rstd, partial, dx, N, C, H, W, (H + 2 - 3) / 2 + 1, (W + 2 - 3) / 2 + 1, groups, dgamma, dbeta, training};
+#ifndef SC_POOL_BWD_ROWS
+#define SC_POOL_BWD_ROWS 1
+#endif
+    if ((W & 1) == 0 && SC_POOL_BWD_ROWS > 0) {      // two gather passes over strips of 2 x 2 blocks
+        hipLaunchKernelGGL((sc::bn_relu_pool_bwd_rows_kernel<1, (SC_POOL_BWD_ROWS > 0 ? SC_POOL_BWD_ROWS : 1)>), grid, dim3(sc::BN_T), 0, st, a);
+        hipLaunchKernelGGL((sc::bn_relu_pool_bwd_rows_kernel<2, (SC_POOL_BWD_ROWS > 0 ? SC_POOL_BWD_ROWS : 1)>), grid, dim3(sc::BN_T), 0, st, a);
+        return (int)hipGetLastError();
+    }
     if ((W & 1) == 0) {      // two gather passes, no full-resolution temporary
         hipLaunchKernelGGL((sc::bn_relu_pool_bwd_gather_kernel<true, 1>), grid, dim3(sc::BN_T), 0, st, a);
         hipLaunchKernelGGL((sc::bn_relu_pool_bwd_gather_kernel<true, 2>), grid, dim3(sc::BN_T), 0, st, a);
