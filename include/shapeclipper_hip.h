@@ -104,6 +104,15 @@ int sc_rgb_composite_forward(const float* points, const float* z_vals, const flo
                              float beta_min, float bgcolor, float normal_pow,
                              float* rgb, float* mask, float* mask_hard, float* depth, float* normal,
                              float* weights, float* alpha, float* rgb_flat, void* stream);
+/* The same, and the post-ReLU activations r0, r1, r2 of the three hidden layers of RGBNetwork (model/implicit.py:233-237) are parked in
+ * rr (3 x TBL64 = 3 x n_rays * 4 * 1024 floats, layer-major; NULL = not parked) for sc_rgb_composite_backward_fused_stash.        */
+int sc_rgb_composite_forward_stash(const float* points, const float* z_vals, const float* depth_fac,
+                                   const float* sdf, const float* grad, const float* feat,
+                                   const float* v_pack, const float* dbias, const float* beta_param,
+                                   int n_rays, int rays_per_image, int n_images, int symmetric,
+                                   float beta_min, float bgcolor, float normal_pow,
+                                   float* rgb, float* mask, float* mask_hard, float* depth, float* normal,
+                                   float* weights, float* alpha, float* rgb_flat, float* rr, void* stream);
 
 /* Reverse pass.  G_* are the upstream per-ray gradients (NULL = zero).  g_beta: SC_RGB_BWD_BETA_PARTS floats, fully
  * written: one partial of d/d(raw beta parameter) per wave of the grid; the gradient is their sum in index order
@@ -144,6 +153,15 @@ int sc_rgb_composite_backward_fused(
     const float* G_rgb, const float* G_mask, const float* G_depth, const float* G_normal,
     float* g_sdf, float* g_grad, float* g_feat, float* g_points, float* g_z, float* g_depth_fac, float* g_beta,
     float* partial, float* v3_part, void* stream);
+/* sc_rgb_composite_backward_fused reading the hidden activations the forward pass parked (rr of sc_rgb_composite_forward_stash) instead
+ * of recomputing the forward chain (a third of the kernel's time); same outputs, same summation orders.                            */
+int sc_rgb_composite_backward_fused_stash(
+    const float* points, const float* z_vals, const float* depth_fac, const float* sdf, const float* grad,
+    const float* feat, const float* v_pack, const float* dbias, const float* beta_param, const float* rgb_flat,
+    int n_rays, int rays_per_image, int n_images, int symmetric, float beta_min, float bgcolor, float normal_pow,
+    const float* G_rgb, const float* G_mask, const float* G_depth, const float* G_normal,
+    float* g_sdf, float* g_grad, float* g_feat, float* g_points, float* g_z, float* g_depth_fac, float* g_beta,
+    float* partial, float* v3_part, const float* rr, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Weight-gradient GEMM  dW[64][nb0+nb1] = sum_points A(p) (x) [B0(p) | B1(p)]  over one or two terms.

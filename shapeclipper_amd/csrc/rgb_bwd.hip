@@ -48,11 +48,36 @@ struct RgbBwdArgs {
 // four more waves (the scheme of sdf_bwdw.hip: the chain waves drop each layer's operand pair -- Gy_l and the layer's input -- into a
 // 4 KiB LDS slot pair, two workgroup barriers bracket the write, wave 4 + w accumulates rows 16 w .. 16 w + 15 of every matrix with fp32
 // MFMAs whose K index is the point) instead of writing Gy_0..2 and r_0..1 to HBM (1.6 GB per bs32 render) for three sc_wgrad launches.
-constexpr int RB_XCH = (RgbLds::TOTAL + 3) & ~3;          // exchange slots [chain wave][A | B][1024]
-constexpr int RB_PTS = RB_XCH + 4 * 2 * 1024;             // point stash [chain wave][16 points][8]: x0 x1 x2 - | - - valid -
-constexpr int RB_LDS_FLOATS = RB_PTS + 4 * 16 * 8;
+// SC_RGBB_DB = 1 (experiment of round 5, correct at every parity bar, NOT faster: 5.52 against 5.54 ms per bs32 training render on one
+// box, profiles/r05_rgb_stash_ab.txt): TWO sets of slots, used alternately by consecutive hand-overs, and ONE barrier per hand-over
+// ("written") instead of two: a chain wave may write set n & 1 as soon as it has passed the barrier of hand-over n - 1, because the
+// weight-gradient waves reach that barrier only after they have consumed hand-over n - 2 -- the last reader of that set.  The point stash
+// alternates by tile for the same reason (written at the first hand-over of a tile, read at its third).  LDS: 63 + 64 + 4 KB.  The
+// product keeps one set and two barriers (63 + 32 + 2 KB): the barriers are not what the chain waves wait for.
+#ifndef SC_RGBB_DB
+#define SC_RGBB_DB 0
+#endif
+constexpr int RB_NBUF = SC_RGBB_DB ? 2 : 1;
+constexpr int RB_XCH = (RgbLds::TOTAL + 3) & ~3;          // exchange slots [set][chain wave][A | B][1024]
+constexpr int RB_XSET = 4 * 2 * 1024;
+constexpr int RB_PTS = RB_XCH + RB_NBUF * RB_XSET;        // point stash [set][chain wave][16 points][8]: x0 x1 x2 - | - - valid -
+constexpr int RB_PSET = 4 * 16 * 8;
+constexpr int RB_LDS_FLOATS = RB_PTS + RB_NBUF * RB_PSET;
 
-template <bool FUSED>
+// Phase profile (tuning tool, tools/prof_rgb_bwd.py; compiled only with -DSC_RGBB_PROFILE): s_memtime stamps of ONE iteration of one
+// workgroup, chain wave 0 and weight-gradient wave 4, into rgbb_prof_buf [8 waves][64].
+#ifdef SC_RGBB_PROFILE
+__device__ unsigned long long* rgbb_prof_buf = nullptr;
+__device__ int rgbb_prof_block = -1, rgbb_prof_iter = -1;
+#define RB_STAMP(ID) if (prof_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (lane == 0) rgbb_prof_buf[wave * 64 + (ID)] = t_; }
+#else
+#define RB_STAMP(ID)
+#endif
+
+// STASH (round 5, second half; FUSED only): the forward pass parked r0, r1, r2 (sc_rgb_composite_forward_stash) and they are LOADED here
+// instead of recomputed -- the phase profile (tools/prof_rgb_bwd.py) charges the recomputed forward chain 48 k of the chain wave's 155 k
+// cycles per ray; the colours come from rgb_flat, which phase 1 loads anyway.
+template <bool FUSED, bool STASH = false>
 __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? 1 : 2) void rgb_composite_bwd_kernel(RgbBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     stage_rgb_weights(lds, a.v, threadIdx.x, FUSED ? 512 : 256);
@@ -87,17 +112,20 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? 1 : 2) void rgb_composit
             }
         };
 #define RB_CONSUME(ACC, PEACC, WITH_PE, RS)                                                 \
-        lds_barrier(); lds_barrier();                                                        \
+        lds_barrier();                                                                       \
+        if (!SC_RGBB_DB) lds_barrier();                                                      \
+        RB_STAMP(1 + 2 * (k * 3 + (2 - RS)))                                                 \
         _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                      \
-            const float* sA = lds + RB_XCH + (c * 2 + 0) * 1024;                             \
-            const float* sB = lds + RB_XCH + (c * 2 + 1) * 1024;                             \
+            const int set_ = SC_RGBB_DB ? ((k + (2 - RS)) & 1) : 0;                          \
+            const float* sA = lds + RB_XCH + set_ * RB_XSET + (c * 2 + 0) * 1024;            \
+            const float* sB = lds + RB_XCH + set_ * RB_XSET + (c * 2 + 1) * 1024;            \
             const float4 af = xch_frag(sA, rd, w);                                           \
             float4 bf[4];                                                                    \
             _Pragma("unroll") for (int n = 0; n < 4; ++n) bf[n] = xch_frag(sB, rd, n);       \
             outer16<4>(af, bf, ACC);                                                         \
             if (WITH_PE) {                                                                   \
                 float4 pf[3];                                                                \
-                pe_frags<1>(lds + RB_PTS + c * 16 * 8, i, kg, symmetric, pf);                \
+                pe_frags<1>(lds + RB_PTS + (SC_RGBB_DB ? (k & 1) : 0) * RB_PSET + c * 16 * 8, i, kg, symmetric, pf); \
                 outer16<3>(af, pf, PEACC);                                                   \
             }                                                                                \
             const float v = (af.x + af.y) + (af.z + af.w);                                   \
@@ -110,9 +138,14 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? 1 : 2) void rgb_composit
                 if (kg == 0 && ray_c < a.n_rays)                                             \
                     cbp[((size_t)min(ray_c / a.rays_per_image, a.n_images - 1) * 3 + RS) * 64 + 16 * w + i] += t; \
             }                                                                                \
-        }
+        }                                                                                    \
+        RB_STAMP(2 + 2 * (k * 3 + (2 - RS)))
 #pragma unroll 1
         for (int it = 0; it < n_iter; ++it) {
+#ifdef SC_RGBB_PROFILE
+            const bool prof_on = (int)blockIdx.x == rgbb_prof_block && it == rgbb_prof_iter && rgbb_prof_buf;
+#endif
+            RB_STAMP(0)
             const int ray0 = (it * (int)gridDim.x + (int)blockIdx.x) * 4, ray3 = min(ray0 + 3, a.n_rays - 1);
             const int img0 = min(min(ray0, a.n_rays - 1) / a.rays_per_image, a.n_images - 1), img3 = min(ray3 / a.rays_per_image, a.n_images - 1);
             if (img0 != cur_img || img3 != img0) {
@@ -142,14 +175,22 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? 1 : 2) void rgb_composit
     }
     const int p = lane & 15, g = lane >> 4;
     RgbLanePtrs L(lds, p, g);
-    [[maybe_unused]] float* slotA = lds + RB_XCH + (wave * 2 + 0) * 1024;
-    [[maybe_unused]] float* slotB = lds + RB_XCH + (wave * 2 + 1) * 1024;
-    [[maybe_unused]] float* ptsw = lds + RB_PTS + wave * 16 * 8;
+    [[maybe_unused]] float* const slot0 = lds + RB_XCH + (wave * 2 + 0) * 1024;       // set 0; set 1 is RB_XSET floats further
+    [[maybe_unused]] float* const pts0 = lds + RB_PTS + wave * 16 * 8;
     [[maybe_unused]] int wr[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) wr[r] = (((p >> 2) * 64 + 4 * g + (r ^ (p >> 2))) << 2) + (p & 3);
-// hand one operand pair to the weight-gradient waves: B1 (they have finished the previous pair), write, B2 (visible)
-#define RB_EXCHANGE(WRITES) if (FUSED) { lds_barrier(); WRITES lds_barrier(); }
+// hand operand pair J (0, 1, 2) of tile k to the weight-gradient waves.  One set of slots: B1 (they have finished the previous pair),
+// write, B2 (visible).  Two sets: write into set (k + J) & 1, one barrier (see SC_RGBB_DB above).
+#define RB_SLOTS(J)                                                                          \
+        [[maybe_unused]] float* slotA = slot0 + (SC_RGBB_DB ? ((k + (J)) & 1) : 0) * RB_XSET; \
+        [[maybe_unused]] float* slotB = slotA + 1024;                                        \
+        [[maybe_unused]] float* ptsw = pts0 + (SC_RGBB_DB ? (k & 1) : 0) * RB_PSET;
+#ifdef SC_RGBB_PROFILE
+#define RB_EXCHANGE(J, WRITES) if (FUSED) { RB_SLOTS(J) if (!SC_RGBB_DB) lds_barrier(); RB_STAMP(sid++) WRITES RB_STAMP(sid++) lds_barrier(); RB_STAMP(sid++) }
+#else
+#define RB_EXCHANGE(J, WRITES) if (FUSED) { RB_SLOTS(J) if (!SC_RGBB_DB) lds_barrier(); WRITES lds_barrier(); }
+#endif
     const float bp = a.beta_param[0];
     const float beta = fabsf(bp) + a.beta_min;
     const float dbeta_dbp = bp > 0.f ? 1.f : (bp < 0.f ? -1.f : 0.f);
@@ -163,14 +204,21 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? 1 : 2) void rgb_composit
 
 #pragma unroll 1
     for (int it = 0; it < n_iter; ++it) {
+#ifdef SC_RGBB_PROFILE
+        const bool prof_on = (int)blockIdx.x == rgbb_prof_block && it == rgbb_prof_iter && rgbb_prof_buf;
+        int sid = 2;
+#endif
+        RB_STAMP(0)
         const int ray = (it * (int)gridDim.x + (int)blockIdx.x) * 4 + wave;
         if (ray >= a.n_rays) {
             if (!FUSED) break;
             for (int st = 0; st < 12; ++st) {               // tail: keep the barrier count of an iteration (4 tiles x 3 steps), feed zeros
-                lds_barrier();
-                if (st == 0) {
-                    xch_zero(slotA, lane); xch_zero(slotB, lane);
-                    if (lane < 32) reinterpret_cast<float4*>(ptsw)[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!SC_RGBB_DB) lds_barrier();
+                if (st < RB_NBUF) {                         // every set is cleared at the hand-over that would write it (st = 3 k + J: set st & 1)
+                    xch_zero(slot0 + st * RB_XSET, lane); xch_zero(slot0 + st * RB_XSET + 1024, lane);
+                }
+                if (st == 0 || (SC_RGBB_DB && st == 3)) {   // ... and so is every point stash (tile k = st / 3: set k & 1)
+                    if (lane < 32) reinterpret_cast<float4*>(pts0 + (st ? RB_PSET : 0))[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
                 lds_barrier();
             }
@@ -256,8 +304,12 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? 1 : 2) void rgb_composit
         if (lane == 0) a.g_depth_fac[ray] = Gdfac;
 
         // ---------------- phase 2: RGB MLP reverse, four 16-point tiles ----------------
+        RB_STAMP(1)
 #pragma unroll 1
         for (int k = 0; k < 4; ++k) {
+#ifdef SC_RGBB_PROFILE
+            sid = 2 + 15 * k;
+#endif
             const int tile = ray * 4 + k;
             const size_t pt = (size_t)tile * TP + p;
             const int src = 16 * k + p;
@@ -269,7 +321,16 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? 1 : 2) void rgb_composit
             tbl_load(a.feat, tile, p, g, f);
             float r[3][ACT_STEPS];
             float col[3];
-            rgb_chain(L, db, e, f, r, col);
+            RB_STAMP(sid++)                                  /* +0: inputs requested, PE evaluated */
+            if (STASH) {
+                tbl_load(a.rr + 0 * tbl, tile, p, g, r[0]);
+                tbl_load(a.rr + 1 * tbl, tile, p, g, r[1]);
+                tbl_load(a.rr + 2 * tbl, tile, p, g, r[2]);
+                col[0] = __shfl(c0, src); col[1] = __shfl(c1, src); col[2] = __shfl(c2, src);
+            } else {
+                rgb_chain(L, db, e, f, r, col);
+            }
+            RB_STAMP(sid++)                                  /* +1: forward chain recomputed */
             if (!FUSED) {
                 tbl_store(a.rr + 0 * tbl, tile, p, g, r[0]);
                 tbl_store(a.rr + 1 * tbl, tile, p, g, r[1]);
@@ -296,7 +357,8 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? 1 : 2) void rgb_composit
                 gyv[s2] = r[2][s2] > 0.f ? gr : 0.f;
             }
             if (!FUSED) tbl_store(a.gy + 2 * tbl, tile, p, g, gyv);
-            RB_EXCHANGE(xch_write(slotA, wr, gyv, 1.f); xch_write(slotB, wr, r[1], 1.f);
+            RB_STAMP(sid++)                                  /* +2: output layer, dV3 sums, Gy2; then exchange 1: +3 B1 passed, +4 written, +5 B2 passed */
+            RB_EXCHANGE(0, xch_write(slotA, wr, gyv, 1.f); xch_write(slotB, wr, r[1], 1.f);
                         if (g == 0) {
                             *reinterpret_cast<float4*>(ptsw + p * 8) = make_float4(x0, x1, x2, 0.f);
                             *reinterpret_cast<float4*>(ptsw + p * 8 + 4) = make_float4(0.f, 0.f, 1.f, 0.f);
@@ -307,18 +369,21 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? 1 : 2) void rgb_composit
 #pragma unroll
             for (int s2 = 0; s2 < ACT_STEPS; ++s2) gyv[s2] = r[1][s2] > 0.f ? acc[s2 >> 2][s2 & 3] : 0.f;
             if (!FUSED) tbl_store(a.gy + 1 * tbl, tile, p, g, gyv);
-            RB_EXCHANGE(xch_write(slotA, wr, gyv, 1.f); xch_write(slotB, wr, r[0], 1.f);)
+            RB_STAMP(sid++)                                  /* +6: V2^T product + mask; exchange 2: +7, +8, +9 */
+            RB_EXCHANGE(1, xch_write(slotA, wr, gyv, 1.f); xch_write(slotB, wr, r[0], 1.f);)
             acc_zero(acc);
             mm_act_t<RgbLds::LD1, NT>(L.v1t, gyv, acc);
 #pragma unroll
             for (int s2 = 0; s2 < ACT_STEPS; ++s2) gyv[s2] = r[0][s2] > 0.f ? acc[s2 >> 2][s2 & 3] : 0.f;
             if (!FUSED) tbl_store(a.gy + 0 * tbl, tile, p, g, gyv);
-            RB_EXCHANGE(xch_write(slotA, wr, gyv, 1.f); xch_write(slotB, wr, f, 1.f);)
+            RB_STAMP(sid++)                                  /* +10: V1^T product + mask; exchange 3: +11, +12, +13 */
+            RB_EXCHANGE(2, xch_write(slotA, wr, gyv, 1.f); xch_write(slotB, wr, f, 1.f);)
             acc_zero(acc);
             mm_act_t<RgbLds::LD0, NT>(L.v0ft, gyv, acc);
             float gf[ACT_STEPS];
             acc_to_regs(acc, gf);
             tbl_store(a.g_feat, tile, p, g, gf);
+            RB_STAMP(sid++)                                  /* +14: V0f^T product, G feature stored; the tile ends at the next tile's +0 (or stamp 62) */
             float gxs[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -334,6 +399,7 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? 1 : 2) void rgb_composit
             }
             if (g == 0) { a.g_points[pt * 3 + 0] = gxs[0]; a.g_points[pt * 3 + 1] = gxs[1]; a.g_points[pt * 3 + 2] = gxs[2]; }
         }
+        RB_STAMP(62)
     }
     const float gb = wave_sum(gbeta_acc);
     if (lane == 0) a.g_beta[blockIdx.x * 4 + wave] = gb * dbeta_dbp;
@@ -411,6 +477,28 @@ extern "C" int sc_rgb_composite_backward_fused(
     return (int)hipGetLastError();
 }
 
+// sc_rgb_composite_backward_fused with the hidden activations of the forward pass (rr: what sc_rgb_composite_forward_stash wrote) instead of
+// their recomputation.  Everything else as above.
+extern "C" int sc_rgb_composite_backward_fused_stash(
+    const float* points, const float* z_vals, const float* depth_fac, const float* sdf, const float* grad,
+    const float* feat, const float* v_pack, const float* dbias, const float* beta_param, const float* rgb_flat,
+    int n_rays, int rays_per_image, int n_images, int symmetric, float beta_min, float bgcolor, float normal_pow,
+    const float* G_rgb, const float* G_mask, const float* G_depth, const float* G_normal,
+    float* g_sdf, float* g_grad, float* g_feat, float* g_points, float* g_z, float* g_depth_fac, float* g_beta,
+    float* partial, float* v3_part, const float* rr, void* stream_) {
+    if (n_rays <= 0) return 0;
+    if (!partial || !v3_part || !rr || n_images <= 0 || n_images > 256) return (int)hipErrorInvalidValue;
+    sc::RgbBwdArgs a{points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta_param, rgb_flat,
+                     n_rays, rays_per_image, n_images, symmetric, beta_min, bgcolor, normal_pow,
+                     G_rgb, G_mask, G_depth, G_normal, g_sdf, g_grad, g_feat, g_points, g_z, g_depth_fac, g_beta,
+                     nullptr, const_cast<float*>(rr), nullptr, partial, sc_rgb_composite_backward_fused_partial_floats(n_images), v3_part};
+    const int blocks = sc_rgb_composite_backward_fused_parts(n_rays);
+    const size_t lds_bytes = (size_t)sc::RB_LDS_FLOATS * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)sc::rgb_composite_bwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL((sc::rgb_composite_bwd_kernel<true, true>), dim3(blocks), dim3(512), lds_bytes, (hipStream_t)stream_, a);
+    return (int)hipGetLastError();
+}
+
 extern "C" int sc_rgb_composite_backward(
     const float* points, const float* z_vals, const float* depth_fac, const float* sdf, const float* grad,
     const float* feat, const float* v_pack, const float* dbias, const float* beta_param, const float* rgb_flat,
@@ -422,3 +510,13 @@ extern "C" int sc_rgb_composite_backward(
                                         n_images, symmetric, beta_min, bgcolor, normal_pow, G_rgb, G_mask, G_depth, G_normal, g_sdf, g_grad, g_feat,
                                         g_points, g_z, g_depth_fac, g_beta, gy, rr, gy3, nullptr, stream_);
 }
+
+#ifdef SC_RGBB_PROFILE
+// tuning tool only: where the stamps go (device buffer of 8 x 64 uint64) and which (workgroup, iteration) writes them
+extern "C" int sc_rgbb_set_prof(unsigned long long* buf, int block, int iter) {
+    int rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(sc::rgbb_prof_buf), &buf, sizeof(buf));
+    if (!rc) rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(sc::rgbb_prof_block), &block, sizeof(block));
+    if (!rc) rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(sc::rgbb_prof_iter), &iter, sizeof(iter));
+    return rc;
+}
+#endif

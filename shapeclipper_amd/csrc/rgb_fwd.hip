@@ -32,6 +32,8 @@ struct RgbFwdArgs {
     float* weights;    // [n_rays][64] or null (kept for tests / visualisation: alpha in `alpha`)
     float* alpha;      // [n_rays][64] or null
     float* rgb_flat;   // [n_rays*64][3] or null (visualisation path, renderer.py:176)
+    float* rr;         // null, or 3 x TBL64 (layer-major): the post-ReLU activations r0, r1, r2 of the hidden layers, parked for
+                       // sc_rgb_composite_backward_fused_stash (which then does not recompute the forward chain)
 };
 
 __global__ __launch_bounds__(256) void rgb_composite_fwd_kernel(RgbFwdArgs a) {
@@ -59,6 +61,12 @@ __global__ __launch_bounds__(256) void rgb_composite_fwd_kernel(RgbFwdArgs a) {
             float y[3][ACT_STEPS];
             float col[3];
             rgb_chain(L, db, e, f, y, col);
+            if (a.rr) {
+                const size_t tbl = (size_t)a.n_rays * 4 * 1024;
+                tbl_store(a.rr + 0 * tbl, tile, p, g, y[0]);
+                tbl_store(a.rr + 1 * tbl, tile, p, g, y[1]);
+                tbl_store(a.rr + 2 * tbl, tile, p, g, y[2]);
+            }
             const float s = a.sdf[pt];
             const float gx = a.grad[pt * 3 + 0], gy = a.grad[pt * 3 + 1], gz = a.grad[pt * 3 + 2];
             const float ex = expf(-fabsf(s) / beta);
@@ -111,6 +119,25 @@ __global__ __launch_bounds__(256) void rgb_composite_fwd_kernel(RgbFwdArgs a) {
 
 }  // namespace sc
 
+// sc_rgb_composite_forward that also parks the hidden activations r0, r1, r2 (rr: 3 x TBL64 = 3 x n_rays * 4 * 1024 floats, or null).
+extern "C" int sc_rgb_composite_forward_stash(const float* points, const float* z_vals, const float* depth_fac,
+                                              const float* sdf, const float* grad, const float* feat,
+                                              const float* v_pack, const float* dbias, const float* beta_param,
+                                              int n_rays, int rays_per_image, int n_images, int symmetric,
+                                              float beta_min, float bgcolor, float normal_pow,
+                                              float* rgb, float* mask, float* mask_hard, float* depth, float* normal,
+                                              float* weights, float* alpha, float* rgb_flat, float* rr, void* stream_) {
+    if (n_rays <= 0) return 0;
+    sc::RgbFwdArgs a{points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta_param, n_rays, rays_per_image,
+                     n_images, symmetric, beta_min, bgcolor, normal_pow, rgb, mask, mask_hard, depth, normal,
+                     weights, alpha, rgb_flat, rr};
+    int blocks = (n_rays + 3) / 4;
+    if (blocks > 512) blocks = 512;   // two 4-wave workgroups per CU (63 KiB LDS each)
+    const size_t lds_bytes = sc::RgbLds::TOTAL * sizeof(float);
+    hipLaunchKernelGGL(sc::rgb_composite_fwd_kernel, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream_, a);
+    return (int)hipGetLastError();
+}
+
 extern "C" int sc_rgb_composite_forward(const float* points, const float* z_vals, const float* depth_fac,
                                         const float* sdf, const float* grad, const float* feat,
                                         const float* v_pack, const float* dbias, const float* beta_param,
@@ -118,13 +145,7 @@ extern "C" int sc_rgb_composite_forward(const float* points, const float* z_vals
                                         float beta_min, float bgcolor, float normal_pow,
                                         float* rgb, float* mask, float* mask_hard, float* depth, float* normal,
                                         float* weights, float* alpha, float* rgb_flat, void* stream_) {
-    if (n_rays <= 0) return 0;
-    sc::RgbFwdArgs a{points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta_param, n_rays, rays_per_image,
-                     n_images, symmetric, beta_min, bgcolor, normal_pow, rgb, mask, mask_hard, depth, normal,
-                     weights, alpha, rgb_flat};
-    int blocks = (n_rays + 3) / 4;
-    if (blocks > 512) blocks = 512;   // two 4-wave workgroups per CU (63 KiB LDS each)
-    const size_t lds_bytes = sc::RgbLds::TOTAL * sizeof(float);
-    hipLaunchKernelGGL(sc::rgb_composite_fwd_kernel, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream_, a);
-    return (int)hipGetLastError();
+    return sc_rgb_composite_forward_stash(points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta_param, n_rays, rays_per_image, n_images,
+                                          symmetric, beta_min, bgcolor, normal_pow, rgb, mask, mask_hard, depth, normal, weights, alpha, rgb_flat,
+                                          nullptr, stream_);
 }

@@ -59,12 +59,13 @@ class RgbCompositeFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         need = any(ctx.needs_input_grad[:9])
         beta1 = beta.reshape(1).contiguous()
+        stash = need and ops.RGB_STASH and ops.FUSED_RGB_WGRAD and dbias.shape[0] <= 256      # what the fused backward takes
         out = ops.rgb_composite_forward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta1,
                                         rays_per_image, symmetric, beta_min, bgcolor, normal_pow,
-                                        keep_samples=keep_samples, keep_rgb_flat=need)
+                                        keep_samples=keep_samples, keep_rgb_flat=need, keep_rr=stash)
         ctx.meta = (rays_per_image, symmetric, beta_min, bgcolor, normal_pow, beta.shape)
         if need:
-            ctx.save_for_backward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta1, out["rgb_flat"])
+            ctx.save_for_backward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta1, out["rgb_flat"], *((out["rr"],) if stash else ()))
         ctx.mark_non_differentiable(out["mask_hard"])
         extra = ()
         if keep_samples:
@@ -75,11 +76,11 @@ class RgbCompositeFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, G_rgb, G_mask, G_mask_hard, G_depth, G_normal, *unused):
         rays_per_image, symmetric, beta_min, bgcolor, normal_pow, beta_shape = ctx.meta
-        points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta1, rgb_flat = ctx.saved_tensors
+        points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta1, rgb_flat, *rr = ctx.saved_tensors
         c = lambda t: t.contiguous() if t is not None else None
         g = ops.rgb_composite_backward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta1, rgb_flat,
                                        rays_per_image, symmetric, beta_min, bgcolor, normal_pow,
-                                       c(G_rgb), c(G_mask), c(G_depth), c(G_normal))
+                                       c(G_rgb), c(G_mask), c(G_depth), c(G_normal), rr=rr[0] if rr else None)
         return (g["points"], g["z_vals"], g["depth_fac"], g["sdf"], g["grad"], g["feat"], g["v_pack"], g["dbias"],
                 g["beta"].reshape(beta_shape), None, None, None, None, None, None)
 

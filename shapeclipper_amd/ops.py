@@ -49,7 +49,7 @@ def sdf_forward(points: torch.Tensor, w_pack: torch.Tensor, cbias: torch.Tensor,
 
 def rgb_composite_forward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta_param,
                           rays_per_image: int, symmetric: bool, beta_min: float, bgcolor: float,
-                          normal_pow: float, keep_samples: bool = False, keep_rgb_flat: bool = False):
+                          normal_pow: float, keep_samples: bool = False, keep_rgb_flat: bool = False, keep_rr: bool = False):
     """Per-ray outputs of the renderer from the per-point SDF results.
 
     points [n_rays*64,3], z_vals [n_rays,64], depth_fac [n_rays], sdf [P], grad [P,3], feat TBL64.
@@ -67,14 +67,16 @@ def rgb_composite_forward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, db
         out.update(weights=torch.empty(n_rays, 64, **f32), alpha=torch.empty(n_rays, 64, **f32))
     if keep_samples or keep_rgb_flat:
         out.update(rgb_flat=torch.empty(n_rays * 64, 3, **f32))
-    code = lib.sc_rgb_composite_forward(
+    if keep_rr:      # the hidden activations r0, r1, r2 (3 x TBL64) for rgb_composite_backward(rr=...): 805 MB per bs32 render
+        out.update(rr=torch.empty(3 * n_rays * 4 * 1024, **f32))
+    code = lib.sc_rgb_composite_forward_stash(
         _lib.ptr(points), _lib.ptr(z_vals), _lib.ptr(depth_fac), _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(feat),
         _lib.ptr(v_pack), _lib.ptr(dbias), _lib.ptr(beta_param), c_int(n_rays), c_int(rays_per_image),
         c_int(dbias.shape[0]), c_int(1 if symmetric else 0), ctypes.c_float(beta_min), ctypes.c_float(bgcolor),
         ctypes.c_float(normal_pow), _lib.ptr(out["rgb"]), _lib.ptr(out["mask"]), _lib.ptr(out["mask_hard"]),
         _lib.ptr(out["depth"]), _lib.ptr(out["normal"]), _lib.ptr(out.get("weights")), _lib.ptr(out.get("alpha")),
-        _lib.ptr(out.get("rgb_flat")), _lib.stream())
-    _lib.check(code, "sc_rgb_composite_forward")
+        _lib.ptr(out.get("rgb_flat")), _lib.ptr(out.get("rr")), _lib.stream())
+    _lib.check(code, "sc_rgb_composite_forward_stash")
     return out
 
 
@@ -269,11 +271,12 @@ def sdf_backward(points, w_pack, n_per_image, n_images, symmetric, stash_a, stas
 
 
 FUSED_RGB_WGRAD = True      # `--hip.fused_rgb_wgrad!`: Gy_l / r_l through HBM and three sc_wgrad launches (the round-4 path)
+RGB_STASH = True            # `--hip.rgb_stash!`: the backward recomputes the RGB forward chain instead of loading r0..r2 parked by the forward
 
 
 def rgb_composite_backward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta_param, rgb_flat,
                            rays_per_image, symmetric, beta_min, bgcolor, normal_pow,
-                           G_rgb, G_mask, G_depth, G_normal):
+                           G_rgb, G_mask, G_depth, G_normal, rr=None):
     """Reverse pass of rgb_composite_forward.
     -> dict(points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta) gradients."""
     from .packing import RGB_OFF, RGB_PACK_FLOATS
@@ -294,14 +297,16 @@ def rgb_composite_backward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, d
         parts = int(lib.sc_rgb_composite_backward_fused_parts(c_int(n_rays)))
         stride = int(lib.sc_rgb_composite_backward_fused_partial_floats(c_int(n_images)))
         partial = torch.empty(parts * stride, **f32)
-        code = lib.sc_rgb_composite_backward_fused(
-            _lib.ptr(points), _lib.ptr(z_vals), _lib.ptr(depth_fac), _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(feat),
-            _lib.ptr(v_pack), _lib.ptr(dbias), _lib.ptr(beta_param), _lib.ptr(rgb_flat), c_int(n_rays),
-            c_int(rays_per_image), c_int(n_images), c_int(1 if symmetric else 0), ctypes.c_float(beta_min),
-            ctypes.c_float(bgcolor), ctypes.c_float(normal_pow), _lib.ptr(G_rgb), _lib.ptr(G_mask), _lib.ptr(G_depth),
-            _lib.ptr(G_normal), _lib.ptr(g["sdf"]), _lib.ptr(g["grad"]), _lib.ptr(g["feat"]), _lib.ptr(g["points"]),
-            _lib.ptr(g["z_vals"]), _lib.ptr(g["depth_fac"]), _lib.ptr(g["beta"]), _lib.ptr(partial), _lib.ptr(v3_part), _lib.stream())
-        _lib.check(code, "sc_rgb_composite_backward_fused")
+        args = (_lib.ptr(points), _lib.ptr(z_vals), _lib.ptr(depth_fac), _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(feat),
+                _lib.ptr(v_pack), _lib.ptr(dbias), _lib.ptr(beta_param), _lib.ptr(rgb_flat), c_int(n_rays),
+                c_int(rays_per_image), c_int(n_images), c_int(1 if symmetric else 0), ctypes.c_float(beta_min),
+                ctypes.c_float(bgcolor), ctypes.c_float(normal_pow), _lib.ptr(G_rgb), _lib.ptr(G_mask), _lib.ptr(G_depth),
+                _lib.ptr(G_normal), _lib.ptr(g["sdf"]), _lib.ptr(g["grad"]), _lib.ptr(g["feat"]), _lib.ptr(g["points"]),
+                _lib.ptr(g["z_vals"]), _lib.ptr(g["depth_fac"]), _lib.ptr(g["beta"]), _lib.ptr(partial), _lib.ptr(v3_part))
+        if rr is not None:      # the forward parked r0..r2: no recomputation of the forward chain
+            _lib.check(lib.sc_rgb_composite_backward_fused_stash(*args, _lib.ptr(rr), _lib.stream()), "sc_rgb_composite_backward_fused_stash")
+        else:
+            _lib.check(lib.sc_rgb_composite_backward_fused(*args, _lib.stream()), "sc_rgb_composite_backward_fused")
         g_all = _partial_reduce(lib, partial, parts, stride, stride, torch.empty(stride, **f32))
         g_v = torch.empty(RGB_PACK_FLOATS, **f32)
         g_v[:RGB_OFF["V3"]] = g_all[:RGB_OFF["V3"]]
