@@ -315,17 +315,20 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? 1 : 2) void rgb_composit
             const int src = 16 * k + p;
             const float gc0 = __shfl(Gc0, src), gc1 = __shfl(Gc1, src), gc2 = __shfl(Gc2, src);
             const float x0 = a.points[pt * 3 + 0], x1 = a.points[pt * 3 + 1], x2 = a.points[pt * 3 + 2];
-            float e[PE_STEPS], d1[PE_STEPS], d2[PE_STEPS];
-            pe_slots<true, false, true>(x0, x1, x2, g, a.symmetric != 0, e, d1, d2);
             float f[ACT_STEPS];
-            tbl_load(a.feat, tile, p, g, f);
             float r[3][ACT_STEPS];
             float col[3];
+            if (STASH) {                                     // requested behind the point and in the order of their first use (the counter retires
+                tbl_load(a.rr + 2 * tbl, tile, p, g, r[2]);  // in order): r2 (output layer, mask of Gy2), r1 (hand-over 1), r0 (hand-over 2), the
+                tbl_load(a.rr + 1 * tbl, tile, p, g, r[1]);  // feature (hand-over 3); the positional encoding is evaluated while they travel
+                tbl_load(a.rr + 0 * tbl, tile, p, g, r[0]);
+            }
+            tbl_load(a.feat, tile, p, g, f);
+            __builtin_amdgcn_sched_barrier(0);
+            float e[PE_STEPS], d1[PE_STEPS], d2[PE_STEPS];
+            pe_slots<true, false, true>(x0, x1, x2, g, a.symmetric != 0, e, d1, d2);
             RB_STAMP(sid++)                                  /* +0: inputs requested, PE evaluated */
             if (STASH) {
-                tbl_load(a.rr + 0 * tbl, tile, p, g, r[0]);
-                tbl_load(a.rr + 1 * tbl, tile, p, g, r[1]);
-                tbl_load(a.rr + 2 * tbl, tile, p, g, r[2]);
                 col[0] = __shfl(c0, src); col[1] = __shfl(c1, src); col[2] = __shfl(c2, src);
             } else {
                 rgb_chain(L, db, e, f, r, col);
