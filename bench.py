@@ -370,7 +370,9 @@ def main():
             durs = [s.elapsed_time(e) for s, e, _ in evs]
             # (sc_rgb_composite_backward_v3 is sc_rgb_composite_backward with the output layer's gradient folded in: one name in the line)
             # (... and sc_rgb_composite_backward_fused is the same reverse pass with the RGB network's weight gradients formed in the kernel, round 5)
-            name = {"sc_rgb_composite_backward_v3": "sc_rgb_composite_backward", "sc_rgb_composite_backward_fused": "sc_rgb_composite_backward"}.get(name, name)
+            # (... and the _stash forms are the same two passes with the RGB network's hidden activations parked by the forward, round 5)
+            name = {"sc_rgb_composite_backward_v3": "sc_rgb_composite_backward", "sc_rgb_composite_backward_fused": "sc_rgb_composite_backward",
+                    "sc_rgb_composite_backward_fused_stash": "sc_rgb_composite_backward", "sc_rgb_composite_forward_stash": "sc_rgb_composite_forward"}.get(name, name)
             per[name] = dict(calls=len(durs), total_ms=sum(durs), mean_ms=sum(durs) / len(durs), max_ms=max(durs))
         n_pts_main = a.batch * opt.render.rand_sample * 64
         dom = max((n for n in per if n in FLOPS_PER_POINT), key=lambda n: per[n]["total_ms"])
