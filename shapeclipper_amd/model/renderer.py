@@ -24,6 +24,24 @@ from ..utils import camera
 from .implicit import LaplaceDensity
 
 
+
+UPLOAD_STREAM = True          # `--hip.upload_stream!`: the CPU-generator draws are copied in the render's own stream
+_upload_streams = {}
+
+
+def _upload(x, dev):
+    """Pinned host tensor -> device on the device's upload stream; the current stream waits for it (an event, no host wait)."""
+    main = torch.cuda.current_stream(dev)
+    side = _upload_streams.get(dev.index)
+    if side is None:
+        side = _upload_streams[dev.index] = torch.cuda.Stream(dev)
+    with torch.cuda.stream(side):
+        d = x.to(dev, non_blocking=True)        # the pinned block is held by the host allocator until this copy has run
+    main.wait_stream(side)
+    d.record_stream(main)                       # allocated on the upload stream, used on the render's
+    return d
+
+
 class UniformSampler(nn.Module):
     """Stratified depth samples in [dist*s - 0.7, dist*s + 0.7] (reference model/renderer.py:8-37)."""
 
@@ -99,7 +117,13 @@ class Renderer(nn.Module):
         # CPU draws land in pinned memory and are copied asynchronously: a pageable H2D copy would drain the stream
         # (one host sync per draw, three per render) and let the GPU idle while the host catches up.
         pin = (not dev_rng) and ray_dirs.is_cuda
-        up = lambda x: x.to(ray_dirs.device, non_blocking=True)
+        # ... and they travel on an UPLOAD stream of their own (round 5): the host is milliseconds ahead of the GPU when it reaches a render, so
+        # the 4 MB of jitter are on the device long before the render's stream gets there -- in that stream the copy was ~100 us per render
+        # with nothing else running (`--hip.upload_stream!`: copy in the render's stream)
+        if pin and UPLOAD_STREAM:
+            up = lambda x: _upload(x, ray_dirs.device)
+        else:
+            up = lambda x: x.to(ray_dirs.device, non_blocking=True)
         t_rand = up(torch.rand(B * R, S, device=rdev, pin_memory=pin)) if training else None
         eik_idx = up(torch.randint(S, (B * R,), device=rdev, pin_memory=pin))
         if self.eager:
