@@ -54,10 +54,14 @@ __global__ __launch_bounds__(256) void rgb_composite_fwd_kernel(RgbFwdArgs a) {
             const int tile = ray * 4 + k;
             const size_t pt = (size_t)tile * TP + p;
             const float x0 = a.points[pt * 3 + 0], x1 = a.points[pt * 3 + 1], x2 = a.points[pt * 3 + 2];
-            float e[PE_STEPS], d1[PE_STEPS], d2[PE_STEPS];
-            pe_slots<false, false>(x0, x1, x2, g, a.symmetric != 0, e, d1, d2);
             float f[ACT_STEPS];
             tbl_load(a.feat, tile, p, g, f);
+            // every input of the tile is requested before the chain (the parked activations are stored behind it: a load below those stores
+            // could not be moved above them by the compiler and would wait with nothing to hide behind)
+            const float s = a.sdf[pt];
+            const float gx = a.grad[pt * 3 + 0], gy = a.grad[pt * 3 + 1], gz = a.grad[pt * 3 + 2];
+            float e[PE_STEPS], d1[PE_STEPS], d2[PE_STEPS];
+            pe_slots<false, false>(x0, x1, x2, g, a.symmetric != 0, e, d1, d2);
             float y[3][ACT_STEPS];
             float col[3];
             rgb_chain(L, db, e, f, y, col);
@@ -67,8 +71,6 @@ __global__ __launch_bounds__(256) void rgb_composite_fwd_kernel(RgbFwdArgs a) {
                 tbl_store(a.rr + 1 * tbl, tile, p, g, y[1]);
                 tbl_store(a.rr + 2 * tbl, tile, p, g, y[2]);
             }
-            const float s = a.sdf[pt];
-            const float gx = a.grad[pt * 3 + 0], gy = a.grad[pt * 3 + 1], gz = a.grad[pt * 3 + 2];
             const float ex = expf(-fabsf(s) / beta);
             const float sg = (1.f / beta) * (s >= 0.f ? 0.5f * ex : 1.f - 0.5f * ex);
             // normal_flat = -d(density)/dx = (0.5/beta^2) exp(-|s|/beta) * g; then F.normalize (eps 1e-12)
