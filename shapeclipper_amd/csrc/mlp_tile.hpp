@@ -439,6 +439,17 @@ __device__ __forceinline__ void tbl_store(float* base, int tile, int p, int g, c
         const f32x4 q = {v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]};
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q), rs, lo, 1024 * t, 0);
     }
+    // gfx950 hazard that hipcc 7.2 does not cover (measured: tools/micro/store_war_hazard.hip, profiles/r05_store_hazard.txt): a VALU
+    // instruction issued DIRECTLY behind a buffer_store_dwordx4 may overwrite the store's data registers before the store has read them --
+    // 3e-4 of the stored values with an SGPR in the soffset field (as here), 6e-2 with an immediate; ONE instruction in between is enough
+    // for the SGPR form.  LLVM's hazard recogniser inserts wait states for the immediate form only (GCNHazardRecognizer::createsVALUHazard:
+    // "this hazard only exists if the instruction is not using a register in the soffset field").  Found when the training instance of
+    // sdf_fwd stored a wrong p0: `buffer_store_dwordx4 v[90:93], ..., s74 offen` / `v_mul_f32 v90, v91, v1`.  The last store of a group is
+    // therefore followed by one pinned s_nop; tools/scan_store_hazard.py checks the compiler's output of every kernel file for the pattern
+    // (tests/test_store_hazard_scan.py).
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 0" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 }
 __device__ __forceinline__ void tbl_load(const float* base, int tile, int p, int g, float (&v)[ACT_STEPS]) {
     const __amdgpu_buffer_rsrc_t rs = tbl_rsrc(base, tile);

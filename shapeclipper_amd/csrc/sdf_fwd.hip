@@ -36,7 +36,10 @@ struct SdfFwdArgs {
 
 constexpr int SDF_WAVES = 8;   // 2 waves per SIMD: the VALU phases of one wave overlap the MFMA phases of the other
 
-template <bool GRAD>
+// STASH: both training stashes are given (a compile-time fact for the training instance: every `if (a.stash_p)` around a store was a
+// branch, and at its join the compiler's wait-count pass has to assume the stores in flight and waits for them before the NEXT load can be
+// used -- on gfx9 loads and stores retire through one in-order counter).  STASH = false keeps the run-time checks (evaluation, odd callers).
+template <bool GRAD, bool STASH = false>
 __global__ __launch_bounds__(64 * SDF_WAVES) void sdf_fwd_kernel(SdfFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     stage_sdf_weights(lds, a.w, threadIdx.x, 64 * SDF_WAVES);
@@ -70,9 +73,9 @@ __global__ __launch_bounds__(64 * SDF_WAVES) void sdf_fwd_kernel(SdfFwdArgs a) {
     // there is one, otherwise a per-wave scratch slot that never leaves L2.
     float* park = a.stash_a;
     size_t park_stride = tbl;
-    if (GRAD && !park) { park = a.scratch + (size_t)(blockIdx.x * SDF_WAVES + wave) * 5 * 1024; park_stride = 1024; }
+    if (!STASH && GRAD && !park) { park = a.scratch + (size_t)(blockIdx.x * SDF_WAVES + wave) * 5 * 1024; park_stride = 1024; }
     for (int tile = blockIdx.x * SDF_WAVES + wave; tile < ntiles; tile += gridDim.x * SDF_WAVES) {
-        const int ptile = a.stash_a ? tile : 0;
+        const int ptile = (STASH || a.stash_a) ? tile : 0;
         const int pt = tile * TP + p;
         const bool valid = pt < a.n_points;
         const int ptc = valid ? pt : a.n_points - 1;
@@ -90,34 +93,50 @@ __global__ __launch_bounds__(64 * SDF_WAVES) void sdf_fwd_kernel(SdfFwdArgs a) {
         {                                                                                  \
             float av[ACT_STEPS];                                                           \
             acc_to_regs(acc, av);                                                          \
-            if (!SC_STASH_H && park) tbl_store(park + (size_t)(L) * park_stride, ptile, p, g, av); \
+            if (!SC_STASH_H && (GRAD || park)) tbl_store(park + (size_t)(L) * park_stride, ptile, p, g, av); \
             _Pragma("unroll") for (int s = 0; s < ACT_STEPS; ++s) {                         \
                 float t, r;                                                                \
                 softplus_parts(av[s], t, r);                                               \
                 h[s] = softplus_val(av[s], t);                                             \
             }                                                                              \
-            if (SC_STASH_H && park) tbl_store(park + (size_t)(L) * park_stride, ptile, p, g, h);   /* the ACTIVATION is parked (mlp_tile.hpp) */ \
+            /* the ACTIVATION is parked (mlp_tile.hpp).  GRAD: park is never null (the launch refuses it) -- saying so removes a branch whose  \
+               join made the compiler's wait-count pass wait for the four stores before the next layer's bias loads could be used */          \
+            if (SC_STASH_H && (GRAD || park)) tbl_store(park + (size_t)(L) * park_stride, ptile, p, g, h); \
         }
 
         // ---- value chain ----
+        // The per-image biases of layer l + 1 are requested BEFORE the park stores of layer l: on gfx9 loads and stores share one in-order
+        // counter, so a bias load issued behind the four stores waits for their acknowledgement as well (read from the ISA: `s_waitcnt
+        // vmcnt(3)` right behind [4 stores, 4 loads], five times per tile).
+        f32x4 bnext[NT];
+#define SC_NEXT_BIAS(L) acc_init(bnext, cb + (L) * 64); __builtin_amdgcn_sched_barrier(0);
+#define SC_TAKE_BIAS_(L) SC_TAKE_BIAS()
+#define SC_TAKE_BIAS() _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = bnext[t];
         acc_init(acc, cb + 0 * 64);
         mm_pe<SdfLds::LD0, NT, 0, PE_STEPS>(w0, e, acc);
+        SC_NEXT_BIAS(1)
         SC_ACTIVATE(0)
-        acc_init(acc, cb + 1 * 64);
+        SC_TAKE_BIAS_(1)
         mm_act<SdfLds::LD1, NT>(w1h, h, acc);
         mm_pe<SdfLds::LD1, NT, 0, PE_STEPS>(w1e, e, acc);
+        SC_NEXT_BIAS(2)
         SC_ACTIVATE(1)
-        acc_init(acc, cb + 2 * 64);
+        SC_TAKE_BIAS_(2)
         mm_act<SdfLds::LD1, NT>(w2h, h, acc);
         mm_pe<SdfLds::LD1, NT, 0, PE_STEPS>(w2e, e, acc);
+        SC_NEXT_BIAS(3)
         SC_ACTIVATE(2)
-        acc_init(acc, cb + 3 * 64);
+        SC_TAKE_BIAS_(3)
         mm_act<SdfLds::LD3, NT>(w3, h, acc);
+        SC_NEXT_BIAS(4)
         SC_ACTIVATE(3)
-        acc_init(acc, cb + 4 * 64);
+        SC_TAKE_BIAS_(4)
         mm_act<SdfLds::LD3, NT>(w4, h, acc);
         SC_ACTIVATE(4)
 #undef SC_ACTIVATE
+#undef SC_NEXT_BIAS
+#undef SC_TAKE_BIAS
+#undef SC_TAKE_BIAS_
 
         // ---- output layer: sdf by VALU dot (row 0), feature rows by MFMA ----
         float sp = 0.f;
@@ -125,7 +144,7 @@ __global__ __launch_bounds__(64 * SDF_WAVES) void sdf_fwd_kernel(SdfFwdArgs a) {
         for (int s = 0; s < ACT_STEPS; ++s) sp = __builtin_fmaf(w5s[kp(s)], h[s], sp);
         const float sdf = group_sum(sp) + b5[0];
         if (a.sdf && valid && g == 0) a.sdf[pt] = sdf;
-        if (a.feat) {
+        if (STASH || a.feat) {
             acc_init(acc, b5 + 1 + 4 * g);
             mm_act<SdfLds::LD3, NT>(w5f, h, acc);
             float fv[ACT_STEPS];
@@ -171,27 +190,27 @@ __global__ __launch_bounds__(64 * SDF_WAVES) void sdf_fwd_kernel(SdfFwdArgs a) {
             SC_DSP_LOAD(3)
             mm_act_t<SdfLds::LD3, NT>(w4t, q, acc);                 // p3 = W4^T q4
             acc_to_regs(acc, pv);
-            if (a.stash_p) tbl_store(a.stash_p + 3 * tbl, tile, p, g, pv);
+            if (STASH || a.stash_p) tbl_store(a.stash_p + 3 * tbl, tile, p, g, pv);
             SC_DSP(3, pv[s])
             acc_zero(acc);
             SC_DSP_LOAD(2)
             mm_act_t<SdfLds::LD3, NT>(w3t, q, acc);                 // p2 = W3^T q3
             acc_to_regs(acc, pv);
-            if (a.stash_p) tbl_store(a.stash_p + 2 * tbl, tile, p, g, pv);
+            if (STASH || a.stash_p) tbl_store(a.stash_p + 2 * tbl, tile, p, g, pv);
             SC_DSP(2, pv[s])
             SC_DSP_LOAD(1)
             SC_PE_JAC(w2e, SdfLds::LD1)
             acc_zero(acc);
             mm_act_t<SdfLds::LD1, NT>(w2t, q, acc);                 // p1 = W2h^T q2
             acc_to_regs(acc, pv);
-            if (a.stash_p) tbl_store(a.stash_p + 1 * tbl, tile, p, g, pv);
+            if (STASH || a.stash_p) tbl_store(a.stash_p + 1 * tbl, tile, p, g, pv);
             SC_DSP(1, pv[s])
             SC_DSP_LOAD(0)
             SC_PE_JAC(w1e, SdfLds::LD1)
             acc_zero(acc);
             mm_act_t<SdfLds::LD1, NT>(w1t, q, acc);                 // p0 = W1h^T q1
             acc_to_regs(acc, pv);
-            if (a.stash_p) tbl_store(a.stash_p + 0 * tbl, tile, p, g, pv);
+            if (STASH || a.stash_p) tbl_store(a.stash_p + 0 * tbl, tile, p, g, pv);
             SC_DSP(0, pv[s])
 #undef SC_DSP_LOAD
 #undef SC_DSP
@@ -220,7 +239,10 @@ extern "C" int sc_sdf_forward(const float* points, const float* w_pack, const fl
     if (grad && !stash_a && !scratch) return (int)hipErrorInvalidValue;
     const size_t lds_bytes = sc::SdfLds::TOTAL * sizeof(float);
     hipStream_t stream = (hipStream_t)stream_;
-    if (grad) {
+    if (grad && stash_a && stash_p) {      // the training render
+        (void)hipFuncSetAttribute((const void*)sc::sdf_fwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipLaunchKernelGGL((sc::sdf_fwd_kernel<true, true>), dim3(blocks), dim3(64 * sc::SDF_WAVES), lds_bytes, stream, a);
+    } else if (grad) {
         (void)hipFuncSetAttribute((const void*)sc::sdf_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);   // per launch: the attribute is per device, no process-wide state
         hipLaunchKernelGGL(sc::sdf_fwd_kernel<true>, dim3(blocks), dim3(64 * sc::SDF_WAVES), lds_bytes, stream, a);
     } else {

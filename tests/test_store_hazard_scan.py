@@ -1,0 +1,40 @@
+"""gfx950 store-data hazard that the compiler does not cover (profiles/r05_store_hazard.txt, tools/micro/store_war_hazard.hip): no kernel
+of the library may contain a buffer_store_dwordx3 / x4 with an SGPR soffset that is followed DIRECTLY by a VALU write of its data
+registers.  Compiles the files that issue such stores to assembly (hipcc cross-compiles without a GPU) and scans them."""
+import glob
+import os
+import re
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "shapeclipper_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_no_wide_buffer_store_is_followed_directly_by_a_write_of_its_data(tmp_path):
+    # only files that can emit raw buffer stores: the MLP chain kernels (tbl_store) and whoever else names the builtin
+    files = [f for f in sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+             if re.search(r"raw_buffer_store|mlp_tile\.hpp|mlp_xch\.hpp|rgb_common\.hpp", open(f).read())]
+    assert len(files) >= 6, files
+
+    def build(f):
+        out = str(tmp_path / (os.path.basename(f)[:-4] + ".s"))
+        extra = ["-ffp-contract=off"] if os.path.basename(f) == "render.hip" else []
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), *extra, "-S",
+                            "--cuda-device-only", f, "-o", out], capture_output=True, text=True, cwd=CSRC)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return out
+    with ThreadPoolExecutor(4) as ex:
+        asm = list(ex.map(build, files))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scan_store_hazard.py"), *asm], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    last = r.stdout.strip().splitlines()[-1]
+    m = re.match(r"(\d+) wide buffer stores with an SGPR soffset, (\d+) followed directly", last)
+    assert m, r.stdout[-1000:]
+    assert int(m.group(1)) >= 100, last           # the scan saw the stores it is about
+    assert int(m.group(2)) == 0, r.stdout[-3000:]
