@@ -36,7 +36,7 @@ struct SdfFwdArgs {
 
 constexpr int SDF_WAVES = 8;   // 2 waves per SIMD: the VALU phases of one wave overlap the MFMA phases of the other
 
-// STASH: both training stashes are given (a compile-time fact for the training instance: every `if (a.stash_p)` around a store was a
+// STASH: both training stashes AND the feature output are given (a compile-time fact for the training instance: every `if (a.stash_p)` around a store was a
 // branch, and at its join the compiler's wait-count pass has to assume the stores in flight and waits for them before the NEXT load can be
 // used -- on gfx9 loads and stores retire through one in-order counter).  STASH = false keeps the run-time checks (evaluation, odd callers).
 template <bool GRAD, bool STASH = false>
@@ -239,7 +239,7 @@ extern "C" int sc_sdf_forward(const float* points, const float* w_pack, const fl
     if (grad && !stash_a && !scratch) return (int)hipErrorInvalidValue;
     const size_t lds_bytes = sc::SdfLds::TOTAL * sizeof(float);
     hipStream_t stream = (hipStream_t)stream_;
-    if (grad && stash_a && stash_p) {      // the training render
+    if (grad && stash_a && stash_p && feat) {      // the training render: both stashes and the feature output (what STASH stands for)
         (void)hipFuncSetAttribute((const void*)sc::sdf_fwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         hipLaunchKernelGGL((sc::sdf_fwd_kernel<true, true>), dim3(blocks), dim3(64 * sc::SDF_WAVES), lds_bytes, stream, a);
     } else if (grad) {
