@@ -2,7 +2,7 @@
 // gfx950?  LLVM's hazard recogniser (GCNHazardRecognizer::createsVALUHazard) inserts a wait state for this write-after-read only when the
 // store has NO register in its soffset field; csrc/mlp_tile.hpp's tbl_store uses an SGPR soffset, and sdf_fwd's training instance stored a
 // wrong p0 once hipcc scheduled `v_mul_f32 v90, ...` directly behind `buffer_store_dwordx4 v[90:93], ..., s74 offen`.
-//   hipcc --offload-arch=gfx950 -O2 tools/micro/store_war_hazard.hip -o /tmp/store_war && /tmp/store_war
+//   make -C tools/micro store_war_hazard.bin && tools/micro/store_war_hazard.bin     (the %.bin rule; *.bin is git-ignored)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <vector>
