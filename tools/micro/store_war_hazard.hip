@@ -37,6 +37,28 @@ RUN(k_imm_gap0, "buffer_store_dwordx4 v[40:43], %[voff], %[rs], 0 offen offset:1
 RUN(k_imm_gap1, "buffer_store_dwordx4 v[40:43], %[voff], %[rs], 0 offen offset:1024", "s_nop 0\n")
 RUN(k_imm_gap2, "buffer_store_dwordx4 v[40:43], %[voff], %[rs], 0 offen offset:1024", "s_nop 1\n")
 
+// the same question for a 128-bit LDS store (no hazard is listed for it; the convolution kernels stage with ds_write_b128)
+#define RUN_LDS(NAME, GAP)                                                                                     \
+    __global__ void NAME(float* out, int n_iter) {                                                            \
+        __shared__ float4 buf[256];                                                                            \
+        const int lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;                \
+        const unsigned addr = (unsigned)(size_t)(buf + threadIdx.x);                                           \
+        const float good = 1.0f, bad = -7.0f;                                                                  \
+        for (int it = 0; it < n_iter; ++it) {                                                                  \
+            asm volatile("v_mov_b32 v40, %[a]\n v_mov_b32 v41, %[a]\n v_mov_b32 v42, %[a]\n v_mov_b32 v43, %[a]\n s_nop 7\n" \
+                         "ds_write_b128 %[addr], v[40:43]\n" GAP                                              \
+                         "v_mov_b32 v40, %[b]\n v_mov_b32 v41, %[b]\n v_mov_b32 v42, %[b]\n v_mov_b32 v43, %[b]\n" \
+                         "s_waitcnt lgkmcnt(0)\n"                                                             \
+                         :: [a] "v"(good), [b] "v"(bad), [addr] "v"(addr) : "v40", "v41", "v42", "v43", "memory"); \
+        }                                                                                                      \
+        __syncthreads();                                                                                       \
+        const float4 v = buf[threadIdx.x];                                                                     \
+        float* dst = out + (size_t)wave * 512 + 256 + lane * 4;                                                \
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;                                                \
+    }
+RUN_LDS(k_lds_gap0, "")
+RUN_LDS(k_lds_gap1, "s_nop 0\n")
+
 template <class K>
 static void run(const char* name, K kern) {
     const int blocks = 1024, threads = 256, waves = blocks * threads / 64;
@@ -67,5 +89,7 @@ int main() {
     run("imm,  gap 0", k_imm_gap0);
     run("imm,  gap 1", k_imm_gap1);
     run("imm,  gap 2", k_imm_gap2);
+    run("lds,  gap 0", k_lds_gap0);
+    run("lds,  gap 1", k_lds_gap1);
     return 0;
 }
