@@ -341,7 +341,7 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? 1 : 2) void rgb_composit
             const float y0 = gc0 * col[0] * (1.f - col[0]);
             const float y1 = gc1 * col[1] * (1.f - col[1]);
             const float y2 = gc2 * col[2] * (1.f - col[2]);
-            if (a.v3_part) {
+            if (FUSED || a.v3_part) {
 #pragma unroll
                 for (int s2 = 0; s2 < ACT_STEPS; ++s2) {
                     v3acc[0][s2] = __builtin_fmaf(y0, r[2][s2], v3acc[0][s2]);
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? 1 : 2) void rgb_composit
     if (lane == 0) a.g_beta[blockIdx.x * 4 + wave] = gb * dbeta_dbp;
     if (blockIdx.x == 0 && wave == 0)               // the waves of the blocks that were not launched (small renders)
         for (int e = gridDim.x * 4 + lane; e < 2048; e += 64) a.g_beta[e] = 0.f;
-    if (a.v3_part) {
+    if (FUSED || a.v3_part) {
         // sum over the 16 point columns of a lane group (xor shuffles stay inside the group of 16), then lane p == 0 of group g writes
         // its 16 channels of every row: a fixed order, per wave
         float* dst = a.v3_part + (size_t)(blockIdx.x * 4 + wave) * 196;

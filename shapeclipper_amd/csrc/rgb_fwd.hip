@@ -36,6 +36,8 @@ struct RgbFwdArgs {
                        // sc_rgb_composite_backward_fused_stash (which then does not recompute the forward chain)
 };
 
+// STASH: rr and rgb_flat are given (the training call): compile-time, so that the stores of the parked activations sit in no branch
+template <bool STASH>
 __global__ __launch_bounds__(256) void rgb_composite_fwd_kernel(RgbFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     stage_rgb_weights(lds, a.v, threadIdx.x, 256);
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(256) void rgb_composite_fwd_kernel(RgbFwdArgs a) {
             float y[3][ACT_STEPS];
             float col[3];
             rgb_chain(L, db, e, f, y, col);
-            if (a.rr) {
+            if (STASH || a.rr) {
                 const size_t tbl = (size_t)a.n_rays * 4 * 1024;
                 tbl_store(a.rr + 0 * tbl, tile, p, g, y[0]);
                 tbl_store(a.rr + 1 * tbl, tile, p, g, y[1]);
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) void rgb_composite_fwd_kernel(RgbFwdArgs a) {
         const float m0 = wave_sum(wn * n0), m1 = wave_sum(wn * n1), m2 = wave_sum(wn * n2);
         if (a.weights) a.weights[(size_t)ray * 64 + lane] = w;
         if (a.alpha) a.alpha[(size_t)ray * 64 + lane] = alpha;
-        if (a.rgb_flat) {
+        if (STASH || a.rgb_flat) {
             a.rgb_flat[((size_t)ray * 64 + lane) * 3 + 0] = c0;
             a.rgb_flat[((size_t)ray * 64 + lane) * 3 + 1] = c1;
             a.rgb_flat[((size_t)ray * 64 + lane) * 3 + 2] = c2;
@@ -136,7 +138,8 @@ extern "C" int sc_rgb_composite_forward_stash(const float* points, const float* 
     int blocks = (n_rays + 3) / 4;
     if (blocks > 512) blocks = 512;   // two 4-wave workgroups per CU (63 KiB LDS each)
     const size_t lds_bytes = sc::RgbLds::TOTAL * sizeof(float);
-    hipLaunchKernelGGL(sc::rgb_composite_fwd_kernel, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream_, a);
+    if (rr && rgb_flat) hipLaunchKernelGGL(sc::rgb_composite_fwd_kernel<true>, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream_, a);
+    else hipLaunchKernelGGL(sc::rgb_composite_fwd_kernel<false>, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream_, a);
     return (int)hipGetLastError();
 }
 
