@@ -38,3 +38,26 @@ def test_no_wide_buffer_store_is_followed_directly_by_a_write_of_its_data(tmp_pa
     assert m, r.stdout[-1000:]
     assert int(m.group(1)) >= 100, last           # the scan saw the stores it is about
     assert int(m.group(2)) == 0, r.stdout[-3000:]
+
+
+def test_the_scanner_sees_the_pattern(tmp_path):
+    """The two lines hipcc produced for sdf_fwd's training instance are reported; the same store with an instruction in between, with an
+    immediate soffset, or followed by a read of its data is not."""
+    asm = tmp_path / "x.s"
+    asm.write_text("\n".join([
+        "_Z1kv:",
+        "\tbuffer_store_dwordx4 v[90:93], v141, s[8:11], s74 offen",
+        "\tv_mul_f32_e32 v90, v91, v1",                                  # hazard
+        "\tbuffer_store_dwordx4 v[82:85], v141, s[8:11], s75 offen",
+        "\ts_nop 0",
+        "\tv_mul_f32_e32 v82, v83, v1",                                  # one instruction in between: fine
+        "\tbuffer_store_dwordx4 v[40:43], v141, s[8:11], 0 offen offset:1024",
+        "\tv_mov_b32_e32 v40, v1",                                       # immediate soffset: the compiler's own wait states cover it
+        "\tbuffer_store_dwordx4 v[20:23], v141, s[8:11], s73 offen",
+        "\tv_mul_f32_e32 v0, v20, v1",                                   # reads the data, writes elsewhere
+        "\tbuffer_store_dwordx3 v[10:12], v141, s[8:11], s73 offen",
+        "\tv_pk_mul_f32 v[12:13], v[2:3], v[4:5]",                       # hazard (overlaps v12)
+        "\ts_endpgm"]) + "\n")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scan_store_hazard.py"), str(asm)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.strip().splitlines()[-1].startswith("4 wide buffer stores with an SGPR soffset, 2 followed directly"), r.stdout
