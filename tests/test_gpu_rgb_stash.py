@@ -33,8 +33,9 @@ def _setup(n_images=3, rays_per_image=40, seed=0):
                 rpi=rays_per_image, n_rays=n_rays, g=g)
 
 
-def test_stash_equals_recomputation():
-    s = _setup()
+@pytest.mark.parametrize("n_images,rays_per_image", [(3, 40), (3, 37), (1, 5)])      # 111 and 5 rays: the last workgroup's idle waves (tail path)
+def test_stash_equals_recomputation(n_images, rays_per_image):
+    s = _setup(n_images, rays_per_image)
     ops = s["ops"]
     common = (s["pts"], s["z"], s["dfac"], s["sdf"], s["grad"], s["feat"], s["rgb_pack"], s["db"], s["beta"], s["rpi"], True, 1e-4, 1.0, 1.0)
     a = ops.rgb_composite_forward(*common, keep_rgb_flat=True, keep_rr=True)
