@@ -94,7 +94,14 @@ class NN_annotator:
         for i in range(0, len(images), opt.batch_size):
             e = self.tower.encode_image(images[i:i + opt.batch_size].to(opt.device)).float()
             feats.append(torch_F.normalize(e, dim=-1))
-        return torch.cat(feats, dim=0)
+        feats = torch.cat(feats, dim=0)
+        # the small-batch tower reports a cluster-barrier time-out (its members were not co-resident: another kernel held CUs) by poisoning
+        # the class-token row, i.e. as NaN embeddings (csrc/clip_cluster.hpp); a nearest-neighbour table must never be built from those
+        if not bool(torch.isfinite(feats).all()):
+            bad = (~torch.isfinite(feats).all(dim=1)).nonzero().flatten().tolist()
+            raise RuntimeError("CLIP tower produced non-finite embeddings for %d image(s) (first: %s): a cluster-barrier time-out of the small-batch "
+                               "kernel or non-finite inputs; re-run with SC_CLIP_CLUSTER_MAX_B=0 to take the launch-per-operation form" % (len(bad), bad[:5]))
+        return feats
 
 
 def main():

@@ -295,7 +295,8 @@ __device__ __forceinline__ void act_from_rows(uint4 (&act)[4][KS], const bf16_t*
 }
 
 // Bounded wait of a cluster: all CL members have arrived `target / CL` times.  Thread 0 publishes and acquires for the workgroup; the two
-// workgroup barriers order the other waves' accesses around it (their stores are acknowledged by L2 before the first: s_waitcnt vmcnt(0)).
+// workgroup barriers order the other waves' accesses around it (their stores are acknowledged by L2 before the first: the explicit
+// s_waitcnt vmcnt(0) every thread executes on entry).
 //   local = false  release / acquire fences at agent scope (L2 write-back + invalidate: buffer_wbl2 sc1 / buffer_inv sc1) -- correct wherever
 //                  the members run; measured ~4 us per barrier inside this kernel
 //   local = true   the members share one XCD, i.e. one L2 (checked at kernel start from the hardware XCC id): what a member wrote is in that
@@ -305,6 +306,10 @@ __device__ __forceinline__ void act_from_rows(uint4 (&act)[4][KS], const bf16_t*
 #define SC_CL_BARRIER 1               // 0: never take the local form (A/B)
 #endif
 __device__ __forceinline__ void cluster_barrier(unsigned* cnt, unsigned target, unsigned* err, bool local) {
+    // Every wave's global stores must be acknowledged by L2 BEFORE thread 0 publishes the arrival: the workgroup barrier below does not
+    // wait on vmcnt by itself (the compiler emits only lgkmcnt(0) in front of s_barrier outside threadgroup-split mode -- ADVICE r05,
+    // read from the ISA), and the local form has no release fence that would.  tools/scan_store_hazard.py checks the instruction stays.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         if (!local) __threadfence();

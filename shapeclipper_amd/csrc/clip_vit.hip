@@ -1382,7 +1382,7 @@ int sc_clip_cluster_pack(const uint16_t* w16, int Kp, int layers, uint16_t* out,
     return sc::cl::launch_cluster_pack(w16 + (size_t)sc::cl::CD * Kp, out, layers, (hipStream_t)stream_);
 }
 // sc_clip_vit_forward / _f16 with the re-packed layer image beside the row-major one (`fp16` != 0: IEEE fp16 operands, else bf16): batches
-// of at most SC_CLIP_CLUSTER_MAX_B (default 64) images run their layers in the cluster form, larger ones exactly as sc_clip_vit_forward.
+// of SC_CLIP_CLUSTER_MIN_B..SC_CLIP_CLUSTER_MAX_B (default 26..32) images run their layers in the cluster form, larger ones exactly as sc_clip_vit_forward.
 int sc_clip_vit_forward_packed(const float* image, int B, int C, int H, int W, int patch, int D, int mlp, int layers, int heads, int proj_dim,
                                const uint16_t* w16, const float* w_f32, const uint16_t* w_cluster, int fp16, float ln_eps, float* out,
                                void* workspace, long long workspace_bytes, void* stream_) {

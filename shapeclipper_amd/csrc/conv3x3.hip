@@ -846,7 +846,10 @@ static const int* conv_spans(int tail_tiles, int nk, int G, int ov2, hipStream_t
     SpanTable& t = cache[key];
     t.host = U;                                                       // the source of the asynchronous copy outlives it
     if (hipMalloc(&t.dev, (size_t)(G + 1) * sizeof(int)) != hipSuccess ||
-        hipMemcpyAsync(t.dev, t.host.data(), (size_t)(G + 1) * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) {
+        hipMemcpyAsync(t.dev, t.host.data(), (size_t)(G + 1) * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess ||
+        // the table is cached and handed to launches on ANY stream (the two trunks run on two streams with equal shapes): the one-time
+        // upload must be complete, not merely ordered on the first launch's stream, before the pointer is published
+        hipStreamSynchronize(st) != hipSuccess) {
         (void)hipGetLastError();
         if (t.dev) (void)hipFree(t.dev);
         t.dev = nullptr;                                              // (null: the kernels fall back to equal spans)

@@ -272,6 +272,8 @@ def bottleneck_linear(x, conv1, bn1, conv2, bn2, groups=1):
             and conv1.bias is None and conv2.bias is None and conv1.weight.shape == (C, C, 1, 1) and conv2.weight.shape == (C, C, 1, 1)
             and x.shape[0] % groups == 0 and ops.linear_bn_supported(x.shape[0], C, C, groups)):
         return None
+    if (bn1.training or bn2.training) and x.shape[0] // groups < 2:
+        return None     # one row per statistics group in training: the operator-by-operator form raises torch's own error, as the reference does
     return BottleneckLinearFunction.apply(x, conv1.weight.view(C, C), bn1.weight, bn1.bias, conv2.weight.view(C, C), bn2.weight, bn2.bias,
                                           _bn_state(bn1), _bn_state(bn2), groups)
 

@@ -145,6 +145,10 @@ class SDFNetwork(nn.Module):
         zkey = (proj_latent.data_ptr(), proj_latent._version, tuple(proj_latent.shape), bool(proj_latent.requires_grad))
         if cache is not None and cache[0] == torch.is_grad_enabled():
             hit = cache[3].get(zkey)
+            # the key is an address: a DIFFERENT autograd tensor on the same storage (a view / alias with its own grad_fn) must not share the
+            # entry, or its gradient would flow into the first tensor's graph only
+            if hit is not None and hit[1] is not proj_latent and proj_latent.requires_grad:
+                hit = None
             if hit is None:
                 hit = cache[3][zkey] = (packing.sdf_cbias(None, proj_latent, gathered=cache[2], arch=self._arch(proj_latent.shape[1])), proj_latent)
             return cache[1], hit[0]

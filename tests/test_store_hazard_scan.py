@@ -61,3 +61,23 @@ def test_the_scanner_sees_the_pattern(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scan_store_hazard.py"), str(asm)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert r.stdout.strip().splitlines()[-1].startswith("4 wide buffer stores with an SGPR soffset, 2 followed directly"), r.stdout
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_cluster_barrier_arrivals_wait_for_their_stores(tmp_path):
+    """the XCD-local cluster barrier of the CLIP tower publishes with a relaxed counter increment; every wave must therefore
+    enter the workgroup barrier in front of it with `s_waitcnt vmcnt(0)` (its att / h / x stores acknowledged by L2).  The compiler does not
+    emit that wait by itself; the explicit one in clip_cluster.hpp must survive in the ISA of both instances of the kernel."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import scan_cluster_barrier
+    out = str(tmp_path / "clip_vit.s")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
+                        os.path.join(CSRC, "clip_vit.hip"), "-o", out], capture_output=True, text=True, cwd=CSRC)
+    assert r.returncode == 0, r.stderr[-2000:]
+    found, bad = scan_cluster_barrier.scan(open(out).read())
+    assert found >= 8 and not bad, bad
+    # the scanner reports the unguarded form
+    f2, b2 = scan_cluster_barrier.scan("\n".join([
+        "_ZN2sc2cl26clip_layers_cluster_kernelILb0EEEvv:", "\tglobal_store_dwordx4 v1, v[2:5], s[0:1]", "\ts_waitcnt lgkmcnt(0)", "\ts_barrier",
+        "\tglobal_atomic_add v34, v1, s[94:95] offset:128", "\ts_endpgm"]))
+    assert f2 == 1 and len(b2) == 1
