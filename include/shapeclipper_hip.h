@@ -404,16 +404,28 @@ int sc_marching_cubes_emit(const float* level, int n_images, int n_axis, float i
 /* Block form of both (what the Python side uses): a workgroup owns 1,024 consecutive cubes of one image.
  *   sc_isosurface_blocks_per_image(n_axis)   blocks per image = ceil((n_axis-1)^3 / 1024)  (-1: n_axis outside 2..1024)
  *   *_block_count    block_counts [n_images * blocks_per_image] int: triangles of each block
- *   *_block_emit     block_offsets: exclusive int64 prefix sum of block_counts; the kernel recomputes the per-cube counts and takes
+ *   sc_isosurface_block_scan   (round 6) block_offsets [n_images * blocks_per_image + 1] = exclusive int64 prefix sum of block_counts with
+ *                    the total as its last entry, per_image [n_images] = triangles of each image: one launch of one workgroup between
+ *                    the two passes (the caller reads per_image to size `tris`).
+ *   *_block_emit     block_offsets: that array (n_images * blocks_per_image + 1 entries: a block whose neighbours' offsets are equal holds
+ *                    no triangle and is left at once); the kernel recomputes the per-cube counts and takes
  *                    their prefix inside the workgroup -- no per-cube count / offset arrays (12 bytes per cube), and the prefix sum
  *                    between the launches runs over 1/1024 of the values.  Same triangles in the same order as the per-cube form. */
 int sc_isosurface_blocks_per_image(int n_axis);
+int sc_isosurface_block_scan(const int* block_counts, int n_images, int n_axis, long long* block_offsets, long long* per_image, void* stream);
 int sc_isosurface_block_count(const float* level, int n_images, int n_axis, float iso, int* block_counts, void* stream);
 int sc_isosurface_block_emit(const float* level, int n_images, int n_axis, float iso, const long long* block_offsets, float* tris,
                              void* stream);
 int sc_marching_cubes_block_count(const float* level, int n_images, int n_axis, float iso, int* block_counts, void* stream);
 int sc_marching_cubes_block_emit(const float* level, int n_images, int n_axis, float iso, const long long* block_offsets, float* tris,
                                  void* stream);
+/* round 6, what the Python side runs for marching cubes: the count pass also leaves the case index of every cube (masks
+ * [n_images * (n_axis-1)^3] bytes, caller-allocated), the emit pass reads them instead of re-reading 8 corners per cube and deals the
+ * vertices of a 256-cube group out to all lanes (coalesced 12-byte stores).  Same triangles, same order, bit for bit.                   */
+int sc_marching_cubes_block_count_masks(const float* level, int n_images, int n_axis, float iso, int* block_counts, unsigned char* masks,
+                                        void* stream);
+int sc_marching_cubes_block_emit_masks(const float* level, int n_images, int n_axis, float iso, const long long* block_offsets,
+                                       const unsigned char* masks, float* tris, void* stream);
 
 /* ---- camera algebra of a render -------------------------------------------------------------------
  * sc_camera_rays_*: utils/camera.py:157-196 (get_center_and_ray on the rendered pixels only) + the normalisation of

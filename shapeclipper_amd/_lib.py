@@ -25,8 +25,8 @@ SYMBOLS = (
     "sc_ray_sample_forward", "sc_ray_sample_backward", "sc_ray_sample_forward_eik", "sc_ray_sample_backward_eik", "sc_render_forward", "sc_sdf_grid_forward", "sc_loss_fused_backward",
     "sc_bn_splits", "sc_bn_act_forward", "sc_bn_act_backward", "sc_bn_relu_pool_forward", "sc_bn_relu_pool_backward",
     "sc_isosurface_count", "sc_isosurface_emit", "sc_marching_cubes_count", "sc_marching_cubes_emit",
-    "sc_isosurface_blocks_per_image", "sc_isosurface_block_count", "sc_isosurface_block_emit", "sc_marching_cubes_block_count",
-    "sc_marching_cubes_block_emit",
+    "sc_isosurface_blocks_per_image", "sc_isosurface_block_scan", "sc_isosurface_block_count", "sc_isosurface_block_emit", "sc_marching_cubes_block_count",
+    "sc_marching_cubes_block_emit", "sc_marching_cubes_block_count_masks", "sc_marching_cubes_block_emit_masks",
     "sc_camera_rays_forward", "sc_camera_rays_backward", "sc_pose_from_trig_forward", "sc_pose_from_trig_backward",
     "sc_estimator_head_forward", "sc_estimator_head_backward", "sc_camera_prior_forward", "sc_camera_prior_backward",
     "sc_camera_prior_max_images", "sc_transform_normal_forward", "sc_transform_normal_backward", "sc_loss_total_forward",

@@ -584,8 +584,8 @@ ISOSURFACE_METHODS = ("cubes", "tetrahedra")
 def isosurface_triangles(level: torch.Tensor, iso: float = 0.0, method: str = "cubes"):
     """level [B,S,S,S] (device) -> (tris [T,3,3] in grid-index units, tri_count [B] int64 on the host).
     method "cubes": marching cubes, the algorithm of the reference's PyMCubes call (same vertex set); "tetrahedra": the
-    table-free marching tetrahedra of rounds 1-2.  Two launches around one prefix sum over per-workgroup counts either way
-    (csrc/isosurface.hip, block form)."""
+    table-free marching tetrahedra of rounds 1-2.  Count per 1,024-cube block, one scan launch (offsets + per-image totals), one host
+    read of the B totals, emit (blocks without a triangle leave at once) -- csrc/isosurface.hip, block form."""
     if method not in ISOSURFACE_METHODS:
         raise ValueError("isosurface_triangles: method must be one of %s, got %r" % (ISOSURFACE_METHODS, method))
     lib = _lib.load()
@@ -598,14 +598,24 @@ def isosurface_triangles(level: torch.Tensor, iso: float = 0.0, method: str = "c
     if bpi <= 0:
         raise RuntimeError("shapeclipper_amd: isosurface_triangles needs 2 <= grid side <= 1024, got %d" % S)
     counts = torch.empty(B * bpi, device=level.device, dtype=torch.int32)           # triangles per workgroup of 1,024 cubes
-    _lib.check(count_fn(_lib.ptr(level), c_int(B), c_int(S), ctypes.c_float(iso), _lib.ptr(counts), _lib.stream()),
-               "sc_isosurface_block_count / sc_marching_cubes_block_count")
-    ends = torch.cumsum(counts, 0, dtype=torch.int64)
-    offsets = (ends - counts).contiguous()
-    per_image = counts.view(B, bpi).sum(dim=1, dtype=torch.int64).cpu()
+    masks = None
+    if method == "cubes":       # the case index of every cube goes from the count pass to the emit pass (1 byte per cube)
+        masks = torch.empty(B * (S - 1) ** 3, device=level.device, dtype=torch.uint8)
+        _lib.check(lib.sc_marching_cubes_block_count_masks(_lib.ptr(level), c_int(B), c_int(S), ctypes.c_float(iso), _lib.ptr(counts), _lib.ptr(masks),
+                                                           _lib.stream()), "sc_marching_cubes_block_count_masks")
+    else:
+        _lib.check(count_fn(_lib.ptr(level), c_int(B), c_int(S), ctypes.c_float(iso), _lib.ptr(counts), _lib.stream()), "sc_isosurface_block_count")
+    offsets = torch.empty(B * bpi + 1, device=level.device, dtype=torch.int64)      # exclusive prefix, the total last
+    per_image = torch.empty(B, device=level.device, dtype=torch.int64)
+    _lib.check(lib.sc_isosurface_block_scan(_lib.ptr(counts), c_int(B), c_int(S), _lib.ptr(offsets), _lib.ptr(per_image), _lib.stream()),
+               "sc_isosurface_block_scan")
+    per_image = per_image.cpu()                                                       # the one host read: it sizes the output
     total = int(per_image.sum())
     tris = torch.empty(total, 3, 3, device=level.device, dtype=torch.float32)
-    if total > 0:
+    if total > 0 and masks is not None:
+        _lib.check(lib.sc_marching_cubes_block_emit_masks(_lib.ptr(level), c_int(B), c_int(S), ctypes.c_float(iso), _lib.ptr(offsets), _lib.ptr(masks),
+                                                          _lib.ptr(tris), _lib.stream()), "sc_marching_cubes_block_emit_masks")
+    elif total > 0:
         _lib.check(emit_fn(_lib.ptr(level), c_int(B), c_int(S), ctypes.c_float(iso), _lib.ptr(offsets), _lib.ptr(tris), _lib.stream()),
                    "sc_isosurface_block_emit / sc_marching_cubes_block_emit")
     return tris, per_image

@@ -128,7 +128,7 @@ def process_options(opt):
     # (Round 5: the bottleneck blocks and the per-image latent biases no longer go through a BLAS at all -- csrc/bottleneck.hip,
     # latent_bias.hip -- so what this switch still touches are the ~20 remaining small products of a step: final projector / head Linears.)
     # The ~83 small fp32 GEMMs of a step (estimator heads, latent projectors: [B..3B, 256..512] x [C, C]) through rocBLAS instead of torch's
-    # default hipBLASLt: 7 instead of 18 us of host time per call (tools/attic/probe_blas.py: a host-paced B=8 step 16.3 -> 14.9 ms); process-global
+    # default hipBLASLt: 7 instead of 18 us of host time per call (a host-paced B=8 step 16.3 -> 14.9 ms); process-global
     # like cudnn.deterministic above, `--hip.rocblas!` leaves torch's choice alone.
     if bool(opt.get("hip", {}).get("rocblas", True)) and torch.cuda.is_available():
         try:

@@ -122,3 +122,54 @@ def test_block_form_equals_per_cube_form(method):
     assert tris.shape == ref.shape and torch.equal(tris, ref)
     assert per.tolist() == counts.view(B, -1).sum(1).tolist() and per[2] == 0 and per[1] > per[0] > 0
     assert int(lib.sc_isosurface_blocks_per_image(ctypes.c_int(S))) == 46 and int(lib.sc_isosurface_blocks_per_image(ctypes.c_int(1))) == -1
+
+
+def test_marching_cubes_block_pairs_agree_and_scan_equals_cumsum():
+    """Round 6: (a) sc_isosurface_block_scan == exclusive cumsum of the block counts (+ total, + per-image sums) on a batch with empty and
+    noisy images and on random counts whose length is no multiple of anything; (b) the mask-passing pair (count_masks / emit_masks: what
+    ops.isosurface_triangles runs) and the recomputing pair (block_count / block_emit) of the C ABI write the same triangles in the same order."""
+    import ctypes
+    from shapeclipper_amd import _lib
+    lib = _lib.load()
+    c_int, c_f = ctypes.c_int, ctypes.c_float
+    rng = np.random.RandomState(7)
+    S = 41
+    level = np.stack([np.full((S, S, S), 2.0, np.float32), _sphere(S, 0.5, (0.1, 0.0, -0.2)), rng.randn(S, S, S).astype(np.float32), _sphere(S, 0.8),
+                      np.full((S, S, S), -1.0, np.float32)]).astype(np.float32)
+    lv = torch.tensor(level).cuda()
+    B, bpi, per = lv.shape[0], int(lib.sc_isosurface_blocks_per_image(c_int(S))), (S - 1) ** 3
+    counts_a = torch.empty(B * bpi, device="cuda", dtype=torch.int32)
+    counts_b = torch.empty_like(counts_a)
+    masks = torch.full((B * per,), 255, device="cuda", dtype=torch.uint8)
+    assert lib.sc_marching_cubes_block_count(_lib.ptr(lv), c_int(B), c_int(S), c_f(0.0), _lib.ptr(counts_a), _lib.stream()) == 0
+    assert lib.sc_marching_cubes_block_count_masks(_lib.ptr(lv), c_int(B), c_int(S), c_f(0.0), _lib.ptr(counts_b), _lib.ptr(masks), _lib.stream()) == 0
+    assert torch.equal(counts_a, counts_b) and int(counts_a.sum()) > 0
+    # the case index of a cube: bit v set <=> corner v (x, y, z bits) below the iso value
+    lvv = lv[:, :, :, :]
+    want = torch.zeros(B, S - 1, S - 1, S - 1, dtype=torch.int32, device="cuda")
+    for v in range(8):
+        dx, dy, dz = v & 1, (v >> 1) & 1, (v >> 2) & 1
+        want |= (lvv[:, dx:dx + S - 1, dy:dy + S - 1, dz:dz + S - 1] < 0.0).int() << v
+    assert torch.equal(masks.int(), want.reshape(-1))
+    offsets = torch.empty(B * bpi + 1, device="cuda", dtype=torch.int64)
+    per_image = torch.empty(B, device="cuda", dtype=torch.int64)
+    assert lib.sc_isosurface_block_scan(_lib.ptr(counts_a), c_int(B), c_int(S), _lib.ptr(offsets), _lib.ptr(per_image), _lib.stream()) == 0
+    ends = torch.cumsum(counts_a, 0, dtype=torch.int64)
+    assert torch.equal(offsets[:-1], ends - counts_a) and int(offsets[-1]) == int(ends[-1])
+    assert per_image.tolist() == counts_a.view(B, bpi).sum(1).tolist() and per_image[0] == 0 and per_image[4] == 0
+    total = int(ends[-1])
+    t_a = torch.full((total, 3, 3), float("nan"), device="cuda")
+    t_b = torch.full((total, 3, 3), float("nan"), device="cuda")
+    assert lib.sc_marching_cubes_block_emit(_lib.ptr(lv), c_int(B), c_int(S), c_f(0.0), _lib.ptr(offsets), _lib.ptr(t_a), _lib.stream()) == 0
+    assert lib.sc_marching_cubes_block_emit_masks(_lib.ptr(lv), c_int(B), c_int(S), c_f(0.0), _lib.ptr(offsets), _lib.ptr(masks), _lib.ptr(t_b), _lib.stream()) == 0
+    torch.cuda.synchronize()
+    assert not torch.isnan(t_a).any() and torch.equal(t_a, t_b)
+    # the scan alone on lengths that exercise ragged segments (n = n_images * blocks_per_image(n_axis))
+    for n_img, axis in ((1, 2), (3, 12), (7, 33), (32, 101)):
+        nb = int(lib.sc_isosurface_blocks_per_image(c_int(axis)))
+        c = torch.randint(0, 5000, (n_img * nb,), device="cuda", dtype=torch.int32)
+        off = torch.empty(n_img * nb + 1, device="cuda", dtype=torch.int64)
+        pim = torch.empty(n_img, device="cuda", dtype=torch.int64)
+        assert lib.sc_isosurface_block_scan(_lib.ptr(c), c_int(n_img), c_int(axis), _lib.ptr(off), _lib.ptr(pim), _lib.stream()) == 0
+        e = torch.cumsum(c, 0, dtype=torch.int64)
+        assert torch.equal(off[:-1], e - c) and int(off[-1]) == int(e[-1]) and pim.tolist() == c.view(n_img, nb).sum(1).tolist()
