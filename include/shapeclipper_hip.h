@@ -323,6 +323,14 @@ int sc_render_backward(
  * points_ws: [n_images*n_axis^3][3] floats of workspace; level: [n_images][n_axis][n_axis][n_axis].       */
 int sc_sdf_grid_forward(const float* sdf_pack, const float* sdf_cbias, float lo, float hi, int n_axis, int n_images,
                         int symmetric, float* points_ws, float* level, void* stream);
+/* round 6: the same grid through the value-only chain in the exact three-piece bf16 split arithmetic with the weights pre-split in LDS
+ * (csrc/sdf_value_split.hip: six piece products per fp32 product on v_mfma_f32_16x16x32_bf16, fp32 accumulation -- the arithmetic of the
+ * trunk convolutions; error against float64 that of the fp32 chain).  sc_sdf_value_forward_split: the same chain on given points
+ * (operands as sc_sdf_forward; sdf [n_points] is the only output).                                                                       */
+int sc_sdf_grid_forward_split(const float* sdf_pack, const float* sdf_cbias, float lo, float hi, int n_axis, int n_images,
+                              int symmetric, float* points_ws, float* level, void* stream);
+int sc_sdf_value_forward_split(const float* points, const float* w_pack, const float* cbias, int n_points, int n_per_image,
+                               int n_images, int symmetric, float* sdf, void* stream);
 
 /* Workgroup-cooperative reverse pass of the SDF MLP (csrc/sdf_bwdw.hip): what sc_sdf_backward + the eight sc_wgrad launches
  * + sc_tbl_sum of the SDF network do, in ONE launch and without the Ga/Gp/r0 hand-off tensors (chain waves and

@@ -22,7 +22,7 @@ SYMBOLS = (
     "sc_rgb_composite_backward", "sc_sdf_backward", "sc_wgrad", "sc_partial_reduce", "sc_tbl_sum", "sc_loss_fused_forward",
     "sc_clip_vit_forward", "sc_gemm_bf16", "sc_f32_to_bf16", "sc_clip_vit_forward_f16", "sc_gemm_f16", "sc_f32_to_f16",
     "sc_clip_cluster_supported", "sc_clip_cluster_pack", "sc_clip_vit_forward_packed", "sc_clip_cluster_set_batch_range",
-    "sc_ray_sample_forward", "sc_ray_sample_backward", "sc_ray_sample_forward_eik", "sc_ray_sample_backward_eik", "sc_render_forward", "sc_sdf_grid_forward", "sc_loss_fused_backward",
+    "sc_ray_sample_forward", "sc_ray_sample_backward", "sc_ray_sample_forward_eik", "sc_ray_sample_backward_eik", "sc_render_forward", "sc_sdf_grid_forward", "sc_sdf_grid_forward_split", "sc_sdf_value_forward_split", "sc_loss_fused_backward",
     "sc_bn_splits", "sc_bn_act_forward", "sc_bn_act_backward", "sc_bn_relu_pool_forward", "sc_bn_relu_pool_backward",
     "sc_isosurface_count", "sc_isosurface_emit", "sc_marching_cubes_count", "sc_marching_cubes_emit",
     "sc_isosurface_blocks_per_image", "sc_isosurface_block_scan", "sc_isosurface_block_count", "sc_isosurface_block_emit", "sc_marching_cubes_block_count",

@@ -191,6 +191,19 @@ int sc_sdf_grid_forward(const float* sdf_pack, const float* sdf_cbias, float lo,
                           nullptr, nullptr, nullptr, nullptr, nullptr, stream_);
 }
 
+// compute_level_grid in the exact three-piece bf16 split arithmetic with pre-split weights (csrc/sdf_value_split.hip, round 6): the same
+// grid points (grid_points_kernel), the value-only chain.  ops.sdf_grid_forward's default since the round-6 A/B.
+int sc_sdf_grid_forward_split(const float* sdf_pack, const float* sdf_cbias, float lo, float hi, int n_axis, int n_images,
+                              int symmetric, float* points_ws, float* level, void* stream_) {
+    const size_t total = (size_t)n_axis * n_axis * n_axis * n_images;
+    if (total == 0) return 0;
+    if (total > 0x7fffffffULL) return (int)hipErrorInvalidValue;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sc::grid_points_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream_, lo, hi, n_axis, n_images, points_ws);
+    return sc_sdf_value_forward_split(points_ws, sdf_pack, sdf_cbias, (int)total, n_axis * n_axis * n_axis, n_images, symmetric, level, stream_);
+}
+
 int sc_loss_fused_backward(const float* G4, float* g_rgb, long long n_rgb, float* g_mask, long long n_mask, float* g_normal,
                            long long n_normal, float* g_eik, long long n_eik, float* g_normal_t, void* stream_) {
     long long n = n_rgb > n_normal ? n_rgb : n_normal;

@@ -23,6 +23,9 @@ def _sdf_scratch(dev):
     return _SCRATCH[key]
 
 
+SDF_VALUE_SPLIT = True    # value-only SDF calls (no gradient, no feature, no stash) take csrc/sdf_value_split.hip; False: sdf_fwd.hip (fp32 MFMA)
+
+
 def sdf_forward(points: torch.Tensor, w_pack: torch.Tensor, cbias: torch.Tensor, n_per_image: int,
                 symmetric: bool = True, want_grad: bool = True, want_feat: bool = True,
                 stash: bool = False):
@@ -32,6 +35,13 @@ def sdf_forward(points: torch.Tensor, w_pack: torch.Tensor, cbias: torch.Tensor,
     dev = points.device
     nt = n_tiles(n)
     sdf = torch.empty(n, device=dev, dtype=torch.float32)
+    if SDF_VALUE_SPLIT and not (want_grad or want_feat or stash):
+        # the value alone (compute_level_grid): the chain in the exact bf16x3 split arithmetic with pre-split weights, 1.6x the fp32-MFMA
+        # chain (csrc/sdf_value_split.hip, profiles/r06_value_chain_split_ab.txt)
+        _lib.check(lib.sc_sdf_value_forward_split(_lib.ptr(points), _lib.ptr(w_pack), _lib.ptr(cbias), c_int(n), c_int(n_per_image),
+                                                  c_int(cbias.shape[0]), c_int(1 if symmetric else 0), _lib.ptr(sdf), _lib.stream()),
+                   "sc_sdf_value_forward_split")
+        return sdf, None, None
     grad = torch.empty(n, 3, device=dev, dtype=torch.float32) if want_grad else None
     feat = torch.empty(nt * 1024, device=dev, dtype=torch.float32) if want_feat else None
     sa = torch.empty(5 * nt * 1024, device=dev, dtype=torch.float32) if stash else None
@@ -433,9 +443,17 @@ def ray_sample_backward(ray_dirs, z_vals, g_points, g_z, rays_per_image, n_image
     return g_o, g_d, g_sd.view(n_images, rays_per_image).sum(dim=1)
 
 
-def sdf_grid_forward(w_pack, cbias, lo, hi, n_axis, symmetric=True):
+def sdf_grid_forward(w_pack, cbias, lo, hi, n_axis, symmetric=True, split=None):
     """compute_level_grid in one call: -> level [n_images, n_axis, n_axis, n_axis]."""
     lib = _lib.load()
+    if SDF_VALUE_SPLIT if split is None else split:
+        B, dev = cbias.shape[0], cbias.device
+        ws = torch.empty(B * n_axis ** 3, 3, device=dev, dtype=torch.float32)
+        level = torch.empty(B, n_axis, n_axis, n_axis, device=dev, dtype=torch.float32)
+        _lib.check(lib.sc_sdf_grid_forward_split(_lib.ptr(w_pack), _lib.ptr(cbias), ctypes.c_float(lo), ctypes.c_float(hi), c_int(n_axis),
+                                                 c_int(B), c_int(1 if symmetric else 0), _lib.ptr(ws), _lib.ptr(level), _lib.stream()),
+                   "sc_sdf_grid_forward_split")
+        return level
     B = cbias.shape[0]
     dev = cbias.device
     ws = torch.empty(B * n_axis ** 3, 3, device=dev, dtype=torch.float32)

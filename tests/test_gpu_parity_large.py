@@ -117,8 +117,11 @@ def test_training_render_b4_r512_vs_oracle_all_gradients(golden):
     assert not bad, bad
 
 
-def test_level_grid_vox100_vs_oracle(golden):
+@pytest.mark.parametrize("value_split", [True, False])
+def test_level_grid_vox100_vs_oracle(golden, value_split):
+    """value_split: the default pre-split bf16x3 value chain (csrc/sdf_value_split.hip, round 6) / the fp32-MFMA chain (`--hip.value_split!`)."""
     from oracle import reference_ops as R
+    from shapeclipper_amd import ops
     from shapeclipper_amd.model.implicit import SDFNetwork
     from shapeclipper_amd.utils import eval_3D
     from shapeclipper_amd.utils.util import EasyDict as edict
@@ -131,7 +134,11 @@ def test_level_grid_vox100_vs_oracle(golden):
     z = torch.randn(1, 64, generator=torch.Generator().manual_seed(3)) * 0.3
     grid = eval_3D.get_dense_3D_grid(o, edict(idx=torch.arange(1)))
     assert grid.shape == (1, 101, 101, 101, 3)
-    lvl = eval_3D.compute_level_grid(o, net, z.cuda(), grid).cpu()
+    try:
+        ops.SDF_VALUE_SPLIT = value_split
+        lvl = eval_3D.compute_level_grid(o, net, z.cuda(), grid).cpu()
+    finally:
+        ops.SDF_VALUE_SPLIT = True
     ref = R.level_grid(R.Cfg(), Ws, z, R.dense_grid(-0.6, 0.6, 100, 1))
     e = float((lvl - ref).abs().max())
     sign_flips = int(((lvl > 0) != (ref > 0))[ref.abs() > 1e-5].sum())

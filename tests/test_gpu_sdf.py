@@ -77,3 +77,71 @@ def test_mirror_symmetry_known_answer():
     assert grad[0, 0].item() == -grad[1, 0].item()
     # geometric-init known answers measured on the reference
     assert abs(sdf[2].item() - (-0.369)) < 2e-3 and abs(sdf[3].item() - 0.0067) < 2e-3
+
+
+# ---- round 6: the value-only chain in the exact bf16x3 split arithmetic with pre-split weights (csrc/sdf_value_split.hip) ----
+@pytest.mark.parametrize("B,N,symmetric", [(1, 1, True), (1, 15, True), (1, 16, False), (2, 17, True), (3, 100, False), (2, 1000, True), (5, 4099, True)])
+def test_value_split_chain_vs_oracle_and_fp32_chain(B, N, symmetric):
+    """What compute_level_grid runs by default: against the float64-free oracle at the bar of the fp32 kernel (2e-5), against the fp32-MFMA
+    kernel at 2e-6 of the value range (both are fp32-accurate: they differ by summation order only), on ragged sizes (a last group with one tile, a last tile
+    with one point), several images (per-image biases), mirror symmetry on and off; run twice: bit-reproducible."""
+    from oracle import reference_ops as R
+    from shapeclipper_amd import ops, packing
+    cfg = R.Cfg()
+    cfg.force_symmetry = symmetric
+    torch.manual_seed(B * 1000 + N)
+    W = R.init_sdf_weights(cfg)
+    W = {k: v + 0.05 * torch.randn_like(v) for k, v in W.items()}
+    z = torch.randn(B, 64)
+    pts = torch.rand(B * N, 3) * 2 - 1
+    pts[0, 0] = 0.0
+    want = R.sdf_conditional(cfg, W, B, pts.clone(), z, compute_grad=False)[0][:, 0].detach()
+    dev = torch.device("cuda:0")
+    pack, cb = packing.pack_sdf({k: v.to(dev) for k, v in W.items()}, z.to(dev))
+    p = pts.to(dev).contiguous()
+    assert ops.SDF_VALUE_SPLIT
+    split1 = ops.sdf_forward(p, pack, cb, N, symmetric=symmetric, want_grad=False, want_feat=False)[0]
+    split2 = ops.sdf_forward(p, pack, cb, N, symmetric=symmetric, want_grad=False, want_feat=False)[0]
+    try:
+        ops.SDF_VALUE_SPLIT = False
+        fp32 = ops.sdf_forward(p, pack, cb, N, symmetric=symmetric, want_grad=False, want_feat=False)[0]
+    finally:
+        ops.SDF_VALUE_SPLIT = True
+    torch.cuda.synchronize()
+    assert torch.equal(split1, split2)
+    assert (split1.cpu() - want).abs().max() < TOL
+    assert (split1 - fp32).abs().max() < 2e-6 * max(1.0, float(fp32.abs().max()))      # a few ulps of the value: summation order only
+    if symmetric:       # sdf(x, y, z) == sdf(-x, y, z), bit for bit (|x| enters the encoding)
+        q = p.clone()
+        q[:, 0] = -q[:, 0]
+        mirrored = ops.sdf_forward(q, pack, cb, N, symmetric=True, want_grad=False, want_feat=False)[0]
+        assert torch.equal(mirrored, split1)
+
+
+def test_value_split_chain_float64_error_is_the_fp32_chains():
+    """The split arithmetic is exact up to fp32 accumulation: on 100,000 points its error against a float64 evaluation of the network is not
+    larger than 1.5x the fp32-MFMA chain's (measured: 3.3e-7 against 3.1e-7 on the evaluation grid, profiles/r06_value_chain_split_ab.txt)."""
+    from oracle import reference_ops as R
+    from shapeclipper_amd import ops, packing
+    cfg = R.Cfg()
+    torch.manual_seed(11)
+    W = R.init_sdf_weights(cfg)
+    W = {k: v + 0.05 * torch.randn_like(v) for k, v in W.items()}
+    z = torch.randn(2, 64) * 0.5
+    n = 50000
+    pts = torch.rand(2 * n, 3) * 1.2 - 0.6
+    W64 = {k: v.double() for k, v in W.items()}
+    want = R.sdf_mlp(cfg, W64, pts.double(), z.double().repeat_interleave(n, 0))[:, 0]
+    dev = torch.device("cuda:0")
+    pack, cb = packing.pack_sdf({k: v.to(dev) for k, v in W.items()}, z.to(dev))
+    p = pts.to(dev).contiguous()
+    split = ops.sdf_forward(p, pack, cb, n, want_grad=False, want_feat=False)[0]
+    try:
+        ops.SDF_VALUE_SPLIT = False
+        fp32 = ops.sdf_forward(p, pack, cb, n, want_grad=False, want_feat=False)[0]
+    finally:
+        ops.SDF_VALUE_SPLIT = True
+    e_split = float((split.double().cpu() - want).abs().max())
+    e_fp32 = float((fp32.double().cpu() - want).abs().max())
+    print("value chain vs float64 on 100,000 points: split %.3e, fp32 MFMA %.3e" % (e_split, e_fp32))
+    assert e_split < 2e-6 and e_split < 1.5 * e_fp32 + 1e-7

@@ -81,3 +81,28 @@ def test_cluster_barrier_arrivals_wait_for_their_stores(tmp_path):
         "_ZN2sc2cl26clip_layers_cluster_kernelILb0EEEvv:", "\tglobal_store_dwordx4 v1, v[2:5], s[0:1]", "\ts_waitcnt lgkmcnt(0)", "\ts_barrier",
         "\tglobal_atomic_add v34, v1, s[94:95] offset:128", "\ts_endpgm"]))
     assert f2 == 1 and len(b2) == 1
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_no_short_mfma_is_fed_by_a_k32_mfma_directly_in_front_of_it(tmp_path):
+    """Round 6 (csrc/sdf_value_split.hip): a v_mfma_f32_16x16x16_bf16 issued directly behind the v_mfma_f32_16x16x32_bf16 that writes its
+    accumulator read the accumulator too early (level grid wrong by 0.4).  No kernel that uses both shapes may contain the pair fewer
+    than 4 instructions apart (tools/scan_mfma_shape_hazard.py); the scanner reports the failing order."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import scan_mfma_shape_hazard as S
+    out = str(tmp_path / "svs.s")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
+                        os.path.join(CSRC, "sdf_value_split.hip"), "-o", out], capture_output=True, text=True, cwd=CSRC)
+    assert r.returncode == 0, r.stderr[-2000:]
+    n, hits = S.scan(open(out).read())
+    assert n >= 100 and not hits, hits[:3]
+    n2, hits2 = S.scan("\n".join([
+        "_Z1kv:",
+        "\tv_mfma_f32_16x16x32_bf16 v[28:31], v[24:27], v[0:3], v[28:31]",
+        "\tv_sub_f32_e32 v26, v16, v12",
+        "\tv_mfma_f32_16x16x16_bf16 v[28:31], v[56:57], v[94:95], v[28:31]",                # hazard: 1 instruction between
+        "\tv_mfma_f32_16x16x32_bf16 v[40:43], v[24:27], v[0:3], v[40:43]",
+        "\tv_mfma_f32_16x16x16_bf16 v[44:47], v[56:57], v[94:95], v[44:47]",                # another accumulator: fine
+        "\tv_mfma_f32_16x16x16_bf16 v[44:47], v[58:59], v[94:95], v[44:47]",                # same shape back to back: forwarded
+        "\ts_endpgm"]))
+    assert n2 == 3 and len(hits2) == 1

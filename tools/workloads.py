@@ -279,13 +279,27 @@ def level_grid_100(with_cpu=True):
     ms, best = _gpu_ms(lambda: eval_3D.compute_level_grid(opt, sdf_net, z, grid), iters=20)
     n = 101 ** 3
     tf = GRID_FLOP_PER_POINT * n / (ms * 1e-3) / 1e12
+    from shapeclipper_amd import ops as _ops
+    split = bool(_ops.SDF_VALUE_SPLIT)
+    # round 6: the value chain runs in the exact three-piece bf16 split arithmetic (csrc/sdf_value_split.hip): its roof is the bf16 matrix
+    # pipe / 6 piece products per fp32 product (the trunk convolutions' roof), no longer the fp32 pipe
+    peak = PEAK_SPLIT if split else PEAK_FP32
     out = dict(workload="SDF level grid, vox_res=100, one image (%d points)" % n, ms=round(ms, 3), ms_best=round(best, 3),
-               algorithmic_flop=GRID_FLOP_PER_POINT * n, algorithmic_bytes=4 * n, achieved=round(tf, 2), peak=PEAK_FP32, unit="TFLOP/s",
-               bound="fp32 MFMA", frac=round(tf / PEAK_FP32, 4),
-               executed_flop=int(GRID_FLOP_PER_POINT * n * EXECUTED_SHARE_GRID), frac_executed=round(tf * EXECUTED_SHARE_GRID / PEAK_FP32, 4),
-               frac_note="frac = reference-dense 80,640 FLOP per point; frac_executed = the 28,032 of 40,320 MACs per point left after folding the "
-                         "latent columns into per-image biases (%.3f) = the matrix pipe's real utilisation" % EXECUTED_SHARE_GRID,
+               algorithmic_flop=GRID_FLOP_PER_POINT * n, algorithmic_bytes=4 * n, achieved=round(tf, 2), peak=peak, unit="TFLOP/s",
+               bound="bf16 MFMA / 6 (exact 3-piece split, fp32 accumulate)" if split else "fp32 MFMA", frac=round(tf / peak, 4),
+               frac_of_fp32_mfma_peak=round(tf / PEAK_FP32, 4),
+               executed_flop=int(GRID_FLOP_PER_POINT * n * EXECUTED_SHARE_GRID), frac_executed=round(tf * EXECUTED_SHARE_GRID / peak, 4),
+               frac_note="frac = reference-dense 80,640 FLOP per point / time / peak; frac_executed = the 28,032 of 40,320 MACs per point left after "
+                         "folding the latent columns into per-image biases (%.3f) = the matrix pipe's real utilisation; round 5 ran this on the "
+                         "fp32 pipe (0.52 ms, 0.97 of 157.3 dense / 0.68 executed)" % EXECUTED_SHARE_GRID,
                mpoints_per_s=round(n / (ms * 1e-3) / 1e6, 1))
+    if split:        # the fp32-MFMA chain on the same grid, same box (`--hip.value_split!`)
+        try:
+            _ops.SDF_VALUE_SPLIT = False
+            ms32, _ = _gpu_ms(lambda: eval_3D.compute_level_grid(opt, sdf_net, z, grid), iters=20)
+        finally:
+            _ops.SDF_VALUE_SPLIT = True
+        out["fp32_mfma_chain_ms"] = round(ms32, 3)
     if with_cpu:
         from oracle import reference_ops as R
         torch.set_num_threads(cpu_threads())
