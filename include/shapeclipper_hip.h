@@ -113,6 +113,17 @@ int sc_rgb_composite_forward_stash(const float* points, const float* z_vals, con
                                    float beta_min, float bgcolor, float normal_pow,
                                    float* rgb, float* mask, float* mask_hard, float* depth, float* normal,
                                    float* weights, float* alpha, float* rgb_flat, float* rr, void* stream);
+/* round 6: sc_rgb_composite_forward_stash with the RGB network in the exact three-piece bf16 split arithmetic, weights pre-split in LDS
+ * (csrc/mlp_presplit.hpp; six piece products per fp32 product on the bf16 matrix pipe, fp32 accumulation -- error against float64 that of
+ * the fp32 chain).  Same operands and outputs; mask / mask_hard / depth / normal do not depend on the RGB network and are bit-identical
+ * to the fp32-MFMA form's, the colours differ by fp32 rounding.                                                                         */
+int sc_rgb_composite_forward_split(const float* points, const float* z_vals, const float* depth_fac,
+                                   const float* sdf, const float* grad, const float* feat,
+                                   const float* v_pack, const float* dbias, const float* beta_param,
+                                   int n_rays, int rays_per_image, int n_images, int symmetric,
+                                   float beta_min, float bgcolor, float normal_pow,
+                                   float* rgb, float* mask, float* mask_hard, float* depth, float* normal,
+                                   float* weights, float* alpha, float* rgb_flat, float* rr, void* stream);
 
 /* Reverse pass.  G_* are the upstream per-ray gradients (NULL = zero).  g_beta: SC_RGB_BWD_BETA_PARTS floats, fully
  * written: one partial of d/d(raw beta parameter) per wave of the grid; the gradient is their sum in index order

@@ -451,6 +451,27 @@ __device__ __forceinline__ void tbl_store(float* base, int tile, int p, int g, c
     asm volatile("s_nop 0" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
+// tbl_store with the four stores pinned back to back: in the round-6 split RGB forward the scheduler moved the bf16 split of the SAME
+// values (v_and / v_sub written in place) between the stores of a group -- the hazard above on stores 2 and 3 of 4 (parked activations wrong
+// in register 1 of a quad, different from run to run; tools/scan_store_hazard.py reported the four places).  Nothing may sit between the
+// stores, and the pinned s_nop follows the last one.
+__device__ __forceinline__ void tbl_store_pinned(float* base, int tile, int p, int g, const float (&v)[ACT_STEPS]) {
+    const __amdgpu_buffer_rsrc_t rs = tbl_rsrc(base, tile);
+    const int lo = (g * 16 + p) * 16;
+    f32x4 q[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) q[t] = f32x4{v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]};
+    // (the values must EXIST before the barrier: without the empty asm statements LLVM sinks the pure instructions that produce them -- the
+    //  ReLU's v_max -- down to their use, i.e. between the stores, and the scheduling barrier has nothing to hold back)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(q[t]));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q[t]), rs, lo, 1024 * t, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 0" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
 __device__ __forceinline__ void tbl_load(const float* base, int tile, int p, int g, float (&v)[ACT_STEPS]) {
     const __amdgpu_buffer_rsrc_t rs = tbl_rsrc(base, tile);
     const int lo = (g * 16 + p) * 16;

@@ -21,14 +21,13 @@
 //
 // LDS image (bytes): per (K-step, channel tile) a FRAGMENT = [piece 0..2][lane 0..63][8 bf16] (3 KiB; K = 16: [piece][lane][4 bf16],
 // 1.5 KiB), every piece one lane-linear KiB: conflict-free ds_read_b128.
-#include "mlp_tile.hpp"
+#include "mlp_presplit.hpp"
 
 namespace sc {
 namespace vs {
 
 constexpr int WAVES = 8;                         // 2 per SIMD
-constexpr int F32B = 3 * 64 * 16, F16B = 3 * 64 * 8;
-constexpr int PE_FRAG = F32B + F16B;             // the encoding's two steps of one channel tile
+using namespace ps;
 constexpr int OFF_L0 = 0;                        // [mt 4] PE_FRAG
 constexpr int OFF_L1 = OFF_L0 + 4 * PE_FRAG;     // [ks 2][mt 4] F32B, then [mt 4] PE_FRAG
 constexpr int OFF_L2 = OFF_L1 + 8 * F32B + 4 * PE_FRAG;
@@ -37,57 +36,6 @@ constexpr int OFF_L4 = OFF_L3 + 8 * F32B;
 constexpr int OFF_W5 = OFF_L4 + 8 * F32B;        // 64 floats: the sdf row of the output layer, + b5[0], fp32
 constexpr int LDS_BYTES = OFF_W5 + 80 * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "the pre-split value chain must fit one CU's LDS");
-
-__device__ __forceinline__ void split3(float v, __bf16& h0, __bf16& h1, __bf16& h2) {
-    h0 = (__bf16)v;
-    const float r1 = v - (float)h0;
-    h1 = (__bf16)r1;
-    h2 = (__bf16)(r1 - (float)h1);
-}
-
-// hidden-input part of a layer: W[64][ld], columns c0 .. c0 + 63 -> [ks][mt] K = 32 fragments
-__device__ __forceinline__ void stage_hidden(char* dst, const float* __restrict__ W, int ld, int c0, int tid, int nthreads) {
-    for (int idx = tid; idx < 2 * 4 * 64 * 8; idx += nthreads) {
-        const int j = idx & 7, lane = (idx >> 3) & 63, mt = (idx >> 9) & 3, ks = idx >> 11;
-        const int row = 16 * mt + (lane & 15), col = c0 + 16 * (2 * ks + (j >> 2)) + 4 * (lane >> 4) + (j & 3);
-        __bf16 h[3];
-        split3(W[row * ld + col], h[0], h[1], h[2]);
-        char* f = dst + (ks * 4 + mt) * F32B + lane * 16 + j * 2;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) *reinterpret_cast<__bf16*>(f + p * 1024) = h[p];
-    }
-}
-// encoding part: packed columns c0 .. c0 + 47 -> [mt] (K = 32 fragment of slots 0..7, K = 16 fragment of slots 8..11)
-__device__ __forceinline__ void stage_pe(char* dst, const float* __restrict__ W, int ld, int c0, int tid, int nthreads) {
-    for (int idx = tid; idx < 4 * 64 * 12; idx += nthreads) {
-        const int s = idx % 12, lane = (idx / 12) & 63, mt = idx / (12 * 64);
-        const int row = 16 * mt + (lane & 15), col = c0 + 4 * s + (lane >> 4);
-        __bf16 h[3];
-        split3(W[row * ld + col], h[0], h[1], h[2]);
-        char* f = dst + mt * PE_FRAG;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            if (s < 8) *reinterpret_cast<__bf16*>(f + p * 1024 + lane * 16 + s * 2) = h[p];
-            else *reinterpret_cast<__bf16*>(f + F32B + p * 512 + lane * 8 + (s - 8) * 2) = h[p];
-        }
-    }
-}
-
-__device__ __forceinline__ MlpPieces<8> frag32(const char* f, int lane) {
-    MlpPieces<8> a;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) a.p[p] = __builtin_bit_cast(mlp_bf16x8, *reinterpret_cast<const uint4*>(f + p * 1024 + lane * 16));
-    return a;
-}
-__device__ __forceinline__ MlpPieces<4> frag16(const char* f, int lane) {
-    MlpPieces<4> a;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        const uint2 v = *reinterpret_cast<const uint2*>(f + p * 512 + lane * 8);
-        a.p[p] = __builtin_bit_cast(mlp_bf16x8, make_uint4(v.x, v.y, 0u, 0u));
-    }
-    return a;
-}
 
 struct Args {
     const float* points;   // [n_points][3]
@@ -137,45 +85,13 @@ __global__ __launch_bounds__(64 * WAVES) void sdf_value_split_kernel(Args a) {
             cb[u] = a.cbias + (size_t)min(ptc / a.n_per_image, a.n_images - 1) * 320 + 4 * g;
             float e[PE_STEPS], d1[PE_STEPS], d2[PE_STEPS];
             pe_slots<false, false>(x0, x1, x2, g, a.symmetric != 0, e, d1, d2);
-            const float ea[8] = {e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]}, eb[4] = {e[8], e[9], e[10], e[11]};
-            mlp_split<8>(ea, e32[u]);
-            mlp_split<4>(eb, e16[u]);
+            split_pe(e, e32[u], e16[u]);
         }
         f32x4 acc[TPW][NT];
         MlpPieces<8> hp[TPW][2];
         float h[TPW][ACT_STEPS];
 
         // acc[u] += W_e e   (the encoding's part of a layer: fragments at `base`)
-        // (all K = 32 products first, then the K = 16 ones: a 16x16x16 MFMA issued DIRECTLY behind the 16x16x32 MFMA that writes its
-        //  accumulator read the accumulator before that write had landed -- values off by the main piece product, 0.4 on the level grid;
-        //  hipcc 7.2 under-counts the passes of the gfx950 K = 32 shape, DESIGN.md 4.1.1.  Here 7 independent products lie between.)
-        auto pe_part = [&](const char* base) {
-#pragma unroll
-            for (int mt = 0; mt < NT; ++mt) {
-                const MlpPieces<8> w32 = frag32(base + mt * PE_FRAG, lane);
-#pragma unroll
-                for (int u = 0; u < TPW; ++u) acc[u][mt] = mlp_six<8>(w32, e32[u], acc[u][mt]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int mt = 0; mt < NT; ++mt) {
-                const MlpPieces<4> w16 = frag16(base + mt * PE_FRAG + F32B, lane);
-#pragma unroll
-                for (int u = 0; u < TPW; ++u) acc[u][mt] = mlp_six<4>(w16, e16[u], acc[u][mt]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        // acc[u] += W_h h   (hidden part: fragments [ks][mt] at `base`)
-        auto hidden_part = [&](const char* base) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int mt = 0; mt < NT; ++mt) {
-                    const MlpPieces<8> w = frag32(base + (ks * 4 + mt) * F32B, lane);
-#pragma unroll
-                    for (int u = 0; u < TPW; ++u) acc[u][mt] = mlp_six<8>(w, hp[u][ks], acc[u][mt]);
-                }
-        };
         // h = softplus(acc); split for the next layer
         auto activate = [&](bool split) {
 #pragma unroll
@@ -187,12 +103,7 @@ __global__ __launch_bounds__(64 * WAVES) void sdf_value_split_kernel(Args a) {
                     softplus_parts(av, t, r);
                     h[u][s] = softplus_val(av, t);
                 }
-                if (split) {
-                    const float ha[8] = {h[u][0], h[u][1], h[u][2], h[u][3], h[u][4], h[u][5], h[u][6], h[u][7]};
-                    const float hb[8] = {h[u][8], h[u][9], h[u][10], h[u][11], h[u][12], h[u][13], h[u][14], h[u][15]};
-                    mlp_split<8>(ha, hp[u][0]);
-                    mlp_split<8>(hb, hp[u][1]);
-                }
+                if (split) split_act(h[u], hp[u]);
             }
         };
         auto bias = [&](int L) {
@@ -201,21 +112,21 @@ __global__ __launch_bounds__(64 * WAVES) void sdf_value_split_kernel(Args a) {
         };
 
         bias(0);
-        pe_part(lds + OFF_L0);
+        pe_part<TPW>(lds + OFF_L0, lane, e32, e16, acc);
         activate(true);
         bias(1);
-        hidden_part(lds + OFF_L1);
-        pe_part(lds + OFF_L1 + 8 * F32B);
+        hidden_part<TPW>(lds + OFF_L1, lane, hp, acc);
+        pe_part<TPW>(lds + OFF_L1 + 8 * F32B, lane, e32, e16, acc);
         activate(true);
         bias(2);
-        hidden_part(lds + OFF_L2);
-        pe_part(lds + OFF_L2 + 8 * F32B);
+        hidden_part<TPW>(lds + OFF_L2, lane, hp, acc);
+        pe_part<TPW>(lds + OFF_L2 + 8 * F32B, lane, e32, e16, acc);
         activate(true);
         bias(3);
-        hidden_part(lds + OFF_L3);
+        hidden_part<TPW>(lds + OFF_L3, lane, hp, acc);
         activate(true);
         bias(4);
-        hidden_part(lds + OFF_L4);
+        hidden_part<TPW>(lds + OFF_L4, lane, hp, acc);
         activate(false);
 
         // output layer, sdf row only: the fp32 dot of sdf_fwd.hip (same order of operations)

@@ -23,6 +23,7 @@ def _sdf_scratch(dev):
     return _SCRATCH[key]
 
 
+RGB_FWD_SPLIT = True      # RGB network of the forward pass from pre-split bf16x3 fragments (csrc/rgb_fwd.hip, mlp_presplit.hpp); False: fp32 MFMA
 SDF_VALUE_SPLIT = True    # value-only SDF calls (no gradient, no feature, no stash) take csrc/sdf_value_split.hip; False: sdf_fwd.hip (fp32 MFMA)
 
 
@@ -79,14 +80,16 @@ def rgb_composite_forward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, db
         out.update(rgb_flat=torch.empty(n_rays * 64, 3, **f32))
     if keep_rr:      # the hidden activations r0, r1, r2 (3 x TBL64) for rgb_composite_backward(rr=...): 805 MB per bs32 render
         out.update(rr=torch.empty(3 * n_rays * 4 * 1024, **f32))
-    code = lib.sc_rgb_composite_forward_stash(
+    # round 6: the RGB network from pre-split bf16x3 weight fragments (csrc/rgb_fwd.hip, `--hip.rgb_split!` keeps the fp32-MFMA chain)
+    fwd = lib.sc_rgb_composite_forward_split if RGB_FWD_SPLIT else lib.sc_rgb_composite_forward_stash
+    code = fwd(
         _lib.ptr(points), _lib.ptr(z_vals), _lib.ptr(depth_fac), _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(feat),
         _lib.ptr(v_pack), _lib.ptr(dbias), _lib.ptr(beta_param), c_int(n_rays), c_int(rays_per_image),
         c_int(dbias.shape[0]), c_int(1 if symmetric else 0), ctypes.c_float(beta_min), ctypes.c_float(bgcolor),
         ctypes.c_float(normal_pow), _lib.ptr(out["rgb"]), _lib.ptr(out["mask"]), _lib.ptr(out["mask_hard"]),
         _lib.ptr(out["depth"]), _lib.ptr(out["normal"]), _lib.ptr(out.get("weights")), _lib.ptr(out.get("alpha")),
         _lib.ptr(out.get("rgb_flat")), _lib.ptr(out.get("rr")), _lib.stream())
-    _lib.check(code, "sc_rgb_composite_forward_stash")
+    _lib.check(code, "sc_rgb_composite_forward_split" if RGB_FWD_SPLIT else "sc_rgb_composite_forward_stash")
     return out
 
 

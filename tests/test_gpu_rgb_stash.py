@@ -30,7 +30,7 @@ def _setup(n_images=3, rays_per_image=40, seed=0):
     sdf, grad, feat = ops.sdf_forward(pts, sdf_pack, cb, rays_per_image * 64)
     beta = torch.tensor([0.1], device=dev)
     return dict(ops=ops, dev=dev, pts=pts, z=z, dfac=dfac, sdf=sdf, grad=grad, feat=feat, rgb_pack=rgb_pack, db=db, beta=beta,
-                rpi=rays_per_image, n_rays=n_rays, g=g)
+                rpi=rays_per_image, n_rays=n_rays, g=g, Wr=Wr, zr=zr)
 
 
 @pytest.mark.parametrize("n_images,rays_per_image", [(3, 40), (3, 37), (1, 5)])      # 111 and 5 rays: the last workgroup's idle waves (tail path)
@@ -72,3 +72,44 @@ def test_stash_entry_point_refuses_a_missing_stash():
                                                    ctypes.c_float(1e-4), ctypes.c_float(1.0), ctypes.c_float(1.0), z, z, z, z, p, p, p, p, p, p, p, p, p, z,
                                                    _lib.stream())
     assert rc != 0          # rr == NULL: an error code, not a launch
+
+
+@pytest.mark.parametrize("n_images,rays_per_image", [(3, 40), (3, 37), (1, 5), (2, 512)])
+def test_split_forward_equals_fp32_forward_up_to_rounding(n_images, rays_per_image):
+    """Round 6: the forward pass with the RGB network from pre-split bf16x3 weight fragments (sc_rgb_composite_forward_split, the default)
+    against the fp32-MFMA form (`--hip.rgb_split!`): what does not depend on the RGB network (mask, mask_hard, depth, normal) is
+    bit-identical; colours, per-sample colours and the parked activations agree to a few fp32 ulps of their range; against a float64
+    restatement of the network the split form's parked activations are as close as the fp32 form's; parked or not, and twice: same bits."""
+    s = _setup(n_images, rays_per_image, seed=5)
+    ops = s["ops"]
+    common = (s["pts"], s["z"], s["dfac"], s["sdf"], s["grad"], s["feat"], s["rgb_pack"], s["db"], s["beta"], s["rpi"], True, 1e-4, 1.0, 1.0)
+    assert ops.RGB_FWD_SPLIT
+    a = ops.rgb_composite_forward(*common, keep_rgb_flat=True, keep_rr=True)
+    a2 = ops.rgb_composite_forward(*common, keep_rgb_flat=True, keep_rr=True)
+    a3 = ops.rgb_composite_forward(*common, keep_rgb_flat=True)
+    try:
+        ops.RGB_FWD_SPLIT = False
+        b = ops.rgb_composite_forward(*common, keep_rgb_flat=True, keep_rr=True)
+    finally:
+        ops.RGB_FWD_SPLIT = True
+    for k in ("rgb", "mask", "mask_hard", "depth", "normal", "rgb_flat", "rr"):
+        assert torch.equal(a[k], a2[k]), k
+        if k != "rr":
+            assert torch.equal(a[k], a3[k]), k
+    for k in ("mask", "mask_hard", "depth", "normal"):
+        assert torch.equal(a[k], b[k]), k
+    assert (a["rgb"] - b["rgb"]).abs().max() < 2e-6 and (a["rgb_flat"] - b["rgb_flat"]).abs().max() < 2e-6
+    scale = float(b["rr"].abs().max())
+    assert (a["rr"] - b["rr"]).abs().max() < 4e-6 * max(1.0, scale)
+    assert not torch.equal(a["rr"], b["rr"]) or rays_per_image < 40        # the two arithmetics really are different code paths
+    # per-sample colours against a float64 evaluation of the network (oracle restatement; the HIP feature tensor as its input)
+    from oracle import reference_ops as R
+    from shapeclipper_amd import packing
+    P = s["n_rays"] * 64
+    feat = packing.tbl_to_rows(s["feat"], P).double().cpu()
+    Wr = {k: v.double().cpu() for k, v in s["Wr"].items()}
+    zr = s["zr"].double().cpu().repeat_interleave(rays_per_image * 64, 0)
+    want = R.rgb_mlp(R.Cfg(), Wr, s["pts"].double().cpu(), zr, feat)
+    ea, eb = (float((t["rgb_flat"].double().cpu() - want).abs().max()) for t in (a, b))
+    print("per-sample colours vs float64: split %.2e, fp32 MFMA %.2e" % (ea, eb))
+    assert ea < 1.5 * eb + 2e-7 and ea < 2e-6

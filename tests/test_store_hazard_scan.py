@@ -19,8 +19,8 @@ HIPCC = "/opt/rocm/bin/hipcc"
 def test_no_wide_buffer_store_is_followed_directly_by_a_write_of_its_data(tmp_path):
     # only files that can emit raw buffer stores: the MLP chain kernels (tbl_store) and whoever else names the builtin
     files = [f for f in sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-             if re.search(r"raw_buffer_store|mlp_tile\.hpp|mlp_xch\.hpp|rgb_common\.hpp", open(f).read())]
-    assert len(files) >= 6, files
+             if re.search(r"raw_buffer_store|mlp_tile\.hpp|mlp_xch\.hpp|rgb_common\.hpp|mlp_presplit\.hpp", open(f).read())]
+    assert len(files) >= 7 and any(f.endswith("sdf_value_split.hip") for f in files), files
 
     def build(f):
         out = str(tmp_path / (os.path.basename(f)[:-4] + ".s"))
@@ -90,12 +90,18 @@ def test_no_short_mfma_is_fed_by_a_k32_mfma_directly_in_front_of_it(tmp_path):
     than 4 instructions apart (tools/scan_mfma_shape_hazard.py); the scanner reports the failing order."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import scan_mfma_shape_hazard as S
-    out = str(tmp_path / "svs.s")
-    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
-                        os.path.join(CSRC, "sdf_value_split.hip"), "-o", out], capture_output=True, text=True, cwd=CSRC)
-    assert r.returncode == 0, r.stderr[-2000:]
-    n, hits = S.scan(open(out).read())
-    assert n >= 100 and not hits, hits[:3]
+    seen = 0
+    for name in ("sdf_value_split.hip", "rgb_fwd.hip"):          # every file that issues both shapes (mlp_presplit.hpp)
+        out = str(tmp_path / (name[:-4] + ".s"))
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
+                            os.path.join(CSRC, name), "-o", out], capture_output=True, text=True, cwd=CSRC)
+        assert r.returncode == 0, r.stderr[-2000:]
+        n, hits = S.scan(open(out).read())
+        assert n >= 40 and not hits, (name, hits[:3])
+        seen += n
+    assert seen >= 200
+    assert sorted(f for f in os.listdir(CSRC) if f.endswith(".hip") and "mlp_presplit.hpp" in open(os.path.join(CSRC, f)).read()) == \
+        ["rgb_fwd.hip", "sdf_value_split.hip"]                    # a new user of the header must be added to the list above
     n2, hits2 = S.scan("\n".join([
         "_Z1kv:",
         "\tv_mfma_f32_16x16x32_bf16 v[28:31], v[24:27], v[0:3], v[28:31]",
