@@ -301,6 +301,8 @@ int sc_ray_sample_backward_eik(const float* ray_dirs, const float* z_vals, const
  * scratch are caller-provided work buffers (sizes as in the three entry points).  Inference: stash_a = stash_p =
  * rgb_flat = NULL.  Training: pass stash_a (5 x TBL64), stash_p (4 x TBL64) and rgb_flat [P][3]; together with
  * z_vals / points / sdf / grad / feat they are what sc_render_backward needs (scratch may then be NULL).    */
+/* (sc_render_forward chains sc_ray_sample_forward, sc_sdf_forward and sc_rgb_composite_forward -- the fp32-MFMA forms; the round-6 split
+ *  forms sc_sdf_forward_stream / sc_rgb_composite_forward_split are what the Python host calls one by one.)                          */
 int sc_render_forward(const float* cam_loc, const float* ray_dirs, const float* depth_fac, const float* scale_dist,
                       const float* u, const float* sdf_pack, const float* sdf_cbias, const float* rgb_pack,
                       const float* rgb_dbias, const float* beta_param, int n_rays, int rays_per_image, int n_images,
@@ -342,6 +344,18 @@ int sc_sdf_grid_forward_split(const float* sdf_pack, const float* sdf_cbias, flo
                               int symmetric, float* points_ws, float* level, void* stream);
 int sc_sdf_value_forward_split(const float* points, const float* w_pack, const float* cbias, int n_points, int n_per_image,
                                int n_images, int symmetric, float* sdf, void* stream);
+/* round 6: sc_sdf_forward (value, feature, d sdf/dx, training stashes: same operands and outputs) in the same split arithmetic with the
+ * pre-split weight fragments STREAMED through LDS one layer at a time (csrc/sdf_fwd_stream.hip: 324 KiB of fragments incl. the transposed
+ * set of the adjoint sweep; the 8 waves of a workgroup walk the chain in lock step, two LDS buffers).
+ *   sc_sdf_stream_pack_bytes()      bytes of the streamed image (331,776)
+ *   sc_sdf_stream_pack              w_pack (fp32 SdfPack image) -> the streamed image; once per weight update
+ *   sc_sdf_forward_stream           grad required; stash_a, stash_p and feat all given = the training render (else per-wave `scratch`
+ *                                   as in sc_sdf_forward); w_pack is read for the fp32 sdf row of the output layer and its biases      */
+long long sc_sdf_stream_pack_bytes(void);
+int sc_sdf_stream_pack(const float* w_pack, void* w_stream, void* stream);
+int sc_sdf_forward_stream(const float* points, const void* w_stream, const float* w_pack, const float* cbias, int n_points,
+                          int n_per_image, int n_images, int symmetric, float* sdf, float* grad, float* feat,
+                          float* stash_a, float* stash_p, float* scratch, void* stream);
 
 /* Workgroup-cooperative reverse pass of the SDF MLP (csrc/sdf_bwdw.hip): what sc_sdf_backward + the eight sc_wgrad launches
  * + sc_tbl_sum of the SDF network do, in ONE launch and without the Ga/Gp/r0 hand-off tensors (chain waves and

@@ -22,7 +22,7 @@ SYMBOLS = (
     "sc_rgb_composite_backward", "sc_sdf_backward", "sc_wgrad", "sc_partial_reduce", "sc_tbl_sum", "sc_loss_fused_forward",
     "sc_clip_vit_forward", "sc_gemm_bf16", "sc_f32_to_bf16", "sc_clip_vit_forward_f16", "sc_gemm_f16", "sc_f32_to_f16",
     "sc_clip_cluster_supported", "sc_clip_cluster_pack", "sc_clip_vit_forward_packed", "sc_clip_cluster_set_batch_range",
-    "sc_ray_sample_forward", "sc_ray_sample_backward", "sc_ray_sample_forward_eik", "sc_ray_sample_backward_eik", "sc_render_forward", "sc_sdf_grid_forward", "sc_sdf_grid_forward_split", "sc_sdf_value_forward_split", "sc_loss_fused_backward",
+    "sc_ray_sample_forward", "sc_ray_sample_backward", "sc_ray_sample_forward_eik", "sc_ray_sample_backward_eik", "sc_render_forward", "sc_sdf_grid_forward", "sc_sdf_grid_forward_split", "sc_sdf_value_forward_split", "sc_sdf_stream_pack_bytes", "sc_sdf_stream_pack", "sc_sdf_forward_stream", "sc_loss_fused_backward",
     "sc_bn_splits", "sc_bn_act_forward", "sc_bn_act_backward", "sc_bn_relu_pool_forward", "sc_bn_relu_pool_backward",
     "sc_isosurface_count", "sc_isosurface_emit", "sc_marching_cubes_count", "sc_marching_cubes_emit",
     "sc_isosurface_blocks_per_image", "sc_isosurface_block_scan", "sc_isosurface_block_count", "sc_isosurface_block_emit", "sc_marching_cubes_block_count",
@@ -45,7 +45,7 @@ _lib: Optional[ctypes.CDLL] = None
 # Optional per-entry-point GPU timing (bench.py): when TIMING is a dict every C-ABI call is bracketed by
 # two events on torch's current stream (the stream the kernels are enqueued on).
 TIMING = None
-TIMING_SKIP = ("sc_rgb_composite_backward_fused_parts", "sc_rgb_composite_backward_fused_partial_floats", "sc_latent_bias_forward", "sc_latent_bias_backward", "sc_set_reserved_cus", "sc_grid_cus", "sc_conv3x3_release_tables", "sc_linear_bn_supported", "sc_linear_bn_forward", "sc_linear_bn_backward", "sc_linear_backward_data", "sc_bn_splits", "sc_isosurface_blocks_per_image", "sc_bn_act_forward", "sc_bn_act_backward", "sc_bn_relu_pool_forward", "sc_bn_relu_pool_backward",
+TIMING_SKIP = ("sc_sdf_stream_pack", "sc_sdf_stream_pack_bytes", "sc_rgb_composite_backward_fused_parts", "sc_rgb_composite_backward_fused_partial_floats", "sc_latent_bias_forward", "sc_latent_bias_backward", "sc_set_reserved_cus", "sc_grid_cus", "sc_conv3x3_release_tables", "sc_linear_bn_supported", "sc_linear_bn_forward", "sc_linear_bn_backward", "sc_linear_backward_data", "sc_bn_splits", "sc_isosurface_blocks_per_image", "sc_bn_act_forward", "sc_bn_act_backward", "sc_bn_relu_pool_forward", "sc_bn_relu_pool_backward",
                # the trunks' convolutions: ~250 calls per step -- two events each cost the step ~1 ms (rocprofv3 covers them: profiles/)
                "sc_conv3x3_forward", "sc_conv3x3_forward_split", "sc_conv3x3_forward_add", "sc_conv3x3_wgrad", "sc_conv3x3_wgrad_split", "sc_conv3x3_pack", "sc_conv3x3_pack_multi", "sc_conv3x3_pack_multi_units",
                "sc_conv_stem_forward", "sc_conv_stem_wgrad", "sc_conv1x1s2_forward", "sc_conv1x1s2_backward_data", "sc_conv1x1s2_wgrad",

@@ -88,35 +88,49 @@ __device__ __forceinline__ void mfma_settle() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// acc[u][mt] += W_e e for TPW tiles (fragments [mt] at `base`): all K = 32 products, then all K = 16 products (see the hazard above)
+// acc[u][mt] += W_e e for TPW tiles (fragments [mt] at `base`): all K = 32 products, then all K = 16 products (see the hazard above).
+// The fragment reads are software-pipelined ONE fragment ahead and pinned there (scheduling barriers): left alone, hipcc hoists the reads
+// of all the fragments of a part in front of its first MFMA -- 96 live registers in the streamed forward kernel, 91 of them spilled.
 template <int TPW>
 __device__ __forceinline__ void pe_part(const char* base, int lane, const MlpPieces<8> (&e32)[TPW], const MlpPieces<4> (&e16)[TPW], f32x4 (&acc)[TPW][NT]) {
+    MlpPieces<8> w32 = frag32(base, lane);
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
-        const MlpPieces<8> w32 = frag32(base + mt * PE_FRAG, lane);
+        MlpPieces<8> n32 = w32;
+        if (mt + 1 < NT) n32 = frag32(base + (mt + 1) * PE_FRAG, lane);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < TPW; ++u) acc[u][mt] = mlp_six<8>(w32, e32[u], acc[u][mt]);
+        __builtin_amdgcn_sched_barrier(0);
+        w32 = n32;
     }
-    __builtin_amdgcn_sched_barrier(0);
+    MlpPieces<4> w16 = frag16(base + F32B, lane);
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) {
-        const MlpPieces<4> w16 = frag16(base + mt * PE_FRAG + F32B, lane);
+        MlpPieces<4> n16 = w16;
+        if (mt + 1 < NT) n16 = frag16(base + (mt + 1) * PE_FRAG + F32B, lane);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < TPW; ++u) acc[u][mt] = mlp_six<4>(w16, e16[u], acc[u][mt]);
+        __builtin_amdgcn_sched_barrier(0);
+        w16 = n16;
     }
     mfma_settle();
 }
 // acc[u][mt] += W_h h (fragments [ks][mt] at `base`; hp[u][ks] = the split activations)
 template <int TPW>
 __device__ __forceinline__ void hidden_part(const char* base, int lane, const MlpPieces<8> (&hp)[TPW][2], f32x4 (&acc)[TPW][NT]) {
+    MlpPieces<8> w = frag32(base, lane);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int f = 0; f < 8; ++f) {
+        MlpPieces<8> wn = w;
+        if (f + 1 < 8) wn = frag32(base + (f + 1) * F32B, lane);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int mt = 0; mt < NT; ++mt) {
-            const MlpPieces<8> w = frag32(base + (ks * 4 + mt) * F32B, lane);
-#pragma unroll
-            for (int u = 0; u < TPW; ++u) acc[u][mt] = mlp_six<8>(w, hp[u][ks], acc[u][mt]);
-        }
+        for (int u = 0; u < TPW; ++u) acc[u][f & 3] = mlp_six<8>(w, hp[u][f >> 2], acc[u][f & 3]);
+        __builtin_amdgcn_sched_barrier(0);
+        w = wn;
+    }
     mfma_settle();
 }
 // the 16 activations of a lane -> its two B fragments

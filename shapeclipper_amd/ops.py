@@ -24,6 +24,7 @@ def _sdf_scratch(dev):
 
 
 RGB_FWD_SPLIT = True      # RGB network of the forward pass from pre-split bf16x3 fragments (csrc/rgb_fwd.hip, mlp_presplit.hpp); False: fp32 MFMA
+SDF_FWD_STREAM = True     # sdf_forward with d sdf/dx from streamed pre-split fragments (csrc/sdf_fwd_stream.hip); False: sdf_fwd.hip (fp32 MFMA)
 SDF_VALUE_SPLIT = True    # value-only SDF calls (no gradient, no feature, no stash) take csrc/sdf_value_split.hip; False: sdf_fwd.hip (fp32 MFMA)
 
 
@@ -49,10 +50,20 @@ def sdf_forward(points: torch.Tensor, w_pack: torch.Tensor, cbias: torch.Tensor,
     sp = torch.empty(4 * nt * 1024, device=dev, dtype=torch.float32) if (stash and want_grad) else None
     # gradient kernel without a training stash: per-wave scratch for the parked pre-activations (L2-resident)
     scratch = _sdf_scratch(dev) if (want_grad and not stash) else None
-    code = lib.sc_sdf_forward(_lib.ptr(points), _lib.ptr(w_pack), _lib.ptr(cbias), c_int(n), c_int(n_per_image),
-                              c_int(cbias.shape[0]), c_int(1 if symmetric else 0), _lib.ptr(sdf), _lib.ptr(grad),
-                              _lib.ptr(feat), _lib.ptr(sa), _lib.ptr(sp), _lib.ptr(scratch), _lib.stream())
-    _lib.check(code, "sc_sdf_forward")
+    if SDF_FWD_STREAM and want_grad and (not stash or (want_feat and sp is not None)):
+        # value + feature + d sdf/dx from pre-split bf16x3 fragments streamed through LDS (csrc/sdf_fwd_stream.hip)
+        lib.sc_sdf_stream_pack_bytes.restype = ctypes.c_longlong
+        img = torch.empty(int(lib.sc_sdf_stream_pack_bytes()), device=dev, dtype=torch.uint8)
+        _lib.check(lib.sc_sdf_stream_pack(_lib.ptr(w_pack), _lib.ptr(img), _lib.stream()), "sc_sdf_stream_pack")
+        code = lib.sc_sdf_forward_stream(_lib.ptr(points), _lib.ptr(img), _lib.ptr(w_pack), _lib.ptr(cbias), c_int(n), c_int(n_per_image),
+                                         c_int(cbias.shape[0]), c_int(1 if symmetric else 0), _lib.ptr(sdf), _lib.ptr(grad),
+                                         _lib.ptr(feat), _lib.ptr(sa), _lib.ptr(sp), _lib.ptr(scratch), _lib.stream())
+        _lib.check(code, "sc_sdf_forward_stream")
+    else:
+        code = lib.sc_sdf_forward(_lib.ptr(points), _lib.ptr(w_pack), _lib.ptr(cbias), c_int(n), c_int(n_per_image),
+                                  c_int(cbias.shape[0]), c_int(1 if symmetric else 0), _lib.ptr(sdf), _lib.ptr(grad),
+                                  _lib.ptr(feat), _lib.ptr(sa), _lib.ptr(sp), _lib.ptr(scratch), _lib.stream())
+        _lib.check(code, "sc_sdf_forward")
     if stash:
         return sdf, grad, feat, sa, sp
     return sdf, grad, feat

@@ -18,8 +18,12 @@ def _close(a, b, tol=1e-5, what=""):
 
 
 @pytest.mark.parametrize("B,R,with_gz", [(2, 32, False), (3, 64, True)])
-def test_render_backward_single_call_equals_autograd_path(golden, B, R, with_gz):
-    from shapeclipper_amd import _lib, packing
+def test_render_backward_single_call_equals_autograd_path(golden, B, R, with_gz, monkeypatch):
+    from shapeclipper_amd import _lib, ops, packing
+    # sc_render_forward / sc_render_backward chain the fp32-MFMA kernels (sdf_fwd.hip, rgb_composite_fwd_kernel): the Python path is
+    # compared in the same arithmetic (round 6: its default forward kernels are the split forms, `--hip.sdf_stream!` / `--hip.rgb_split!`)
+    monkeypatch.setattr(ops, "SDF_FWD_STREAM", False)
+    monkeypatch.setattr(ops, "RGB_FWD_SPLIT", False)
     from shapeclipper_amd.functional import RaySampleFunction, RgbCompositeFunction, SdfFunction
     from shapeclipper_amd.packing import n_tiles
     lib = _lib.load()

@@ -61,9 +61,17 @@ def test_value_only_kernel_matches_grad_kernel():
     W = R.init_sdf_weights(cfg)
     z = torch.randn(2, 64)
     pts = torch.rand(2 * 333, 3) * 2 - 1
-    s1, _, f1 = hip_sdf(W, z, pts, 333, want_grad=True)
-    s2, g2, f2 = hip_sdf(W, z, pts, 333, want_grad=False)
+    from shapeclipper_amd import ops
+    s2, g2, f2 = hip_sdf(W, z, pts, 333, want_grad=False)            # value + feature: sdf_fwd.hip (fp32 MFMA)
+    try:                                                              # the same kernel file with the gradient sweep: same bits
+        ops.SDF_FWD_STREAM = False
+        s1, _, f1 = hip_sdf(W, z, pts, 333, want_grad=True)
+    finally:
+        ops.SDF_FWD_STREAM = True
     assert g2 is None and torch.equal(s1, s2) and torch.equal(f1, f2)
+    # round 6 default for calls with a gradient: streamed pre-split fragments (sdf_fwd_stream.hip) -- another arithmetic, fp32-accurate
+    s3, _, f3 = hip_sdf(W, z, pts, 333, want_grad=True)
+    assert (s3 - s2).abs().max() < 2e-6 * max(1.0, float(s2.abs().max())) and (f3 - f2).abs().max() < 2e-6 * max(1.0, float(f2.abs().max()))
 
 
 def test_mirror_symmetry_known_answer():
@@ -145,3 +153,47 @@ def test_value_split_chain_float64_error_is_the_fp32_chains():
     e_fp32 = float((fp32.double().cpu() - want).abs().max())
     print("value chain vs float64 on 100,000 points: split %.3e, fp32 MFMA %.3e" % (e_split, e_fp32))
     assert e_split < 2e-6 and e_split < 1.5 * e_fp32 + 1e-7
+
+
+# ---- round 6: value + feature + d sdf/dx from STREAMED pre-split fragments (csrc/sdf_fwd_stream.hip), the default of calls with a gradient ----
+@pytest.mark.parametrize("B,N,symmetric,stash", [(1, 1, True, False), (1, 15, True, False), (2, 17, False, False), (3, 100, True, False),
+                                                 (2, 1000, True, False), (2, 1000, False, True), (3, 1371, True, True), (1, 40000, True, True)])
+def test_streamed_forward_vs_oracle_and_fp32_kernel(B, N, symmetric, stash):
+    """Against the oracle at the bars of the fp32 kernel (2e-5 on sdf / feature, 2e-4 relative on the gradient) and against sdf_fwd.hip at a
+    few ulps of each tensor's range (4e-6; 2e-5 for the adjoint quantities) -- sdf, d sdf/dx, feature and, in the training form, the parked activations and adjoints.  Sizes: fewer
+    tiles than waves (most waves idle through every phase barrier), a ragged last tile, more rounds than one (40,000 points = 2,500 tiles
+    on 2,048 waves: the last round is mostly idle waves), several images, symmetry on and off.  Twice: same bits."""
+    from oracle import reference_ops as R
+    from shapeclipper_amd import ops, packing
+    cfg = R.Cfg()
+    cfg.force_symmetry = symmetric
+    torch.manual_seed(B * 1000 + N)
+    W = R.init_sdf_weights(cfg)
+    W = {k: v + 0.05 * torch.randn_like(v) for k, v in W.items()}
+    z = torch.randn(B, 64)
+    pts = torch.rand(B * N, 3) * 2 - 1
+    pts[0, 0] = 0.0
+    dev = torch.device("cuda:0")
+    pack, cb = packing.pack_sdf({k: v.to(dev) for k, v in W.items()}, z.to(dev))
+    p = pts.to(dev).contiguous()
+    assert ops.SDF_FWD_STREAM
+    a = ops.sdf_forward(p, pack, cb, N, symmetric=symmetric, want_grad=True, want_feat=True, stash=stash)
+    a2 = ops.sdf_forward(p, pack, cb, N, symmetric=symmetric, want_grad=True, want_feat=True, stash=stash)
+    try:
+        ops.SDF_FWD_STREAM = False
+        b = ops.sdf_forward(p, pack, cb, N, symmetric=symmetric, want_grad=True, want_feat=True, stash=stash)
+    finally:
+        ops.SDF_FWD_STREAM = True
+    torch.cuda.synchronize()
+    names = ["sdf", "grad", "feat", "stash_a", "stash_p"][:len(a)]
+    for n, x, x2, y in zip(names, a, a2, b):
+        assert torch.equal(x, x2), n
+        scale = max(1.0, float(y.abs().max()))
+        bar = 2e-5 if n in ("grad", "stash_p") else 4e-6          # the adjoint sweep chains five layers of rounding differences
+        assert float((x - y).abs().max()) < bar * scale, (n, float((x - y).abs().max()), scale)
+    if B * N <= 4000:
+        o_sdf, o_feat, o_grad = R.sdf_conditional(cfg, W, B, pts.clone(), z, compute_grad=True)
+        assert (a[0].cpu() - o_sdf[:, 0].detach()).abs().max() < TOL
+        assert (packing.tbl_to_rows(a[2], B * N).cpu() - o_feat.detach()).abs().max() < TOL
+        assert (a[1].cpu() - o_grad.detach()).abs().max() < 2e-4 * max(1.0, o_grad.abs().max().item())
+    assert a[1][0, 0].item() == 0.0 or not symmetric      # x0 == 0: sign(0) = 0 (implicit.py:142-143)
