@@ -93,15 +93,17 @@ STABLE_NAME = {
     "sc_sdf_forward_stream": "sc_sdf_forward",                                # value + feature + d sdf/dx from streamed pre-split fragments (round 6)
     "sc_rgb_composite_forward_split": "sc_rgb_composite_forward",             # ... with the RGB network from pre-split bf16x3 fragments (round 6)
 }
-# what holds each kernel below its roof (phase profiles under profiles/; DESIGN.md section 4.1): a statement about THAT kernel only
+# what holds each kernel below its roof (phase profiles under profiles/; DESIGN.md section 4.1, 4.1.2): a statement about THAT kernel only
 LIMITER = {
     "sc_sdf_backward_fused": "issue: 87 k cycles per 4 tiles against 60 k of MFMAs; both roles of the workgroup are busy (chain waves wait 11 k, "
                              "weight-gradient waves 23 k: profiles/r05_bwdw_phase_profile_final.txt); restructurings that shift work between the "
                              "roles were built and are slower (DESIGN.md 4.1)",
-    "sc_sdf_forward": "issue: the latent columns are folded into per-image biases, so 67 % of the reference-dense MFMAs are executed; softplus / "
-                      "sigmoid VALU work shares the issue slots with the MFMAs (DESIGN.md 4.1)",
+    "sc_sdf_forward": "round 6: exact bf16x3 split arithmetic from pre-split weight fragments streamed through LDS (csrc/sdf_fwd_stream.hip), 1.2x the "
+                      "fp32-MFMA kernel; what is left is vector work (softplus, the activation splits, the accurate sincosf of the value path) and "
+                      "one tile per wave at 256 registers (profiles/r06_sdf_stream_ablation.txt)",
     "sc_sdf_backward": "issue: same chain as the fused form without the weight-gradient role (DESIGN.md 4.1)",
-    "sc_rgb_composite_forward": "issue + the activation stash it writes (768 B per point, profiles/r05_traffic.json)",
+    "sc_rgb_composite_forward": "round 6: RGB network from pre-split bf16x3 fragments resident in LDS (1.3x at the training shape, 1.46x at the "
+                                "evaluation shape); vector work + the activation stash it writes (768 B per point, profiles/r06_traffic.json)",
     "sc_rgb_composite_backward": "issue: reverse sweep + weight-gradient MFMAs in one workgroup; reads the parked activations (DESIGN.md 4.1)",
 }
 

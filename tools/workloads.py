@@ -238,13 +238,26 @@ def render_eval_128(B=32, with_cpu=True):
     ms, best = _gpu_ms(run, iters=5)
     rays = B * 128 * 128
     tf = RENDER_EVAL_FLOP_PER_RAY * rays / (ms * 1e-3) / 1e12
+    from shapeclipper_amd import ops as _ops
+    split = bool(_ops.SDF_FWD_STREAM and _ops.RGB_FWD_SPLIT)
+    # round 6: both networks run in the exact three-piece bf16 split arithmetic (csrc/sdf_fwd_stream.hip, rgb_fwd.hip): the roof is the bf16
+    # matrix pipe / 6 piece products per fp32 product (the trunk convolutions' roof); `frac_of_fp32_mfma_peak` keeps the old yardstick
+    peak = PEAK_SPLIT if split else PEAK_FP32
+    ms32 = None
+    if split:       # the fp32-MFMA kernels on the same inputs, same box (`--hip.sdf_stream! --hip.rgb_split!`)
+        try:
+            _ops.SDF_FWD_STREAM = _ops.RGB_FWD_SPLIT = False
+            ms32, _ = _gpu_ms(run, iters=3)
+        finally:
+            _ops.SDF_FWD_STREAM = _ops.RGB_FWD_SPLIT = True
     out = dict(workload="full-frame evaluation render 128x128, B=%d (%d rays x 64 samples)" % (B, rays), ms=round(ms, 3),
                ms_best=round(best, 3), algorithmic_flop=RENDER_EVAL_FLOP_PER_RAY * rays, algorithmic_bytes=rays * 44,
-               achieved=round(tf, 2), peak=PEAK_FP32, unit="TFLOP/s", bound="fp32 MFMA", frac=round(tf / PEAK_FP32, 4),
+               achieved=round(tf, 2), peak=peak, unit="TFLOP/s", bound="bf16 MFMA / 6 (exact 3-piece split, fp32 accumulate)" if split else "fp32 MFMA",
+               frac=round(tf / peak, 4), frac_of_fp32_mfma_peak=round(tf / PEAK_FP32, 4), fp32_mfma_kernels_ms=round(ms32, 3) if ms32 else None,
                # `frac` counts the reference-dense FLOPs of SURVEY 8(d); the kernels fold the 64 latent columns of the
                # conditioned layers into per-image biases (28,032 of 40,320 SDF MACs -- value and d/dx sweep alike -- and 14,976 of 19,072 RGB
                # MACs per point are executed), so the matrix pipe does EXECUTED_SHARE of the counted work: the real utilisation is the second figure
-               executed_flop=int(RENDER_EVAL_FLOP_PER_RAY * rays * EXECUTED_SHARE_RENDER), frac_executed=round(tf * EXECUTED_SHARE_RENDER / PEAK_FP32, 4),
+               executed_flop=int(RENDER_EVAL_FLOP_PER_RAY * rays * EXECUTED_SHARE_RENDER), frac_executed=round(tf * EXECUTED_SHARE_RENDER / peak, 4),
                frac_note="frac = reference-dense FLOPs (SURVEY 8d) / time / peak; frac_executed = the MACs the kernels execute after folding the "
                          "latent columns into per-image biases (%.3f of the dense count) / time / peak = the matrix pipe's real utilisation" % EXECUTED_SHARE_RENDER,
                mrays_per_s=round(rays / (ms * 1e-3) / 1e6, 2))
