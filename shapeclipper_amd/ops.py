@@ -23,6 +23,26 @@ def _sdf_scratch(dev):
     return _SCRATCH[key]
 
 
+_STREAM_IMG = {}
+
+
+def _sdf_stream_image(w_pack):
+    """The pre-split fragment image of sc_sdf_forward_stream for this packed weight tensor.  The four SDF calls of a training step (two renders,
+    two eikonal batches) share ONE w_pack tensor (SDFNetwork.packed): the image is built once for it.  A hit needs the SAME tensor object at
+    the same version on the same stream -- the entry keeps the tensor alive, so its address cannot be handed to another tensor meanwhile."""
+    dev = w_pack.device
+    key = (dev.index, _lib.raw_stream(dev.index))
+    hit = _STREAM_IMG.get(key)
+    if hit is not None and hit[0] is w_pack and hit[1] == w_pack._version:
+        return hit[2]
+    lib = _lib.load()
+    lib.sc_sdf_stream_pack_bytes.restype = ctypes.c_longlong
+    img = torch.empty(int(lib.sc_sdf_stream_pack_bytes()), device=dev, dtype=torch.uint8)
+    _lib.check(lib.sc_sdf_stream_pack(_lib.ptr(w_pack), _lib.ptr(img), _lib.stream()), "sc_sdf_stream_pack")
+    _STREAM_IMG[key] = (w_pack, w_pack._version, img)
+    return img
+
+
 RGB_FWD_SPLIT = True      # RGB network of the forward pass from pre-split bf16x3 fragments (csrc/rgb_fwd.hip, mlp_presplit.hpp); False: fp32 MFMA
 SDF_FWD_STREAM = True     # sdf_forward with d sdf/dx from streamed pre-split fragments (csrc/sdf_fwd_stream.hip); False: sdf_fwd.hip (fp32 MFMA)
 SDF_VALUE_SPLIT = True    # value-only SDF calls (no gradient, no feature, no stash) take csrc/sdf_value_split.hip; False: sdf_fwd.hip (fp32 MFMA)
@@ -52,9 +72,7 @@ def sdf_forward(points: torch.Tensor, w_pack: torch.Tensor, cbias: torch.Tensor,
     scratch = _sdf_scratch(dev) if (want_grad and not stash) else None
     if SDF_FWD_STREAM and want_grad and (not stash or (want_feat and sp is not None)):
         # value + feature + d sdf/dx from pre-split bf16x3 fragments streamed through LDS (csrc/sdf_fwd_stream.hip)
-        lib.sc_sdf_stream_pack_bytes.restype = ctypes.c_longlong
-        img = torch.empty(int(lib.sc_sdf_stream_pack_bytes()), device=dev, dtype=torch.uint8)
-        _lib.check(lib.sc_sdf_stream_pack(_lib.ptr(w_pack), _lib.ptr(img), _lib.stream()), "sc_sdf_stream_pack")
+        img = _sdf_stream_image(w_pack)
         code = lib.sc_sdf_forward_stream(_lib.ptr(points), _lib.ptr(img), _lib.ptr(w_pack), _lib.ptr(cbias), c_int(n), c_int(n_per_image),
                                          c_int(cbias.shape[0]), c_int(1 if symmetric else 0), _lib.ptr(sdf), _lib.ptr(grad),
                                          _lib.ptr(feat), _lib.ptr(sa), _lib.ptr(sp), _lib.ptr(scratch), _lib.stream())

@@ -2,7 +2,7 @@
 export MIOPEN_LOG_LEVEL=1
 OUT=gpurun_out/${1:-r6a}
 mkdir -p $OUT
-timeout 3000 python -m pytest tests -m gpu -x -q -p no:cacheprovider --timeout 1500 2>&1 | tail -30 > $OUT/gputest.log
+timeout 3000 python -m pytest tests -m gpu -x -q -p no:cacheprovider --timeout 1500 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" | tail -30 > $OUT/gputest.log
 cat $OUT/gputest.log
 REPS=${2:-10}
 : > $OUT/eight_ranks.log
