@@ -168,16 +168,19 @@ def test_two_rank_sharded_evaluation_on_one_gpu(tmp_path):
 def _run(cmd, env, timeout=900):
     import subprocess
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    if r.returncode != 0:
+        print("---- failed command: %s\n---- stdout tail:\n%s\n---- stderr tail:\n%s" % (" ".join(cmd), r.stdout[-3000:], r.stderr[-6000:]))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     return r.stdout + r.stderr
 
 
-@pytest.mark.timeout(1200)
+@pytest.mark.timeout(2400)
 def test_train_and_evaluate_scripts_under_the_launcher(tmp_path):
     """The drop-in scripts end to end (train.py:37-41 / evaluate.py:16-18 of the reference; BASELINE config[3] and config[4] in small):
     `python -m torch.distributed.run --nproc-per-node 2 train.py ...` on the synthetic dataset -- two ranks on the box's one GPU over gloo
     (SHAPECLIPPER_DIST_BACKEND) -- trains two epochs with the sharded sampler, evaluates and checkpoints on rank 0; evaluate.py then restores
-    the best checkpoint (a) in one process and (b) sharded over two ranks: same chamfer.txt, and the CD the training run reported as best."""
+    the best checkpoint (a) in one process and (b) sharded over two ranks: same chamfer.txt, and the CD the training run reported as best; then (c) at
+    config[4]'s own resolution, `--eval.vox_res=100`, in one process and sharded over eight ranks."""
     import re
     import sys
     common = ["--yaml=%s/options/pix3d/config.yaml" % ROOT, "--name=e2e", "--output_root=%s" % tmp_path, "--data.dataset=synthetic",
@@ -201,3 +204,17 @@ def test_train_and_evaluate_scripts_under_the_launcher(tmp_path):
     assert single.shape == sharded.shape == (8, 3) and torch.allclose(single, sharded, atol=1e-6), (single, sharded)
     cd = float((single[:, 1].mean() + single[:, 2].mean()) / 2)
     assert abs(cd - best) < 2e-4, (cd, best)                             # the checkpoint evaluate.py restores is the one training called best
+    # BASELINE config[4] at its own sizes: `evaluate.py --eval.vox_res=100` (1,030,301 grid points per sample through the pre-split value
+    # chain, marching cubes, 100k x 100k Chamfer) in one process and sharded over EIGHT ranks (one sample each; the ranks share the box's
+    # one GPU over gloo) -- same records
+    big = [a for a in common if not a.startswith(("--eval.vox_res", "--batch_size"))] + ["--eval.vox_res=100", "--batch_size=8", "--resume"]   # (the training batch is divided by the ranks)
+    launch8 = lambda: [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                       "--master-port", str(_free_port())]
+    os.remove(os.path.join(out, "chamfer.txt"))
+    _run([sys.executable, os.path.join(ROOT, "evaluate.py")] + big, dict(env, SHAPECLIPPER_DIST_BACKEND="nccl"))
+    single100 = read()
+    os.remove(os.path.join(out, "chamfer.txt"))
+    _run(launch8() + [os.path.join(ROOT, "evaluate.py")] + big, dict(env, OMP_NUM_THREADS="4"), timeout=1200)
+    sharded100 = read()
+    assert single100.shape == sharded100.shape == (8, 3) and torch.allclose(single100, sharded100, atol=1e-6), (single100, sharded100)
+    assert not torch.allclose(single100[:, 1:], single[:, 1:], atol=1e-6)        # the finer grid really was evaluated
