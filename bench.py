@@ -89,6 +89,7 @@ STABLE_NAME = {
     "sc_rgb_composite_backward_v3": "sc_rgb_composite_backward",              # output layer's gradient folded in
     "sc_rgb_composite_backward_fused": "sc_rgb_composite_backward",           # RGB weight gradients formed in the kernel (round 5)
     "sc_rgb_composite_backward_fused_stash": "sc_rgb_composite_backward",     # ... reading the activations the forward parked (round 5)
+    "sc_rgb_composite_backward_fused_split": "sc_rgb_composite_backward",     # ... with the reverse chain from pre-split bf16x3 fragments (round 6)
     "sc_rgb_composite_forward_stash": "sc_rgb_composite_forward",             # the forward that parks them
     "sc_sdf_forward_stream": "sc_sdf_forward",                                # value + feature + d sdf/dx from streamed pre-split fragments (round 6)
     "sc_rgb_composite_forward_split": "sc_rgb_composite_forward",             # ... with the RGB network from pre-split bf16x3 fragments (round 6)

@@ -173,6 +173,15 @@ int sc_rgb_composite_backward_fused_stash(
     const float* G_rgb, const float* G_mask, const float* G_depth, const float* G_normal,
     float* g_sdf, float* g_grad, float* g_feat, float* g_points, float* g_z, float* g_depth_fac, float* g_beta,
     float* partial, float* v3_part, const float* rr, void* stream);
+/* round 6: the same reverse pass with its three transposed products (V2^T, V1^T, V0f^T) and the encoding's Jacobian in the exact bf16x3
+ * split arithmetic from pre-split fragments (csrc/mlp_presplit.hpp); same operands and outputs, gradients equal up to fp32 rounding.     */
+int sc_rgb_composite_backward_fused_split(
+    const float* points, const float* z_vals, const float* depth_fac, const float* sdf, const float* grad,
+    const float* feat, const float* v_pack, const float* dbias, const float* beta_param, const float* rgb_flat,
+    int n_rays, int rays_per_image, int n_images, int symmetric, float beta_min, float bgcolor, float normal_pow,
+    const float* G_rgb, const float* G_mask, const float* G_depth, const float* G_normal,
+    float* g_sdf, float* g_grad, float* g_feat, float* g_points, float* g_z, float* g_depth_fac, float* g_beta,
+    float* partial, float* v3_part, const float* rr, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Weight-gradient GEMM  dW[64][nb0+nb1] = sum_points A(p) (x) [B0(p) | B1(p)]  over one or two terms.

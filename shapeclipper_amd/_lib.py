@@ -34,7 +34,7 @@ SYMBOLS = (
     "sc_render_backward", "sc_sdf_backward_fused", "sc_sdf_backward_fused_parts", "sc_sdf_backward_fused_partial_floats", "sc_tbl_sum_blocks", "sc_conv3x3_pack", "sc_conv3x3_forward", "sc_conv3x3_pack_multi", "sc_conv3x3_pack_multi_units", "sc_conv3x3_tile_channels", "sc_conv3x3_wgrad", "sc_conv3x3_wgrad_split", "sc_conv3x3_forward_split", "sc_conv3x3_forward_add", "sc_conv3x3_tile_channels_split", "sc_conv_stem_forward", "sc_conv_stem_wgrad", "sc_conv1x1s2_forward", "sc_conv1x1s2_backward_data", "sc_conv1x1s2_wgrad", "sc_conv3x3s2_forward", "sc_conv3x3s2_bd_pack", "sc_conv3x3s2_backward_data", "sc_conv3x3s2_wgrad",
     "sc_basic_block_forward", "sc_basic_block_backward", "sc_rgb_composite_backward_v3", "sc_set_reserved_cus", "sc_grid_cus", "sc_conv3x3_release_tables",
     "sc_linear_bn_supported", "sc_linear_bn_forward", "sc_linear_bn_backward", "sc_linear_backward_data",
-    "sc_latent_bias_forward", "sc_latent_bias_backward", "sc_rgb_composite_backward_fused", "sc_rgb_composite_backward_fused_stash", "sc_rgb_composite_forward_stash", "sc_rgb_composite_forward_split", "sc_rgb_composite_backward_fused_parts",
+    "sc_latent_bias_forward", "sc_latent_bias_backward", "sc_rgb_composite_backward_fused", "sc_rgb_composite_backward_fused_stash", "sc_rgb_composite_backward_fused_split", "sc_rgb_composite_forward_stash", "sc_rgb_composite_forward_split", "sc_rgb_composite_backward_fused_parts",
     "sc_rgb_composite_backward_fused_partial_floats",
 )
 # entry points that do not return an int status

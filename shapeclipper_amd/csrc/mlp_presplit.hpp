@@ -146,5 +146,39 @@ __device__ __forceinline__ void split_pe(const float (&e)[PE_STEPS], MlpPieces<8
     mlp_split<4>(eb, e16);
 }
 
+// acc[mt] += W_e[:, slots of coordinate c] dE_c with the forward encoding fragments: c = 0 / 1 the low / high half of the K = 32 step
+// (dj = the 4 Jacobian slots of the coordinate in that half, zeros in the other), c = 2 the K = 16 step
+__device__ __forceinline__ void jac_part(const char* base, int lane, int c, const float* dj, f32x4 (&t)[NT]) {
+    if (c < 2) {
+        const float bv[8] = {c == 0 ? dj[0] : 0.f, c == 0 ? dj[1] : 0.f, c == 0 ? dj[2] : 0.f, c == 0 ? dj[3] : 0.f,
+                             c == 1 ? dj[0] : 0.f, c == 1 ? dj[1] : 0.f, c == 1 ? dj[2] : 0.f, c == 1 ? dj[3] : 0.f};
+        MlpPieces<8> b;
+        mlp_split<8>(bv, b);
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) t[mt] = mlp_six<8>(frag32(base + mt * PE_FRAG, lane), b, t[mt]);
+    } else {
+        const float bv[4] = {dj[0], dj[1], dj[2], dj[3]};
+        MlpPieces<4> b;
+        mlp_split<4>(bv, b);
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) t[mt] = mlp_six<4>(frag16(base + mt * PE_FRAG + F32B, lane), b, t[mt]);
+    }
+    mfma_settle();
+}
+
+// TRANSPOSED hidden block (a reverse sweep's W^T g: contraction over the layer's OUTPUT channels): fragment rows are the layer's INPUT
+// channels c0 + a, K index k runs over the rows of W
+__device__ __forceinline__ void stage_hidden_t(char* dst, const float* __restrict__ W, int ld, int c0, int tid, int nthreads) {
+    for (int idx = tid; idx < 2 * 4 * 64 * 8; idx += nthreads) {
+        const int j = idx & 7, lane = (idx >> 3) & 63, mt = (idx >> 9) & 3, ks = idx >> 11;
+        const int a = 16 * mt + (lane & 15), k = 16 * (2 * ks + (j >> 2)) + 4 * (lane >> 4) + (j & 3);
+        __bf16 h[3];
+        split3(W[k * ld + c0 + a], h[0], h[1], h[2]);
+        char* f = dst + (ks * 4 + mt) * F32B + lane * 16 + j * 2;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<__bf16*>(f + p * 1024) = h[p];
+    }
+}
+
 }  // namespace ps
 }  // namespace sc

@@ -13,6 +13,7 @@
 //   Gy_l / r_l in HBM (TBL64) for the weight-gradient GEMMs (wgrad.hip).
 #include "rgb_common.hpp"
 #include "mlp_xch.hpp"
+#include "mlp_presplit.hpp"
 
 namespace sc {
 
@@ -63,6 +64,16 @@ constexpr int RB_XSET = 4 * 2 * 1024;
 constexpr int RB_PTS = RB_XCH + RB_NBUF * RB_XSET;        // point stash [set][chain wave][16 points][8]: x0 x1 x2 - | - - valid -
 constexpr int RB_PSET = 4 * 16 * 8;
 constexpr int RB_LDS_FLOATS = RB_PTS + RB_NBUF * RB_PSET;
+// SPLIT (round 6; FUSED + STASH only): the three transposed products of the reverse chain (V2^T, V1^T, V0f^T) and the encoding's Jacobian
+// (V0e) in the exact bf16x3 split arithmetic from PRE-SPLIT fragments (mlp_presplit.hpp) -- the parked activations make the forward
+// matrices unnecessary here, so the fp32 weight image (63 KiB) gives way to [V2^T | V1^T | V0f^T | V0e] = 90 KiB of fragments + V3 / b3 in
+// fp32; the exchange slots and the point stash follow.  144 K = 32 MFMAs (2.3 k matrix cycles) instead of 192 fp32 ones (6.1 k) per tile
+// on the chain waves, whose SIMD's matrix pipe is shared with a weight-gradient wave.
+constexpr int RBS_V2T = 0, RBS_V1T = ps::HID_BYTES, RBS_V0FT = 2 * ps::HID_BYTES, RBS_V0E = 3 * ps::HID_BYTES;       // bytes
+constexpr int RBS_V3 = (3 * ps::HID_BYTES + ps::PE_BYTES) / 4;                                                       // floats: V3 [3][64], b3 [3]
+constexpr int RBS_XCH = (RBS_V3 + 196 + 3) & ~3;
+constexpr int RBS_LDS_FLOATS = RBS_XCH + RB_NBUF * RB_XSET + RB_NBUF * RB_PSET;
+static_assert(RBS_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget of the split reverse kernel");
 
 // Phase profile (tuning tool, tools/prof_rgb_bwd.py; compiled only with -DSC_RGBB_PROFILE): s_memtime stamps of ONE iteration of one
 // workgroup, chain wave 0 and weight-gradient wave 4, into rgbb_prof_buf [8 waves][64].
@@ -77,12 +88,23 @@ __device__ int rgbb_prof_block = -1, rgbb_prof_iter = -1;
 // STASH (round 5, second half; FUSED only): the forward pass parked r0, r1, r2 (sc_rgb_composite_forward_stash) and they are LOADED here
 // instead of recomputed -- the phase profile (tools/prof_rgb_bwd.py) charges the recomputed forward chain 48 k of the chain wave's 155 k
 // cycles per ray; the colours come from rgb_flat, which phase 1 loads anyway.
-template <bool FUSED, bool STASH = false>
+template <bool FUSED, bool STASH = false, bool SPLIT = false>
 __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? 1 : 2) void rgb_composite_bwd_kernel(RgbBwdArgs a) {
+    static_assert(!SPLIT || (FUSED && STASH), "the split reverse chain exists for the fused form that reads the parked activations");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    stage_rgb_weights(lds, a.v, threadIdx.x, FUSED ? 512 : 256);
+    constexpr int XCH = SPLIT ? RBS_XCH : RB_XCH, PTS = XCH + RB_NBUF * RB_XSET, LDS_FLOATS = PTS + RB_NBUF * RB_PSET;
+    [[maybe_unused]] char* const ldsc = reinterpret_cast<char*>(lds);
+    if (SPLIT) {
+        ps::stage_hidden_t(ldsc + RBS_V2T, a.v + RgbPack::V2, 64, 0, threadIdx.x, 512);
+        ps::stage_hidden_t(ldsc + RBS_V1T, a.v + RgbPack::V1, 64, 0, threadIdx.x, 512);
+        ps::stage_hidden_t(ldsc + RBS_V0FT, a.v + RgbPack::V0, 112, 48, threadIdx.x, 512);
+        ps::stage_pe(ldsc + RBS_V0E, a.v + RgbPack::V0, 112, 0, threadIdx.x, 512);
+        if (threadIdx.x < 196) lds[RBS_V3 + threadIdx.x] = threadIdx.x < 195 ? a.v[RgbPack::V3 + threadIdx.x] : 0.f;
+    } else {
+        stage_rgb_weights(lds, a.v, threadIdx.x, FUSED ? 512 : 256);
+    }
     if (FUSED) {
-        for (int e = threadIdx.x; e < RB_LDS_FLOATS - RB_XCH; e += 512) lds[RB_XCH + e] = 0.f;
+        for (int e = threadIdx.x; e < LDS_FLOATS - XCH; e += 512) lds[XCH + e] = 0.f;
         float* cbz = a.partial + (size_t)blockIdx.x * a.partial_stride + RgbPack::V3;
         for (int e = threadIdx.x; e < a.n_images * 192; e += 512) cbz[e] = 0.f;
     }
@@ -117,15 +139,15 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? 1 : 2) void rgb_composit
         RB_STAMP(1 + 2 * (k * 3 + (2 - RS)))                                                 \
         _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                      \
             const int set_ = SC_RGBB_DB ? ((k + (2 - RS)) & 1) : 0;                          \
-            const float* sA = lds + RB_XCH + set_ * RB_XSET + (c * 2 + 0) * 1024;            \
-            const float* sB = lds + RB_XCH + set_ * RB_XSET + (c * 2 + 1) * 1024;            \
+            const float* sA = lds + XCH + set_ * RB_XSET + (c * 2 + 0) * 1024;            \
+            const float* sB = lds + XCH + set_ * RB_XSET + (c * 2 + 1) * 1024;            \
             const float4 af = xch_frag(sA, rd, w);                                           \
             float4 bf[4];                                                                    \
             _Pragma("unroll") for (int n = 0; n < 4; ++n) bf[n] = xch_frag(sB, rd, n);       \
             outer16<4>(af, bf, ACC);                                                         \
             if (WITH_PE) {                                                                   \
                 float4 pf[3];                                                                \
-                pe_frags<1>(lds + RB_PTS + (SC_RGBB_DB ? (k & 1) : 0) * RB_PSET + c * 16 * 8, i, kg, symmetric, pf); \
+                pe_frags<1>(lds + PTS + (SC_RGBB_DB ? (k & 1) : 0) * RB_PSET + c * 16 * 8, i, kg, symmetric, pf); \
                 outer16<3>(af, pf, PEACC);                                                   \
             }                                                                                \
             const float v = (af.x + af.y) + (af.z + af.w);                                   \
@@ -175,8 +197,9 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? 1 : 2) void rgb_composit
     }
     const int p = lane & 15, g = lane >> 4;
     RgbLanePtrs L(lds, p, g);
-    [[maybe_unused]] float* const slot0 = lds + RB_XCH + (wave * 2 + 0) * 1024;       // set 0; set 1 is RB_XSET floats further
-    [[maybe_unused]] float* const pts0 = lds + RB_PTS + wave * 16 * 8;
+    const float* const v3p = SPLIT ? lds + RBS_V3 + 4 * g : L.v3;            // V3 [3][64] (+ 4 g), fp32 in both layouts
+    [[maybe_unused]] float* const slot0 = lds + XCH + (wave * 2 + 0) * 1024;       // set 0; set 1 is RB_XSET floats further
+    [[maybe_unused]] float* const pts0 = lds + PTS + wave * 16 * 8;
     [[maybe_unused]] int wr[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) wr[r] = (((p >> 2) * 64 + 4 * g + (r ^ (p >> 2))) << 2) + (p & 3);
@@ -356,7 +379,7 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? 1 : 2) void rgb_composit
             float gyv[ACT_STEPS];
 #pragma unroll
             for (int s2 = 0; s2 < ACT_STEPS; ++s2) {
-                const float gr = L.v3[kp(s2)] * y0 + L.v3[64 + kp(s2)] * y1 + L.v3[128 + kp(s2)] * y2;
+                const float gr = v3p[kp(s2)] * y0 + v3p[64 + kp(s2)] * y1 + v3p[128 + kp(s2)] * y2;
                 gyv[s2] = r[2][s2] > 0.f ? gr : 0.f;
             }
             if (!FUSED) tbl_store(a.gy + 2 * tbl, tile, p, g, gyv);
@@ -366,23 +389,28 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? 1 : 2) void rgb_composit
                             *reinterpret_cast<float4*>(ptsw + p * 8) = make_float4(x0, x1, x2, 0.f);
                             *reinterpret_cast<float4*>(ptsw + p * 8 + 4) = make_float4(0.f, 0.f, 1.f, 0.f);
                         })
-            f32x4 acc[NT];
+            f32x4 acc1[1][NT];
+            f32x4 (&acc)[NT] = acc1[0];
+            [[maybe_unused]] MlpPieces<8> gp[1][2];
             acc_zero(acc);
-            mm_act_t<RgbLds::LD1, NT>(L.v2t, gyv, acc);
+            if constexpr (SPLIT) { ps::split_act(gyv, gp[0]); ps::hidden_part<1>(ldsc + RBS_V2T, lane, gp, acc1); }
+            else mm_act_t<RgbLds::LD1, NT>(L.v2t, gyv, acc);
 #pragma unroll
             for (int s2 = 0; s2 < ACT_STEPS; ++s2) gyv[s2] = r[1][s2] > 0.f ? acc[s2 >> 2][s2 & 3] : 0.f;
             if (!FUSED) tbl_store(a.gy + 1 * tbl, tile, p, g, gyv);
             RB_STAMP(sid++)                                  /* +6: V2^T product + mask; exchange 2: +7, +8, +9 */
             RB_EXCHANGE(1, xch_write(slotA, wr, gyv, 1.f); xch_write(slotB, wr, r[0], 1.f);)
             acc_zero(acc);
-            mm_act_t<RgbLds::LD1, NT>(L.v1t, gyv, acc);
+            if constexpr (SPLIT) { ps::split_act(gyv, gp[0]); ps::hidden_part<1>(ldsc + RBS_V1T, lane, gp, acc1); }
+            else mm_act_t<RgbLds::LD1, NT>(L.v1t, gyv, acc);
 #pragma unroll
             for (int s2 = 0; s2 < ACT_STEPS; ++s2) gyv[s2] = r[0][s2] > 0.f ? acc[s2 >> 2][s2 & 3] : 0.f;
             if (!FUSED) tbl_store(a.gy + 0 * tbl, tile, p, g, gyv);
             RB_STAMP(sid++)                                  /* +10: V1^T product + mask; exchange 3: +11, +12, +13 */
             RB_EXCHANGE(2, xch_write(slotA, wr, gyv, 1.f); xch_write(slotB, wr, f, 1.f);)
             acc_zero(acc);
-            mm_act_t<RgbLds::LD0, NT>(L.v0ft, gyv, acc);
+            if constexpr (SPLIT) { ps::split_act(gyv, gp[0]); ps::hidden_part<1>(ldsc + RBS_V0FT, lane, gp, acc1); }
+            else mm_act_t<RgbLds::LD0, NT>(L.v0ft, gyv, acc);
             float gf[ACT_STEPS];
             acc_to_regs(acc, gf);
             tbl_store(a.g_feat, tile, p, g, gf);
@@ -392,9 +420,12 @@ __global__ __launch_bounds__(FUSED ? 512 : 256, FUSED ? 1 : 2) void rgb_composit
             for (int c = 0; c < 3; ++c) {
                 f32x4 tacc[NT];
                 acc_zero(tacc);
-                if (c == 0) mm_pe<RgbLds::LD0, NT, 0, 4>(L.v0e, d1 + 0, tacc);
-                if (c == 1) mm_pe<RgbLds::LD0, NT, 4, 4>(L.v0e, d1 + 4, tacc);
-                if (c == 2) mm_pe<RgbLds::LD0, NT, 8, 4>(L.v0e, d1 + 8, tacc);
+                if constexpr (SPLIT) ps::jac_part(ldsc + RBS_V0E, lane, c, d1 + 4 * c, tacc);
+                else {
+                    if (c == 0) mm_pe<RgbLds::LD0, NT, 0, 4>(L.v0e, d1 + 0, tacc);
+                    if (c == 1) mm_pe<RgbLds::LD0, NT, 4, 4>(L.v0e, d1 + 4, tacc);
+                    if (c == 2) mm_pe<RgbLds::LD0, NT, 8, 4>(L.v0e, d1 + 8, tacc);
+                }
                 float dsum = 0.f;
 #pragma unroll
                 for (int s2 = 0; s2 < ACT_STEPS; ++s2) dsum = __builtin_fmaf(gyv[s2], tacc[s2 >> 2][s2 & 3], dsum);
@@ -499,6 +530,28 @@ extern "C" int sc_rgb_composite_backward_fused_stash(
     const size_t lds_bytes = (size_t)sc::RB_LDS_FLOATS * sizeof(float);
     (void)hipFuncSetAttribute((const void*)sc::rgb_composite_bwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     hipLaunchKernelGGL((sc::rgb_composite_bwd_kernel<true, true>), dim3(blocks), dim3(512), lds_bytes, (hipStream_t)stream_, a);
+    return (int)hipGetLastError();
+}
+
+// sc_rgb_composite_backward_fused_stash with the reverse chain's transposed products and the encoding's Jacobian in the exact bf16x3 split
+// arithmetic from pre-split fragments (round 6; same operands and outputs, gradients equal up to fp32 rounding).
+extern "C" int sc_rgb_composite_backward_fused_split(
+    const float* points, const float* z_vals, const float* depth_fac, const float* sdf, const float* grad,
+    const float* feat, const float* v_pack, const float* dbias, const float* beta_param, const float* rgb_flat,
+    int n_rays, int rays_per_image, int n_images, int symmetric, float beta_min, float bgcolor, float normal_pow,
+    const float* G_rgb, const float* G_mask, const float* G_depth, const float* G_normal,
+    float* g_sdf, float* g_grad, float* g_feat, float* g_points, float* g_z, float* g_depth_fac, float* g_beta,
+    float* partial, float* v3_part, const float* rr, void* stream_) {
+    if (n_rays <= 0) return 0;
+    if (!partial || !v3_part || !rr || n_images <= 0 || n_images > 256) return (int)hipErrorInvalidValue;
+    sc::RgbBwdArgs a{points, z_vals, depth_fac, sdf, grad, feat, v_pack, dbias, beta_param, rgb_flat,
+                     n_rays, rays_per_image, n_images, symmetric, beta_min, bgcolor, normal_pow,
+                     G_rgb, G_mask, G_depth, G_normal, g_sdf, g_grad, g_feat, g_points, g_z, g_depth_fac, g_beta,
+                     nullptr, const_cast<float*>(rr), nullptr, partial, sc_rgb_composite_backward_fused_partial_floats(n_images), v3_part};
+    const int blocks = sc_rgb_composite_backward_fused_parts(n_rays);
+    const size_t lds_bytes = (size_t)sc::RBS_LDS_FLOATS * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)sc::rgb_composite_bwd_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL((sc::rgb_composite_bwd_kernel<true, true, true>), dim3(blocks), dim3(512), lds_bytes, (hipStream_t)stream_, a);
     return (int)hipGetLastError();
 }
 

@@ -113,26 +113,6 @@ struct Args {
     float* scratch;        // GRAD without stash_a: [gridDim.x * WAVES][5][1024] floats of per-wave scratch
 };
 
-// acc[mt] += W_e[:, slots of coordinate c] dE_c with the forward encoding fragments: c = 0 / 1 the low / high half of the K = 32 step
-// (dj = the 4 Jacobian slots of the coordinate in that half, zeros in the other), c = 2 the K = 16 step
-__device__ __forceinline__ void jac_part(const char* base, int lane, int c, const float* dj, f32x4 (&t)[NT]) {
-    if (c < 2) {
-        const float bv[8] = {c == 0 ? dj[0] : 0.f, c == 0 ? dj[1] : 0.f, c == 0 ? dj[2] : 0.f, c == 0 ? dj[3] : 0.f,
-                             c == 1 ? dj[0] : 0.f, c == 1 ? dj[1] : 0.f, c == 1 ? dj[2] : 0.f, c == 1 ? dj[3] : 0.f};
-        MlpPieces<8> b;
-        mlp_split<8>(bv, b);
-#pragma unroll
-        for (int mt = 0; mt < NT; ++mt) t[mt] = mlp_six<8>(frag32(base + mt * PE_FRAG, lane), b, t[mt]);
-    } else {
-        const float bv[4] = {dj[0], dj[1], dj[2], dj[3]};
-        MlpPieces<4> b;
-        mlp_split<4>(bv, b);
-#pragma unroll
-        for (int mt = 0; mt < NT; ++mt) t[mt] = mlp_six<4>(frag16(base + mt * PE_FRAG + F32B, lane), b, t[mt]);
-    }
-    mfma_settle();
-}
-
 template <bool STASH>
 __global__ __launch_bounds__(64 * WAVES) void sdf_fwd_stream_kernel(Args a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];

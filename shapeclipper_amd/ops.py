@@ -31,6 +31,7 @@ def _sdf_stream_image(w_pack):
     two eikonal batches) share ONE w_pack tensor (SDFNetwork.packed): the image is built once for it.  A hit needs the SAME tensor object at
     the same version on the same stream -- the entry keeps the tensor alive, so its address cannot be handed to another tensor meanwhile."""
     dev = w_pack.device
+    _lib.ptr(w_pack)                    # (a CPU tensor is refused here with the product's own message: there is no CPU fallback)
     key = (dev.index, _lib.raw_stream(dev.index))
     hit = _STREAM_IMG.get(key)
     if hit is not None and hit[0] is w_pack and hit[1] == w_pack._version:
@@ -43,6 +44,7 @@ def _sdf_stream_image(w_pack):
     return img
 
 
+RGB_BWD_SPLIT = True      # reverse chain of the RGB network (fused form that reads the parked activations) from pre-split transposed fragments
 RGB_FWD_SPLIT = True      # RGB network of the forward pass from pre-split bf16x3 fragments (csrc/rgb_fwd.hip, mlp_presplit.hpp); False: fp32 MFMA
 SDF_FWD_STREAM = True     # sdf_forward with d sdf/dx from streamed pre-split fragments (csrc/sdf_fwd_stream.hip); False: sdf_fwd.hip (fp32 MFMA)
 SDF_VALUE_SPLIT = True    # value-only SDF calls (no gradient, no feature, no stash) take csrc/sdf_value_split.hip; False: sdf_fwd.hip (fp32 MFMA)
@@ -346,7 +348,10 @@ def rgb_composite_backward(points, z_vals, depth_fac, sdf, grad, feat, v_pack, d
                 _lib.ptr(G_normal), _lib.ptr(g["sdf"]), _lib.ptr(g["grad"]), _lib.ptr(g["feat"]), _lib.ptr(g["points"]),
                 _lib.ptr(g["z_vals"]), _lib.ptr(g["depth_fac"]), _lib.ptr(g["beta"]), _lib.ptr(partial), _lib.ptr(v3_part))
         if rr is not None:      # the forward parked r0..r2: no recomputation of the forward chain
-            _lib.check(lib.sc_rgb_composite_backward_fused_stash(*args, _lib.ptr(rr), _lib.stream()), "sc_rgb_composite_backward_fused_stash")
+            if RGB_BWD_SPLIT:      # round 6: the reverse chain's transposed products from pre-split bf16x3 fragments (`--hip.rgb_bwd_split!`: fp32 MFMA)
+                _lib.check(lib.sc_rgb_composite_backward_fused_split(*args, _lib.ptr(rr), _lib.stream()), "sc_rgb_composite_backward_fused_split")
+            else:
+                _lib.check(lib.sc_rgb_composite_backward_fused_stash(*args, _lib.ptr(rr), _lib.stream()), "sc_rgb_composite_backward_fused_stash")
         else:
             _lib.check(lib.sc_rgb_composite_backward_fused(*args, _lib.stream()), "sc_rgb_composite_backward_fused")
         g_all = _partial_reduce(lib, partial, parts, stride, stride, torch.empty(stride, **f32))

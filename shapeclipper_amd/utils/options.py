@@ -22,7 +22,7 @@ torch.backends.cudnn.benchmark = False
 # defaults for keys this build adds (a reference YAML without them still loads)
 # deterministic_conv: the reference sets cudnn.deterministic=True globally (utils/options.py:14); on ROCm that
 # restricts MIOpen to GEMM-based backward solvers (measured 437 ms of 640 ms per bs32 step), so it is opt-in here.
-HIP_DEFAULTS = dict(hip=dict(device_rng=False, device_choice=True, fused_backward=True, deterministic_conv=False, fused_loss=True, fused_adam=True, guarded_step=True, batched_encoders=True, two_streams=True, overlap_allreduce=False, reserve_cus=0, fused_block=True, fused_bottleneck=True, fused_rgb_wgrad=True, rgb_stash=True, value_split=True, rgb_split=True, sdf_stream=True, upload_stream=True, rocblas=True, conv3x3=True, conv3x3_split=True, conv_stem=True, conv1x1=True, conv3x3s2=True, conv3x3s2_grads=True))
+HIP_DEFAULTS = dict(hip=dict(device_rng=False, device_choice=True, fused_backward=True, deterministic_conv=False, fused_loss=True, fused_adam=True, guarded_step=True, batched_encoders=True, two_streams=True, overlap_allreduce=False, reserve_cus=0, fused_block=True, fused_bottleneck=True, fused_rgb_wgrad=True, rgb_stash=True, value_split=True, rgb_split=True, rgb_bwd_split=True, sdf_stream=True, upload_stream=True, rocblas=True, conv3x3=True, conv3x3_split=True, conv_stem=True, conv1x1=True, conv3x3s2=True, conv3x3s2_grads=True))
 
 
 def parse_arguments(args):
@@ -122,6 +122,7 @@ def process_options(opt):
     _ops.FUSED_RGB_WGRAD = bool(opt.get("hip", {}).get("fused_rgb_wgrad", True))
     _ops.RGB_STASH = bool(opt.get("hip", {}).get("rgb_stash", True))
     _ops.SDF_FWD_STREAM = bool(opt.get("hip", {}).get("sdf_stream", True))       # SDF forward (value, feature, d sdf/dx) from streamed pre-split fragments
+    _ops.RGB_BWD_SPLIT = bool(opt.get("hip", {}).get("rgb_bwd_split", True)) and _ops.RGB_STASH and _ops.FUSED_RGB_WGRAD
     _ops.RGB_FWD_SPLIT = bool(opt.get("hip", {}).get("rgb_split", True))         # forward RGB network from pre-split bf16x3 fragments
     _ops.SDF_VALUE_SPLIT = bool(opt.get("hip", {}).get("value_split", True))     # evaluation grid: the pre-split bf16x3 value chain
     from ..model import renderer as _renderer

@@ -113,3 +113,38 @@ def test_split_forward_equals_fp32_forward_up_to_rounding(n_images, rays_per_ima
     ea, eb = (float((t["rgb_flat"].double().cpu() - want).abs().max()) for t in (a, b))
     print("per-sample colours vs float64: split %.2e, fp32 MFMA %.2e" % (ea, eb))
     assert ea < 1.5 * eb + 2e-7 and ea < 2e-6
+
+
+@pytest.mark.parametrize("n_images,rays_per_image", [(3, 40), (3, 37), (1, 5), (2, 512)])
+def test_split_reverse_chain_equals_fp32_reverse_chain_up_to_rounding(n_images, rays_per_image):
+    """Round 6: sc_rgb_composite_backward_fused_split (V2^T, V1^T, V0f^T and the encoding's Jacobian from pre-split bf16x3 fragments) against
+    sc_rgb_composite_backward_fused_stash (fp32 MFMA) on the same parked activations: what does not pass through those products (g_sdf,
+    g_grad, g_z, depth_fac, beta) is bit-identical, every other gradient agrees to 2e-5 of its largest entry (the bar between the parked
+    and the recomputed fp32 forms above); twice: same bits."""
+    s = _setup(n_images, rays_per_image, seed=9)
+    ops = s["ops"]
+    common = (s["pts"], s["z"], s["dfac"], s["sdf"], s["grad"], s["feat"], s["rgb_pack"], s["db"], s["beta"], s["rpi"], True, 1e-4, 1.0, 1.0)
+    a = ops.rgb_composite_forward(*common, keep_rgb_flat=True, keep_rr=True)
+    gen = s["g"]
+    G = [torch.randn(s["n_rays"], 3, generator=gen).to(s["dev"]), torch.randn(s["n_rays"], generator=gen).to(s["dev"]),
+         torch.randn(s["n_rays"], generator=gen).to(s["dev"]), torch.randn(s["n_rays"], 3, generator=gen).to(s["dev"])]
+    back = lambda: ops.rgb_composite_backward(s["pts"], s["z"], s["dfac"], s["sdf"], s["grad"], s["feat"], s["rgb_pack"], s["db"], s["beta"],
+                                              a["rgb_flat"], s["rpi"], True, 1e-4, 1.0, 1.0, *G, rr=a["rr"])
+    saved = ops.RGB_BWD_SPLIT
+    try:
+        ops.RGB_BWD_SPLIT = True
+        g1, g1b = back(), back()
+        ops.RGB_BWD_SPLIT = False
+        g0 = back()
+    finally:
+        ops.RGB_BWD_SPLIT = saved
+    worst = {}
+    for k in g0:
+        assert torch.equal(g1[k], g1b[k]), "not reproducible: " + k
+        scale = max(float(g0[k].abs().max()), 1e-6)
+        worst[k] = float((g1[k] - g0[k]).abs().max()) / scale
+    print("split vs fp32 reverse chain (max abs / max |fp32|):", {k: "%.1e" % v for k, v in worst.items()})
+    for k in ("sdf", "grad", "z_vals", "depth_fac", "beta"):
+        assert worst[k] == 0.0, (k, worst[k])
+    assert all(v <= 2e-5 for v in worst.values()), worst
+    assert any(v > 0 for v in worst.values())                  # two arithmetics, not one code path

@@ -326,7 +326,7 @@ def _load_bench():
 RAW_ENTRY_POINTS = ["sc_sdf_forward", "sc_sdf_forward_stream", "sc_sdf_backward", "sc_sdf_backward_fused", "sc_rgb_composite_forward", "sc_rgb_composite_forward_stash",
                     "sc_rgb_composite_forward_split",
                     "sc_rgb_composite_backward", "sc_rgb_composite_backward_v3", "sc_rgb_composite_backward_fused",
-                    "sc_rgb_composite_backward_fused_stash"]
+                    "sc_rgb_composite_backward_fused_stash", "sc_rgb_composite_backward_fused_split"]
 
 
 @pytest.mark.parametrize("dominant", RAW_ENTRY_POINTS)
