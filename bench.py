@@ -105,7 +105,8 @@ LIMITER = {
     "sc_sdf_backward": "issue: same chain as the fused form without the weight-gradient role (DESIGN.md 4.1)",
     "sc_rgb_composite_forward": "round 6: RGB network from pre-split bf16x3 fragments resident in LDS (1.3x at the training shape, 1.46x at the "
                                 "evaluation shape); vector work + the activation stash it writes (768 B per point, profiles/r06_traffic.json)",
-    "sc_rgb_composite_backward": "issue: reverse sweep + weight-gradient MFMAs in one workgroup; reads the parked activations (DESIGN.md 4.1)",
+    "sc_rgb_composite_backward": "issue: reverse sweep (round 6: its transposed products from pre-split bf16x3 fragments) + fp32 weight-gradient MFMAs "
+                                 "in one workgroup; reads the parked activations (DESIGN.md 4.1, 4.1.2)",
 }
 
 
