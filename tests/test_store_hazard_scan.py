@@ -91,17 +91,17 @@ def test_no_short_mfma_is_fed_by_a_k32_mfma_directly_in_front_of_it(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import scan_mfma_shape_hazard as S
     seen = 0
-    for name in ("sdf_value_split.hip", "rgb_fwd.hip", "sdf_fwd_stream.hip"):          # every file that issues both shapes (mlp_presplit.hpp)
+    for name in ("sdf_value_split.hip", "rgb_fwd.hip", "sdf_fwd_stream.hip", "rgb_bwd.hip"):          # every file that issues both shapes (mlp_presplit.hpp)
         out = str(tmp_path / (name[:-4] + ".s"))
         r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only",
                             os.path.join(CSRC, name), "-o", out], capture_output=True, text=True, cwd=CSRC)
         assert r.returncode == 0, r.stderr[-2000:]
         n, hits = S.scan(open(out).read())
-        assert n >= 40 and not hits, (name, hits[:3])
+        assert n >= 20 and not hits, (name, hits[:3])
         seen += n
     assert seen >= 300
     assert sorted(f for f in os.listdir(CSRC) if f.endswith(".hip") and "mlp_presplit.hpp" in open(os.path.join(CSRC, f)).read()) == \
-        ["rgb_fwd.hip", "sdf_fwd_stream.hip", "sdf_value_split.hip"]                    # a new user of the header must be added to the list above
+        ["rgb_bwd.hip", "rgb_fwd.hip", "sdf_fwd_stream.hip", "sdf_value_split.hip"]                    # a new user of the header must be added to the list above
     n2, hits2 = S.scan("\n".join([
         "_Z1kv:",
         "\tv_mfma_f32_16x16x32_bf16 v[28:31], v[24:27], v[0:3], v[28:31]",
