@@ -202,7 +202,7 @@ def test_flat_reducer_path_on_rccl_single_rank():
 
 @pytest.mark.parametrize("flag", ["--hip.two_streams!", "--hip.batched_encoders!", "--hip.fused_loss!", "--hip.fused_adam!", "--hip.device_rng",
                                   "--hip.fused_backward!", "--hip.fused_rgb_wgrad!", "--hip.rgb_stash!", "--hip.upload_stream!", "--hip.device_choice!", "--hip.conv3x3!", "--hip.conv3x3_split!", "--hip.conv_stem!", "--hip.conv1x1!", "--hip.conv3x3s2!",
-                                  "--hip.overlap_allreduce", "--hip.fused_block!", "--hip.fused_bottleneck!", "--hip.rocblas!", "--arch.impl_sdf.weight_norm", "--arch.impl_rgb.weight_norm"])
+                                  "--hip.overlap_allreduce", "--hip.sdf_stream!", "--hip.rgb_split!", "--hip.rgb_bwd_split!", "--hip.value_split!", "--hip.fused_block!", "--hip.fused_bottleneck!", "--hip.rocblas!", "--arch.impl_sdf.weight_norm", "--arch.impl_rgb.weight_norm"])
 def test_every_hip_option_has_a_working_alternate_path(flag):
     """Each fast path of this build can be switched off (README): the step still runs and gives the same loss
     (device_rng draws different jitter, so only finiteness is compared there).  The two weight_norm switches of the reference's
