@@ -1,7 +1,9 @@
 """Same-box A/B of the CLIP image tower between two builds of the C ABI (the driver's B=256 / ViT-L/14 lines read 3.354 ->
 3.579 ms and 7.754 -> 8.050 ms from round 4 to round 5 on two different boxes): the round-4 library (shapeclipper_amd/lib/variants/lib_r04.so,
 built from commit 9c0e07c) against the tree's, through the entry point both export (sc_clip_vit_forward_f16: the launch-per-operation
-tower), alternating, same weights, same input.   python tools/r6_clip_ab.py"""
+tower), alternating, same weights, same input.   python tools/r6_clip_ab.py
+(the variant library is not kept in the tree: `git worktree add /tmp/r04 9c0e07c && make -C /tmp/r04/shapeclipper_amd/csrc && mkdir -p
+shapeclipper_amd/lib/variants && cp /tmp/r04/shapeclipper_amd/lib/libshapeclipper_hip.so shapeclipper_amd/lib/variants/lib_r04.so`)"""
 import ctypes, os, sys, time
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import torch
