@@ -266,6 +266,10 @@ using Wg7S2 = WgCfg<7, 7, 2, 1, 2>;
 // cycles (the fp32 kernel: 21 MFMAs of 64 cycles per 14 pixels and tap row).  K-steps are sized by LDS (6 bytes per element instead
 // of 4): 2 rows of a 56-wide map, 4 of 28, 7 of 14, two 7 x 7 images.  Partial blocks and the fixed-order reduction are those above.
 typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float wg_f32x4 __attribute__((ext_vector_type(4)));
+#ifndef SC_WGRAD_S16
+#define SC_WGRAD_S16 0          // 1: v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (round-6 A/B, tools/build_variants.sh conv3x3_wgrad.hip SC_WGRAD_S16 0 1)
+#endif
 
 template <int W_, int NR_, int NIMG_>
 struct WsCfg {
@@ -377,6 +381,21 @@ __global__ __launch_bounds__(768, 1) void conv3x3_wgrad_split_kernel(const float
         }
     };
 
+#if SC_WGRAD_S16
+    // Round 6: the same products on v_mfma_f32_16x16x32_bf16 -- the chip sustains 0.84 of the nominal bf16 rate on that shape against 0.73 on
+    // 32x32x16 under random operands (profiles/r04_mfma_sustained.txt).  A K = 32 step covers TWO adjacent 16-slot groups: lane quarter q
+    // owns slots 8 q .. 8 q + 7 of the pair, i.e. half q & 1 of group 2 G + (q >> 1): the gy fragment is still one ds_read_b128 per piece at
+    // 32 G + 8 q, the patch window the same five dwords at boff(group, half).  The wave's 32 x 32 (co, ci) tile is 2 x 2 tiles of 16 x 16.
+    // An odd group count (14 x 14, 7 x 7) ends with a half-empty pair: quarters 2, 3 multiply zeros.
+    wg_f32x4 acc[3][2][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[t][u >> 1][u & 1] = wg_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int q4 = lane >> 4, l16 = lane & 15;
+    const __bf16* Ab = As + ((wt >> 1) * 32 + l16) * C::ASTR + 8 * q4;                       // + 16 sa rows
+    const unsigned* Bb = reinterpret_cast<const unsigned*>(Xs + ((wt & 1) * 32 + l16) * C::BSTR + ky * Wp);      // + 16 sb rows
+#else
     wg_f32x16 acc[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t)
@@ -385,6 +404,7 @@ __global__ __launch_bounds__(768, 1) void conv3x3_wgrad_split_kernel(const float
 
     const __bf16* Ab = As + ((wt >> 1) * 32 + (lane & 31)) * C::ASTR + 8 * half;
     const unsigned* Bb = reinterpret_cast<const unsigned*>(Xs + ((wt & 1) * 32 + (lane & 31)) * C::BSTR + ky * Wp);
+#endif
 
     WG_STAMP(0)
     if (k_lo < k_hi) load(k_lo);
@@ -401,6 +421,58 @@ __global__ __launch_bounds__(768, 1) void conv3x3_wgrad_split_kernel(const float
         const unsigned long long ts1 = __builtin_amdgcn_s_memrealtime();
 #endif
         if (kstep + 1 < k_hi) load(kstep + 1);
+#if SC_WGRAD_S16
+#pragma unroll
+        for (int G2 = 0; G2 < (C::G + 1) / 2; ++G2) {
+            constexpr int NG = C::G;
+            const bool tail = 2 * G2 + 1 >= NG;                                // (compile-time per unrolled iteration) the pair's second group does not exist
+            const bool dead = tail && q4 >= 2;
+            const int g1 = tail ? 2 * G2 : 2 * G2 + 1;
+            const int bo = (q4 == 0 ? C::boff(2 * G2, 0) : q4 == 1 ? C::boff(2 * G2, 1) : q4 == 2 ? C::boff(g1, 0) : C::boff(g1, 1)) >> 1;
+            float4 a[3][2];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float4 av = *reinterpret_cast<const float4*>(Ab + pc * 64 * C::ASTR + u * 16 * C::ASTR + (dead ? 0 : 32 * G2));
+                    a[pc][u] = dead ? make_float4(0.f, 0.f, 0.f, 0.f) : av;
+                }
+            // one ci half at a time: 15 patch dwords live beside the 24 of the two gy fragments (both halves at once spilled 177 registers:
+            // three waves per SIMD leave 168)
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                unsigned d[3][5];
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) d[pc][q] = Bb[pc * 32 * C::BSTR + sb * 8 * C::BSTR + bo + q];
+#pragma unroll
+                for (int term = 0; term < 6; ++term) {
+                    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+                    const unsigned* q = d[PB[term]];
+                    const uint4 b0 = {q[0], q[1], q[2], q[3]}, b2 = {q[1], q[2], q[3], q[4]};
+                    const uint4 b1 = {__builtin_amdgcn_alignbit(q[1], q[0], 16), __builtin_amdgcn_alignbit(q[2], q[1], 16),
+                                      __builtin_amdgcn_alignbit(q[3], q[2], 16), __builtin_amdgcn_alignbit(q[4], q[3], 16)};
+#pragma unroll
+                    for (int sa = 0; sa < 2; ++sa) {
+                        const wg_bf16x8 av = __builtin_bit_cast(wg_bf16x8, a[PA[term]][sa]);
+                        acc[0][sa][sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(wg_bf16x8, b0), acc[0][sa][sb], 0, 0, 0);
+                        acc[1][sa][sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(wg_bf16x8, b1), acc[1][sa][sb], 0, 0, 0);
+                        acc[2][sa][sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(wg_bf16x8, b2), acc[2][sa][sb], 0, 0, 0);
+                    }
+                }
+                // the operands stay live until the last MFMA that reads them has issued: the K = 32 shape reads its operands after the first
+                // pass and hipcc may otherwise place a destination on a dying operand
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+                    asm volatile("" : "+v"(acc[0][0][sb]) : "v"(d[pc][0]), "v"(d[pc][1]), "v"(d[pc][2]), "v"(d[pc][3]), "v"(d[pc][4]));
+            }
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+                asm volatile("" : "+v"(acc[0][0][0]) : "v"(__builtin_bit_cast(wg_f32x4, a[pc][0])), "v"(__builtin_bit_cast(wg_f32x4, a[pc][1])));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#else
 #pragma unroll
         for (int g = 0; g < C::G; ++g) {
             float4 a[3];
@@ -425,6 +497,7 @@ __global__ __launch_bounds__(768, 1) void conv3x3_wgrad_split_kernel(const float
                 acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(wg_bf16x8, b2), acc[2], 0, 0, 0);
             }
         }
+#endif
         __syncthreads();                                                      // every wave is done reading this K-step's tiles
 #ifdef SC_WGRAD_PROFILE
         WG_ACCUM(5, ts1)                                                      // load issue + MFMA loop + barrier
@@ -432,10 +505,24 @@ __global__ __launch_bounds__(768, 1) void conv3x3_wgrad_split_kernel(const float
     }
     WG_STAMP(2)
     float* dst = partial + (size_t)blockIdx.x * (64 * 64 * 9);
+#if SC_WGRAD_S16
+    // into the partial layout of the 32 x 32 form (what conv3x3_wgrad_reduce_kernel reads): element (co, ci) of the wave's tile sits at
+    // register (co & 3) + 4 (co >> 3) of lane ci + 32 ((co >> 2) & 1); here co = 16 sa + 4 q4 + r, ci = 16 sb + l16
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int sa = 0; sa < 2; ++sa)
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    dst[((wt * 9 + ky * 3 + t) * 16 + r + 4 * (2 * sa + (q4 >> 1))) * 64 + 16 * sb + l16 + 32 * (q4 & 1)] = acc[t][sa][sb][r];
+#else
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dst[((wt * 9 + ky * 3 + t) * 16 + r) * 64 + lane] = acc[t][r];
+#endif
 #ifdef SC_WGRAD_PROFILE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     WG_STAMP(3)
